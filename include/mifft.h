@@ -1,0 +1,164 @@
+/*
+ * mifft.h -- C ABI of libmifft.so, the MI355X (gfx950) batched power-of-two c2c FFT engine
+ * behind pyfft's Plan()/execute() API.
+ *
+ * This is the drop-in boundary.  In the reference (fjarri-attic/pyfft 0.3.9) the host side
+ * (pyfft/plan.py, pyfft/kernel.py) reaches the device through a duck-typed
+ * Context / Module / Function protocol implemented on PyCUDA (pyfft/cuda.py:19-113):
+ *
+ *   context.allocate(nbytes)                          cuda.py:85-89     -> mifft_malloc / mifft_free
+ *   context.compile(src, fast_math) -> Module         cuda.py:52-61,91  -> (none: kernels are AOT-compiled
+ *   module.getFunction(name, split, block) -> Function cuda.py:19-30        into this library; a pass is
+ *   func.isExecutable()                               cuda.py:48-49         selected by mifft_pass_supported)
+ *   func.prepare(grid, S); func(stream, *ptrs)        cuda.py:32-46     -> mifft_launch_pass / mifft_launch_chain
+ *   context.createQueue()/wait()/flush()/getQueue()   cuda.py:94-107    -> mifft_stream_create / _sync / _destroy
+ *   device limits read in Context.__init__            cuda.py:72-83     -> mifft_device_props
+ *
+ * and the generated kernels have the signature fft{Fwd,Inv}(in, out, int S) or
+ * (in_re, in_im, out_re, out_im, int S) (pyfft/kernel.mako:690-697).  A `mifft_pass` describes one
+ * such launch: one Stockham pass of pyfft/kernel.mako:805-1047 (globalKernel) or a whole LDS-resident
+ * transform along the contiguous axis (kernel.mako:725-803, localKernel).
+ *
+ * Conventions
+ *   - plain C, no C++ types or exceptions cross the boundary;
+ *   - every function returns 0 on success, a positive hipError_t, or a negative MIFFT_E_* code, and
+ *     records a thread-local message readable with mifft_last_error();
+ *   - all device buffers (user data, temp, twiddle tables) are owned by the caller and only borrowed for
+ *     the duration of the enqueued work; the library keeps no mutable global state;
+ *   - launches are asynchronous on the caller's stream; nothing here synchronises except the *_sync calls.
+ */
+#ifndef MIFFT_H
+#define MIFFT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIFFT_ABI_VERSION 1
+
+/* negative library error codes (positive values are hipError_t) */
+#define MIFFT_E_INVALID      (-1)  /* malformed descriptor / argument              */
+#define MIFFT_E_UNSUPPORTED  (-2)  /* no compiled kernel for this (precision, L, mode) */
+#define MIFFT_E_NODEVICE     (-3)  /* no HIP device visible                         */
+
+/* precision of the arithmetic and of the buffers */
+#define MIFFT_F32 0
+#define MIFFT_F64 1
+
+/* buffer layout: interleaved (re,im) pairs, or two scalar planes
+ * (pyfft/plan.py:26-35: complex dtypes -> interleaved, float dtypes -> split) */
+#define MIFFT_INTERLEAVED 0
+#define MIFFT_SPLIT       1
+
+/* pass kinds */
+#define MIFFT_PASS_COL 0  /* strided pass: [outer][L][M*S] -> [outer][M][L][S]  (kernel.mako:805-1047) */
+#define MIFFT_PASS_ROW 1  /* contiguous pass: `outer` rows of L points, in place  (kernel.mako:725-803)  */
+
+typedef void *mifft_stream_t; /* hipStream_t; NULL = the default stream */
+typedef void *mifft_event_t;  /* hipEvent_t */
+
+/*
+ * One launch.  With w(m) = exp(-2*pi*i/m) (forward; the inverse conjugates input and output):
+ *
+ *   MIFFT_PASS_COL  in  viewed as [outer][L][M][S]   (element strides L*M*S? no: see outer_stride)
+ *                   out viewed as [outer][M][L][S]
+ *       out[o][l][q][j] = scale * w(L*M)^(l*q) * sum_r in[o][r][l][j] * w(L)^(r*q)
+ *     M == 1  -> plain strided transform (last pass of an axis), in-place capable;
+ *     S == 1  -> first pass of a long contiguous axis: the write is a transposition.
+ *
+ *   MIFFT_PASS_ROW  in/out viewed as [outer][L]:  out[o][q] = scale * sum_r in[o][r] * w(L)^(r*q)
+ *
+ * Matrix `o` starts at element o*outer_stride_{in,out} (elements of the complex type; for split layout
+ * the same offset applies to both planes).  Sizes are powers of two except `outer`.
+ */
+typedef struct mifft_pass {
+    int32_t kind;        /* MIFFT_PASS_COL | MIFFT_PASS_ROW */
+    int32_t precision;   /* MIFFT_F32 | MIFFT_F64 */
+    int32_t layout;      /* MIFFT_INTERLEAVED | MIFFT_SPLIT (same for input and output) */
+    int32_t inverse;     /* 0 forward (numpy.fft.fft sign), 1 inverse (unnormalised unless `scale`) */
+    int32_t L;           /* transform length of this launch (the radix of the pass) */
+    int32_t variant;     /* kernel variant selector, 0 = library default */
+    int64_t M;           /* not-yet-transformed extent of the axis after this pass (COL), 1 for ROW */
+    int64_t S;           /* extent of everything faster than the digit being transformed (COL), 1 for ROW */
+    int64_t outer;       /* number of independent matrices / rows */
+    int64_t outer_stride_in;   /* elements between consecutive matrices in the input  */
+    int64_t outer_stride_out;  /* elements between consecutive matrices in the output */
+    double  scale;       /* every output is multiplied by this (1.0 except in a plan's last pass,
+                            pyfft/kernel.py:23-37, pyfft/plan.py:125-128) */
+    const void *tw_L;    /* device: L entries w(L)^k, complex of `precision` */
+    const void *tw_lo;   /* device: 2^tw_shift entries w(L*M)^k            (NULL when M == 1) */
+    const void *tw_hi;   /* device: (L*M)>>tw_shift entries w(L*M)^(k<<tw_shift) (NULL when M == 1) */
+    int32_t tw_shift;
+    int32_t src;         /* for mifft_launch_chain: index of the buffer read  (0 in, 1 out, 2 temp) */
+    int32_t dst;         /* for mifft_launch_chain: index of the buffer written */
+    int32_t reserved;
+} mifft_pass;
+
+typedef struct mifft_device_props {
+    char    name[256];
+    char    gcn_arch[64];
+    int32_t compute_units;
+    int32_t wavefront_size;
+    int32_t max_threads_per_block;
+    int32_t max_grid_x;
+    int64_t lds_bytes_per_block;
+    int64_t total_mem_bytes;
+    int32_t clock_khz;
+    int32_t l2_bytes;
+} mifft_device_props;
+
+/* ---- library ------------------------------------------------------------------------------------- */
+int         mifft_abi_version(void);
+const char *mifft_last_error(void);
+
+/* ---- runtime shim (replaces cuda.py Context: allocate / stream lifecycle / device limits) ---------- */
+int mifft_device_count(int *count);
+int mifft_set_device(int device);
+int mifft_get_device(int *device);
+int mifft_device_props_get(int device, mifft_device_props *props);
+int mifft_malloc(void **ptr, size_t nbytes);
+int mifft_free(void *ptr);
+int mifft_memset(void *ptr, int value, size_t nbytes, mifft_stream_t stream);
+int mifft_memcpy_h2d(void *dst, const void *src, size_t nbytes, mifft_stream_t stream);
+int mifft_memcpy_d2h(void *dst, const void *src, size_t nbytes, mifft_stream_t stream);
+int mifft_memcpy_d2d(void *dst, const void *src, size_t nbytes, mifft_stream_t stream);
+int mifft_stream_create(mifft_stream_t *stream);
+int mifft_stream_destroy(mifft_stream_t stream);
+int mifft_stream_sync(mifft_stream_t stream);
+int mifft_device_sync(void);
+int mifft_event_create(mifft_event_t *event);
+int mifft_event_destroy(mifft_event_t event);
+int mifft_event_record(mifft_event_t event, mifft_stream_t stream);
+int mifft_event_sync(mifft_event_t event);
+int mifft_event_elapsed_ms(float *ms, mifft_event_t start, mifft_event_t stop);
+
+/* ---- pass launchers (replace cuda.py Function.__call__, cuda.py:35-46) ----------------------------- */
+
+/* 0 if a compiled kernel exists for (kind, precision, L, variant), else MIFFT_E_UNSUPPORTED.
+ * Counterpart of Function.isExecutable (cuda.py:48-49) for AOT kernels. */
+int mifft_pass_supported(int32_t kind, int32_t precision, int32_t L, int32_t variant);
+
+/* Enqueue one pass.  in1/out1 are the imaginary planes for MIFFT_SPLIT and must be NULL for
+ * MIFFT_INTERLEAVED.  In-place (out == in) is allowed for MIFFT_PASS_ROW and for MIFFT_PASS_COL with
+ * M == 1 (pyfft/kernel.py:144,238-241). */
+int mifft_launch_pass(const mifft_pass *pass, const void *in0, const void *in1, void *out0, void *out1,
+                      mifft_stream_t stream);
+
+/* Enqueue a whole plan: passes[i] reads bufs0/bufs1[passes[i].src] and writes [passes[i].dst]
+ * (0 = data_in, 1 = data_out, 2 = temp -- the ping-pong loop of pyfft/plan.py:217-248 with the
+ * schedule already decided by the Python plan).  bufs1 may be NULL for interleaved layout. */
+int mifft_launch_chain(const mifft_pass *passes, int32_t npasses, void *const bufs0[3], void *const bufs1[3],
+                       mifft_stream_t stream);
+
+/* Same as mifft_launch_chain but brackets the chain with two events on `stream` and, after
+ * synchronising, reports the elapsed device time of `repeats` back-to-back chains. (bench/test helper) */
+int mifft_time_chain(const mifft_pass *passes, int32_t npasses, void *const bufs0[3], void *const bufs1[3],
+                     mifft_stream_t stream, int32_t repeats, float *ms_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIFFT_H */

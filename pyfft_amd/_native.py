@@ -1,0 +1,141 @@
+"""ctypes binding of libmifft.so (C ABI declared in include/mifft.h).
+
+The product path has no CPU fallback: if the HIP library is missing or cannot be loaded,
+importing this module raises ImportError, and every failing call raises RuntimeError carrying
+the C side's error string (the reference surfaces PyCUDA driver errors the same way,
+pyfft/cuda.py:41-46).
+"""
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmifft.so")
+
+ABI_VERSION = 1
+
+E_INVALID = -1
+E_UNSUPPORTED = -2
+E_NODEVICE = -3
+
+F32, F64 = 0, 1
+INTERLEAVED, SPLIT = 0, 1
+PASS_COL, PASS_ROW = 0, 1
+
+
+class MifftPass(ctypes.Structure):
+    """struct mifft_pass (include/mifft.h)."""
+    _fields_ = [
+        ("kind", ctypes.c_int32),
+        ("precision", ctypes.c_int32),
+        ("layout", ctypes.c_int32),
+        ("inverse", ctypes.c_int32),
+        ("L", ctypes.c_int32),
+        ("variant", ctypes.c_int32),
+        ("M", ctypes.c_int64),
+        ("S", ctypes.c_int64),
+        ("outer", ctypes.c_int64),
+        ("outer_stride_in", ctypes.c_int64),
+        ("outer_stride_out", ctypes.c_int64),
+        ("scale", ctypes.c_double),
+        ("tw_L", ctypes.c_void_p),
+        ("tw_lo", ctypes.c_void_p),
+        ("tw_hi", ctypes.c_void_p),
+        ("tw_shift", ctypes.c_int32),
+        ("src", ctypes.c_int32),
+        ("dst", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+class MifftDeviceProps(ctypes.Structure):
+    """struct mifft_device_props (include/mifft.h)."""
+    _fields_ = [
+        ("name", ctypes.c_char * 256),
+        ("gcn_arch", ctypes.c_char * 64),
+        ("compute_units", ctypes.c_int32),
+        ("wavefront_size", ctypes.c_int32),
+        ("max_threads_per_block", ctypes.c_int32),
+        ("max_grid_x", ctypes.c_int32),
+        ("lds_bytes_per_block", ctypes.c_int64),
+        ("total_mem_bytes", ctypes.c_int64),
+        ("clock_khz", ctypes.c_int32),
+        ("l2_bytes", ctypes.c_int32),
+    ]
+
+
+_vp = ctypes.c_void_p
+_vpp = ctypes.POINTER(ctypes.c_void_p)
+_i32 = ctypes.c_int32
+_sz = ctypes.c_size_t
+_pass_p = ctypes.POINTER(MifftPass)
+_buf3 = ctypes.c_void_p * 3
+
+# name -> (restype, argtypes); every symbol include/mifft.h declares
+PROTOTYPES = {
+    "mifft_abi_version": (ctypes.c_int, []),
+    "mifft_last_error": (ctypes.c_char_p, []),
+    "mifft_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "mifft_set_device": (ctypes.c_int, [ctypes.c_int]),
+    "mifft_get_device": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "mifft_device_props_get": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(MifftDeviceProps)]),
+    "mifft_malloc": (ctypes.c_int, [_vpp, _sz]),
+    "mifft_free": (ctypes.c_int, [_vp]),
+    "mifft_memset": (ctypes.c_int, [_vp, ctypes.c_int, _sz, _vp]),
+    "mifft_memcpy_h2d": (ctypes.c_int, [_vp, _vp, _sz, _vp]),
+    "mifft_memcpy_d2h": (ctypes.c_int, [_vp, _vp, _sz, _vp]),
+    "mifft_memcpy_d2d": (ctypes.c_int, [_vp, _vp, _sz, _vp]),
+    "mifft_stream_create": (ctypes.c_int, [_vpp]),
+    "mifft_stream_destroy": (ctypes.c_int, [_vp]),
+    "mifft_stream_sync": (ctypes.c_int, [_vp]),
+    "mifft_device_sync": (ctypes.c_int, []),
+    "mifft_event_create": (ctypes.c_int, [_vpp]),
+    "mifft_event_destroy": (ctypes.c_int, [_vp]),
+    "mifft_event_record": (ctypes.c_int, [_vp, _vp]),
+    "mifft_event_sync": (ctypes.c_int, [_vp]),
+    "mifft_event_elapsed_ms": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), _vp, _vp]),
+    "mifft_pass_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
+    "mifft_launch_pass": (ctypes.c_int, [_pass_p, _vp, _vp, _vp, _vp, _vp]),
+    "mifft_launch_chain": (ctypes.c_int, [_pass_p, _i32, _buf3, _buf3, _vp]),
+    "mifft_time_chain": (ctypes.c_int, [_pass_p, _i32, _buf3, _buf3, _vp, _i32, ctypes.POINTER(ctypes.c_float)]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "pyfft_amd: %s not found -- build it with `make -C pyfft_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise ImportError("pyfft_amd: cannot load %s: %s" % (LIB_PATH, e))
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.mifft_abi_version() != ABI_VERSION:
+        raise ImportError("pyfft_amd: libmifft.so ABI %d != expected %d" % (lib.mifft_abi_version(), ABI_VERSION))
+    return lib
+
+
+lib = _load()
+
+
+def last_error():
+    msg = lib.mifft_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc, what=""):
+    """Raise RuntimeError (ValueError for descriptor errors) with the C side's message."""
+    if rc == 0:
+        return
+    msg = "%s failed (code %d): %s" % (what or "libmifft call", rc, last_error())
+    if rc == E_INVALID:
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def make_buf3(a, b, c):
+    return _buf3(a, b, c)

@@ -1,0 +1,268 @@
+// Tile FFT kernels for gfx950 (MI355X).
+//
+// One work-group owns a tile of P = L * W complex points: W independent length-L transforms.
+//   COL tile: the transform runs along a strided axis and the W columns are adjacent in memory
+//             (one Stockham pass of a long/strided axis; counterpart of pyfft/kernel.mako:805-1047).
+//   ROW tile: the transform runs along the contiguous axis, the tile is W consecutive rows
+//             (whole LDS-resident transform; counterpart of pyfft/kernel.mako:725-803).
+// Data flow: 16-byte coalesced global loads -> LDS -> [radix stage: LDS -> VGPR butterflies -> LDS]* ->
+// 16-byte coalesced global stores.  Every thread keeps PPT = P / NT points in registers per stage and
+// runs PPT / R radix-R butterflies (R in {2,4,8,16}), with Stockham autosort indexing so the result is
+// in natural order without a bit-reversal pass.
+//
+// The inverse transform is conj -> forward -> conj, folded into the load and the scaled store.
+#pragma once
+#include "fft_butterfly.hpp"
+
+namespace mifft {
+
+struct TileArgs {
+    const void* in0;
+    const void* in1;
+    void* out0;
+    void* out1;
+    const void* tw_L;   // L entries   w(L)^k
+    const void* tw_lo;  // 2^tw_shift entries w(L*M)^k
+    const void* tw_hi;  // (L*M) >> tw_shift entries w(L*M)^(k << tw_shift)
+    long long ostride_in;
+    long long ostride_out;
+    long long total;  // COL: outer * M * S columns;  ROW: number of rows
+    int logMS;        // COL: log2(M*S)
+    int logS;         // COL: log2(S)
+    int tw_shift;
+    int split;
+    int inverse;
+    int has_tw;  // COL: M > 1 -> multiply by the inter-pass twiddle w(L*M)^(l*q)
+    double scale;
+};
+
+template <int... Rs> struct RadixList {};
+
+template <typename T> __device__ __forceinline__ void load_pair(const TileArgs& a, long long g, cplx<T>& p0,
+                                                                cplx<T>& p1) {
+    using V4 = T __attribute__((ext_vector_type(4)));
+    if (!a.split) {
+        V4 t = *reinterpret_cast<const V4*>(reinterpret_cast<const cplx<T>*>(a.in0) + g);
+        p0.x = t.x; p0.y = t.y; p1.x = t.z; p1.y = t.w;
+    } else {
+        cplx<T> re = *reinterpret_cast<const cplx<T>*>(reinterpret_cast<const T*>(a.in0) + g);
+        cplx<T> im = *reinterpret_cast<const cplx<T>*>(reinterpret_cast<const T*>(a.in1) + g);
+        p0.x = re.x; p0.y = im.x; p1.x = re.y; p1.y = im.y;
+    }
+}
+
+template <typename T> __device__ __forceinline__ void store_pair(const TileArgs& a, long long g, cplx<T> p0,
+                                                                 cplx<T> p1) {
+    using V4 = T __attribute__((ext_vector_type(4)));
+    if (!a.split) {
+        V4 t;
+        t.x = p0.x; t.y = p0.y; t.z = p1.x; t.w = p1.y;
+        *reinterpret_cast<V4*>(reinterpret_cast<cplx<T>*>(a.out0) + g) = t;
+    } else {
+        cplx<T> re, im;
+        re.x = p0.x; re.y = p1.x; im.x = p0.y; im.y = p1.y;
+        *reinterpret_cast<cplx<T>*>(reinterpret_cast<T*>(a.out0) + g) = re;
+        *reinterpret_cast<cplx<T>*>(reinterpret_cast<T*>(a.out1) + g) = im;
+    }
+}
+
+// LDS addressing ---------------------------------------------------------------------------------------
+// COL layout A: [idx][c]            (c fastest: the W adjacent columns)
+// COL layout B: [c][idx], row pitch L+1 (used for the last stage of a transposing pass)
+// ROW layout  : [c][idx + idx/16], row pitch LP
+template <int L> struct RowPitch {
+    static constexpr int value = L + (L >= 16 ? L / 16 : 1);
+};
+
+template <int L, int W, bool ROW> __device__ __forceinline__ int lds_addr(int idx, int c) {
+    if constexpr (ROW)
+        return c * RowPitch<L>::value + idx + (idx >> 4);
+    else
+        return idx * W + c;
+}
+
+template <typename T, int L, int W, int NT, bool ROW, bool TR, int Ns, typename RL> struct Stages;
+
+template <typename T, int L, int W, int NT, bool ROW, bool TR, int Ns> struct Stages<T, L, W, NT, ROW, TR, Ns, RadixList<>> {
+    static __device__ __forceinline__ void run(cplx<T>*, cplx<T>*, const TileArgs&, int, long long) {}
+};
+
+template <typename T, int L, int W, int NT, bool ROW, bool TR, int Ns, int R, int... Rest>
+struct Stages<T, L, W, NT, ROW, TR, Ns, RadixList<R, Rest...>> {
+    static constexpr int P = L * W;
+    static constexpr int PPT = P / NT;
+    static constexpr int NB = PPT / R;  // butterflies per thread
+    static constexpr int LR = L / R;    // butterflies per transform
+    static constexpr bool LAST = sizeof...(Rest) == 0;
+    static_assert(NB >= 1 && NB * R == PPT, "radix must divide the points per thread");
+    static_assert(LR >= 1 && LR * R == L, "radix must divide L");
+
+    static __device__ __forceinline__ void split_bid(int bid, int& j, int& c) {
+        if constexpr (ROW) {
+            j = bid % LR;
+            c = bid / LR;
+        } else {
+            c = bid % W;
+            j = bid / W;
+        }
+    }
+
+    static __device__ __forceinline__ void run(cplx<T>* lds, cplx<T>* v, const TileArgs& a, int tid, long long col0) {
+        const cplx<T>* twL = reinterpret_cast<const cplx<T>*>(a.tw_L);
+        // ---- LDS -> registers, stage twiddle, butterfly
+        static_for<NB>([&](auto bb) {
+            constexpr int b = bb;
+            int j, c;
+            split_bid(b * NT + tid, j, c);
+            static_for<R>([&](auto kk) {
+                constexpr int k = kk;
+                v[b * R + k] = lds[lds_addr<L, W, ROW>(j + k * LR, c)];
+            });
+            if constexpr (Ns > 1) {
+                const int ai = (j & (Ns - 1)) * (L / (Ns * R));
+                static_for<R - 1>([&](auto kk) {
+                    constexpr int k = kk + 1;
+                    v[b * R + k] = cmul<T>(v[b * R + k], twL[k * ai]);
+                });
+            }
+            Dft<R, T>::run(v + b * R);
+        });
+        __syncthreads();
+        // ---- registers -> LDS at the autosort position
+        static_for<NB>([&](auto bb) {
+            constexpr int b = bb;
+            int j, c;
+            split_bid(b * NT + tid, j, c);
+            const int idxD = (j & ~(Ns - 1)) * R + (j & (Ns - 1));
+            if constexpr (LAST && !ROW) {
+                if (a.has_tw) {
+                    const cplx<T>* twlo = reinterpret_cast<const cplx<T>*>(a.tw_lo);
+                    const cplx<T>* twhi = reinterpret_cast<const cplx<T>*>(a.tw_hi);
+                    const unsigned rem = (unsigned)((col0 + c) & ((1ll << a.logMS) - 1));
+                    const unsigned l = rem >> a.logS;
+                    const unsigned lomask = (1u << a.tw_shift) - 1u;
+                    static_for<R>([&](auto kk) {
+                        constexpr int k = kk;
+                        const unsigned e = l * (unsigned)(idxD + k * Ns);
+                        cplx<T> w = cmul<T>(twlo[e & lomask], twhi[e >> a.tw_shift]);
+                        v[b * R + k] = cmul<T>(v[b * R + k], w);
+                    });
+                }
+            }
+            static_for<R>([&](auto kk) {
+                constexpr int k = kk;
+                const int idx = idxD + k * Ns;
+                if constexpr (LAST && TR)
+                    lds[c * (L + 1) + idx] = v[b * R + k];
+                else
+                    lds[lds_addr<L, W, ROW>(idx, c)] = v[b * R + k];
+            });
+        });
+        __syncthreads();
+        if constexpr (!LAST) Stages<T, L, W, NT, ROW, TR, Ns * R, RadixList<Rest...>>::run(lds, v, a, tid, col0);
+    }
+};
+
+template <typename T, int L, int W, bool ROW, bool TR> struct LdsSize {
+    static constexpr int P = L * W;
+    static constexpr int value = ROW ? W * RowPitch<L>::value : (TR ? (W * (L + 1) > P ? W * (L + 1) : P) : P);
+};
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int L, int W, int NT, bool ROW, bool TR, typename RL>
+__global__ void __launch_bounds__(NT) fft_tile_kernel(const TileArgs a) {
+    constexpr int P = L * W;
+    constexpr int PPT = P / NT;
+    static_assert(PPT * NT == P && PPT >= 2 && (PPT % 2) == 0, "bad tile configuration");
+    static_assert(!(ROW && TR), "TR applies to COL tiles only");
+    __shared__ __attribute__((aligned(16))) cplx<T> lds[LdsSize<T, L, W, ROW, TR>::value];
+
+    const int tid = threadIdx.x;
+    const long long col0 = (long long)blockIdx.x * W;  // first column (COL) / first row (ROW) of the tile
+    const long long MSmask = (1ll << a.logMS) - 1;
+    cplx<T> v[PPT];
+
+    // ---- global -> registers (all loads in flight), then -> LDS
+    static_for<PPT / 2>([&](auto ii) {
+        constexpr int it = ii;
+        const int e = (it * NT + tid) * 2;
+        cplx<T> p0, p1;
+        p0.x = 0; p0.y = 0; p1.x = 0; p1.y = 0;
+        if constexpr (ROW) {
+            const int c = e / L, r = e % L;
+            const long long rr = col0 + c;
+            if (rr < a.total) load_pair<T>(a, rr * a.ostride_in + r, p0, p1);
+        } else {
+            const int r = e / W, c = e % W;
+            const long long cc = col0 + c;
+            if (cc < a.total) {
+                const long long o = cc >> a.logMS, rem = cc & MSmask;
+                load_pair<T>(a, o * a.ostride_in + ((long long)r << a.logMS) + rem, p0, p1);
+            }
+        }
+        v[2 * it] = p0;
+        v[2 * it + 1] = p1;
+    });
+    const T csign = a.inverse ? (T)-1 : (T)1;
+    static_for<PPT / 2>([&](auto ii) {
+        constexpr int it = ii;
+        const int e = (it * NT + tid) * 2;
+        cplx<T> p0 = v[2 * it], p1 = v[2 * it + 1];
+        p0.y *= csign;
+        p1.y *= csign;
+        if constexpr (ROW) {
+            const int c = e / L, r = e % L;
+            lds[lds_addr<L, W, ROW>(r, c)] = p0;
+            lds[lds_addr<L, W, ROW>(r + 1, c)] = p1;
+        } else {
+            const int r = e / W, c = e % W;
+            lds[lds_addr<L, W, ROW>(r, c)] = p0;
+            lds[lds_addr<L, W, ROW>(r, c + 1)] = p1;
+        }
+    });
+    __syncthreads();
+
+    Stages<T, L, W, NT, ROW, TR, 1, RL>::run(lds, v, a, tid, col0);
+
+    // ---- LDS -> global (scaled, conjugated back for the inverse)
+    const T sx = (T)a.scale;
+    const T sy = a.inverse ? -sx : sx;
+    static_for<PPT / 2>([&](auto ii) {
+        constexpr int it = ii;
+        const int e = (it * NT + tid) * 2;
+        cplx<T> p0, p1;
+        long long g;
+        bool valid;
+        if constexpr (ROW) {
+            const int c = e / L, r = e % L;
+            const long long rr = col0 + c;
+            valid = rr < a.total;
+            g = rr * a.ostride_out + r;
+            p0 = lds[lds_addr<L, W, ROW>(r, c)];
+            p1 = lds[lds_addr<L, W, ROW>(r + 1, c)];
+        } else if constexpr (TR) {
+            // S == 1: out[o][l][q], q contiguous
+            const int c = e / L, q = e % L;
+            const long long cc = col0 + c;
+            valid = cc < a.total;
+            const long long o = cc >> a.logMS, rem = cc & MSmask;
+            g = o * a.ostride_out + rem * L + q;
+            p0 = lds[c * (L + 1) + q];
+            p1 = lds[c * (L + 1) + q + 1];
+        } else {
+            // out[o][l][q][j'], j' contiguous (S >= 2)
+            const int q = e / W, c = e % W;
+            const long long cc = col0 + c;
+            valid = cc < a.total;
+            const long long o = cc >> a.logMS, rem = cc & MSmask;
+            const long long l = rem >> a.logS, jp = rem & ((1ll << a.logS) - 1);
+            g = o * a.ostride_out + (((l * L) + q) << a.logS) + jp;
+            p0 = lds[lds_addr<L, W, ROW>(q, c)];
+            p1 = lds[lds_addr<L, W, ROW>(q, c + 1)];
+        }
+        p0.x *= sx; p0.y *= sy; p1.x *= sx; p1.y *= sy;
+        if (valid) store_pair<T>(a, g, p0, p1);
+    });
+}
+
+}  // namespace mifft

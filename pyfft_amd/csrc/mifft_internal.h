@@ -1,0 +1,33 @@
+// Internal glue between the C-ABI runtime (mifft_runtime.cpp) and the per-precision kernel tables.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fft_tile.hpp"
+
+// Each returns 0 on success, MIFFT_E_UNSUPPORTED (-2) when no kernel is compiled for (L, tr, variant),
+// or a hipError_t.  With query_only != 0 nothing is launched.
+extern "C" {
+int mifft_dispatch_col_f32(int L, int tr, int variant, const mifft::TileArgs* a, hipStream_t s, int query_only);
+int mifft_dispatch_row_f32(int L, int variant, const mifft::TileArgs* a, hipStream_t s, int query_only);
+int mifft_dispatch_col_f64(int L, int tr, int variant, const mifft::TileArgs* a, hipStream_t s, int query_only);
+int mifft_dispatch_row_f64(int L, int variant, const mifft::TileArgs* a, hipStream_t s, int query_only);
+}
+
+namespace mifft {
+template <typename T, int L, int W, int NT, bool ROW, bool TR, typename RL>
+static inline int launch_tile(const TileArgs* a, hipStream_t s, int query_only) {
+    if (query_only) return 0;
+    const long long tiles = (a->total + W - 1) / W;
+    if (tiles <= 0) return 0;
+    if (tiles > 2147483647ll) return -1;
+    hipLaunchKernelGGL((fft_tile_kernel<T, L, W, NT, ROW, TR, RL>), dim3((unsigned)tiles), dim3(NT), 0, s, *a);
+    return (int)hipGetLastError();
+}
+}  // namespace mifft
+
+#define MIFFT_COL_CASE(T, Lv, Wv, NTv, ...)                                                             \
+    case Lv:                                                                                            \
+        return tr ? mifft::launch_tile<T, Lv, Wv, NTv, false, true, mifft::RadixList<__VA_ARGS__>>(a, s, query_only) \
+                  : mifft::launch_tile<T, Lv, Wv, NTv, false, false, mifft::RadixList<__VA_ARGS__>>(a, s, query_only);
+#define MIFFT_ROW_CASE(T, Lv, Wv, NTv, ...)                                                             \
+    case Lv:                                                                                            \
+        return mifft::launch_tile<T, Lv, Wv, NTv, true, false, mifft::RadixList<__VA_ARGS__>>(a, s, query_only);

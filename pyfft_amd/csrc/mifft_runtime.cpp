@@ -1,0 +1,257 @@
+// C-ABI runtime shim + pass launchers of libmifft.so (see include/mifft.h for the contract and for
+// the reference interfaces each entry point replaces).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/mifft.h"
+#include "mifft_internal.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int set_err(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_check(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    return set_err((int)e, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+}
+
+bool is_pow2(long long v) { return v > 0 && (v & (v - 1)) == 0; }
+int ilog2(long long v) {
+    int r = 0;
+    while (v > 1) {
+        v >>= 1;
+        ++r;
+    }
+    return r;
+}
+
+int validate(const mifft_pass* p) {
+    if (!p) return set_err(MIFFT_E_INVALID, "null pass descriptor");
+    if (p->kind != MIFFT_PASS_COL && p->kind != MIFFT_PASS_ROW) return set_err(MIFFT_E_INVALID, "bad pass kind %d", p->kind);
+    if (p->precision != MIFFT_F32 && p->precision != MIFFT_F64) return set_err(MIFFT_E_INVALID, "bad precision %d", p->precision);
+    if (p->layout != MIFFT_INTERLEAVED && p->layout != MIFFT_SPLIT) return set_err(MIFFT_E_INVALID, "bad layout %d", p->layout);
+    if (!is_pow2(p->L) || p->L < 2) return set_err(MIFFT_E_INVALID, "L=%d is not a power of two >= 2", p->L);
+    if (p->outer < 0) return set_err(MIFFT_E_INVALID, "negative outer count");
+    if (!p->tw_L) return set_err(MIFFT_E_INVALID, "tw_L table missing");
+    if (p->kind == MIFFT_PASS_COL) {
+        if (!is_pow2(p->M) || !is_pow2(p->S)) return set_err(MIFFT_E_INVALID, "M and S must be powers of two");
+        if (p->M * p->S < 2) return set_err(MIFFT_E_INVALID, "a COL pass needs M*S >= 2 (use a ROW pass)");
+        if ((long long)p->L * p->M > (1ll << 30)) return set_err(MIFFT_E_INVALID, "axis longer than 2^30");
+        if (p->M > 1) {
+            if (!p->tw_lo || !p->tw_hi) return set_err(MIFFT_E_INVALID, "inter-pass twiddle tables missing (M > 1)");
+            if (p->tw_shift < 0 || p->tw_shift > 30) return set_err(MIFFT_E_INVALID, "bad tw_shift");
+        }
+    } else {
+        if (p->M != 1 || p->S != 1) return set_err(MIFFT_E_INVALID, "a ROW pass has M == S == 1");
+    }
+    return 0;
+}
+
+int dispatch(const mifft_pass* p, const mifft::TileArgs* a, hipStream_t s, int query_only) {
+    const int tr = (p->kind == MIFFT_PASS_COL && p->S == 1) ? 1 : 0;
+    int rc;
+    if (p->kind == MIFFT_PASS_COL)
+        rc = p->precision == MIFFT_F32 ? mifft_dispatch_col_f32(p->L, tr, p->variant, a, s, query_only)
+                                       : mifft_dispatch_col_f64(p->L, tr, p->variant, a, s, query_only);
+    else
+        rc = p->precision == MIFFT_F32 ? mifft_dispatch_row_f32(p->L, p->variant, a, s, query_only)
+                                       : mifft_dispatch_row_f64(p->L, p->variant, a, s, query_only);
+    if (rc == MIFFT_E_UNSUPPORTED)
+        return set_err(rc, "no compiled kernel for kind=%d precision=%d L=%d variant=%d", p->kind, p->precision, p->L, p->variant);
+    if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
+    if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mifft_abi_version(void) { return MIFFT_ABI_VERSION; }
+const char* mifft_last_error(void) { return g_err; }
+
+int mifft_device_count(int* count) {
+    if (!count) return set_err(MIFFT_E_INVALID, "null argument");
+    hipError_t e = hipGetDeviceCount(count);
+    if (e == hipErrorNoDevice) {
+        *count = 0;
+        (void)hipGetLastError();
+        return 0;
+    }
+    return hip_check(e, "hipGetDeviceCount");
+}
+int mifft_set_device(int device) { return hip_check(hipSetDevice(device), "hipSetDevice"); }
+int mifft_get_device(int* device) { return hip_check(hipGetDevice(device), "hipGetDevice"); }
+
+int mifft_device_props_get(int device, mifft_device_props* props) {
+    if (!props) return set_err(MIFFT_E_INVALID, "null argument");
+    hipDeviceProp_t p;
+    int rc = hip_check(hipGetDeviceProperties(&p, device), "hipGetDeviceProperties");
+    if (rc) return rc;
+    memset(props, 0, sizeof(*props));
+    snprintf(props->name, sizeof(props->name), "%s", p.name);
+    snprintf(props->gcn_arch, sizeof(props->gcn_arch), "%s", p.gcnArchName);
+    props->compute_units = p.multiProcessorCount;
+    props->wavefront_size = p.warpSize;
+    props->max_threads_per_block = p.maxThreadsPerBlock;
+    props->max_grid_x = p.maxGridSize[0];
+    props->lds_bytes_per_block = (int64_t)p.sharedMemPerBlock;
+    props->total_mem_bytes = (int64_t)p.totalGlobalMem;
+    props->clock_khz = p.clockRate;
+    props->l2_bytes = p.l2CacheSize;
+    return 0;
+}
+
+int mifft_malloc(void** ptr, size_t nbytes) {
+    if (!ptr) return set_err(MIFFT_E_INVALID, "null argument");
+    return hip_check(hipMalloc(ptr, nbytes ? nbytes : 1), "hipMalloc");
+}
+int mifft_free(void* ptr) { return hip_check(hipFree(ptr), "hipFree"); }
+int mifft_memset(void* ptr, int value, size_t nbytes, mifft_stream_t stream) {
+    return hip_check(hipMemsetAsync(ptr, value, nbytes, (hipStream_t)stream), "hipMemsetAsync");
+}
+int mifft_memcpy_h2d(void* dst, const void* src, size_t nbytes, mifft_stream_t stream) {
+    int rc = hip_check(hipMemcpyAsync(dst, src, nbytes, hipMemcpyHostToDevice, (hipStream_t)stream), "hipMemcpyAsync(h2d)");
+    if (rc) return rc;
+    return hip_check(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
+}
+int mifft_memcpy_d2h(void* dst, const void* src, size_t nbytes, mifft_stream_t stream) {
+    int rc = hip_check(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, (hipStream_t)stream), "hipMemcpyAsync(d2h)");
+    if (rc) return rc;
+    return hip_check(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
+}
+int mifft_memcpy_d2d(void* dst, const void* src, size_t nbytes, mifft_stream_t stream) {
+    return hip_check(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream), "hipMemcpyAsync(d2d)");
+}
+int mifft_stream_create(mifft_stream_t* stream) {
+    if (!stream) return set_err(MIFFT_E_INVALID, "null argument");
+    hipStream_t s;
+    int rc = hip_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+    if (rc) return rc;
+    *stream = (mifft_stream_t)s;
+    return 0;
+}
+int mifft_stream_destroy(mifft_stream_t stream) { return hip_check(hipStreamDestroy((hipStream_t)stream), "hipStreamDestroy"); }
+int mifft_stream_sync(mifft_stream_t stream) { return hip_check(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize"); }
+int mifft_device_sync(void) { return hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize"); }
+int mifft_event_create(mifft_event_t* event) {
+    if (!event) return set_err(MIFFT_E_INVALID, "null argument");
+    hipEvent_t e;
+    int rc = hip_check(hipEventCreate(&e), "hipEventCreate");
+    if (rc) return rc;
+    *event = (mifft_event_t)e;
+    return 0;
+}
+int mifft_event_destroy(mifft_event_t event) { return hip_check(hipEventDestroy((hipEvent_t)event), "hipEventDestroy"); }
+int mifft_event_record(mifft_event_t event, mifft_stream_t stream) {
+    return hip_check(hipEventRecord((hipEvent_t)event, (hipStream_t)stream), "hipEventRecord");
+}
+int mifft_event_sync(mifft_event_t event) { return hip_check(hipEventSynchronize((hipEvent_t)event), "hipEventSynchronize"); }
+int mifft_event_elapsed_ms(float* ms, mifft_event_t start, mifft_event_t stop) {
+    return hip_check(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop), "hipEventElapsedTime");
+}
+
+int mifft_pass_supported(int32_t kind, int32_t precision, int32_t L, int32_t variant) {
+    mifft_pass p;
+    memset(&p, 0, sizeof(p));
+    p.kind = kind;
+    p.precision = precision;
+    p.L = L;
+    p.variant = variant;
+    p.M = 1;
+    p.S = (kind == MIFFT_PASS_COL) ? 2 : 1;
+    int rc0 = dispatch(&p, nullptr, nullptr, 1);
+    if (rc0 || kind != MIFFT_PASS_COL) return rc0;
+    p.S = 1;  // transposing form
+    p.M = 2;
+    return dispatch(&p, nullptr, nullptr, 1);
+}
+
+int mifft_launch_pass(const mifft_pass* p, const void* in0, const void* in1, void* out0, void* out1, mifft_stream_t stream) {
+    int rc = validate(p);
+    if (rc) return rc;
+    if (!in0 || !out0) return set_err(MIFFT_E_INVALID, "null data buffer");
+    const bool split = p->layout == MIFFT_SPLIT;
+    if (split && (!in1 || !out1)) return set_err(MIFFT_E_INVALID, "split layout needs imaginary planes");
+    if (!split && (in1 || out1)) return set_err(MIFFT_E_INVALID, "interleaved layout takes no imaginary planes");
+    const uintptr_t align_mask = 15;
+    if (((uintptr_t)in0 | (uintptr_t)out0 | (uintptr_t)in1 | (uintptr_t)out1) & align_mask)
+        return set_err(MIFFT_E_INVALID, "data buffers must be 16-byte aligned");
+    if ((p->outer_stride_in | p->outer_stride_out) & 1) return set_err(MIFFT_E_INVALID, "outer strides must be even");
+    if (p->kind == MIFFT_PASS_COL && p->M > 1 && (in0 == out0 || (split && in1 == out1)))
+        return set_err(MIFFT_E_INVALID, "a COL pass with M > 1 cannot run in place");
+    if (p->outer == 0) return 0;
+
+    mifft::TileArgs a;
+    a.in0 = in0;
+    a.in1 = in1;
+    a.out0 = out0;
+    a.out1 = out1;
+    a.tw_L = p->tw_L;
+    a.tw_lo = p->tw_lo;
+    a.tw_hi = p->tw_hi;
+    a.ostride_in = p->outer_stride_in;
+    a.ostride_out = p->outer_stride_out;
+    if (p->kind == MIFFT_PASS_COL) {
+        a.total = p->outer * p->M * p->S;
+        a.logMS = ilog2(p->M * p->S);
+        a.logS = ilog2(p->S);
+    } else {
+        a.total = p->outer;
+        a.logMS = 0;
+        a.logS = 0;
+    }
+    a.tw_shift = p->tw_shift;
+    a.split = split ? 1 : 0;
+    a.inverse = p->inverse ? 1 : 0;
+    a.has_tw = (p->kind == MIFFT_PASS_COL && p->M > 1) ? 1 : 0;
+    a.scale = p->scale;
+    return dispatch(p, &a, (hipStream_t)stream, 0);
+}
+
+int mifft_launch_chain(const mifft_pass* passes, int32_t npasses, void* const bufs0[3], void* const bufs1[3], mifft_stream_t stream) {
+    if (npasses < 0 || (npasses > 0 && !passes) || !bufs0) return set_err(MIFFT_E_INVALID, "bad chain arguments");
+    for (int i = 0; i < npasses; ++i) {
+        const mifft_pass* p = &passes[i];
+        if (p->src < 0 || p->src > 2 || p->dst < 0 || p->dst > 2) return set_err(MIFFT_E_INVALID, "pass %d: bad buffer index", i);
+        const void* i1 = bufs1 ? bufs1[p->src] : nullptr;
+        void* o1 = bufs1 ? bufs1[p->dst] : nullptr;
+        int rc = mifft_launch_pass(p, bufs0[p->src], i1, bufs0[p->dst], o1, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int mifft_time_chain(const mifft_pass* passes, int32_t npasses, void* const bufs0[3], void* const bufs1[3], mifft_stream_t stream,
+                     int32_t repeats, float* ms_total) {
+    if (!ms_total || repeats < 1) return set_err(MIFFT_E_INVALID, "bad timing arguments");
+    hipEvent_t e0, e1;
+    int rc = hip_check(hipEventCreate(&e0), "hipEventCreate");
+    if (rc) return rc;
+    rc = hip_check(hipEventCreate(&e1), "hipEventCreate");
+    if (rc) {
+        hipEventDestroy(e0);
+        return rc;
+    }
+    rc = hip_check(hipEventRecord(e0, (hipStream_t)stream), "hipEventRecord");
+    for (int r = 0; r < repeats && !rc; ++r) rc = mifft_launch_chain(passes, npasses, bufs0, bufs1, stream);
+    if (!rc) rc = hip_check(hipEventRecord(e1, (hipStream_t)stream), "hipEventRecord");
+    if (!rc) rc = hip_check(hipEventSynchronize(e1), "hipEventSynchronize");
+    if (!rc) rc = hip_check(hipEventElapsedTime(ms_total, e0, e1), "hipEventElapsedTime");
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return rc;
+}
+
+}  // extern "C"

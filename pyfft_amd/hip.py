@@ -1,0 +1,280 @@
+"""HIP backend of the pyfft API for MI355X: `Plan()` factory and execution context.
+
+Counterpart of the reference's pyfft/cuda.py.  Usage is the reference's with the module name
+changed:
+
+    from pyfft_amd.hip import Plan          # was: from pyfft.cuda import Plan
+    plan = Plan((1024, 1024), dtype=numpy.complex64, stream=my_stream)
+    plan.execute(gpu_buf)                   # in place
+    plan.execute(gpu_in, gpu_out, inverse=True, batch=8)
+
+Buffers may be anything that exposes a device address: a `DeviceArray` from this module, a
+torch-ROCm tensor (`data_ptr()`), an object with `gpudata` / `ptr` / `__cuda_array_interface__`,
+a ctypes pointer or a plain int ("GPUArray or anything that can be cast to a pointer",
+doc/source/index.rst:243-246, cuda.py:36-39).
+"""
+
+import ctypes
+
+import numpy
+
+from . import _native as N
+from .plan import FFTPlan
+
+
+def device_pointer(obj):
+    """Device address of a buffer-like object (counterpart of the GPUArray -> gpudata unwrapping
+    in Function.__call__, cuda.py:36-39)."""
+    if obj is None:
+        return None
+    if isinstance(obj, (int, numpy.integer)) and not isinstance(obj, bool):
+        return int(obj)
+    if isinstance(obj, DeviceArray) or isinstance(obj, DeviceAllocation):
+        return obj.ptr
+    if hasattr(obj, "data_ptr"):            # torch tensor
+        return int(obj.data_ptr())
+    if hasattr(obj, "gpudata"):             # PyCUDA-style
+        return int(obj.gpudata)
+    if hasattr(obj, "__cuda_array_interface__"):
+        return int(obj.__cuda_array_interface__["data"][0])
+    if hasattr(obj, "__hip_array_interface__"):
+        return int(obj.__hip_array_interface__["data"][0])
+    if isinstance(obj, ctypes.c_void_p):
+        return obj.value
+    if hasattr(obj, "ptr"):
+        return int(obj.ptr)
+    try:
+        return int(obj)
+    except (TypeError, ValueError):
+        raise TypeError("cannot obtain a device pointer from %r" % (type(obj),))
+
+
+class DeviceAllocation(object):
+    """Owning handle of a hipMalloc block (counterpart of pycuda.driver.DeviceAllocation)."""
+
+    def __init__(self, nbytes):
+        p = ctypes.c_void_p()
+        N.check(N.lib.mifft_malloc(ctypes.byref(p), int(nbytes)), "mifft_malloc(%d)" % nbytes)
+        self.ptr = p.value
+        self.nbytes = int(nbytes)
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            N.lib.mifft_free(self.ptr)
+            self.ptr = None
+
+    def __int__(self):
+        return self.ptr
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceArray(object):
+    """Minimal device array (counterpart of pycuda.gpuarray.GPUArray as the tests use it:
+    allocate, to_gpu, get)."""
+
+    def __init__(self, shape, dtype, allocation=None):
+        self.shape = tuple(shape) if isinstance(shape, (tuple, list)) else (int(shape),)
+        self.dtype = numpy.dtype(dtype)
+        self.size = int(numpy.prod(self.shape)) if len(self.shape) else 1
+        self.nbytes = self.size * self.dtype.itemsize
+        self._alloc = allocation if allocation is not None else DeviceAllocation(self.nbytes)
+        self.ptr = self._alloc.ptr
+
+    @property
+    def gpudata(self):
+        return self.ptr
+
+    def set(self, host, stream=None):
+        host = numpy.ascontiguousarray(host, dtype=self.dtype)
+        assert host.nbytes == self.nbytes
+        N.check(N.lib.mifft_memcpy_h2d(self.ptr, host.ctypes.data, self.nbytes, _stream_handle(stream)),
+                "mifft_memcpy_h2d")
+        return self
+
+    def get(self, stream=None):
+        host = numpy.empty(self.shape, self.dtype)
+        N.check(N.lib.mifft_memcpy_d2h(host.ctypes.data, self.ptr, self.nbytes, _stream_handle(stream)),
+                "mifft_memcpy_d2h")
+        return host
+
+    def __int__(self):
+        return self.ptr
+
+
+def to_gpu(host):
+    host = numpy.ascontiguousarray(host)
+    return DeviceArray(host.shape, host.dtype).set(host)
+
+
+class Stream(object):
+    """Owning wrapper of a hipStream_t (counterpart of pycuda.driver.Stream)."""
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        N.check(N.lib.mifft_stream_create(ctypes.byref(h)), "mifft_stream_create")
+        self.handle = h.value
+
+    def synchronize(self):
+        N.check(N.lib.mifft_stream_sync(self.handle), "mifft_stream_sync")
+
+    finish = synchronize  # PyOpenCL spelling (cl.py queue.finish())
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                N.lib.mifft_stream_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def _stream_handle(stream):
+    """hipStream_t value of a stream-like object: Stream, torch.cuda.Stream (cuda_stream), int, None."""
+    if stream is None:
+        return None
+    if isinstance(stream, Stream):
+        return stream.handle
+    if hasattr(stream, "cuda_stream"):
+        return int(stream.cuda_stream)
+    if hasattr(stream, "handle"):
+        h = stream.handle
+        return h.value if isinstance(h, ctypes.c_void_p) else int(h)
+    if isinstance(stream, ctypes.c_void_p):
+        return stream.value
+    return int(stream)
+
+
+class Event(object):
+    def __init__(self):
+        h = ctypes.c_void_p()
+        N.check(N.lib.mifft_event_create(ctypes.byref(h)), "mifft_event_create")
+        self.handle = h.value
+
+    def record(self, stream=None):
+        N.check(N.lib.mifft_event_record(self.handle, _stream_handle(stream)), "mifft_event_record")
+        return self
+
+    def synchronize(self):
+        N.check(N.lib.mifft_event_sync(self.handle), "mifft_event_sync")
+
+    def time_since(self, start):
+        ms = ctypes.c_float()
+        N.check(N.lib.mifft_event_elapsed_ms(ctypes.byref(ms), start.handle, self.handle), "mifft_event_elapsed_ms")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                N.lib.mifft_event_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def device_count():
+    n = ctypes.c_int()
+    N.check(N.lib.mifft_device_count(ctypes.byref(n)), "mifft_device_count")
+    return n.value
+
+
+def device_props(device=None):
+    if device is None:
+        d = ctypes.c_int()
+        N.check(N.lib.mifft_get_device(ctypes.byref(d)), "mifft_get_device")
+        device = d.value
+    props = N.MifftDeviceProps()
+    N.check(N.lib.mifft_device_props_get(int(device), ctypes.byref(props)), "mifft_device_props_get")
+    return props
+
+
+class Context(object):
+    """Plan execution context (cuda.py:64-113): stream lifecycle, allocator, device limits."""
+
+    def __init__(self, device, stream, mempool):
+        self._device = device
+        self._stream = stream
+        self._recreate_stream = stream is None
+        props = device_props(device)
+        self.device_name = props.name.decode()
+        self.gcn_arch = props.gcn_arch.decode()
+        self.compute_units = props.compute_units
+        self.max_block_size = props.max_threads_per_block
+        self.max_shared_mem = props.lds_bytes_per_block
+        self.max_grid_x = props.max_grid_x
+        self.wavefront_size = props.wavefront_size
+        self._mempool = mempool
+        if mempool is None:
+            self.allocate = self.allocate_raw
+        else:
+            self.allocate = mempool.allocate
+
+    def allocate_raw(self, nbytes):
+        return DeviceAllocation(nbytes)
+
+    def upload(self, mem, host):
+        N.check(N.lib.mifft_memcpy_h2d(device_pointer(mem), host.ctypes.data, host.nbytes, None), "mifft_memcpy_h2d")
+
+    pointer_of = staticmethod(device_pointer)
+
+    def createQueue(self):
+        if self._recreate_stream and self._stream is None:
+            self._stream = Stream()
+
+    def stream_handle(self):
+        return _stream_handle(self._stream)
+
+    def wait(self):
+        N.check(N.lib.mifft_stream_sync(self.stream_handle()), "mifft_stream_sync")
+
+    def flush(self):
+        pass
+
+    def getQueue(self):
+        return self._stream
+
+    def isCuda(self):
+        return False
+
+
+def Plan(*args, **kwds):
+    """Create an FFT plan (cuda.py:116-138).
+
+    Plan(shape, dtype=numpy.complex64, mempool=None, context=None, stream=None, normalize=True,
+         wait_for_finish=None, fast_math=True, scale=1.0)
+
+    `stream`: a pyfft_amd.hip.Stream, a torch.cuda.Stream, or a raw hipStream_t value; when given,
+    execute() is asynchronous by default and returns the stream.  `context`: accepted for
+    signature parity (a device index or None: HIP has one primary context per device).
+    `mempool`: any object with an allocate(nbytes) method returning a buffer-like object.
+    """
+    mempool = kwds.pop('mempool', None)
+    context_obj = kwds.pop('context', None)
+    stream_obj = kwds.pop('stream', None)
+
+    if device_count() < 1:
+        raise RuntimeError("pyfft_amd: no HIP device visible (there is no CPU fallback)")
+
+    device = None
+    if stream_obj is not None:
+        wait_for_finish = False
+    elif context_obj is not None:
+        if isinstance(context_obj, (int, numpy.integer)):
+            device = int(context_obj)
+        elif hasattr(context_obj, "device"):
+            device = context_obj.device
+        wait_for_finish = True
+        stream_obj = None
+    else:
+        stream_obj = Stream()
+        wait_for_finish = True
+
+    if 'wait_for_finish' not in kwds or kwds['wait_for_finish'] is None:
+        kwds['wait_for_finish'] = wait_for_finish
+
+    context = Context(device, stream_obj, mempool)
+    return FFTPlan(context, *args, **kwds)

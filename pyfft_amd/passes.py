@@ -1,0 +1,167 @@
+"""Axis -> pass decomposition for gfx950 (host side; counterpart of pyfft/kernel.py and
+pyfft/kernel_helpers.py in the reference).
+
+The reference factors a long or strided axis in base 128 (kernel_helpers.py:67-122) and an
+LDS-resident axis by a fixed table up to n = 2048 (kernel_helpers.py:10-65) because of 16 KiB
+of shared memory and 512-thread blocks.  MI355X has 160 KiB of LDS per CU and 1024-thread
+work-groups, so the factorisation here is different: a contiguous axis up to 4096 points is one
+ROW launch, a strided axis up to 1024 points is one COL launch, and longer axes are split into
+the fewest near-equal COL passes (every pass is a full HBM round trip, so fewer is better).
+The pass algebra itself is the reference's (kernel.mako:805-1047):
+
+    view in as [outer][R][M][S], out as [outer][M][R][S]
+    out[l][q][j] = w(R*M)^(l*q) * sum_r in[r][l][j] * w(R)^(r*q)
+"""
+
+from . import _native as N
+
+X_DIRECTION, Y_DIRECTION, Z_DIRECTION = 0, 1, 2
+
+
+def log2(n):
+    """Integer log2 (kernel_helpers.py:2-8)."""
+    n = int(n)
+    r = 0
+    while n > 1:
+        n >>= 1
+        r += 1
+    return r
+
+
+def is_pow2(n):
+    return n >= 1 and (n & (n - 1)) == 0
+
+
+_support_cache = {}
+
+
+def _max_len(kind, precision):
+    """Largest L the library has a compiled kernel for (Function.isExecutable counterpart,
+    cuda.py:48-49)."""
+    key = (kind, precision)
+    if key not in _support_cache:
+        best = 0
+        L = 2
+        while L <= (1 << 16):
+            if N.lib.mifft_pass_supported(kind, precision, L, 0) == 0:
+                best = L
+            L *= 2
+        _support_cache[key] = best
+    return _support_cache[key]
+
+
+def row_max(precision):
+    return _max_len(N.PASS_ROW, precision)
+
+
+def col_max(precision):
+    return _max_len(N.PASS_COL, precision)
+
+
+def split_radices(n, max_radix):
+    """Fewest near-equal power-of-two factors of n, each <= max_radix, largest first."""
+    bits = log2(n)
+    maxbits = log2(max_radix)
+    npass = max(1, -(-bits // maxbits))
+    base, extra = divmod(bits, npass)
+    return [1 << (base + (1 if i < extra else 0)) for i in range(npass)]
+
+
+class PassSpec(object):
+    """Shape of one launch, independent of batch/direction (those are filled in by the plan).
+    Counterpart of a compiled LocalFFTKernel / GlobalFFTKernel object (kernel.py:124-283)."""
+
+    __slots__ = ("kind", "axis", "n", "L", "M", "S", "outer_per_batch", "outer_stride",
+                 "in_place_possible", "curr_n")
+
+    def __init__(self, kind, axis, n, L, M, S, outer_per_batch, outer_stride, in_place_possible):
+        self.kind = kind
+        self.axis = axis
+        self.n = n
+        self.L = L
+        self.M = M
+        self.S = S
+        self.outer_per_batch = outer_per_batch
+        self.outer_stride = outer_stride
+        self.in_place_possible = in_place_possible
+        self.curr_n = L * M
+
+    def __repr__(self):
+        name = "row" if self.kind == N.PASS_ROW else "col"
+        return "%s(L=%d,M=%d,S=%d)%s" % (name, self.L, self.M, self.S, "*" if self.in_place_possible else "")
+
+
+def col_chain(axis, n, radix_init, outer_per_batch, precision):
+    """Chain of COL passes for an axis of length n whose faster axes multiply to radix_init
+    (GlobalFFTKernel.createChain, kernel.py:259-283; strides kernel.py:196-204).  Only the last
+    pass (M == 1) can run in place (cf. kernel.py:238-241)."""
+    radices = split_radices(n, col_max(precision))
+    chain = []
+    S = radix_init
+    curr_n = n
+    for R in radices:
+        M = curr_n // R
+        chain.append(PassSpec(N.PASS_COL, axis, n, R, M, S, outer_per_batch, n * radix_init, M == 1))
+        S *= R
+        curr_n //= R
+    return chain
+
+
+def build_chain(x, y, z, precision):
+    """Kernel chain for a (z, y, x) array with x contiguous (FFTPlan._generateKernelCode and
+    _fft1D, plan.py:111-171): X passes, then the Y chain, then the Z chain.  Axes of length 1 are
+    skipped (plan.py:149,160,164)."""
+    chain = []
+    if x > 1:
+        if x <= row_max(precision):
+            chain.append(PassSpec(N.PASS_ROW, X_DIRECTION, x, x, 1, 1, y * z, x, True))
+        else:
+            chain.extend(col_chain(X_DIRECTION, x, 1, y * z, precision))
+    if y > 1:
+        if x == 1:
+            # degenerate: the y axis is the contiguous one
+            sub = build_chain(y, 1, 1, precision)
+            for p in sub:
+                p.axis = Y_DIRECTION
+                p.outer_per_batch *= z
+            chain.extend(sub)
+        else:
+            chain.extend(col_chain(Y_DIRECTION, y, x, z, precision))
+    if z > 1:
+        if x * y == 1:
+            sub = build_chain(z, 1, 1, precision)
+            for p in sub:
+                p.axis = Z_DIRECTION
+            chain.extend(sub)
+        else:
+            chain.extend(col_chain(Z_DIRECTION, z, x * y, 1, precision))
+    return chain
+
+
+def buffer_schedule(chain, is_inplace):
+    """Buffer ping-pong of FFTPlan._execute (plan.py:194-248): returns (temp_needed,
+    [(src, dst), ...]) with 0 = data_in, 1 = data_out, 2 = temp.  Contract: an out-of-place
+    call never writes data_in; an in-place call leaves the result in data_in (for which
+    data_out aliases data_in, so index 1 is the user's buffer in both cases)."""
+    temp_needed = any(not p.in_place_possible for p in chain)
+    odd = (len(chain) % 2 == 1)
+    sched = []
+    curr_read, curr_write = 0, 1
+    if temp_needed:
+        inplace_done = False
+        if is_inplace:
+            curr_read, curr_write = 1, 2
+        else:
+            curr_write = 1 if odd else 2
+        for p in chain:
+            if is_inplace and odd and not inplace_done and p.in_place_possible:
+                curr_write = curr_read
+                inplace_done = True
+            sched.append((curr_read, curr_write))
+            curr_read = 1 if curr_write == 1 else 2
+            curr_write = 2 if curr_write == 1 else 1
+    else:
+        for p in chain:
+            sched.append((curr_read, curr_write))
+            curr_read, curr_write = 1, 1
+    return temp_needed, sched

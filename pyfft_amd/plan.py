@@ -1,0 +1,301 @@
+"""FFTPlan: plan construction and execution (host side of the hot path).
+
+Drop-in for the reference's pyfft/plan.py: same constructor arguments, same `execute`
+signatures bound by data layout, same normalize/scale rule, same buffer contract and sync
+policy.  Differences that are not observable through the API: kernels are precompiled HIP
+(no run-time code generation), the axis factorisation is the gfx950 one (passes.py), and the
+whole pass list is enqueued by one native call (mifft_launch_chain) instead of a Python loop.
+"""
+
+import ctypes
+
+import numpy
+
+from . import _native as N
+from . import passes as P
+
+_FFT_1D, _FFT_2D, _FFT_3D = 1, 2, 3
+
+
+class _FFTParams(object):
+    """Plan parameters derived from shape and dtype (plan.py:10-63)."""
+
+    def __init__(self, shape, dtype, context, fast_math):
+        self.x, self.y, self.z = shape
+        for v in shape:
+            if not isinstance(v, (int, numpy.integer)) or isinstance(v, bool) or v < 1:
+                raise ValueError("Wrong shape")
+        self.size = int(self.x) * int(self.y) * int(self.z)
+        self.context = context
+        self.fast_math = fast_math
+
+        # the reference only checks the product (plan.py:23-24); every axis is checked here
+        if not all(P.is_pow2(int(v)) for v in shape):
+            raise ValueError("Array dimensions must be powers of two")
+        if self.size < 2:
+            raise ValueError("Array must have at least two elements")
+
+        try:
+            dt = numpy.dtype(dtype)
+        except TypeError:
+            raise ValueError("Data type " + str(dtype) + " is not supported")
+        if dt == numpy.complex64 or dt == numpy.float32:      # plan.py:26-32
+            self.split = (dt == numpy.float32)
+            self.precision = N.F32
+            self.scalar_dtype = numpy.dtype(numpy.float32)
+            self.complex_dtype = numpy.dtype(numpy.complex64)
+        elif dt == numpy.complex128 or dt == numpy.float64:  # plan.py:33-46
+            self.split = (dt == numpy.float64)
+            self.precision = N.F64
+            self.scalar_dtype = numpy.dtype(numpy.float64)
+            self.complex_dtype = numpy.dtype(numpy.complex128)
+        else:
+            raise ValueError("Data type " + str(dtype) + " is not supported")
+        self.scalar_nbytes = self.scalar_dtype.itemsize
+        self.complex_nbytes = self.complex_dtype.itemsize
+        self.layout = N.SPLIT if self.split else N.INTERLEAVED
+
+
+def _twiddle_table(n, count, step, complex_dtype):
+    """w(n)^(k*step), k < count, evaluated in float64 then rounded to the working precision.
+    (The reference evaluates sincos on the device in working precision, kernel.mako:36-44.)"""
+    k = (numpy.arange(count, dtype=numpy.int64) * step) % n
+    # reduce to the first octant-free form: exact integer phase, float64 trig
+    ang = -2.0 * numpy.pi * (k.astype(numpy.float64) / float(n))
+    return (numpy.cos(ang) + 1j * numpy.sin(ang)).astype(complex_dtype)
+
+
+class FFTPlan(object):
+    """Class for FFT plan preparation and execution (plan.py:66-284)."""
+
+    def __init__(self, context, shape, dtype=numpy.complex64, normalize=True,
+                 wait_for_finish=None, fast_math=True, scale=1.0):
+        # shape normalisation: x is the fastest-varying (last numpy) axis (plan.py:73-89)
+        if isinstance(shape, (int, numpy.integer)) and not isinstance(shape, bool):
+            self._dim = _FFT_1D
+            shape = (int(shape), 1, 1)
+        elif isinstance(shape, tuple):
+            if len(shape) == 1:
+                self._dim = _FFT_1D
+                shape = (shape[0], 1, 1)
+            elif len(shape) == 2:
+                self._dim = _FFT_2D
+                shape = (shape[1], shape[0], 1)
+            elif len(shape) == 3:
+                self._dim = _FFT_3D
+                shape = tuple(reversed(shape))
+            else:
+                raise ValueError("Wrong shape")
+        else:
+            raise ValueError("Wrong shape")
+
+        self._context = context
+        self._params = _FFTParams(shape, dtype, context, fast_math)
+        self._normalize = normalize
+        self._scale = float(scale)
+        self._wait_for_finish = wait_for_finish
+
+        self._tempmemobj = None
+        self._tempmemobj_re = None
+        self._tempmemobj_im = None
+        self._last_batch_size = 0
+        self._desc_cache = {}
+
+        if self._params.split:
+            self.execute = self._executeSplit
+        else:
+            self.execute = self._executeInterleaved
+
+        self._generateKernelCode()
+
+    # ------------------------------------------------------------------------------------
+    def _generateKernelCode(self):
+        """Select the pass chain and upload twiddle tables (plan.py:111-133; nothing is
+        compiled here -- the kernels are ahead-of-time HIP)."""
+        p = self._params
+        self._kernels = P.build_chain(int(p.x), int(p.y), int(p.z), p.precision)
+        self._temp_buffer_needed = any(not k.in_place_possible for k in self._kernels)
+
+        self._tables = {}      # key -> device allocation
+        self._table_ptrs = []  # per pass: (tw_L, tw_lo, tw_hi, shift)
+        for k in self._kernels:
+            twL = self._device_table(("L", k.L), lambda L=k.L: _twiddle_table(L, L, 1, p.complex_dtype))
+            if k.M > 1:
+                n = k.curr_n
+                shift = (P.log2(n) + 1) // 2
+                lo = self._device_table(("lo", n, shift),
+                                        lambda n=n, s=shift: _twiddle_table(n, 1 << s, 1, p.complex_dtype))
+                hi = self._device_table(("hi", n, shift),
+                                        lambda n=n, s=shift: _twiddle_table(n, n >> s, 1 << s, p.complex_dtype))
+                self._table_ptrs.append((twL, lo, hi, shift))
+            else:
+                self._table_ptrs.append((twL, None, None, 0))
+
+    def _device_table(self, key, make):
+        if key not in self._tables:
+            host = numpy.ascontiguousarray(make())
+            mem = self._context.allocate_raw(host.nbytes)
+            self._context.upload(mem, host)
+            self._tables[key] = mem
+        return self._context.pointer_of(self._tables[key])
+
+    # ------------------------------------------------------------------------------------
+    def _scale_factor(self, inverse):
+        """Multiplier applied by the plan's last pass: the reciprocal of the divisor of
+        _FFTKernel.getScaleCoeffFunc (kernel.py:23-37)."""
+        if not inverse:
+            return self._scale
+        coeff = (self._params.size if self._normalize else 1.0) * self._scale
+        return 1.0 / coeff
+
+    def _descriptors(self, batch, is_inplace, inverse):
+        """Pass descriptor array for (batch, schedule, direction); cached like the reference's
+        kernel.prepare(batch) (kernel.py:85-93)."""
+        key = (batch, is_inplace, inverse)
+        d = self._desc_cache.get(key)
+        if d is not None:
+            return d
+        p = self._params
+        _, sched = P.buffer_schedule(self._kernels, is_inplace)
+        arr = (N.MifftPass * max(1, len(self._kernels)))()
+        last = len(self._kernels) - 1
+        for i, (k, (src, dst), (twL, lo, hi, shift)) in enumerate(zip(self._kernels, sched, self._table_ptrs)):
+            d = arr[i]
+            d.kind = k.kind
+            d.precision = p.precision
+            d.layout = p.layout
+            d.inverse = 1 if inverse else 0
+            d.L = k.L
+            d.variant = 0
+            d.M = k.M
+            d.S = k.S
+            d.outer = k.outer_per_batch * batch
+            d.outer_stride_in = k.outer_stride
+            d.outer_stride_out = k.outer_stride
+            d.scale = self._scale_factor(inverse) if i == last else 1.0
+            d.tw_L = twL
+            d.tw_lo = lo
+            d.tw_hi = hi
+            d.tw_shift = shift
+            # in-place call: data_out aliases data_in, the schedule only uses indices 1 and 2
+            d.src = src
+            d.dst = dst
+        if len(self._desc_cache) > 64:
+            self._desc_cache.clear()
+        self._desc_cache[key] = arr
+        return arr
+
+    # ------------------------------------------------------------------------------------
+    def _execute(self, wait_for_finish, is_inplace, inverse, batch, *args):
+        """Execute plan for given data type (plan.py:173-259)."""
+        ctx = self._context
+        p = self._params
+        split = p.split
+        batch = int(batch)
+        if batch < 1:
+            raise ValueError("batch must be positive")
+
+        new_batch = self._last_batch_size != batch
+        if new_batch:
+            self._last_batch_size = batch
+        if self._temp_buffer_needed and new_batch:       # plan.py:184-192
+            buffer_size = p.size * batch * p.scalar_nbytes
+            if split:
+                self._tempmemobj_re = ctx.allocate(buffer_size)
+                self._tempmemobj_im = ctx.allocate(buffer_size)
+            else:
+                self._tempmemobj = ctx.allocate(buffer_size * 2)
+
+        ptr = ctx.pointer_of
+        if split:
+            in_re, in_im, out_re, out_im = (ptr(a) for a in args)
+            # explicit aliasing is an in-place call (Appendix A item 5 of SURVEY.md)
+            if not is_inplace and (in_re == out_re or in_im == out_im):
+                if in_re == out_re and in_im == out_im:
+                    is_inplace = True
+                else:
+                    raise ValueError("partially aliased split buffers")
+            bufs0 = N.make_buf3(in_re, out_re, ptr(self._tempmemobj_re) if self._tempmemobj_re is not None else None)
+            bufs1 = N.make_buf3(in_im, out_im, ptr(self._tempmemobj_im) if self._tempmemobj_im is not None else None)
+        else:
+            d_in, d_out = (ptr(a) for a in args)
+            if not is_inplace and d_in == d_out:
+                is_inplace = True
+            bufs0 = N.make_buf3(d_in, d_out, ptr(self._tempmemobj) if self._tempmemobj is not None else None)
+            bufs1 = None
+
+        descs = self._descriptors(batch, is_inplace, bool(inverse))
+
+        ctx.createQueue()
+        stream = ctx.stream_handle()
+        N.check(N.lib.mifft_launch_chain(descs, len(self._kernels), bufs0, bufs1, stream), "mifft_launch_chain")
+
+        # global wait setting has lower priority than the local one (plan.py:250-253)
+        wait = self._wait_for_finish
+        if wait_for_finish is not None:
+            wait = wait_for_finish
+
+        if wait:
+            ctx.wait()
+        else:
+            ctx.flush()
+            return ctx.getQueue()
+
+    def _executeInterleaved(self, data_in, data_out=None, inverse=False, batch=1, wait_for_finish=None):
+        """Execute plan for interleaved complex array (plan.py:261-271)."""
+        if data_out is None:
+            data_out = data_in
+            is_inplace = True
+        else:
+            is_inplace = False
+        return self._execute(wait_for_finish, is_inplace, inverse, batch, data_in, data_out)
+
+    def _executeSplit(self, data_in_re, data_in_im, data_out_re=None, data_out_im=None,
+                      inverse=False, batch=1, wait_for_finish=None):
+        """Execute plan for split complex array (plan.py:273-284)."""
+        if data_out_re is None and data_out_im is None:
+            data_out_re = data_in_re
+            data_out_im = data_in_im
+            is_inplace = True
+        else:
+            if data_out_re is None or data_out_im is None:
+                raise ValueError("both output planes must be given")
+            is_inplace = False
+        return self._execute(wait_for_finish, is_inplace, inverse, batch,
+                             data_in_re, data_in_im, data_out_re, data_out_im)
+
+    # ------------------------------------------------------------------------------------
+    # introspection helpers used by bench.py / tests (not part of the reference API)
+    def pass_list(self):
+        return list(self._kernels)
+
+    def timed_execute(self, repeats, is_inplace, inverse, batch, bufs_in, bufs_out):
+        """Device time (ms) of `repeats` back-to-back executions, measured with HIP events on the
+        plan's stream by mifft_time_chain (hipEvents see the stream the kernels are launched on)."""
+        ctx = self._context
+        p = self._params
+        ptr = ctx.pointer_of
+        batch = int(batch)
+        if self._temp_buffer_needed and self._last_batch_size != batch:
+            self._last_batch_size = batch
+            buffer_size = p.size * batch * p.scalar_nbytes
+            if p.split:
+                self._tempmemobj_re = ctx.allocate(buffer_size)
+                self._tempmemobj_im = ctx.allocate(buffer_size)
+            else:
+                self._tempmemobj = ctx.allocate(buffer_size * 2)
+        if p.split:
+            bufs0 = N.make_buf3(ptr(bufs_in[0]), ptr(bufs_out[0]),
+                                ptr(self._tempmemobj_re) if self._tempmemobj_re is not None else None)
+            bufs1 = N.make_buf3(ptr(bufs_in[1]), ptr(bufs_out[1]),
+                                ptr(self._tempmemobj_im) if self._tempmemobj_im is not None else None)
+        else:
+            bufs0 = N.make_buf3(ptr(bufs_in[0]), ptr(bufs_out[0]),
+                                ptr(self._tempmemobj) if self._tempmemobj is not None else None)
+            bufs1 = None
+        descs = self._descriptors(batch, is_inplace, bool(inverse))
+        ctx.createQueue()
+        ms = ctypes.c_float(0.0)
+        N.check(N.lib.mifft_time_chain(descs, len(self._kernels), bufs0, bufs1, ctx.stream_handle(),
+                                       int(repeats), ctypes.byref(ms)), "mifft_time_chain")
+        return float(ms.value)

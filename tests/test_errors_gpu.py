@@ -1,0 +1,141 @@
+"""GPU parity tests: the reference's accuracy protocol (test/test_errors.py:18-114) run against
+the HIP path through the C ABI, with numpy.fft on the complex128-upcast input as the reference
+answer and the CPU oracle's restatement of the reference chain as a second checker.
+
+Tolerances are the reference's own: L1-relative `difference` < 1.1e-6 (fp32) / 1e-11 (fp64)
+(test_errors.py:20-23), plus the north star's max-norm bound max|out-ref| <= 1e-5 * max|ref|.
+"""
+import numpy
+import pytest
+
+import pyfft_oracle as oracle
+from helpers import COMPLEX_DTYPES, DOUBLE_DTYPES, getDimensions
+
+pytestmark = pytest.mark.gpu
+
+
+def run_protocol(ctx, shape, dtype, batch, seed=1234, fast_math=True, check_oracle=True):
+    epsilon = 1e-11 if dtype in DOUBLE_DTYPES else 1.1e-6
+    split = dtype not in COMPLEX_DTYPES
+    complex_dtype = numpy.complex128 if dtype in DOUBLE_DTYPES else numpy.complex64
+
+    if split:
+        data_re, data_im = oracle.get_test_data(shape, dtype, batch, seed)
+        data = (data_re + 1j * data_im).astype(complex_dtype)
+    else:
+        data = oracle.get_test_data(shape, dtype, batch, seed)
+
+    numpy_fw = oracle.numpy_fft(numpy.fft.fftn, data, batch)
+    numpy_res = oracle.numpy_fft(numpy.fft.ifftn, numpy_fw, batch)
+    numpy_err = oracle.difference(numpy_res, data, batch)
+
+    if split:
+        a_re, a_im = ctx.toGpu(data_re), ctx.toGpu(data_im)
+        b_re, b_im = ctx.allocate(data_re.shape, data_re.dtype), ctx.allocate(data_im.shape, data_im.dtype)
+    else:
+        a_gpu = ctx.toGpu(data)
+        b_gpu = ctx.allocate(data.shape, data.dtype)
+
+    plan = ctx.getPlan(shape, dtype=dtype, context=ctx.context, normalize=True,
+                       wait_for_finish=True, fast_math=fast_math)
+
+    def fetch(re, im=None):
+        if split:
+            return ctx.fromGpu(re, data_re.shape, data_re.dtype) + 1j * ctx.fromGpu(im, data_im.shape, data_im.dtype)
+        return ctx.fromGpu(re, data.shape, data.dtype)
+
+    # out of place forward; the input must not be modified (plan.py:200-248 contract)
+    if split:
+        plan.execute(a_re, a_im, b_re, b_im, batch=batch)
+        fw_outplace = fetch(b_re, b_im)
+        assert numpy.array_equal(fetch(a_re, a_im), data), "out-of-place execute modified its input"
+        plan.execute(b_re, b_im, a_re, a_im, batch=batch, inverse=True)
+        res_outplace = fetch(a_re, a_im)
+    else:
+        plan.execute(a_gpu, b_gpu, batch=batch)
+        fw_outplace = fetch(b_gpu)
+        assert numpy.array_equal(fetch(a_gpu), data), "out-of-place execute modified its input"
+        plan.execute(b_gpu, a_gpu, batch=batch, inverse=True)
+        res_outplace = fetch(a_gpu)
+    err_outplace = oracle.difference(res_outplace, data, batch)
+
+    # in place forward / inverse
+    if split:
+        a_re, a_im = ctx.toGpu(data_re), ctx.toGpu(data_im)
+        plan.execute(a_re, a_im, batch=batch)
+        fw_inplace = fetch(a_re, a_im)
+        plan.execute(a_re, a_im, batch=batch, inverse=True)
+        res_inplace = fetch(a_re, a_im)
+    else:
+        a_gpu = ctx.toGpu(data)
+        plan.execute(a_gpu, batch=batch)
+        fw_inplace = fetch(a_gpu)
+        plan.execute(a_gpu, batch=batch, inverse=True)
+        res_inplace = fetch(a_gpu)
+    err_inplace = oracle.difference(res_inplace, data, batch)
+
+    err_inout_fw = oracle.difference(fw_inplace, fw_outplace, batch)
+    err_inout_res = oracle.difference(res_inplace, res_outplace, batch)
+    diff_err = oracle.difference(numpy_fw, fw_inplace, batch)
+    max_err = numpy.abs(fw_inplace - numpy_fw).max() / numpy.abs(numpy_fw).max()
+
+    assert err_inout_fw < epsilon, "inplace-outplace intermediate error: %g" % err_inout_fw
+    assert err_inout_res < epsilon, "inplace-outplace final error: %g" % err_inout_res
+    assert numpy_err < epsilon, "numpy forward-inverse error: %g" % numpy_err
+    assert err_inplace < epsilon, "forward-inverse inplace error: %g" % err_inplace
+    assert err_outplace < epsilon, "forward-inverse outplace error: %g" % err_outplace
+    assert diff_err < epsilon, "difference between HIP path and numpy: %g" % diff_err
+    assert max_err <= (1e-5 if dtype not in DOUBLE_DTYPES else 1e-10), "max-norm error %g" % max_err
+
+    if check_oracle:
+        # the CPU restatement of the reference's own kernel chain, same inputs
+        ora_fw = oracle.execute(data, shape, dtype=dtype, batch=batch)
+        assert oracle.difference(ora_fw.astype(numpy.complex128), fw_inplace, batch) < 2 * epsilon
+    return err_inplace, diff_err
+
+
+# one representative of every row of SURVEY.md Appendix B: single launch, 2-pass, 3-pass 1-D,
+# short and long strided axes, with and without temp, odd and even chain lengths
+SHAPES_1D = [(2,), (4,), (8,), (16,), (32,), (64,), (128,), (256,), (512,), (1024,), (2048,), (4096,),
+             (8192,), (1 << 14,), (1 << 16,), (1 << 17,)]
+SHAPES_2D = [(16, 16), (128, 32), (64, 256), (2, 2), (4, 1024), (1024, 4), (256, 256), (2048, 8), (8, 8192)]
+SHAPES_3D = [(16, 16, 16), (8, 8, 64), (32, 16, 8), (2, 4, 2), (128, 16, 16), (16, 128, 4), (4, 4, 2048)]
+ALL_DTYPES = [numpy.complex64, numpy.float32, numpy.complex128, numpy.float64]
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES, ids=lambda d: numpy.dtype(d).name)
+@pytest.mark.parametrize("shape", SHAPES_1D + SHAPES_2D + SHAPES_3D, ids=str)
+def test_errors_batch_1_and_3(ctx, shape, dtype):
+    x, y, z = getDimensions(shape)
+    for batch in (1, 3):
+        if x * y * z * batch > (1 << 19):
+            continue
+        run_protocol(ctx, shape, dtype, batch, seed=1000 + batch)
+
+
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.float64], ids=lambda d: numpy.dtype(d).name)
+@pytest.mark.parametrize("shape,batch", [((8,), 4096), ((16,), 1024), ((256,), 128), ((1024,), 16), ((16, 16), 128),
+                                         ((16, 16, 16), 16), ((128, 128), 16), ((8192,), 16), ((13,), 0)][:-1], ids=str)
+def test_errors_batched(ctx, shape, batch, dtype):
+    """Batch sizes of the reference sweep (test_errors.py:139) incl. ragged tails of tiles."""
+    run_protocol(ctx, shape, dtype, batch, seed=77)
+    run_protocol(ctx, shape, dtype, batch - 1 if batch > 1 else 5, seed=78, check_oracle=False)
+
+
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.float32], ids=lambda d: numpy.dtype(d).name)
+def test_errors_large_1d(ctx, dtype):
+    """N = 2^20 (BASELINE config 2 shape, small batch): the reference's largest 1-D test size
+    (test_errors.py:125-126)."""
+    run_protocol(ctx, (1 << 20,), dtype, 2, seed=1002, check_oracle=False)
+
+
+def test_errors_config3_shape(ctx):
+    """1024 x 1024 c64 (BASELINE config 3 shape) at batch 2."""
+    run_protocol(ctx, (1024, 1024), numpy.complex64, 2, seed=1003, check_oracle=False)
+
+
+@pytest.mark.parametrize("dtype", [numpy.complex128, numpy.float64], ids=lambda d: numpy.dtype(d).name)
+def test_errors_config4_shape_reduced(ctx, dtype):
+    """3-D fp64 in both layouts (BASELINE config 4 at 64^3 and 256x16x16)."""
+    run_protocol(ctx, (64, 64, 64), dtype, 1, seed=1004, check_oracle=False)
+    run_protocol(ctx, (256, 16, 16), dtype, 2, seed=1004, check_oracle=False)

@@ -1,0 +1,63 @@
+"""Quick per-shape timing sweep on one GPU (development tool, not the judged bench)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy
+from pyfft_amd.hip import Plan, DeviceArray, to_gpu, device_props
+
+def run(shape, dtype, batch, iters=5, inplace=False):
+    dt = numpy.dtype(dtype)
+    size = int(numpy.prod(shape))
+    split = dt.kind == 'f'
+    itemsize = dt.itemsize * (2 if split else 1)
+    rng = numpy.random.default_rng(1)
+    nel = size * batch
+    blk = min(nel, 1 << 22)
+    host = (rng.standard_normal(blk * 2).astype(dt if split else (numpy.float32 if dt == numpy.complex64 else numpy.float64)))
+    plan = Plan(shape, dtype=dtype)
+    if split:
+        bufs_in = [DeviceArray((nel,), dt), DeviceArray((nel,), dt)]
+        bufs_out = bufs_in if inplace else [DeviceArray((nel,), dt), DeviceArray((nel,), dt)]
+    else:
+        bufs_in = [DeviceArray((nel,), dt)]
+        bufs_out = bufs_in if inplace else [DeviceArray((nel,), dt)]
+    # fill with random data by tiling one host block
+    import ctypes
+    from pyfft_amd import _native as N
+    for b in bufs_in:
+        nb = b.nbytes
+        hb = host.view(numpy.uint8)[:min(nb, host.nbytes)]
+        N.check(N.lib.mifft_memcpy_h2d(b.ptr, hb.ctypes.data, hb.nbytes, None))
+        done = hb.nbytes
+        while done < nb:
+            n = min(done, nb - done)
+            N.check(N.lib.mifft_memcpy_d2d(b.ptr + done, b.ptr, n, None))
+            done += n
+        N.check(N.lib.mifft_device_sync())
+    plan.timed_execute(1, inplace, False, batch, bufs_in, bufs_out)  # warm-up
+    best = 1e30
+    for _ in range(3):
+        ms = plan.timed_execute(iters, inplace, False, batch, bufs_in, bufs_out) / iters
+        best = min(best, ms)
+    alg = 2.0 * nel * itemsize
+    flops = 5.0 * size * numpy.log2(size) * batch
+    print("%-18s %-10s batch %-7d %s passes=%s  %.3f ms  %.1f GB/s alg (%.1f%% of 8TB/s)  %.0f GFLOPS" % (
+        str(shape), dt.name, batch, "inpl" if inplace else "outp", plan.pass_list(), best,
+        alg / best / 1e6, alg / best / 1e6 / 80.0, flops / best / 1e6), flush=True)
+
+if __name__ == "__main__":
+    p = device_props()
+    print(p.name.decode(), p.gcn_arch.decode(), "CUs", p.compute_units, flush=True)
+    c64, c128, f32, f64 = numpy.complex64, numpy.complex128, numpy.float32, numpy.float64
+    cases = [
+        ((1024,), c64, 1 << 16), ((4096,), c64, 1 << 14), ((256,), c64, 1 << 18), ((16,), c64, 1 << 22),
+        ((1 << 20,), c64, 64), ((1 << 20,), c64, 256), ((1 << 20,), f32, 64),
+        ((1 << 16,), c64, 1024), ((8192,), c64, 8192),
+        ((1024, 1024), c64, 64), ((1024, 1024), c64, 256),
+        ((256, 256, 256), c128, 4), ((256, 256, 256), f64, 4), ((128, 128, 128), c64, 32),
+        ((1 << 22,), c64, 32),
+    ]
+    for shape, dt, batch in cases:
+        try:
+            run(shape, dt, batch)
+        except Exception as e:
+            print("FAILED", shape, dt, batch, repr(e), flush=True)
