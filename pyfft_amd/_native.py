@@ -96,8 +96,8 @@ PROTOTYPES = {
     "mifft_event_elapsed_ms": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), _vp, _vp]),
     "mifft_pass_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
     "mifft_launch_pass": (ctypes.c_int, [_pass_p, _vp, _vp, _vp, _vp, _vp]),
-    "mifft_launch_chain": (ctypes.c_int, [_pass_p, _i32, _buf3, _buf3, _vp]),
-    "mifft_time_chain": (ctypes.c_int, [_pass_p, _i32, _buf3, _buf3, _vp, _i32, ctypes.POINTER(ctypes.c_float)]),
+    "mifft_launch_chain": (ctypes.c_int, [_pass_p, _i32, _vpp, _vpp, _vp]),
+    "mifft_time_chain": (ctypes.c_int, [_pass_p, _i32, _vpp, _vpp, _vp, _i32, ctypes.POINTER(ctypes.c_float)]),
 }
 
 
