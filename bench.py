@@ -1,0 +1,393 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X batched FFT hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): batched 1-D c2c fp32, N = 2^20, batch 4096 per GPU, out of
+place, synthetic N(0,1) data resident in HBM before the timed region.  One "step" = one
+plan.execute() over the whole per-GPU batch (every pass of the transform).  N > 1: one process per
+GPU (torch.distributed / RCCL only for the barrier and the max-over-ranks reduction -- the batch is
+sharded across ranks and the hot path has no collective), weak scaling.
+
+Prints ONE JSON line on rank 0.  `value` = nominal 5*N*log2(N) GFLOPS of the whole job
+(test/test_performance.py:24 in the reference); the line also carries transforms/s, the algorithmic
+HBM GB/s, the roofline object (HIP events on the plan's stream) and the CPU baseline.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+CONFIGS = {
+    # name: (shape, dtype name, per-GPU batch, seed)            BASELINE.json configs[i]
+    "c1": ((1024,), "complex64", 1, 1001),
+    "c2": ((1 << 20,), "complex64", 4096, 1002),
+    "c3": ((1024, 1024), "complex64", 512, 1003),
+    "c4": ((256, 256, 256), "complex128", 64, 1004),
+    "c4s": ((256, 256, 256), "float64", 64, 1004),
+    "c5": ((1 << 22,), "complex64", 256, 1005),   # per-GPU resident chunk of config 5 (8 GiB in + 8 GiB out)
+}
+
+
+def shard_batch(global_batch, rank, world):
+    """Contiguous slice [start, start+count) of the batch axis owned by `rank`:
+    independent transforms, no exchange."""
+    base, extra = divmod(global_batch, world)
+    count = base + (1 if rank < extra else 0)
+    start = rank * base + min(rank, extra)
+    return start, count
+
+
+def dist_env():
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    return rank, local_rank, world
+
+
+def selftest_dist(args):
+    """CPU self-test of the multi-process harness (gloo): sharding, barrier, max-over-ranks.
+    No FFT is computed and no benchmark number is produced."""
+    import torch
+    import torch.distributed as dist
+    rank, local_rank, world = dist_env()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gb = 4096 * world + 3
+    start, count = shard_batch(gb, rank, world)
+    t = torch.tensor([float(count), float(start)])
+    gathered = [torch.zeros(2) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))          # stand-in for K steps; rank-dependent on purpose
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    mx = el.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        counts = [int(g[0]) for g in gathered]
+        starts = [int(g[1]) for g in gathered]
+        ok = sum(counts) == gb and starts == [sum(counts[:i]) for i in range(world)] and mx.item() >= el.item()
+        print(json.dumps({"selftest": True, "world": world, "counts": counts, "starts": starts,
+                          "max_s": mx.item(), "ok": bool(ok)}))
+    dist.destroy_process_group()
+
+
+def fill_device(N, dst_ptr, nbytes, host_block):
+    """Upload one host block and tile it across the buffer with device-to-device copies."""
+    hb = host_block.view("uint8").reshape(-1)
+    n0 = min(nbytes, hb.nbytes)
+    N.check(N.lib.mifft_memcpy_h2d(dst_ptr, hb.ctypes.data, n0, None), "h2d")
+    done = n0
+    while done < nbytes:
+        n = min(done, nbytes - done)
+        N.check(N.lib.mifft_memcpy_d2d(dst_ptr + done, dst_ptr, n, None), "d2d")
+        done += n
+    N.check(N.lib.mifft_device_sync(), "sync")
+
+
+def cpu_baseline(shape, dtype, host_items, flop_per_xform, budget_s=25.0):
+    """CPU figures on this box's host cores for the same transforms.
+    host_items: array [n, *shape] of the very data the GPU transforms."""
+    import numpy
+    res = {}
+    axes = tuple(range(1, host_items.ndim))
+    cores = os.cpu_count() or 1
+    n = host_items.shape[0]
+    # (1) numpy.fft (pocketfft, one thread) -- the reference's own CPU oracle (test/test_errors.py:35)
+    t0 = time.perf_counter()
+    done = 0
+    for i in range(n):
+        numpy.fft.fftn(host_items[i])
+        done += 1
+        if time.perf_counter() - t0 > budget_s / 3:
+            break
+    dt = time.perf_counter() - t0
+    res["numpy_fft_1core_gflops"] = flop_per_xform * done / dt / 1e9
+    res["numpy_fft_1core_xforms_per_s"] = done / dt
+    res["numpy_sample_xforms"] = done
+    # (2) scipy.fft with all cores
+    best = None
+    try:
+        import scipy.fft
+        scipy.fft.fftn(host_items[:1], axes=axes, workers=cores)
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            scipy.fft.fftn(host_items, axes=axes, workers=cores)
+            reps += 1
+            if time.perf_counter() - t0 > budget_s / 3 or reps >= 8:
+                break
+        dt = time.perf_counter() - t0
+        res["scipy_fft_allcores_gflops"] = flop_per_xform * n * reps / dt / 1e9
+        res["scipy_fft_allcores_xforms_per_s"] = n * reps / dt
+        best = ("scipy.fft.fftn workers=%d" % cores, res["scipy_fft_allcores_gflops"], cores, n * reps)
+    except Exception as e:  # scipy missing
+        res["scipy_error"] = repr(e)
+    # (3) the oracle's plain-C restatement of the reference chain (scalar port, one core)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import c_oracle
+        import pyfft_oracle
+        if c_oracle.available():
+            _, xyz = pyfft_oracle.normalize_shape(tuple(shape))
+            t0 = time.perf_counter()
+            k = 0
+            while k < n:
+                c_oracle.execute(host_items[k].reshape(-1), xyz, batch=1)
+                k += 1
+                if time.perf_counter() - t0 > budget_s / 3:
+                    break
+            dt = time.perf_counter() - t0
+            res["oracle_c_port_1core_gflops"] = flop_per_xform * k / dt / 1e9
+            res["oracle_c_port_sample_xforms"] = k
+    except Exception as e:
+        res["oracle_port_error"] = repr(e)
+    if best is None:
+        best = ("numpy.fft.fftn (1 thread)", res["numpy_fft_1core_gflops"], 1, done)
+    out = {"value": best[1], "unit": "GFLOPS", "cores": best[2], "kind": "port",
+           "impl": best[0],
+           "sample": "%d transforms of the same %s %s data the GPU transforms (host copy), nominal 5*N*log2(N) flop" %
+                     (best[3], "x".join(map(str, shape)), dtype),
+           "host_cores": cores}
+    out.update(res)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS.keys()))
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (development only)")
+    ap.add_argument("--inplace", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--selftest-dist", action="store_true", help="CPU/gloo self-test of the multi-process harness")
+    args = ap.parse_args()
+
+    if args.selftest_dist:
+        return selftest_dist(args)
+
+    rank, local_rank, world = dist_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+
+    import numpy
+    torch = None
+    try:
+        import torch  # first, so that this process uses one HIP runtime for torch and libmifft
+    except Exception:
+        if world > 1:
+            raise
+    dist = None
+    if torch is not None and torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from pyfft_amd import _native as N
+    from pyfft_amd.hip import Plan, DeviceArray, Event, device_props
+    N.check(N.lib.mifft_set_device(local_rank), "set_device")
+    props = device_props(local_rank)
+
+    shape, dtname, batch, seed = CONFIGS[args.config]
+    if args.batch:
+        batch = args.batch
+    dtype = numpy.dtype(dtname)
+    split = dtype.kind == "f"
+    cdtype = numpy.dtype(numpy.complex64 if dtype in (numpy.complex64, numpy.float32) else numpy.complex128)
+    size = int(numpy.prod(shape))
+    log2n = sum(int(round(numpy.log2(s))) for s in shape)
+    flop_per_xform = 5.0 * size * log2n
+    alg_bytes_per_xform = 2.0 * size * cdtype.itemsize          # read once + write once
+    gstart, _ = shard_batch(batch * world, rank, world)          # this rank's slice of the global batch
+
+    # ---- synthetic data: one host block of <= 64 transforms, tiled across the batch on the device
+    blk = min(batch, max(1, (512 << 20) // (size * cdtype.itemsize)), 64)
+    rng = numpy.random.default_rng(seed + rank)
+    fdt = numpy.float32 if cdtype == numpy.complex64 else numpy.float64
+    host_re = rng.standard_normal((blk,) + tuple(shape)).astype(fdt)
+    host_im = rng.standard_normal((blk,) + tuple(shape)).astype(fdt)
+    nel = size * batch
+    if split:
+        ins = [DeviceArray((nel,), dtype), DeviceArray((nel,), dtype)]
+        outs = ins if args.inplace else [DeviceArray((nel,), dtype), DeviceArray((nel,), dtype)]
+        fill_device(N, ins[0].ptr, ins[0].nbytes, host_re)
+        fill_device(N, ins[1].ptr, ins[1].nbytes, host_im)
+        host_c = host_re.astype(numpy.complex128) + 1j * host_im
+    else:
+        host_c = numpy.empty((blk,) + tuple(shape), cdtype)
+        host_c.real = host_re
+        host_c.imag = host_im
+        ins = [DeviceArray((nel,), dtype)]
+        outs = ins if args.inplace else [DeviceArray((nel,), dtype)]
+        fill_device(N, ins[0].ptr, ins[0].nbytes, host_c)
+    del host_re, host_im
+
+    plan = Plan(shape if len(shape) > 1 else shape[0], dtype=dtype, wait_for_finish=False)
+    stream = plan._context.getQueue()
+
+    def step():
+        if split:
+            if args.inplace:
+                plan.execute(ins[0], ins[1], batch=batch)
+            else:
+                plan.execute(ins[0], ins[1], outs[0], outs[1], batch=batch)
+        else:
+            if args.inplace:
+                plan.execute(ins[0], batch=batch)
+            else:
+                plan.execute(ins[0], outs[0], batch=batch)
+
+    def sync_all():
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        else:
+            N.check(N.lib.mifft_device_sync(), "sync")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    # ---- parity gate (before timing, on the untouched input): sampled batch items vs numpy.fft
+    parity = None
+    if not args.inplace:
+        step()
+        stream.synchronize()
+        samples = sorted(set([0, 1 % batch, (blk - 1) % batch, blk % batch, batch // 2, batch - 1]))
+        worst_diff, worst_max = 0.0, 0.0
+        isz = dtype.itemsize
+        for s in samples:
+            if split:
+                re = numpy.empty(size, dtype)
+                im = numpy.empty(size, dtype)
+                N.check(N.lib.mifft_memcpy_d2h(re.ctypes.data, outs[0].ptr + s * size * isz, size * isz, None), "d2h")
+                N.check(N.lib.mifft_memcpy_d2h(im.ctypes.data, outs[1].ptr + s * size * isz, size * isz, None), "d2h")
+                got = re.astype(numpy.complex128) + 1j * im
+            else:
+                got = numpy.empty(size, dtype)
+                N.check(N.lib.mifft_memcpy_d2h(got.ctypes.data, outs[0].ptr + s * size * isz, size * isz, None), "d2h")
+                got = got.astype(numpy.complex128)
+            ref = numpy.fft.fftn(host_c[s % blk].astype(numpy.complex128)).reshape(-1)
+            worst_diff = max(worst_diff, float(numpy.abs(ref - got).sum() / numpy.abs(ref).sum()))
+            worst_max = max(worst_max, float(numpy.abs(ref - got).max() / numpy.abs(ref).max()))
+        eps = 1.1e-6 if cdtype == numpy.complex64 else 1e-11
+        mx = 1e-5 if cdtype == numpy.complex64 else 1e-10
+        parity = {"samples": len(samples), "difference": worst_diff, "max_rel": worst_max,
+                  "tol_difference": eps, "tol_max_rel": mx, "ok": bool(worst_diff < eps and worst_max <= mx)}
+        if not parity["ok"]:
+            raise SystemExit("PARITY FAILURE: %r" % (parity,))
+
+    # ---- warm-up, then EXACTLY K timed steps bracketed by barrier + device sync on both sides
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    barrier()
+    sync_all()
+    ev0, ev1 = Event(), Event()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    sync_all()
+    barrier()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev1.time_since(ev0)          # HIP events on the stream the kernels are launched on
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-pass device time (separate, untimed-for-value measurement; HIP events between launches)
+    import ctypes
+    descs = plan._descriptors(batch, args.inplace, False)
+    npass = len(plan.pass_list())
+    ptr = plan._context.pointer_of
+    if split:
+        b0 = [ins[0].ptr, outs[0].ptr, ptr(plan._tempmemobj_re) if plan._tempmemobj_re is not None else None]
+        b1 = [ins[1].ptr, outs[1].ptr, ptr(plan._tempmemobj_im) if plan._tempmemobj_im is not None else None]
+    else:
+        b0 = [ins[0].ptr, outs[0].ptr, ptr(plan._tempmemobj) if plan._tempmemobj is not None else None]
+        b1 = [None, None, None]
+    pass_ms = []
+    reps = 3
+    for i in range(npass):
+        d = descs[i]
+        e0, e1 = Event(), Event()
+        e0.record(stream)
+        for _ in range(reps):
+            N.check(N.lib.mifft_launch_pass(ctypes.byref(d), b0[d.src], b1[d.src], b0[d.dst], b1[d.dst],
+                                            plan._context.stream_handle()), "launch_pass")
+        e1.record(stream)
+        e1.synchronize()
+        pass_ms.append(e1.time_since(e0) / reps)
+
+    total_xforms = batch * world * args.steps
+    ms_per_step = elapsed * 1e3 / args.steps
+    gflops = flop_per_xform * total_xforms / elapsed / 1e9
+    alg_gbs = alg_bytes_per_xform * total_xforms / elapsed / 1e9
+    chain_ms = dev_ms / args.steps
+    achieved = alg_bytes_per_xform * batch / (chain_ms * 1e-3) / 1e9
+
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get("hbm_bytes_per_step")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "batched_c2c_fft_gflops_5NlogN_1d_n2^20" if args.config == "c2" else "batched_c2c_fft_gflops_5NlogN_" + args.config,
+        "value": gflops,
+        "unit": "GFLOPS",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32" if cdtype == numpy.complex64 else "f64",
+        "data": "synthetic",
+        "config": {"workload": "%s: %s c2c %s, batch %d per GPU, %s, %s" % (
+            args.config, "x".join(map(str, shape)), dtname, batch,
+            "split re/im planes" if split else "interleaved", "in place" if args.inplace else "out of place"),
+            "global_batch": batch * world, "first_transform_of_rank0": gstart,
+            "parallelism": "batch-sharded x%d, no collective" % world,
+            "passes": [repr(p) for p in plan.pass_list()]},
+        "transforms_per_s": total_xforms / elapsed,
+        "algorithmic_GBps": alg_gbs,
+        "hbm_fraction_of_8TBps": alg_gbs / world / HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "fft_tile_kernel chain (%d launches per step)" % npass,
+                     "algorithmic_bytes_per_step": alg_bytes_per_xform * batch,
+                     "chain_ms_hip_events": chain_ms, "pass_ms_hip_events": pass_ms},
+        "parity": parity,
+        "device": "%s (%s), %d CUs" % (props.name.decode(), props.gcn_arch.decode(), props.compute_units),
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(shape, dtname, host_c[:min(blk, 16)], flop_per_xform)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

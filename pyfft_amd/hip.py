@@ -256,6 +256,8 @@ def Plan(*args, **kwds):
     context_obj = kwds.pop('context', None)
     stream_obj = kwds.pop('stream', None)
 
+    # argument errors first (ValueError, as in the reference), then the device
+    FFTPlan.validate(*args, **kwds)
     if device_count() < 1:
         raise RuntimeError("pyfft_amd: no HIP device visible (there is no CPU fallback)")
 

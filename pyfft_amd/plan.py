@@ -65,29 +65,32 @@ def _twiddle_table(n, count, step, complex_dtype):
     return (numpy.cos(ang) + 1j * numpy.sin(ang)).astype(complex_dtype)
 
 
+def normalize_shape(shape):
+    """Shape normalisation: x is the fastest-varying (last numpy) axis (plan.py:73-89)."""
+    if isinstance(shape, (int, numpy.integer)) and not isinstance(shape, bool):
+        return _FFT_1D, (int(shape), 1, 1)
+    if isinstance(shape, tuple):
+        if len(shape) == 1:
+            return _FFT_1D, (shape[0], 1, 1)
+        if len(shape) == 2:
+            return _FFT_2D, (shape[1], shape[0], 1)
+        if len(shape) == 3:
+            return _FFT_3D, tuple(reversed(shape))
+    raise ValueError("Wrong shape")
+
+
 class FFTPlan(object):
     """Class for FFT plan preparation and execution (plan.py:66-284)."""
 
+    @staticmethod
+    def validate(shape, dtype=numpy.complex64, normalize=True, wait_for_finish=None, fast_math=True, scale=1.0):
+        """Raise the reference's ValueErrors (plan.py:24,48,87,89) without touching a device."""
+        _, xyz = normalize_shape(shape)
+        _FFTParams(xyz, dtype, None, fast_math)
+
     def __init__(self, context, shape, dtype=numpy.complex64, normalize=True,
                  wait_for_finish=None, fast_math=True, scale=1.0):
-        # shape normalisation: x is the fastest-varying (last numpy) axis (plan.py:73-89)
-        if isinstance(shape, (int, numpy.integer)) and not isinstance(shape, bool):
-            self._dim = _FFT_1D
-            shape = (int(shape), 1, 1)
-        elif isinstance(shape, tuple):
-            if len(shape) == 1:
-                self._dim = _FFT_1D
-                shape = (shape[0], 1, 1)
-            elif len(shape) == 2:
-                self._dim = _FFT_2D
-                shape = (shape[1], shape[0], 1)
-            elif len(shape) == 3:
-                self._dim = _FFT_3D
-                shape = tuple(reversed(shape))
-            else:
-                raise ValueError("Wrong shape")
-        else:
-            raise ValueError("Wrong shape")
+        self._dim, shape = normalize_shape(shape)
 
         self._context = context
         self._params = _FFTParams(shape, dtype, context, fast_math)

@@ -1,0 +1,197 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, the
+gfx950 pass decomposition is consistent with the oracle's pass algebra, and the Python API raises
+the reference's errors.  No compute calls (no GPU here)."""
+import os
+import re
+
+import numpy
+import pytest
+
+import pyfft_oracle as oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    import ctypes
+    from pyfft_amd import _native as N
+    header = open(os.path.join(ROOT, "include", "mifft.h")).read()
+    declared = set(re.findall(r"\b(mifft_[a-z0-9_]+)\s*\(", header))
+    declared -= {"mifft_pass", "mifft_device_props"}
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(N.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libmifft.so does not export %s" % name
+    assert declared == set(N.PROTOTYPES.keys())
+    assert N.lib.mifft_abi_version() == N.ABI_VERSION
+
+
+def test_struct_layout_matches_header():
+    import ctypes
+    from pyfft_amd import _native as N
+    assert ctypes.sizeof(N.MifftPass) == 112
+    assert N.MifftPass.scale.offset == 64 and N.MifftPass.tw_L.offset == 72 and N.MifftPass.src.offset == 100
+
+
+def test_supported_lengths():
+    from pyfft_amd import _native as N
+    from pyfft_amd import passes as P
+    for prec in (N.F32, N.F64):
+        assert P.row_max(prec) >= 2048 and P.col_max(prec) >= 256
+        L = 2
+        while L <= P.row_max(prec):
+            assert N.lib.mifft_pass_supported(N.PASS_ROW, prec, L, 0) == 0
+            L *= 2
+        L = 2
+        while L <= P.col_max(prec):
+            assert N.lib.mifft_pass_supported(N.PASS_COL, prec, L, 0) == 0
+            L *= 2
+        assert N.lib.mifft_pass_supported(N.PASS_ROW, prec, 3, 0) == N.E_UNSUPPORTED
+        assert N.lib.mifft_pass_supported(N.PASS_COL, prec, 1 << 20, 0) == N.E_UNSUPPORTED
+
+
+def test_launch_rejects_bad_descriptors_without_touching_the_gpu():
+    import ctypes
+    from pyfft_amd import _native as N
+    p = N.MifftPass()
+    p.kind, p.precision, p.layout, p.L, p.M, p.S, p.outer = N.PASS_ROW, N.F32, N.INTERLEAVED, 12, 1, 1, 1
+    p.tw_L = 16
+    assert N.lib.mifft_launch_pass(ctypes.byref(p), 16, None, 16, None, None) == N.E_INVALID
+    assert "power of two" in N.last_error()
+    p.L = 16
+    assert N.lib.mifft_launch_pass(ctypes.byref(p), 8, None, 16, None, None) == N.E_INVALID   # misaligned
+    p.kind, p.M, p.S = N.PASS_COL, 4, 1
+    assert N.lib.mifft_launch_pass(ctypes.byref(p), 16, None, 32, None, None) == N.E_INVALID  # tables missing
+    with pytest.raises(ValueError):
+        N.check(N.E_INVALID, "x")
+    with pytest.raises(RuntimeError):
+        N.check(N.E_UNSUPPORTED, "x")
+
+
+SHAPES = [(2, 1, 1), (1024, 1, 1), (4096, 1, 1), (8192, 1, 1), (1 << 16, 1, 1), (1 << 20, 1, 1), (1 << 22, 1, 1),
+          (1 << 24, 1, 1), (16, 16, 1), (1024, 1024, 1), (4, 2048, 1), (2048, 8, 1), (256, 256, 256), (16, 16, 16),
+          (64, 8, 8), (2, 4, 2), (1, 16, 1), (1, 1, 64), (1, 8, 8), (16, 1, 8)]
+
+
+@pytest.mark.parametrize("xyz", SHAPES, ids=str)
+def test_gfx950_chain_is_a_valid_factorisation_and_matches_numpy(xyz):
+    """Run the build's own chain (passes.build_chain) through the oracle's pass algebra
+    (global_pass) on a small batch: the decomposition + the reference formula == numpy.fft."""
+    from pyfft_amd import _native as N
+    from pyfft_amd import passes as P
+    x, y, z = xyz
+    chain = P.build_chain(x, y, z, N.F32)
+    per_axis = {}
+    for k in chain:
+        per_axis[k.axis] = per_axis.get(k.axis, 1) * k.L
+        assert k.L >= 2 and (k.kind == N.PASS_ROW) == (k.M * k.S == 1)
+        assert k.in_place_possible == (k.M == 1)
+        assert k.L <= (P.row_max(N.F32) if k.kind == N.PASS_ROW else P.col_max(N.F32))
+    for axis, n in zip((0, 1, 2), (x, y, z)):
+        assert per_axis.get(axis, 1) == n
+    if x * y * z > (1 << 16):
+        return
+    batch = 2
+    rng = numpy.random.default_rng(3)
+    data = rng.standard_normal((batch, z, y, x)) + 1j * rng.standard_normal((batch, z, y, x))
+    cur = data.reshape(-1).copy()
+    for k in chain:
+        per = k.outer_stride
+        assert cur.size == k.outer_per_batch * batch * per
+        cur = oracle.global_pass(cur, k.L, k.M, k.S, -1).reshape(-1)
+    ref = numpy.fft.fftn(data, axes=(1, 2, 3)).reshape(-1)
+    assert numpy.abs(cur - ref).max() < 1e-9 * max(1.0, numpy.abs(ref).max())
+
+
+@pytest.mark.parametrize("xyz", SHAPES, ids=str)
+def test_buffer_schedule_contract(xyz):
+    from pyfft_amd import _native as N
+    from pyfft_amd import passes as P
+    chain = P.build_chain(*xyz, N.F32)
+    for inplace in (False, True):
+        temp, sched = P.buffer_schedule(chain, inplace)
+        assert len(sched) == len(chain) and sched[-1][1] == 1
+        loc = 1 if inplace else 0
+        for k, (r, w) in zip(chain, sched):
+            if inplace and r == 0:
+                r = 1              # in place: data_out aliases data_in
+            assert r == loc
+            if not inplace:
+                assert w != 0                 # out-of-place never writes data_in
+            if not k.in_place_possible:
+                assert r != w
+            if 2 in (r, w):
+                assert temp
+            loc = w
+    # same rules as the oracle's restatement of plan.py:200-248
+    class K(object):
+        def __init__(self, ip):
+            self.in_place_possible = ip
+    for flags in [(True,), (False, True), (False, False, True), (True, False, True), (True, True, True, False, True)]:
+        ks = [K(f) for f in flags]
+        for inplace in (False, True):
+            assert P.buffer_schedule(ks, inplace) == oracle.buffer_schedule(ks, inplace)
+
+
+def test_plan_argument_errors_without_device():
+    """test_functionality.py:129-139: ValueError for bad size / dtype / shape, raised before any
+    device is touched; with valid arguments and no GPU the factory fails loudly (no CPU fallback)."""
+    import pyfft_amd.hip as hip
+    with pytest.raises(ValueError):
+        hip.Plan((17,), dtype=numpy.complex64)
+    with pytest.raises(ValueError):
+        hip.Plan((16,), dtype=numpy.int32)
+    with pytest.raises(ValueError):
+        hip.Plan((16, 16, 16, 16), dtype=numpy.complex64)
+    with pytest.raises(ValueError):
+        hip.Plan("16", dtype=numpy.complex64)
+    with pytest.raises(ValueError):
+        hip.Plan((16, 24), dtype=numpy.complex64)     # per-axis check (the reference only checks the product)
+    if hip.device_count() == 0:
+        with pytest.raises(RuntimeError):
+            hip.Plan((16,), dtype=numpy.complex64)
+
+
+def test_version_is_tuple_of_ints():
+    import pyfft_amd
+    assert isinstance(pyfft_amd.VERSION, tuple) and all(isinstance(v, int) for v in pyfft_amd.VERSION)
+
+
+def test_device_pointer_extraction():
+    import ctypes
+    import pyfft_amd.hip as hip
+
+    class WithGpudata(object):
+        gpudata = 4096
+
+    class WithIface(object):
+        __cuda_array_interface__ = {"data": (8192, False)}
+
+    assert hip.device_pointer(1234) == 1234
+    assert hip.device_pointer(WithGpudata()) == 4096
+    assert hip.device_pointer(WithIface()) == 8192
+    assert hip.device_pointer(ctypes.c_void_p(64)) == 64
+    assert hip.device_pointer(None) is None
+    torch = pytest.importorskip("torch")
+    t = torch.zeros(4)
+    assert hip.device_pointer(t) == t.data_ptr()
+    with pytest.raises(TypeError):
+        hip.device_pointer("nope")
+
+
+def test_kernel_model_matches_oracle():
+    """The numpy model of fft_tile.hpp's index algebra (tests/kernel_model.py) against the oracle."""
+    import kernel_model as km
+    rng = numpy.random.default_rng(0)
+
+    def rnd(n):
+        return rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    for L, W, NT, rad in [(16, 8, 8, [16]), (64, 4, 16, [8, 8]), (1024, 1, 64, [16, 16, 4]), (2, 32, 4, [2])]:
+        x = rnd(5 * L)
+        y = km.run_pass(x, True, L, 1, 1, 5, L, W, NT, rad)
+        assert numpy.abs(y - numpy.fft.fft(x.reshape(5, L), axis=1).ravel()).max() < 1e-9
+    for L, M, S, W, NT, rad, outer in [(16, 1, 8, 8, 8, [16], 3), (16, 4, 1, 8, 8, [16], 3), (64, 2, 4, 4, 16, [8, 8], 2),
+                                       (32, 8, 1, 4, 8, [8, 4], 1), (128, 4, 2, 4, 32, [16, 8], 1)]:
+        x = rnd(outer * L * M * S)
+        y = km.run_pass(x, False, L, M, S, outer, L * M * S, W, NT, rad)
+        assert numpy.abs(y - oracle.global_pass(x, L, M, S, -1)).max() < 1e-9
