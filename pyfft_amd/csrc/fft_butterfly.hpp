@@ -94,6 +94,41 @@ template <int E, typename T> __device__ __forceinline__ cplx<T> mul_w32(cplx<T> 
     return r;
 }
 
+// cos(2*pi*k/64), k = 0..16
+__device__ constexpr double kCos64[17] = {1.0,
+                                          0.99518472667219688624483695310948,
+                                          0.98078528040323044912618223613424,
+                                          0.95694033573220886493579788698027,
+                                          0.92387953251128675612818318939679,
+                                          0.88192126434835502971275686366039,
+                                          0.83146961230254523707878837761791,
+                                          0.77301045336273696081090660975847,
+                                          0.70710678118654752440084436210485,
+                                          0.63439328416364549821517161322549,
+                                          0.55557023301960222474283081394853,
+                                          0.47139673682599764855638762590525,
+                                          0.38268343236508977172845998403040,
+                                          0.29028467725446236763619237581740,
+                                          0.19509032201612826784828486847702,
+                                          0.09801714032956060199419556388864,
+                                          0.0};
+
+// v * w(64)^E, w(64) = exp(-2*pi*i/64): E = 16*n + m -> (-i)^n * (cos(t) - i sin(t)), t = 2*pi*m/64
+template <int E, typename T> __device__ __forceinline__ cplx<T> mul_w64(cplx<T> v) {
+    constexpr int e = E & 63;
+    if constexpr ((e & 1) == 0) {
+        return mul_w32<e / 2, T>(v);
+    } else {
+        constexpr int n = e >> 4, m = e & 15;
+        constexpr T c = (T)kCos64[m];
+        constexpr T sn = (T)kCos64[16 - m];
+        cplx<T> r;
+        r.x = v.x * c + v.y * sn;
+        r.y = v.y * c - v.x * sn;
+        return mul_w32<8 * n, T>(r);
+    }
+}
+
 template <int R, typename T> struct Dft;
 
 template <typename T> struct Dft<1, T> {

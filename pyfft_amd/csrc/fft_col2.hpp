@@ -1,0 +1,216 @@
+// "Two-phase" strided-axis (COL) kernels for gfx950: L = 16 * A * 16 with A in {1, 2, 4}
+// (L = 256, 512, 1024), W = 16 adjacent columns per work-group, 256 threads, A*16 points per thread.
+//
+// Why a second COL kernel: the generic tile kernel (fft_tile.hpp) keeps the whole L x 16 tile in LDS, which at
+// L = 1024 is 128 KiB -> one work-group per CU -> its LDS/butterfly phases cannot overlap another work-group's
+// HBM phase (measured 3.3-4.2 TB/s against a 5.3-5.6 TB/s streaming ceiling for the same access pattern).
+// Here the first two radix stages run in registers directly on the global loads, only ONE exchange goes through
+// LDS (a 2 x 34 KiB double buffer, one radix-16 slab per round), and the last radix-16 stage stores straight from
+// registers.  LDS traffic per point drops from 4 writes + 4 reads to 1 + 1, barriers from 8 to A, and two
+// work-groups fit a CU so that one computes while the other streams.
+//
+// Pass algebra (SURVEY.md 3.3 / pyfft/kernel.mako:805-1047), one tile = 16 columns of the [L][M*S] matrix:
+//     out[l][q][j] = scale * w(L*M)^(l*q) * sum_r in[r][l][j] * w(L)^(r*q)
+// with r = b1*(16A) + a*16 + b0 and q = qb0*(16A) + qa*16 + qb1 (decimation in frequency, Stockham order):
+//     stage 1: radix-16 over b1, twiddle w(L)^((a*16 + b0)*qb1) = w(L)^(b0*qb1) * w(16A)^(a*qb1)   [2nd factor constant]
+//     stage 2: radix-A  over a,  twiddle w(16A)^(b0*qa)
+//     ---- LDS exchange, one qa slab per round: (b0, c) threads -> (qb1, c) threads ----
+//     stage 3: radix-16 over b0
+// Phase-2 lanes hold 16 consecutive q (qb1), so both the transposing store (S == 1, contiguous in q) and the
+// strided store (128-byte column segments) are issued per round straight from registers.
+#pragma once
+#include "fft_tile.hpp"
+
+namespace mifft {
+
+template <int A, int E, typename T> __device__ __forceinline__ cplx<T> mul_w16A(cplx<T> v) {
+    if constexpr (A == 4)
+        return mul_w64<E, T>(v);
+    else
+        return mul_w32<E, T>(v);  // A == 2: w(32)
+}
+
+// TR: S == 1 (first pass of a long contiguous axis; the store is a transposition)
+// TW: multiply by the inter-pass twiddle w(L*M)^(l*q)
+template <typename T, int A, bool TR, bool TW, bool SPLIT>
+__global__ void __launch_bounds__(256, 2) fft_col2_kernel(const TileArgs a) {
+    constexpr int L = A * 256;
+    constexpr int PPT = A * 16;
+    constexpr int PITCH = TR ? 17 : 16;   // TR: [b0][c][qb1 + pad]; else [b0][qb1][c]
+    constexpr int BUF = 16 * 16 * PITCH;  // complex elements per exchange buffer
+    __shared__ __attribute__((aligned(16))) cplx<T> lds[(A > 1 ? 2 : 1) * BUF];
+
+    const int tid = threadIdx.x;
+    const int c = tid & 15, b0 = tid >> 4;
+    const long long col0 = (long long)blockIdx.x * 16;
+    const long long o = col0 >> a.logMS;
+    const long long rem0 = col0 & ((1ll << a.logMS) - 1);
+    const cplx<T>* twL = reinterpret_cast<const cplx<T>*>(a.tw_L);
+    const T csign = a.inverse ? (T)-1 : (T)1;
+
+    // ---- phase 1: global -> registers.  v[a*16 + b1] = in[b1*16A + a*16 + b0][column c]
+    // Addresses are (wave-uniform 64-bit base, SGPRs) + (per-thread 32-bit byte offset, one VGPR) so that the
+    // A*16 loads in flight do not each hold a 64-bit address pair (the dispatcher guarantees the offset fits).
+    cplx<T> v[PPT];
+    {
+        const long long ubase = o * a.ostride_in + rem0;  // uniform, elements
+        const unsigned voff = (((unsigned)b0 << a.logMS) + (unsigned)c);
+        if constexpr (!SPLIT) {
+            const char* src = reinterpret_cast<const char*>(reinterpret_cast<const cplx<T>*>(a.in0) + ubase);
+            const unsigned vb = voff * (unsigned)sizeof(cplx<T>);
+            static_for<PPT>([&](auto kk) {
+                constexpr int k = kk, ia = k >> 4, b1 = k & 15;
+                const char* p = src + (((long long)(b1 * 16 * A + ia * 16) << a.logMS) * (long long)sizeof(cplx<T>));
+                v[k] = *reinterpret_cast<const cplx<T>*>(p + vb);
+            });
+        } else {
+            const char* sre = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.in0) + ubase);
+            const char* sim = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.in1) + ubase);
+            const unsigned vb = voff * (unsigned)sizeof(T);
+            static_for<PPT>([&](auto kk) {
+                constexpr int k = kk, ia = k >> 4, b1 = k & 15;
+                const long long off = ((long long)(b1 * 16 * A + ia * 16) << a.logMS) * (long long)sizeof(T);
+                v[k].x = *reinterpret_cast<const T*>(sre + off + vb);
+                v[k].y = *reinterpret_cast<const T*>(sim + off + vb);
+            });
+        }
+    }
+    static_for<PPT>([&](auto kk) {
+        constexpr int k = kk;
+        v[k].y *= csign;
+    });
+
+    // ---- stage 1: radix-16 over b1 (A butterflies), twiddle w(L)^(b0*qb1) [table] * w(16A)^(a*qb1) [constant]
+    {
+        cplx<T> twB[15];
+        static_for<15>([&](auto qq) {
+            constexpr int qb1 = qq + 1;
+            twB[qq] = twL[b0 * qb1];
+        });
+        static_for<A>([&](auto aa) {
+            constexpr int ia = aa;
+            Dft<16, T>::run(v + ia * 16);
+            static_for<15>([&](auto q2) {
+                constexpr int qb1 = q2 + 1;
+                cplx<T> t = v[ia * 16 + qb1];
+                if constexpr (ia > 0) t = mul_w16A<A, ia * qb1, T>(t);
+                v[ia * 16 + qb1] = cmul<T>(t, twB[q2]);
+            });
+            __builtin_amdgcn_sched_barrier(0);  // one butterfly's temporaries at a time
+        });
+    }
+    // ---- stage 2: radix-A over a (16 butterflies), twiddle w(16A)^(b0*qa) = w(L)^(16*b0*qa)
+    if constexpr (A > 1) {
+        cplx<T> twA[A - 1];
+        static_for<A - 1>([&](auto qq) {
+            constexpr int qa = qq + 1;
+            twA[qq] = twL[16 * b0 * qa];
+        });
+        static_for<16>([&](auto bb) {
+            constexpr int qb1 = bb;
+            cplx<T> t[A];
+            static_for<A>([&](auto aa) {
+                constexpr int ia = aa;
+                t[ia] = v[ia * 16 + qb1];
+            });
+            Dft<A, T>::run(t);
+            v[qb1] = t[0];
+            static_for<A - 1>([&](auto qq) {
+                constexpr int qa = qq + 1;
+                v[qa * 16 + qb1] = cmul<T>(t[qa], twA[qq]);
+            });
+        });
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- exchange + stage 3, one qa slab per round
+    // phase-2 thread roles: non-TR (u = tid>>4, c2 = tid&15): lanes along the columns (128-byte row segments)
+    //                       TR     (u = tid&15, c2 = tid>>4): lanes along q (the write is contiguous in q)
+    const int u = TR ? (tid & 15) : (tid >> 4);
+    const int c2 = TR ? (tid >> 4) : (tid & 15);
+    // output addressing, again uniform base + 32-bit per-thread offset.  The tile's 16 columns start at rem0
+    // (a multiple of 16): l0/jp0 are uniform, (dl, djp) is the per-thread part (dl > 0 only when S < 16).
+    const long long l0 = rem0 >> a.logS;
+    const long long jp0 = rem0 & ((1ll << a.logS) - 1);
+    const unsigned dl = (unsigned)(((rem0 + c2) >> a.logS) - l0);
+    const unsigned djp = (unsigned)(((rem0 + c2) & ((1ll << a.logS) - 1)) - jp0);
+    const unsigned l = (unsigned)l0 + dl;  // row index of this thread's column in the inter-pass twiddle
+    const T sx = (T)a.scale;
+    const T sy = a.inverse ? -sx : sx;
+    const cplx<T>* twlo = reinterpret_cast<const cplx<T>*>(a.tw_lo);
+    const cplx<T>* twhi = reinterpret_cast<const cplx<T>*>(a.tw_hi);
+    const unsigned lomask = (1u << a.tw_shift) - 1u;
+    // q = qb0*16A + qa*16 + u
+    // non-TR: out[o][l][q][jp] -> uniform o*ostride + ((l0*L + qconst) << logS) + jp0 ; thread ((dl*L + u) << logS) + djp
+    // TR (S == 1): out[o][l][q] -> uniform o*ostride + rem0*L + qconst ; thread c2*L + u
+    const long long oubase = TR ? (a.ostride_out * o + rem0 * L) : (a.ostride_out * o + ((l0 * L) << a.logS) + jp0);
+    const unsigned ovoff = TR ? ((unsigned)c2 * L + (unsigned)u) : ((((unsigned)dl * L + (unsigned)u) << a.logS) + djp);
+
+    static_for<A>([&](auto rr) {
+        constexpr int qa = rr;
+        cplx<T>* buf = lds + (qa & 1) * BUF;
+        static_for<16>([&](auto ss) {
+            constexpr int qb1 = ss;
+            if constexpr (TR)
+                buf[(b0 * 16 + c) * PITCH + qb1] = v[qa * 16 + qb1];
+            else
+                buf[(b0 * 16 + qb1) * 16 + c] = v[qa * 16 + qb1];
+        });
+        __syncthreads();
+        cplx<T> x[16];
+        static_for<16>([&](auto bb) {
+            constexpr int bi = bb;
+            if constexpr (TR)
+                x[bi] = buf[(bi * 16 + c2) * PITCH + u];
+            else
+                x[bi] = buf[(bi * 16 + u) * 16 + c2];
+        });
+        Dft<16, T>::run(x);
+        if constexpr (TW) {
+            // w(L*M)^(l*q), q = qb0*16A + qlow = w^(l*qlow) * s^qb0 with s = w^(l*16A).
+            // Table look-ups (two-level, tw_lo * tw_hi) for w^(l*qlow), s, s^2, s^4, s^8; the other powers by at
+            // most three multiplications (rebuilt every round on purpose: keeping 15 factors live across the
+            // rounds costs more registers than the 11 multiplies; twiddle error 5e-8 rms / 2e-7 max in fp32).
+            auto look = [&](unsigned e) { return cmul<T>(twlo[e & lomask], twhi[e >> a.tw_shift]); };
+            const cplx<T> wb = look(l * (unsigned)(qa * 16 + u));
+            cplx<T> pw[15];
+            pw[0] = look(l * (16u * A));
+            pw[1] = look(l * (32u * A));
+            pw[3] = look(l * (64u * A));
+            pw[7] = look(l * (128u * A));
+            pw[2] = cmul<T>(pw[0], pw[1]);
+            pw[4] = cmul<T>(pw[3], pw[0]);
+            pw[5] = cmul<T>(pw[3], pw[1]);
+            pw[6] = cmul<T>(pw[3], pw[2]);
+            static_for<7>([&](auto qq) {
+                constexpr int k = qq;  // pw[8 + k] = s^8 * s^(k+1)
+                pw[8 + k] = cmul<T>(pw[7], pw[k]);
+            });
+            x[0] = cmul<T>(x[0], wb);
+            static_for<15>([&](auto qq) {
+                constexpr int qb0 = qq + 1;
+                x[qb0] = cmul<T>(x[qb0], cmul<T>(wb, pw[qq]));
+            });
+        }
+        static_for<16>([&](auto qq) {
+            constexpr int qb0 = qq;
+            // uniform part of the output element index
+            const long long gu = TR ? (oubase + qb0 * 16 * A + 16 * qa)
+                                    : (oubase + ((long long)(qb0 * 16 * A + 16 * qa) << a.logS));
+            cplx<T> r;
+            r.x = x[qb0].x * sx;
+            r.y = x[qb0].y * sy;
+            if constexpr (!SPLIT) {
+                char* p = reinterpret_cast<char*>(reinterpret_cast<cplx<T>*>(a.out0) + gu);
+                *reinterpret_cast<cplx<T>*>(p + ovoff * (unsigned)sizeof(cplx<T>)) = r;
+            } else {
+                char* pr = reinterpret_cast<char*>(reinterpret_cast<T*>(a.out0) + gu);
+                char* pi = reinterpret_cast<char*>(reinterpret_cast<T*>(a.out1) + gu);
+                *reinterpret_cast<T*>(pr + ovoff * (unsigned)sizeof(T)) = r.x;
+                *reinterpret_cast<T*>(pi + ovoff * (unsigned)sizeof(T)) = r.y;
+            }
+        });
+    });
+}
+
+}  // namespace mifft

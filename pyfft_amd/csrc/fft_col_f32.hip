@@ -1,7 +1,15 @@
 // fp32 strided-axis (COL) tile kernels: P = L*W points per work-group, 16 points per thread.
 #include "mifft_internal.h"
+
+// two-phase kernels for L = 256/512/1024 live in their own translation unit (fft_col2_f32.hip)
+extern "C" int mifft_col2_f32_eligible(int L, int tr, const mifft::TileArgs* a);
+extern "C" int mifft_col2_f32_launch(int L, int tr, const mifft::TileArgs* a, hipStream_t s);
+
+// variant 0: library default (two-phase kernel for L = 256/512/1024 when the tile is 16 whole columns of one
+//            matrix, i.e. M*S >= 16; generic tile kernel otherwise);  variant 1: always the generic tile kernel.
 extern "C" int mifft_dispatch_col_f32(int L, int tr, int variant, const mifft::TileArgs* a, hipStream_t s, int query_only) {
-    if (variant != 0) return -2;
+    if (variant != 0 && variant != 1) return -2;
+    if (variant == 0 && !query_only && mifft_col2_f32_eligible(L, tr, a)) return mifft_col2_f32_launch(L, tr, a, s);
     switch (L) {
         MIFFT_COL_CASE(float, 2, 2048, 256, 2)
         MIFFT_COL_CASE(float, 4, 1024, 256, 4)

@@ -241,7 +241,7 @@ int mifft_time_chain(const mifft_pass* passes, int32_t npasses, void* const bufs
     if (rc) return rc;
     rc = hip_check(hipEventCreate(&e1), "hipEventCreate");
     if (rc) {
-        hipEventDestroy(e0);
+        (void)hipEventDestroy(e0);
         return rc;
     }
     rc = hip_check(hipEventRecord(e0, (hipStream_t)stream), "hipEventRecord");
@@ -249,8 +249,8 @@ int mifft_time_chain(const mifft_pass* passes, int32_t npasses, void* const bufs
     if (!rc) rc = hip_check(hipEventRecord(e1, (hipStream_t)stream), "hipEventRecord");
     if (!rc) rc = hip_check(hipEventSynchronize(e1), "hipEventSynchronize");
     if (!rc) rc = hip_check(hipEventElapsedTime(ms_total, e0, e1), "hipEventElapsedTime");
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return rc;
 }
 
