@@ -310,29 +310,36 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- per-pass device time (separate, untimed-for-value measurement; HIP events between launches)
+    # ---- per-pass device time (separate, untimed-for-value measurement; HIP events between launches).
+    # Only meaningful for the one-launch-per-pass strategy; the fused / pipelined strategies own a small scratch.
     import ctypes
-    descs = plan._descriptors(batch, args.inplace, False)
+    strategy = plan.strategy(batch)
     npass = len(plan.pass_list())
-    ptr = plan._context.pointer_of
-    if split:
-        b0 = [ins[0].ptr, outs[0].ptr, ptr(plan._tempmemobj_re) if plan._tempmemobj_re is not None else None]
-        b1 = [ins[1].ptr, outs[1].ptr, ptr(plan._tempmemobj_im) if plan._tempmemobj_im is not None else None]
-    else:
-        b0 = [ins[0].ptr, outs[0].ptr, ptr(plan._tempmemobj) if plan._tempmemobj is not None else None]
-        b1 = [None, None, None]
-    pass_ms = []
-    reps = 3
-    for i in range(npass):
-        d = descs[i]
-        e0, e1 = Event(), Event()
-        e0.record(stream)
-        for _ in range(reps):
-            N.check(N.lib.mifft_launch_pass(ctypes.byref(d), b0[d.src], b1[d.src], b0[d.dst], b1[d.dst],
-                                            plan._context.stream_handle()), "launch_pass")
-        e1.record(stream)
-        e1.synchronize()
-        pass_ms.append(e1.time_since(e0) / reps)
+    pass_ms = None
+    if strategy[0] == "chain":
+        descs = plan._descriptors(batch, args.inplace, False)
+        ptr = plan._context.pointer_of
+        if split:
+            b0 = [ins[0].ptr, outs[0].ptr, ptr(plan._tempmemobj_re) if plan._tempmemobj_re is not None else None]
+            b1 = [ins[1].ptr, outs[1].ptr, ptr(plan._tempmemobj_im) if plan._tempmemobj_im is not None else None]
+        else:
+            b0 = [ins[0].ptr, outs[0].ptr, ptr(plan._tempmemobj) if plan._tempmemobj is not None else None]
+            b1 = [None, None, None]
+        pass_ms = []
+        reps = 3
+        for i in range(npass):
+            d = descs[i]
+            e0, e1 = Event(), Event()
+            e0.record(stream)
+            for _ in range(reps):
+                N.check(N.lib.mifft_launch_pass(ctypes.byref(d), b0[d.src], b1[d.src], b0[d.dst], b1[d.dst],
+                                                plan._context.stream_handle()), "launch_pass")
+            e1.record(stream)
+            e1.synchronize()
+            pass_ms.append(e1.time_since(e0) / reps)
+    launches = {"chain": "%d launches per step" % npass,
+                "fused2": "1 persistent launch per step (both passes, lag %s, ring %s)" % (strategy[1:3] if len(strategy) > 2 else ("", "")),
+                "pipelined": "%d launches per chunk, chunks of %s items on %s streams" % ((npass,) + tuple(strategy[1:3]) if len(strategy) > 2 else (npass, "", ""))}[strategy[0]]
 
     total_xforms = batch * world * args.steps
     ms_per_step = elapsed * 1e3 / args.steps
@@ -367,13 +374,13 @@ def main():
             "split re/im planes" if split else "interleaved", "in place" if args.inplace else "out of place"),
             "global_batch": batch * world, "first_transform_of_rank0": gstart,
             "parallelism": "batch-sharded x%d, no collective" % world,
-            "passes": [repr(p) for p in plan.pass_list()]},
+            "passes": [repr(p) for p in plan.pass_list()], "strategy": strategy[0]},
         "transforms_per_s": total_xforms / elapsed,
         "algorithmic_GBps": alg_gbs,
         "hbm_fraction_of_8TBps": alg_gbs / world / HBM_PEAK_GBS,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "fft_tile_kernel chain (%d launches per step)" % npass,
+                     "kernel": "%s: %s" % (strategy[0], launches),
                      "algorithmic_bytes_per_step": alg_bytes_per_xform * batch,
                      "chain_ms_hip_events": chain_ms, "pass_ms_hip_events": pass_ms},
         "parity": parity,

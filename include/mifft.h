@@ -63,7 +63,7 @@ typedef void *mifft_event_t;  /* hipEvent_t */
 /*
  * One launch.  With w(m) = exp(-2*pi*i/m) (forward; the inverse conjugates input and output):
  *
- *   MIFFT_PASS_COL  in  viewed as [outer][L][M][S]   (element strides L*M*S? no: see outer_stride)
+ *   MIFFT_PASS_COL  in  viewed as [outer][L][M][S]
  *                   out viewed as [outer][M][L][S]
  *       out[o][l][q][j] = scale * w(L*M)^(l*q) * sum_r in[o][r][l][j] * w(L)^(r*q)
  *     M == 1  -> plain strided transform (last pass of an axis), in-place capable;
@@ -152,6 +152,34 @@ int mifft_launch_pass(const mifft_pass *pass, const void *in0, const void *in1, 
  * schedule already decided by the Python plan).  bufs1 may be NULL for interleaved layout. */
 int mifft_launch_chain(const mifft_pass *passes, int32_t npasses, void *const bufs0[3], void *const bufs1[3],
                        mifft_stream_t stream);
+
+/*
+ * Pipelined form of mifft_launch_chain for plans that need a temp buffer (counterpart of the batch loop the
+ * reference runs inside each kernel grid, pyfft/kernel.py:99-121, re-cut for the MI355X memory system):
+ * the batch is processed in chunks of `chunk` items; chunk i runs the whole pass chain on side stream
+ * i % nside with temp slot i % nside, so the inter-pass intermediate of a chunk is consumed while it is still
+ * in the 256 MiB Infinity Cache and kernels of different chunks overlap each other's launch tails.
+ *   - `passes` describe the FULL batch (outer = outer_per_item * batch); `item_elems` = elements per batch item
+ *     (per plane for split layout);  bufs*[2] (temp) must hold nside * chunk items.
+ *   - ordering: side streams wait for everything enqueued on `stream` so far; `stream` waits for all side
+ *     streams before the call's work counts as done.  events[0..nside] are caller-owned scratch events.
+ */
+int mifft_launch_chain_pipelined(const mifft_pass *passes, int32_t npasses, void *const bufs0[3], void *const bufs1[3],
+                                 int64_t batch, int64_t chunk, int64_t item_elems, mifft_stream_t stream,
+                                 const mifft_stream_t *side, int32_t nside, const mifft_event_t *events);
+
+/*
+ * Fused form of a two-pass long contiguous axis (N = p0->L * p1->L, both in {256, 512, 1024}, fp32): both
+ * Stockham passes of all `p0->outer` transforms in ONE persistent launch, pass 1 of transform t trailing pass 0
+ * by `lag` transforms, with the intermediate in a scratch ring of `ring_slots` transforms (ring_slots > lag) that
+ * stays in the Infinity Cache.  p0 must be the transposing first pass (COL, S == 1, M == p1->L), p1 the plain
+ * strided last pass (COL, M == 1, S == p0->L).  `counters` = caller-owned device buffer of at least
+ * (2 + 2 * outer) uint32 (zeroed by this call on `stream`); after completion counters[1] != 0 reports a
+ * dependency time-out (results invalid).  Returns MIFFT_E_UNSUPPORTED when the shape has no fused kernel.
+ */
+int mifft_launch_fused2(const mifft_pass *p0, const mifft_pass *p1, const void *in0, const void *in1, void *out0,
+                        void *out1, void *ring0, void *ring1, int32_t ring_slots, int32_t lag, void *counters,
+                        int32_t grid, mifft_stream_t stream);
 
 /* Same as mifft_launch_chain but brackets the chain with two events on `stream` and, after
  * synchronising, reports the elapsed device time of `repeats` back-to-back chains. (bench/test helper) */

@@ -97,6 +97,9 @@ PROTOTYPES = {
     "mifft_pass_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
     "mifft_launch_pass": (ctypes.c_int, [_pass_p, _vp, _vp, _vp, _vp, _vp]),
     "mifft_launch_chain": (ctypes.c_int, [_pass_p, _i32, _vpp, _vpp, _vp]),
+    "mifft_launch_chain_pipelined": (ctypes.c_int, [_pass_p, _i32, _vpp, _vpp, ctypes.c_int64, ctypes.c_int64,
+                                                      ctypes.c_int64, _vp, _vpp, _i32, _vpp]),
+    "mifft_launch_fused2": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "mifft_time_chain": (ctypes.c_int, [_pass_p, _i32, _vpp, _vpp, _vp, _i32, ctypes.POINTER(ctypes.c_float)]),
 }
 

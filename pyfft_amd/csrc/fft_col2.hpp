@@ -30,21 +30,34 @@ template <int A, int E, typename T> __device__ __forceinline__ cplx<T> mul_w16A(
         return mul_w32<E, T>(v);  // A == 2: w(32)
 }
 
-// TR: S == 1 (first pass of a long contiguous axis; the store is a transposition)
-// TW: multiply by the inter-pass twiddle w(L*M)^(l*q)
-template <typename T, int A, bool TR, bool TW, bool SPLIT>
-__global__ void __launch_bounds__(256, 2) fft_col2_kernel(const TileArgs a) {
+template <int A, bool TR> struct Col2Lds {
+    static constexpr int PITCH = TR ? 17 : 16;   // TR: [b0][c][qb1 + pad]; else [b0][qb1][c]
+    static constexpr int BUF = 16 * 16 * PITCH;  // complex elements per exchange buffer
+    static constexpr int ELEMS = (A > 1 ? 2 : 1) * BUF;
+};
+
+// One tile = 16 adjacent columns starting at column rem0 (a multiple of 16) of matrix o_in; the result goes to
+// matrix o_out (same index for a plain launch; a scratch-ring slot in the fused two-pass kernel).
+// WT: write the result with write-through (agent-coherent, "sc1") stores -- used by the fused kernel for the
+//     intermediate so that publishing it needs no release fence (interleaved fp32 only).
+// NTIN / NTOUT: non-temporal hint on the input loads / output stores (streamed-once data in the fused kernel).
+template <typename T, int A, bool TR, bool TW, bool SPLIT, bool WT = false, bool NTIN = false, bool NTOUT = false,
+          typename LdsPtr = cplx<T>*>
+__device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_in, const long long o_out,
+                                          const long long rem0, LdsPtr lds) {
     constexpr int L = A * 256;
     constexpr int PPT = A * 16;
-    constexpr int PITCH = TR ? 17 : 16;   // TR: [b0][c][qb1 + pad]; else [b0][qb1][c]
-    constexpr int BUF = 16 * 16 * PITCH;  // complex elements per exchange buffer
-    __shared__ __attribute__((aligned(16))) cplx<T> lds[(A > 1 ? 2 : 1) * BUF];
+    constexpr int PITCH = Col2Lds<A, TR>::PITCH;
+    constexpr int BUF = Col2Lds<A, TR>::BUF;
 
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // same reason as below, for the per-thread (VGPR) address pieces
     const int c = tid & 15, b0 = tid >> 4;
-    const long long col0 = (long long)blockIdx.x * 16;
-    const long long o = col0 >> a.logMS;
-    const long long rem0 = col0 & ((1ll << a.logMS) - 1);
+    // The shift amounts are laundered through an empty asm so that, when this body sits inside the persistent
+    // loop of the fused kernel, the ~130 wave-uniform row offsets derived from them are recomputed per tile
+    // (2 SALU ops each) instead of being hoisted out of the loop and spilled (measured: 453 SGPR spills).
+    int logMS = a.logMS, logS = a.logS;
+    asm volatile("" : "+s"(logMS), "+s"(logS));
     const cplx<T>* twL = reinterpret_cast<const cplx<T>*>(a.tw_L);
     const T csign = a.inverse ? (T)-1 : (T)1;
 
@@ -53,15 +66,18 @@ __global__ void __launch_bounds__(256, 2) fft_col2_kernel(const TileArgs a) {
     // A*16 loads in flight do not each hold a 64-bit address pair (the dispatcher guarantees the offset fits).
     cplx<T> v[PPT];
     {
-        const long long ubase = o * a.ostride_in + rem0;  // uniform, elements
-        const unsigned voff = (((unsigned)b0 << a.logMS) + (unsigned)c);
+        const long long ubase = o_in * a.ostride_in + rem0;  // uniform, elements
+        const unsigned voff = (((unsigned)b0 << logMS) + (unsigned)c);
         if constexpr (!SPLIT) {
             const char* src = reinterpret_cast<const char*>(reinterpret_cast<const cplx<T>*>(a.in0) + ubase);
             const unsigned vb = voff * (unsigned)sizeof(cplx<T>);
             static_for<PPT>([&](auto kk) {
                 constexpr int k = kk, ia = k >> 4, b1 = k & 15;
-                const char* p = src + (((long long)(b1 * 16 * A + ia * 16) << a.logMS) * (long long)sizeof(cplx<T>));
-                v[k] = *reinterpret_cast<const cplx<T>*>(p + vb);
+                const char* p = src + (((long long)(b1 * 16 * A + ia * 16) << logMS) * (long long)sizeof(cplx<T>));
+                if constexpr (NTIN)
+                    v[k] = __builtin_nontemporal_load(reinterpret_cast<const cplx<T>*>(p + vb));
+                else
+                    v[k] = *reinterpret_cast<const cplx<T>*>(p + vb);
             });
         } else {
             const char* sre = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.in0) + ubase);
@@ -69,7 +85,7 @@ __global__ void __launch_bounds__(256, 2) fft_col2_kernel(const TileArgs a) {
             const unsigned vb = voff * (unsigned)sizeof(T);
             static_for<PPT>([&](auto kk) {
                 constexpr int k = kk, ia = k >> 4, b1 = k & 15;
-                const long long off = ((long long)(b1 * 16 * A + ia * 16) << a.logMS) * (long long)sizeof(T);
+                const long long off = ((long long)(b1 * 16 * A + ia * 16) << logMS) * (long long)sizeof(T);
                 v[k].x = *reinterpret_cast<const T*>(sre + off + vb);
                 v[k].y = *reinterpret_cast<const T*>(sim + off + vb);
             });
@@ -81,12 +97,29 @@ __global__ void __launch_bounds__(256, 2) fft_col2_kernel(const TileArgs a) {
     });
 
     // ---- stage 1: radix-16 over b1 (A butterflies), twiddle w(L)^(b0*qb1) [table] * w(16A)^(a*qb1) [constant]
+    // The 15 table twiddles s^k, s = w(L)^b0, are four look-ups (k = 1, 2, 4, 8) plus products of at most three
+    // of them, and are held only as long as needed (saves ~14 VGPRs against 15 look-ups held across the stage).
     {
-        cplx<T> twB[15];
-        static_for<15>([&](auto qq) {
-            constexpr int qb1 = qq + 1;
-            twB[qq] = twL[b0 * qb1];
-        });
+        const cplx<T> s1 = twL[b0], s2 = twL[2 * b0], s4 = twL[4 * b0], s8 = twL[8 * b0];
+        const cplx<T> s3 = cmul<T>(s1, s2), s5 = cmul<T>(s4, s1), s6 = cmul<T>(s4, s2), s7 = cmul<T>(s4, s3);
+        auto tw = [&](auto kk) -> cplx<T> {
+            constexpr int k = kk;  // s^k, k = 1..15
+            if constexpr (k == 1) return s1;
+            else if constexpr (k == 2) return s2;
+            else if constexpr (k == 3) return s3;
+            else if constexpr (k == 4) return s4;
+            else if constexpr (k == 5) return s5;
+            else if constexpr (k == 6) return s6;
+            else if constexpr (k == 7) return s7;
+            else if constexpr (k == 8) return s8;
+            else if constexpr (k == 9) return cmul<T>(s8, s1);
+            else if constexpr (k == 10) return cmul<T>(s8, s2);
+            else if constexpr (k == 11) return cmul<T>(s8, s3);
+            else if constexpr (k == 12) return cmul<T>(s8, s4);
+            else if constexpr (k == 13) return cmul<T>(s8, s5);
+            else if constexpr (k == 14) return cmul<T>(s8, s6);
+            else return cmul<T>(s8, s7);
+        };
         static_for<A>([&](auto aa) {
             constexpr int ia = aa;
             Dft<16, T>::run(v + ia * 16);
@@ -94,7 +127,7 @@ __global__ void __launch_bounds__(256, 2) fft_col2_kernel(const TileArgs a) {
                 constexpr int qb1 = q2 + 1;
                 cplx<T> t = v[ia * 16 + qb1];
                 if constexpr (ia > 0) t = mul_w16A<A, ia * qb1, T>(t);
-                v[ia * 16 + qb1] = cmul<T>(t, twB[q2]);
+                v[ia * 16 + qb1] = cmul<T>(t, tw(IC<qb1>{}));
             });
             __builtin_amdgcn_sched_barrier(0);  // one butterfly's temporaries at a time
         });
@@ -130,25 +163,26 @@ __global__ void __launch_bounds__(256, 2) fft_col2_kernel(const TileArgs a) {
     const int c2 = TR ? (tid >> 4) : (tid & 15);
     // output addressing, again uniform base + 32-bit per-thread offset.  The tile's 16 columns start at rem0
     // (a multiple of 16): l0/jp0 are uniform, (dl, djp) is the per-thread part (dl > 0 only when S < 16).
-    const long long l0 = rem0 >> a.logS;
-    const long long jp0 = rem0 & ((1ll << a.logS) - 1);
-    const unsigned dl = (unsigned)(((rem0 + c2) >> a.logS) - l0);
-    const unsigned djp = (unsigned)(((rem0 + c2) & ((1ll << a.logS) - 1)) - jp0);
+    const long long l0 = rem0 >> logS;
+    const long long jp0 = rem0 & ((1ll << logS) - 1);
+    const unsigned dl = (unsigned)(((rem0 + c2) >> logS) - l0);
+    const unsigned djp = (unsigned)(((rem0 + c2) & ((1ll << logS) - 1)) - jp0);
     const unsigned l = (unsigned)l0 + dl;  // row index of this thread's column in the inter-pass twiddle
     const T sx = (T)a.scale;
     const T sy = a.inverse ? -sx : sx;
     const cplx<T>* twlo = reinterpret_cast<const cplx<T>*>(a.tw_lo);
     const cplx<T>* twhi = reinterpret_cast<const cplx<T>*>(a.tw_hi);
-    const unsigned lomask = (1u << a.tw_shift) - 1u;
+    const int tw_shift = a.tw_shift;
+    const unsigned lomask = (1u << tw_shift) - 1u;
     // q = qb0*16A + qa*16 + u
     // non-TR: out[o][l][q][jp] -> uniform o*ostride + ((l0*L + qconst) << logS) + jp0 ; thread ((dl*L + u) << logS) + djp
     // TR (S == 1): out[o][l][q] -> uniform o*ostride + rem0*L + qconst ; thread c2*L + u
-    const long long oubase = TR ? (a.ostride_out * o + rem0 * L) : (a.ostride_out * o + ((l0 * L) << a.logS) + jp0);
-    const unsigned ovoff = TR ? ((unsigned)c2 * L + (unsigned)u) : ((((unsigned)dl * L + (unsigned)u) << a.logS) + djp);
+    const long long oubase = TR ? (a.ostride_out * o_out + rem0 * L) : (a.ostride_out * o_out + ((l0 * L) << logS) + jp0);
+    const unsigned ovoff = TR ? ((unsigned)c2 * L + (unsigned)u) : ((((unsigned)dl * L + (unsigned)u) << logS) + djp);
 
     static_for<A>([&](auto rr) {
         constexpr int qa = rr;
-        cplx<T>* buf = lds + (qa & 1) * BUF;
+        LdsPtr buf = lds + (qa & 1) * BUF;
         static_for<16>([&](auto ss) {
             constexpr int qb1 = ss;
             if constexpr (TR)
@@ -167,42 +201,41 @@ __global__ void __launch_bounds__(256, 2) fft_col2_kernel(const TileArgs a) {
         });
         Dft<16, T>::run(x);
         if constexpr (TW) {
-            // w(L*M)^(l*q), q = qb0*16A + qlow = w^(l*qlow) * s^qb0 with s = w^(l*16A).
-            // Table look-ups (two-level, tw_lo * tw_hi) for w^(l*qlow), s, s^2, s^4, s^8; the other powers by at
-            // most three multiplications (rebuilt every round on purpose: keeping 15 factors live across the
-            // rounds costs more registers than the 11 multiplies; twiddle error 5e-8 rms / 2e-7 max in fp32).
-            auto look = [&](unsigned e) { return cmul<T>(twlo[e & lomask], twhi[e >> a.tw_shift]); };
-            const cplx<T> wb = look(l * (unsigned)(qa * 16 + u));
-            cplx<T> pw[15];
-            pw[0] = look(l * (16u * A));
-            pw[1] = look(l * (32u * A));
-            pw[3] = look(l * (64u * A));
-            pw[7] = look(l * (128u * A));
-            pw[2] = cmul<T>(pw[0], pw[1]);
-            pw[4] = cmul<T>(pw[3], pw[0]);
-            pw[5] = cmul<T>(pw[3], pw[1]);
-            pw[6] = cmul<T>(pw[3], pw[2]);
-            static_for<7>([&](auto qq) {
-                constexpr int k = qq;  // pw[8 + k] = s^8 * s^(k+1)
-                pw[8 + k] = cmul<T>(pw[7], pw[k]);
-            });
-            x[0] = cmul<T>(x[0], wb);
-            static_for<15>([&](auto qq) {
-                constexpr int qb0 = qq + 1;
-                x[qb0] = cmul<T>(x[qb0], cmul<T>(wb, pw[qq]));
+            // w(L*M)^(l*q) for q = qb0*16A + qlow, qlow = qa*16 + u.  Four anchors (qb0 = 0, 4, 8, 12) come from
+            // the two-level table (tw_lo * tw_hi); the three factors after each anchor are one multiplication by
+            // s = w^(l*16A) each.  Depth <= 3 keeps the fp32 twiddle error at ~2.5e-7 max while only ~10 VGPRs are
+            // live (15 table factors held at once made this kernel spill).
+            auto look = [&](unsigned e) { return cmul<T>(twlo[e & lomask], twhi[e >> tw_shift]); };
+            const cplx<T> sstep = look(l * (16u * A));
+            static_for<4>([&](auto jj) {
+                constexpr int j = jj;
+                cplx<T> cur = look(l * (unsigned)(qa * 16 + u + 64 * A * j));
+                static_for<4>([&](auto ii) {
+                    constexpr int qb0 = 4 * j + ii;
+                    x[qb0] = cmul<T>(x[qb0], cur);
+                    if constexpr (ii < 3) cur = cmul<T>(cur, sstep);
+                });
             });
         }
         static_for<16>([&](auto qq) {
             constexpr int qb0 = qq;
             // uniform part of the output element index
             const long long gu = TR ? (oubase + qb0 * 16 * A + 16 * qa)
-                                    : (oubase + ((long long)(qb0 * 16 * A + 16 * qa) << a.logS));
+                                    : (oubase + ((long long)(qb0 * 16 * A + 16 * qa) << logS));
             cplx<T> r;
             r.x = x[qb0].x * sx;
             r.y = x[qb0].y * sy;
             if constexpr (!SPLIT) {
                 char* p = reinterpret_cast<char*>(reinterpret_cast<cplx<T>*>(a.out0) + gu);
-                *reinterpret_cast<cplx<T>*>(p + ovoff * (unsigned)sizeof(cplx<T>)) = r;
+                if constexpr (WT) {
+                    static_assert(!WT || sizeof(cplx<T>) == 8, "write-through path is fp32 interleaved only");
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p + ovoff * (unsigned)sizeof(cplx<T>)),
+                                       __builtin_bit_cast(unsigned long long, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if constexpr (NTOUT) {
+                    __builtin_nontemporal_store(r, reinterpret_cast<cplx<T>*>(p + ovoff * (unsigned)sizeof(cplx<T>)));
+                } else {
+                    *reinterpret_cast<cplx<T>*>(p + ovoff * (unsigned)sizeof(cplx<T>)) = r;
+                }
             } else {
                 char* pr = reinterpret_cast<char*>(reinterpret_cast<T*>(a.out0) + gu);
                 char* pi = reinterpret_cast<char*>(reinterpret_cast<T*>(a.out1) + gu);
@@ -211,6 +244,17 @@ __global__ void __launch_bounds__(256, 2) fft_col2_kernel(const TileArgs a) {
             }
         });
     });
+}
+
+// TR: S == 1 (first pass of a long contiguous axis; the store is a transposition)
+// TW: multiply by the inter-pass twiddle w(L*M)^(l*q)
+template <typename T, int A, bool TR, bool TW, bool SPLIT>
+__global__ void __launch_bounds__(256, 2) fft_col2_kernel(const TileArgs a) {
+    __shared__ __attribute__((aligned(16))) cplx<T> lds[Col2Lds<A, TR>::ELEMS];
+    const long long col0 = (long long)blockIdx.x * 16;
+    const long long o = col0 >> a.logMS;
+    const long long rem0 = col0 & ((1ll << a.logMS) - 1);
+    col2_tile<T, A, TR, TW, SPLIT>(a, o, o, rem0, lds);
 }
 
 }  // namespace mifft

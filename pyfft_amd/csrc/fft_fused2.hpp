@@ -1,0 +1,111 @@
+// Fused two-pass kernel for a long contiguous axis N = L0 * L1 (L0, L1 in {256, 512, 1024}): both Stockham
+// passes of every transform run inside ONE persistent launch, in dependency order, so the inter-pass
+// intermediate of a transform is consumed a few transforms later while it is still in the 256 MiB Infinity
+// Cache, and there are no launch boundaries (with 128 KiB tiles a cache-sized chunk is only ~2 machine-waves
+// of tiles, so per-chunk launches lose the cache gain to their tails).
+//
+// Work list (one global ticket counter): group g holds the pass-0 tiles of transform g interleaved with the
+// pass-1 tiles of transform g - lag.  Dependencies, all on LOWER ticket numbers (=> no deadlock for any
+// dispatch order / placement / residency):
+//     pass-1 tile of t   waits until all pass-0 tiles of t have published            (wdone[t] == tiles0)
+//     pass-0 tile of t   waits until all pass-1 tiles of t - ring have finished reading the ring slot it
+//                        is about to overwrite                                       (rdone[t-ring] == tiles1)
+// Hand-off (cdna_hip_programming.md Guideline 16, write-through form): the intermediate is written with
+// agent-coherent write-through stores, every storing wave drains vmcnt, the work-group barrier, one lane bumps
+// the counter (relaxed, agent scope); the consumer's one lane polls relaxed, ONE acquire fence, vmcnt drain,
+// barrier, then plain loads.  (A release fence per tile -- buffer_wbl2 -- made this kernel 2x slower than two
+// launches.)  The split-plane layout keeps the fence form: 4-byte write-through stores are too slow.
+// Every spin is bounded; on timeout an error word is set (the host checks it) instead of hanging the GPU.
+#pragma once
+#include "fft_col2.hpp"
+
+namespace mifft {
+
+struct FusedArgs {
+    TileArgs p0;         // pass 0: in = user input,  out = scratch ring (matrix index = ring slot)
+    TileArgs p1;         // pass 1: in = scratch ring, out = user output
+    unsigned* counters;  // [0] ticket, [1] error, [2 .. 2+batch) wdone, [2+batch .. 2+2*batch) rdone  (zeroed per launch)
+    unsigned batch;      // number of transforms
+    unsigned lag;        // pass 1 of transform t is queued with pass 0 of transform t + lag
+    unsigned ring;       // scratch ring slots (transforms); ring > lag
+    unsigned tiles0;     // 16-column tiles per transform in pass 0 (= L1 / 16)
+    unsigned tiles1;     // 16-column tiles per transform in pass 1 (= L0 / 16)
+};
+
+// wait until *ctr >= target (one lane polls, bounded); ACQ: also make other work-groups' published data visible
+template <bool ACQ> __device__ __forceinline__ void fused_wait_ge(unsigned* ctr, unsigned target, unsigned* err) {
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > (1u << 22)) {  // ~ seconds: never hang the GPU
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        if constexpr (ACQ) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+}
+
+// full agent-scope publication (release fence) -- only used by the split-plane layout
+__device__ __forceinline__ void fused_publish(unsigned* ctr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// signal "this tile is done".  The data a later tile depends on was written with write-through stores (pass 0) or
+// is only a read-completion (pass 1), so no release fence is needed: every wave drains its own memory
+// operations, the work-group barrier joins them, one lane bumps the counter.
+__device__ __forceinline__ void fused_signal(unsigned* ctr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename T, int A0, int A1, bool SPLIT, bool NT>
+__global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
+    constexpr int E0 = Col2Lds<A0, true>::ELEMS, E1 = Col2Lds<A1, false>::ELEMS;
+    __shared__ __attribute__((aligned(16))) cplx<T> lds[E0 > E1 ? E0 : E1];
+    __shared__ unsigned s_item;
+
+    unsigned* const next = f.counters;
+    unsigned* const err = f.counters + 1;
+    unsigned* const wdone = f.counters + 2;
+    unsigned* const rdone = wdone + f.batch;
+    const unsigned gsize = 2u * (f.tiles0 > f.tiles1 ? f.tiles0 : f.tiles1);
+    const unsigned total = (f.batch + f.lag) * gsize;
+
+    for (;;) {
+        __syncthreads();  // the previous item's LDS traffic and its s_item read are over
+        if (threadIdx.x == 0) s_item = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned item = s_item;
+        if (item >= total) break;
+        const unsigned g = item / gsize, k = item % gsize, tile = k >> 1;
+        if ((k & 1u) == 0u) {
+            if (g >= f.batch || tile >= f.tiles0) continue;
+            const unsigned t = g;
+            if (t >= f.ring) fused_wait_ge<false>(rdone + (t - f.ring), f.tiles1, err);
+            col2_tile<T, A0, true, true, SPLIT, !SPLIT, NT, false>(f.p0, (long long)t, (long long)(t % f.ring), (long long)tile * 16, lds);
+            if constexpr (SPLIT) fused_publish(wdone + t); else fused_signal(wdone + t);
+        } else {
+            if (g < f.lag) continue;
+            const unsigned t = g - f.lag;
+            if (t >= f.batch || tile >= f.tiles1) continue;
+            fused_wait_ge<true>(wdone + t, f.tiles0, err);
+            col2_tile<T, A1, false, false, SPLIT, false, false, NT>(f.p1, (long long)(t % f.ring), (long long)t, (long long)tile * 16, lds);
+            fused_signal(rdone + t);
+        }
+    }
+}
+
+}  // namespace mifft

@@ -1,0 +1,33 @@
+// fp32 instances of the fused two-pass kernel (fft_fused2.hpp).  -fno-slp-vectorize: see fft_col2_f32.hip.
+#include <cstdlib>
+#include "mifft_internal.h"
+#include "fft_fused2.hpp"
+
+namespace {
+template <int A0, int A1> int launch(const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s) {
+    static const bool nt = getenv("MIFFT_FUSED_NT") != nullptr;  // development switch: non-temporal streaming side
+    if (split)
+        hipLaunchKernelGGL((mifft::fft_fused2_kernel<float, A0, A1, true, false>), dim3(grid), dim3(256), 0, s, *f);
+    else if (nt && A0 == 4 && A1 == 4)
+        hipLaunchKernelGGL((mifft::fft_fused2_kernel<float, A0, A1, false, true>), dim3(grid), dim3(256), 0, s, *f);
+    else
+        hipLaunchKernelGGL((mifft::fft_fused2_kernel<float, A0, A1, false, false>), dim3(grid), dim3(256), 0, s, *f);
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int mifft_fused2_f32_launch(int L0, int L1, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s) {
+    const int key = (L0 / 256) * 10 + (L1 / 256);
+    switch (key) {
+        case 11: return launch<1, 1>(f, split, grid, s);
+        case 12: return launch<1, 2>(f, split, grid, s);
+        case 14: return launch<1, 4>(f, split, grid, s);
+        case 21: return launch<2, 1>(f, split, grid, s);
+        case 22: return launch<2, 2>(f, split, grid, s);
+        case 24: return launch<2, 4>(f, split, grid, s);
+        case 41: return launch<4, 1>(f, split, grid, s);
+        case 42: return launch<4, 2>(f, split, grid, s);
+        case 44: return launch<4, 4>(f, split, grid, s);
+    }
+    return -2;
+}

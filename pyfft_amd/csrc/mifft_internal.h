@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "fft_tile.hpp"
+#include "fft_fused2.hpp"
 
 // Each returns 0 on success, MIFFT_E_UNSUPPORTED (-2) when no kernel is compiled for (L, tr, variant),
 // or a hipError_t.  With query_only != 0 nothing is launched.
@@ -10,6 +11,7 @@ int mifft_dispatch_col_f32(int L, int tr, int variant, const mifft::TileArgs* a,
 int mifft_dispatch_row_f32(int L, int variant, const mifft::TileArgs* a, hipStream_t s, int query_only);
 int mifft_dispatch_col_f64(int L, int tr, int variant, const mifft::TileArgs* a, hipStream_t s, int query_only);
 int mifft_dispatch_row_f64(int L, int variant, const mifft::TileArgs* a, hipStream_t s, int query_only);
+int mifft_fused2_f32_launch(int L0, int L1, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
 }
 
 namespace mifft {

@@ -58,6 +58,34 @@ int validate(const mifft_pass* p) {
     return 0;
 }
 
+void fill_args(const mifft_pass* p, const void* in0, const void* in1, void* out0, void* out1, mifft::TileArgs* pa) {
+    mifft::TileArgs& a = *pa;
+    const bool split = p->layout == MIFFT_SPLIT;
+    a.in0 = in0;
+    a.in1 = in1;
+    a.out0 = out0;
+    a.out1 = out1;
+    a.tw_L = p->tw_L;
+    a.tw_lo = p->tw_lo;
+    a.tw_hi = p->tw_hi;
+    a.ostride_in = p->outer_stride_in;
+    a.ostride_out = p->outer_stride_out;
+    if (p->kind == MIFFT_PASS_COL) {
+        a.total = p->outer * p->M * p->S;
+        a.logMS = ilog2(p->M * p->S);
+        a.logS = ilog2(p->S);
+    } else {
+        a.total = p->outer;
+        a.logMS = 0;
+        a.logS = 0;
+    }
+    a.tw_shift = p->tw_shift;
+    a.split = split ? 1 : 0;
+    a.inverse = p->inverse ? 1 : 0;
+    a.has_tw = (p->kind == MIFFT_PASS_COL && p->M > 1) ? 1 : 0;
+    a.scale = p->scale;
+}
+
 int dispatch(const mifft_pass* p, const mifft::TileArgs* a, hipStream_t s, int query_only) {
     const int tr = (p->kind == MIFFT_PASS_COL && p->S == 1) ? 1 : 0;
     int rc;
@@ -194,29 +222,7 @@ int mifft_launch_pass(const mifft_pass* p, const void* in0, const void* in1, voi
     if (p->outer == 0) return 0;
 
     mifft::TileArgs a;
-    a.in0 = in0;
-    a.in1 = in1;
-    a.out0 = out0;
-    a.out1 = out1;
-    a.tw_L = p->tw_L;
-    a.tw_lo = p->tw_lo;
-    a.tw_hi = p->tw_hi;
-    a.ostride_in = p->outer_stride_in;
-    a.ostride_out = p->outer_stride_out;
-    if (p->kind == MIFFT_PASS_COL) {
-        a.total = p->outer * p->M * p->S;
-        a.logMS = ilog2(p->M * p->S);
-        a.logS = ilog2(p->S);
-    } else {
-        a.total = p->outer;
-        a.logMS = 0;
-        a.logS = 0;
-    }
-    a.tw_shift = p->tw_shift;
-    a.split = split ? 1 : 0;
-    a.inverse = p->inverse ? 1 : 0;
-    a.has_tw = (p->kind == MIFFT_PASS_COL && p->M > 1) ? 1 : 0;
-    a.scale = p->scale;
+    fill_args(p, in0, in1, out0, out1, &a);
     return dispatch(p, &a, (hipStream_t)stream, 0);
 }
 
@@ -228,6 +234,95 @@ int mifft_launch_chain(const mifft_pass* passes, int32_t npasses, void* const bu
         const void* i1 = bufs1 ? bufs1[p->src] : nullptr;
         void* o1 = bufs1 ? bufs1[p->dst] : nullptr;
         int rc = mifft_launch_pass(p, bufs0[p->src], i1, bufs0[p->dst], o1, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* in0, const void* in1, void* out0, void* out1,
+                        void* ring0, void* ring1, int32_t ring_slots, int32_t lag, void* counters, int32_t grid,
+                        mifft_stream_t stream) {
+    int rc = validate(p0);
+    if (rc) return rc;
+    rc = validate(p1);
+    if (rc) return rc;
+    if (p0->precision != MIFFT_F32 || p1->precision != MIFFT_F32) return set_err(MIFFT_E_UNSUPPORTED, "fused2: fp32 only");
+    if (p0->kind != MIFFT_PASS_COL || p1->kind != MIFFT_PASS_COL || p0->S != 1 || p0->M != p1->L || p1->M != 1 ||
+        p1->S != p0->L || p0->outer != p1->outer || p0->layout != p1->layout || p0->inverse != p1->inverse)
+        return set_err(MIFFT_E_INVALID, "fused2: passes are not the two passes of one long contiguous axis");
+    auto ok_len = [](int L) { return L == 256 || L == 512 || L == 1024; };
+    if (!ok_len(p0->L) || !ok_len(p1->L)) return set_err(MIFFT_E_UNSUPPORTED, "fused2: no kernel for %d x %d", p0->L, p1->L);
+    const bool split = p0->layout == MIFFT_SPLIT;
+    if (!in0 || !out0 || !ring0 || !counters || (split && (!in1 || !out1 || !ring1))) return set_err(MIFFT_E_INVALID, "fused2: null buffer");
+    if (ring_slots < 2 || lag < 1 || lag >= ring_slots || grid < 1) return set_err(MIFFT_E_INVALID, "fused2: need 1 <= lag < ring_slots, grid >= 1");
+    if (((uintptr_t)in0 | (uintptr_t)out0 | (uintptr_t)ring0 | (uintptr_t)in1 | (uintptr_t)out1 | (uintptr_t)ring1) & 15)
+        return set_err(MIFFT_E_INVALID, "data buffers must be 16-byte aligned");
+    if (p0->outer == 0) return 0;
+    if (p0->outer > 0x3fffffff) return set_err(MIFFT_E_INVALID, "fused2: batch too large");
+    const int64_t n = (int64_t)p0->L * p1->L;
+    mifft::FusedArgs f;
+    fill_args(p0, in0, in1, ring0, ring1, &f.p0);
+    fill_args(p1, ring0, ring1, out0, out1, &f.p1);
+    f.p0.ostride_out = n;  // ring slot pitch
+    f.p1.ostride_in = n;
+    f.counters = (unsigned*)counters;
+    f.batch = (unsigned)p0->outer;
+    f.lag = (unsigned)lag;
+    f.ring = (unsigned)ring_slots;
+    f.tiles0 = (unsigned)(p0->M / 16);
+    f.tiles1 = (unsigned)(p1->S / 16);
+    rc = hip_check(hipMemsetAsync(counters, 0, (size_t)(2 + 2 * p0->outer) * 4, (hipStream_t)stream), "hipMemsetAsync");
+    if (rc) return rc;
+    rc = mifft_fused2_f32_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream);
+    if (rc == MIFFT_E_UNSUPPORTED) return set_err(rc, "fused2: no kernel for %d x %d", p0->L, p1->L);
+    if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
+    return 0;
+}
+
+int mifft_launch_chain_pipelined(const mifft_pass* passes, int32_t npasses, void* const bufs0[3], void* const bufs1[3],
+                                 int64_t batch, int64_t chunk, int64_t item_elems, mifft_stream_t stream,
+                                 const mifft_stream_t* side, int32_t nside, const mifft_event_t* events) {
+    if (npasses < 0 || (npasses > 0 && !passes) || !bufs0) return set_err(MIFFT_E_INVALID, "bad chain arguments");
+    if (batch < 1 || chunk < 1 || item_elems < 1 || nside < 1 || !side || !events)
+        return set_err(MIFFT_E_INVALID, "bad pipeline arguments");
+    for (int i = 0; i < npasses; ++i) {
+        const mifft_pass* p = &passes[i];
+        if (p->src < 0 || p->src > 2 || p->dst < 0 || p->dst > 2) return set_err(MIFFT_E_INVALID, "pass %d: bad buffer index", i);
+        if (p->outer % batch) return set_err(MIFFT_E_INVALID, "pass %d: outer is not a multiple of the batch", i);
+    }
+    if (npasses == 0) return 0;
+    const bool f64 = passes[0].precision == MIFFT_F64;
+    const bool split = passes[0].layout == MIFFT_SPLIT;
+    const int64_t ebytes = (split ? 1 : 2) * (f64 ? 8 : 4);
+    int rc = hip_check(hipEventRecord((hipEvent_t)events[0], (hipStream_t)stream), "hipEventRecord");
+    if (rc) return rc;
+    const int64_t nchunks = (batch + chunk - 1) / chunk;
+    const int used = (int)(nchunks < nside ? nchunks : nside);
+    for (int s = 0; s < used; ++s) {
+        rc = hip_check(hipStreamWaitEvent((hipStream_t)side[s], (hipEvent_t)events[0], 0), "hipStreamWaitEvent");
+        if (rc) return rc;
+    }
+    for (int64_t c = 0; c < nchunks; ++c) {
+        const int64_t nb = (c + 1) * chunk <= batch ? chunk : batch - c * chunk;
+        const int slot = (int)(c % nside);
+        const int64_t off_io = c * chunk * item_elems * ebytes;
+        const int64_t off_tmp = (int64_t)slot * chunk * item_elems * ebytes;
+        for (int i = 0; i < npasses; ++i) {
+            mifft_pass p = passes[i];
+            p.outer = p.outer / batch * nb;
+            auto at = [&](void* const* bufs, int idx) -> void* {
+                if (!bufs || !bufs[idx]) return nullptr;
+                return (char*)bufs[idx] + (idx == 2 ? off_tmp : off_io);
+            };
+            rc = mifft_launch_pass(&p, at(bufs0, p.src), split ? at(bufs1, p.src) : nullptr, at(bufs0, p.dst),
+                                   split ? at(bufs1, p.dst) : nullptr, side[slot]);
+            if (rc) return rc;
+        }
+    }
+    for (int s = 0; s < used; ++s) {
+        rc = hip_check(hipEventRecord((hipEvent_t)events[1 + s], (hipStream_t)side[s]), "hipEventRecord");
+        if (rc) return rc;
+        rc = hip_check(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)events[1 + s], 0), "hipStreamWaitEvent");
         if (rc) return rc;
     }
     return 0;

@@ -8,6 +8,7 @@ whole pass list is enqueued by one native call (mifft_launch_chain) instead of a
 """
 
 import ctypes
+import os
 
 import numpy
 
@@ -103,6 +104,10 @@ class FFTPlan(object):
         self._tempmemobj_im = None
         self._last_batch_size = 0
         self._desc_cache = {}
+        self._strategy = ("chain",)
+        self._counters = None
+        self._side_streams = None
+        self._side_events = None
 
         if self._params.split:
             self.execute = self._executeSplit
@@ -189,28 +194,103 @@ class FFTPlan(object):
         return arr
 
     # ------------------------------------------------------------------------------------
-    def _execute(self, wait_for_finish, is_inplace, inverse, batch, *args):
-        """Execute plan for given data type (plan.py:173-259)."""
+    # ------------------------------------------------------------------------------------
+    # execution strategies (all enqueue the same passes; they differ in how the batch is cut and overlapped)
+    #   chain      one launch per pass over the whole batch (the reference's loop, plan.py:217-248)
+    #   pipelined  batch cut into Infinity-Cache-sized chunks, chunk i on side stream i % n with its own temp
+    #              slot (mifft_launch_chain_pipelined)
+    #   fused2     both passes of a long 1-D fp32 transform in one persistent launch (mifft_launch_fused2)
+    PIPELINE_TARGET_BYTES = 64 << 20
+    PIPELINE_STREAMS = 2
+
+    def _fused2_eligible(self):
+        p = self._params
+        k = self._kernels
+        return (p.precision == N.F32 and not p.split and len(k) == 2 and int(p.y) == 1 and int(p.z) == 1
+                and k[0].kind == N.PASS_COL and k[1].kind == N.PASS_COL and k[0].S == 1 and k[0].M == k[1].L
+                and k[1].M == 1 and k[0].L in (256, 512, 1024) and k[1].L in (256, 512, 1024))
+
+    def _select_strategy(self, batch):
+        forced = os.environ.get("PYFFT_AMD_STRATEGY", "auto")
+        p = self._params
+        item_bytes = p.size * p.complex_nbytes
+        chunk = max(1, self.PIPELINE_TARGET_BYTES // item_bytes)
+        strat = ("chain",)
+        if self._temp_buffer_needed and forced in ("auto", "fused") and self._fused2_eligible():
+            grid = 2 * self._context.compute_units
+            gsize = 2 * max(self._kernels[0].M // 16, self._kernels[1].S // 16)
+            lag = max(2, -(-9 * grid // (4 * gsize)))
+            ring = 2 * lag
+            # measured on MI355X: the persistent kernel beats stream-pipelined chunks only for 1024 x 1024
+            big = min(self._kernels[0].L, self._kernels[1].L) >= 1024
+            if batch >= 2 * ring and (big or forced == "fused"):
+                return ("fused2", lag, ring, grid)
+        if self._temp_buffer_needed and forced in ("auto", "pipelined") and batch >= 4 * chunk:
+            return ("pipelined", chunk, self.PIPELINE_STREAMS)
+        return strat
+
+    def _prepare(self, batch):
+        """(Re)allocate the plan-owned scratch when the batch changes (plan.py:179-192)."""
         ctx = self._context
         p = self._params
-        split = p.split
-        batch = int(batch)
-        if batch < 1:
-            raise ValueError("batch must be positive")
+        if self._last_batch_size == batch:
+            return
+        self._last_batch_size = batch
+        self._strategy = self._select_strategy(batch)
+        self._tempmemobj = self._tempmemobj_re = self._tempmemobj_im = None
+        if not self._temp_buffer_needed:
+            return
+        if self._strategy[0] == "fused2":
+            items = self._strategy[2]                     # ring slots
+            self._counters = ctx.allocate_raw((2 + 2 * batch) * 4)
+        elif self._strategy[0] == "pipelined":
+            items = self._strategy[1] * self._strategy[2]  # chunk * streams
+            if self._side_streams is None:
+                from .hip import Stream, Event
+                self._side_streams = [Stream() for _ in range(self._strategy[2])]
+                self._side_events = [Event() for _ in range(self._strategy[2] + 1)]
+        else:
+            items = batch
+        buffer_size = p.size * items * p.scalar_nbytes
+        if p.split:
+            self._tempmemobj_re = ctx.allocate(buffer_size)
+            self._tempmemobj_im = ctx.allocate(buffer_size)
+        else:
+            self._tempmemobj = ctx.allocate(buffer_size * 2)
 
-        new_batch = self._last_batch_size != batch
-        if new_batch:
-            self._last_batch_size = batch
-        if self._temp_buffer_needed and new_batch:       # plan.py:184-192
-            buffer_size = p.size * batch * p.scalar_nbytes
-            if split:
-                self._tempmemobj_re = ctx.allocate(buffer_size)
-                self._tempmemobj_im = ctx.allocate(buffer_size)
-            else:
-                self._tempmemobj = ctx.allocate(buffer_size * 2)
+    def _enqueue(self, batch, is_inplace, inverse, bufs0, bufs1):
+        ctx = self._context
+        descs = self._descriptors(batch, is_inplace, bool(inverse))
+        stream = ctx.stream_handle()
+        strat = self._strategy
+        if strat[0] == "fused2":
+            _, lag, ring, grid = strat
+            d0, d1 = descs[0], descs[1]
+            # the two-pass schedule is in -> temp -> out for both in-place and out-of-place calls
+            N.check(N.lib.mifft_launch_fused2(ctypes.byref(d0), ctypes.byref(d1), bufs0[d0.src], None, bufs0[d1.dst], None,
+                                              bufs0[2], None, ring, lag, ctx.pointer_of(self._counters), grid, stream),
+                    "mifft_launch_fused2")
+        elif strat[0] == "pipelined":
+            _, chunk, nside = strat
+            side = (ctypes.c_void_p * nside)(*[s.handle for s in self._side_streams])
+            evs = (ctypes.c_void_p * (nside + 1))(*[e.handle for e in self._side_events])
+            N.check(N.lib.mifft_launch_chain_pipelined(descs, len(self._kernels), bufs0, bufs1, batch, chunk,
+                                                       self._params.size, stream, side, nside, evs),
+                    "mifft_launch_chain_pipelined")
+        else:
+            N.check(N.lib.mifft_launch_chain(descs, len(self._kernels), bufs0, bufs1, stream), "mifft_launch_chain")
 
-        ptr = ctx.pointer_of
-        if split:
+    def _check_fused(self):
+        """After a synchronisation: the fused kernel's dependency time-out word must be clear."""
+        if self._strategy[0] == "fused2":
+            flag = numpy.zeros(2, numpy.uint32)
+            N.check(N.lib.mifft_memcpy_d2h(flag.ctypes.data, self._context.pointer_of(self._counters), 8, None), "d2h")
+            if flag[1] != 0:
+                raise RuntimeError("pyfft_amd: fused kernel dependency time-out (results invalid)")
+
+    def _buffers(self, is_inplace, args):
+        ptr = self._context.pointer_of
+        if self._params.split:
             in_re, in_im, out_re, out_im = (ptr(a) for a in args)
             # explicit aliasing is an in-place call (Appendix A item 5 of SURVEY.md)
             if not is_inplace and (in_re == out_re or in_im == out_im):
@@ -226,12 +306,19 @@ class FFTPlan(object):
                 is_inplace = True
             bufs0 = N.make_buf3(d_in, d_out, ptr(self._tempmemobj) if self._tempmemobj is not None else None)
             bufs1 = None
+        return is_inplace, bufs0, bufs1
 
-        descs = self._descriptors(batch, is_inplace, bool(inverse))
+    def _execute(self, wait_for_finish, is_inplace, inverse, batch, *args):
+        """Execute plan for given data type (plan.py:173-259)."""
+        ctx = self._context
+        batch = int(batch)
+        if batch < 1:
+            raise ValueError("batch must be positive")
+        self._prepare(batch)
+        is_inplace, bufs0, bufs1 = self._buffers(is_inplace, args)
 
         ctx.createQueue()
-        stream = ctx.stream_handle()
-        N.check(N.lib.mifft_launch_chain(descs, len(self._kernels), bufs0, bufs1, stream), "mifft_launch_chain")
+        self._enqueue(batch, is_inplace, inverse, bufs0, bufs1)
 
         # global wait setting has lower priority than the local one (plan.py:250-253)
         wait = self._wait_for_finish
@@ -240,6 +327,7 @@ class FFTPlan(object):
 
         if wait:
             ctx.wait()
+            self._check_fused()
         else:
             ctx.flush()
             return ctx.getQueue()
@@ -272,33 +360,25 @@ class FFTPlan(object):
     def pass_list(self):
         return list(self._kernels)
 
+    def strategy(self, batch):
+        self._prepare(int(batch))
+        return self._strategy
+
     def timed_execute(self, repeats, is_inplace, inverse, batch, bufs_in, bufs_out):
-        """Device time (ms) of `repeats` back-to-back executions, measured with HIP events on the
-        plan's stream by mifft_time_chain (hipEvents see the stream the kernels are launched on)."""
+        """Device time (ms) of `repeats` back-to-back executions, measured with HIP events recorded on the
+        plan's stream (hipEvents see the stream the kernels are launched on)."""
+        from .hip import Event
         ctx = self._context
-        p = self._params
-        ptr = ctx.pointer_of
         batch = int(batch)
-        if self._temp_buffer_needed and self._last_batch_size != batch:
-            self._last_batch_size = batch
-            buffer_size = p.size * batch * p.scalar_nbytes
-            if p.split:
-                self._tempmemobj_re = ctx.allocate(buffer_size)
-                self._tempmemobj_im = ctx.allocate(buffer_size)
-            else:
-                self._tempmemobj = ctx.allocate(buffer_size * 2)
-        if p.split:
-            bufs0 = N.make_buf3(ptr(bufs_in[0]), ptr(bufs_out[0]),
-                                ptr(self._tempmemobj_re) if self._tempmemobj_re is not None else None)
-            bufs1 = N.make_buf3(ptr(bufs_in[1]), ptr(bufs_out[1]),
-                                ptr(self._tempmemobj_im) if self._tempmemobj_im is not None else None)
-        else:
-            bufs0 = N.make_buf3(ptr(bufs_in[0]), ptr(bufs_out[0]),
-                                ptr(self._tempmemobj) if self._tempmemobj is not None else None)
-            bufs1 = None
-        descs = self._descriptors(batch, is_inplace, bool(inverse))
+        self._prepare(batch)
+        args = (bufs_in[0], bufs_in[1], bufs_out[0], bufs_out[1]) if self._params.split else (bufs_in[0], bufs_out[0])
+        is_inplace, bufs0, bufs1 = self._buffers(is_inplace, args)
         ctx.createQueue()
-        ms = ctypes.c_float(0.0)
-        N.check(N.lib.mifft_time_chain(descs, len(self._kernels), bufs0, bufs1, ctx.stream_handle(),
-                                       int(repeats), ctypes.byref(ms)), "mifft_time_chain")
-        return float(ms.value)
+        e0, e1 = Event(), Event()
+        e0.record(ctx.getQueue())
+        for _ in range(int(repeats)):
+            self._enqueue(batch, is_inplace, inverse, bufs0, bufs1)
+        e1.record(ctx.getQueue())
+        e1.synchronize()
+        self._check_fused()
+        return e1.time_since(e0)

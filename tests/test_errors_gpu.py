@@ -139,3 +139,48 @@ def test_errors_config4_shape_reduced(ctx, dtype):
     """3-D fp64 in both layouts (BASELINE config 4 at 64^3 and 256x16x16)."""
     run_protocol(ctx, (64, 64, 64), dtype, 1, seed=1004, check_oracle=False)
     run_protocol(ctx, (256, 16, 16), dtype, 2, seed=1004, check_oracle=False)
+
+
+# ---- execution strategies: the fused persistent kernel and the stream-pipelined chunks must give exactly the
+# ---- bits of the one-launch-per-pass chain (same kernels' arithmetic), and the reference protocol must hold
+def _run_strategy(ctx, monkeypatch, strat, shape, batch, data, inplace=False, inverse=False):
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", strat)
+    plan = ctx.getPlan(shape, dtype=numpy.complex64)
+    assert plan.strategy(batch)[0] == {"fused": "fused2", "chain": "chain", "pipelined": "pipelined"}[strat]
+    a = ctx.toGpu(data)
+    if inplace:
+        plan.execute(a, batch=batch, inverse=inverse)
+        return a.get()
+    b = ctx.allocate(data.shape, data.dtype)
+    plan.execute(a, b, batch=batch, inverse=inverse)
+    assert numpy.array_equal(a.get(), data)
+    return b.get()
+
+
+@pytest.mark.parametrize("n,batch", [(1 << 16, 160), (1 << 17, 96), (1 << 18, 80), (1 << 19, 40), (1 << 20, 37)], ids=str)
+def test_fused_two_pass_kernel(ctx, monkeypatch, n, batch):
+    data = oracle.get_test_data((n,), numpy.complex64, batch, 4242)
+    want = _run_strategy(ctx, monkeypatch, "chain", (n,), batch, data)
+    got = _run_strategy(ctx, monkeypatch, "fused", (n,), batch, data)
+    assert numpy.array_equal(want, got), "fused kernel differs from the two-launch chain"
+    got_ip = _run_strategy(ctx, monkeypatch, "fused", (n,), batch, data, inplace=True)
+    assert numpy.array_equal(want, got_ip), "fused in-place differs"
+    for item in (0, batch // 2, batch - 1):
+        ref = numpy.fft.fft(data[item * n:(item + 1) * n].astype(numpy.complex128))
+        g = got[item * n:(item + 1) * n]
+        assert numpy.abs(ref - g).sum() / numpy.abs(ref).sum() < 1.1e-6
+        assert numpy.abs(ref - g).max() <= 1e-5 * numpy.abs(ref).max()
+    back = _run_strategy(ctx, monkeypatch, "fused", (n,), batch, got, inverse=True)
+    assert oracle.difference(data, back, batch) < 1.1e-6
+
+
+@pytest.mark.parametrize("shape,batch", [((8192,), 4099), ((1 << 16,), 515), ((4096, 2), 4100)], ids=str)
+def test_pipelined_chunks(ctx, monkeypatch, shape, batch):
+    data = oracle.get_test_data(shape, numpy.complex64, batch, 777)
+    want = _run_strategy(ctx, monkeypatch, "chain", shape, batch, data)
+    got = _run_strategy(ctx, monkeypatch, "pipelined", shape, batch, data)
+    assert numpy.array_equal(want, got), "pipelined execution differs from the plain chain"
+    got_ip = _run_strategy(ctx, monkeypatch, "pipelined", shape, batch, data, inplace=True)
+    assert numpy.array_equal(want, got_ip)
+    ref = oracle.numpy_fft(numpy.fft.fftn, data[:shape[0] * 2], 2)
+    assert oracle.difference(ref, got[:shape[0] * 2], 2) < 1.1e-6

@@ -40,22 +40,25 @@ def run(shape, dtype, batch, iters=5, inplace=False):
         best = min(best, ms)
     alg = 2.0 * nel * itemsize
     flops = 5.0 * size * numpy.log2(size) * batch
-    print("%-18s %-10s batch %-7d %s passes=%s  %.3f ms  %.1f GB/s alg (%.1f%% of 8TB/s)  %.0f GFLOPS" % (
-        str(shape), dt.name, batch, "inpl" if inplace else "outp", plan.pass_list(), best,
+    print("%-18s %-10s batch %-7d %s %s passes=%s  %.3f ms  %.1f GB/s alg (%.1f%% of 8TB/s)  %.0f GFLOPS" % (
+        str(shape), dt.name, batch, "inpl" if inplace else "outp", plan.strategy(batch)[0], plan.pass_list(), best,
         alg / best / 1e6, alg / best / 1e6 / 80.0, flops / best / 1e6), flush=True)
 
 if __name__ == "__main__":
     p = device_props()
     print(p.name.decode(), p.gcn_arch.decode(), "CUs", p.compute_units, flush=True)
     c64, c128, f32, f64 = numpy.complex64, numpy.complex128, numpy.float32, numpy.float64
-    cases = [
-        ((1024,), c64, 1 << 16), ((4096,), c64, 1 << 14), ((256,), c64, 1 << 18), ((16,), c64, 1 << 22),
-        ((1 << 20,), c64, 64), ((1 << 20,), c64, 256), ((1 << 20,), f32, 64),
-        ((1 << 16,), c64, 1024), ((8192,), c64, 8192),
-        ((1024, 1024), c64, 64), ((1024, 1024), c64, 256),
-        ((256, 256, 256), c128, 4), ((256, 256, 256), f64, 4), ((128, 128, 128), c64, 32),
-        ((1 << 22,), c64, 32),
-    ]
+    if len(sys.argv) > 1 and sys.argv[1] == "1d":
+        cases = [((1 << k,), c64, max(64, (1 << 31) >> (k + 3))) for k in (13, 14, 15, 16, 17, 18, 19, 20, 21, 22)]
+    else:
+        cases = [
+            ((1024,), c64, 1 << 16), ((4096,), c64, 1 << 14), ((256,), c64, 1 << 18), ((16,), c64, 1 << 22),
+            ((1 << 20,), c64, 256), ((1 << 20,), f32, 64),
+            ((1 << 16,), c64, 1024), ((8192,), c64, 8192),
+            ((1024, 1024), c64, 256),
+            ((256, 256, 256), c128, 4), ((256, 256, 256), f64, 4), ((128, 128, 128), c64, 32),
+            ((1 << 22,), c64, 32),
+        ]
     for shape, dt, batch in cases:
         try:
             run(shape, dt, batch)
