@@ -171,6 +171,7 @@ def main():
     ap.add_argument("--inplace", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--selftest-dist", action="store_true", help="CPU/gloo self-test of the multi-process harness")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even at world size 1 (test)")
     args = ap.parse_args()
 
     if args.selftest_dist:
@@ -190,7 +191,7 @@ def main():
     dist = None
     if torch is not None and torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world)
 

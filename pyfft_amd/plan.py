@@ -225,7 +225,9 @@ class FFTPlan(object):
             big = min(self._kernels[0].L, self._kernels[1].L) >= 1024
             if batch >= 2 * ring and (big or forced == "fused"):
                 return ("fused2", lag, ring, grid)
-        if self._temp_buffer_needed and forced in ("auto", "pipelined") and batch >= 4 * chunk:
+        # any multi-pass plan gains from cache-sized chunks (the second pass re-reads what the first just wrote),
+        # whether or not it needs a temp buffer
+        if len(self._kernels) >= 2 and forced in ("auto", "pipelined") and batch >= 4 * chunk:
             return ("pipelined", chunk, self.PIPELINE_STREAMS)
         return strat
 
@@ -238,6 +240,10 @@ class FFTPlan(object):
         self._last_batch_size = batch
         self._strategy = self._select_strategy(batch)
         self._tempmemobj = self._tempmemobj_re = self._tempmemobj_im = None
+        if self._strategy[0] == "pipelined" and self._side_streams is None:
+            from .hip import Stream, Event
+            self._side_streams = [Stream() for _ in range(self._strategy[2])]
+            self._side_events = [Event() for _ in range(self._strategy[2] + 1)]
         if not self._temp_buffer_needed:
             return
         if self._strategy[0] == "fused2":
@@ -245,10 +251,6 @@ class FFTPlan(object):
             self._counters = ctx.allocate_raw((2 + 2 * batch) * 4)
         elif self._strategy[0] == "pipelined":
             items = self._strategy[1] * self._strategy[2]  # chunk * streams
-            if self._side_streams is None:
-                from .hip import Stream, Event
-                self._side_streams = [Stream() for _ in range(self._strategy[2])]
-                self._side_events = [Event() for _ in range(self._strategy[2] + 1)]
         else:
             items = batch
         buffer_size = p.size * items * p.scalar_nbytes

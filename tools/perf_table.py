@@ -1,0 +1,48 @@
+"""Counterpart of the reference's test/test_performance.py: the 11 published shapes, batch chosen to fill a
+32 MiB buffer (test_performance.py:11), 1 warm-up + 10 timed out-of-place executes, GFLOPS by
+5e-9 * (log2 x + log2 y + log2 z) * x*y*z * batch / t (test_performance.py:24).  Prints a table next to the
+reference's published Tesla C2050 numbers (doc/source/index.rst:357-373)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy
+from pyfft_amd.hip import Plan, DeviceArray, Event
+from pyfft_amd import _native as N
+
+PUBLISHED_C2050 = {  # shape -> (pyfft sp, cufft sp, pyfft dp, cufft dp) GFLOPS
+    (16,): (91.4, 127.1, 37.8, 28.3), (1024,): (254.0, 316.2, 28.4, 75.9), (8192,): (117.3, 250.6, 29.3, 94.7),
+    (16, 16): (106.7, 119.7, 43.4, 39.4), (128, 128): (187.2, 198.7, 47.4, 53.4), (1024, 1024): (168.5, 184.4, 27.7, 73.7),
+    (16, 16, 16): (117.6, 117.6, 47.0, 45.0), (32, 32, 128): (163.9, 161.6, 58.8, 63.2), (128, 128, 128): (184.7, 191.2, 44.6, 52.2),
+}
+SHAPES = [(16,), (1024,), (8192,), (16, 16), (128, 128), (1024, 1024), (8, 8, 64), (16, 16, 16), (16, 16, 128),
+          (32, 32, 128), (128, 128, 128)]
+
+def run(shape, double, buffer_mib):
+    dtype = numpy.complex128 if double else numpy.complex64
+    size = int(numpy.prod(shape))
+    batch = (buffer_mib << 20) // (size * numpy.dtype(dtype).itemsize)
+    if batch == 0:
+        return None
+    rng = numpy.random.default_rng(5)
+    fdt = numpy.float64 if double else numpy.float32
+    data = (rng.standard_normal(size * batch).astype(fdt) + 1j * rng.standard_normal(size * batch).astype(fdt)).astype(dtype)
+    a = DeviceArray((size * batch,), dtype).set(data)
+    b = DeviceArray((size * batch,), dtype)
+    plan = Plan(shape if len(shape) > 1 else shape[0], dtype=dtype, wait_for_finish=True)
+    gflop = 5.0e-9 * sum(numpy.log2(s) for s in shape) * size * batch
+    plan.execute(a, b, batch=batch)
+    st = plan._context.getQueue()
+    e0 = Event().record(st)
+    for _ in range(10):
+        plan.execute(a, b, batch=batch, wait_for_finish=False)
+    e1 = Event().record(st); e1.synchronize()
+    t = e1.time_since(e0) / 1e3 / 10
+    return batch, t, gflop / t
+
+if __name__ == "__main__":
+    for buffer_mib in (32, 1024):
+        print("buffer %d MiB (the reference uses 32 MiB, test/helpers.py:7)" % buffer_mib)
+        print("%-16s %8s %12s %12s   %s" % ("shape", "batch", "sp GFLOPS", "dp GFLOPS", "published C2050 pyfft/cufft sp, pyfft/cufft dp"))
+        for shape in SHAPES:
+            sp = run(shape, False, buffer_mib); dp = run(shape, True, buffer_mib)
+            pub = PUBLISHED_C2050.get(shape)
+            print("%-16s %8d %12.1f %12.1f   %s" % (str(shape), sp[0], sp[2], dp[2], pub if pub else "-"), flush=True)
