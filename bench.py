@@ -351,7 +351,7 @@ def main():
 
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
-    if os.path.exists(tf):
+    if os.path.exists(tf) and not args.batch and not args.inplace:   # measured on the default workload only
         try:
             traffic = json.load(open(tf)).get("hbm_bytes_per_step")
         except Exception:
