@@ -1,0 +1,28 @@
+// fp64 two-phase strided-axis kernel (fft_col2.hpp) for L = 256 (16 points per thread, one 64 KiB LDS exchange,
+// two work-groups per CU; 16 columns = 256-byte segments interleaved, 128-byte segments per plane when split).
+// L = 512 / 1024 in fp64 would need 128 KiB of LDS or 256 data VGPRs per thread and stay on the generic tile kernel.
+#include "mifft_internal.h"
+#include "fft_col2.hpp"
+
+namespace {
+template <bool TR, bool TW> int launch_l(const mifft::TileArgs* a, hipStream_t s) {
+    const long long tiles = a->total / 16;
+    if (tiles > 2147483647ll) return -1;
+    if (a->split)
+        hipLaunchKernelGGL((mifft::fft_col2_kernel<double, 1, TR, TW, true>), dim3((unsigned)tiles), dim3(256), 0, s, *a);
+    else
+        hipLaunchKernelGGL((mifft::fft_col2_kernel<double, 1, TR, TW, false>), dim3((unsigned)tiles), dim3(256), 0, s, *a);
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int mifft_col2_f64_eligible(int L, int tr, const mifft::TileArgs* a) {
+    if (L != 256) return 0;
+    if (a->total <= 0 || a->logMS < 4 || a->logMS > 23 || a->logS > 21) return 0;
+    return tr ? (a->has_tw != 0) : (a->has_tw == 0);
+}
+
+extern "C" int mifft_col2_f64_launch(int L, int tr, const mifft::TileArgs* a, hipStream_t s) {
+    if (L != 256) return -2;
+    return tr ? launch_l<true, true>(a, s) : launch_l<false, false>(a, s);
+}
