@@ -66,6 +66,32 @@ template <typename T> __device__ __forceinline__ void store_pair(const TileArgs&
     }
 }
 
+// V consecutive points (V = 2: one 16-byte access interleaved / one 8-byte access per plane when split;
+// V = 4: split planes only, one 16-byte access per plane)
+template <typename T, int V> __device__ __forceinline__ void load_vec(const TileArgs& a, long long g, cplx<T>* p) {
+    if constexpr (V == 2) {
+        load_pair<T>(a, g, p[0], p[1]);
+    } else {
+        using V4 = T __attribute__((ext_vector_type(4)));
+        const V4 re = *reinterpret_cast<const V4*>(reinterpret_cast<const T*>(a.in0) + g);
+        const V4 im = *reinterpret_cast<const V4*>(reinterpret_cast<const T*>(a.in1) + g);
+        p[0].x = re.x; p[0].y = im.x; p[1].x = re.y; p[1].y = im.y;
+        p[2].x = re.z; p[2].y = im.z; p[3].x = re.w; p[3].y = im.w;
+    }
+}
+template <typename T, int V> __device__ __forceinline__ void store_vec(const TileArgs& a, long long g, const cplx<T>* p) {
+    if constexpr (V == 2) {
+        store_pair<T>(a, g, p[0], p[1]);
+    } else {
+        using V4 = T __attribute__((ext_vector_type(4)));
+        V4 re, im;
+        re.x = p[0].x; im.x = p[0].y; re.y = p[1].x; im.y = p[1].y;
+        re.z = p[2].x; im.z = p[2].y; re.w = p[3].x; im.w = p[3].y;
+        *reinterpret_cast<V4*>(reinterpret_cast<T*>(a.out0) + g) = re;
+        *reinterpret_cast<V4*>(reinterpret_cast<T*>(a.out1) + g) = im;
+    }
+}
+
 // LDS addressing ---------------------------------------------------------------------------------------
 // COL layout A: [idx][c]            (c fastest: the W adjacent columns)
 // COL layout B: [c][idx], row pitch L+1 (used for the last stage of a transposing pass)
@@ -182,44 +208,57 @@ __global__ void __launch_bounds__(NT) fft_tile_kernel(const TileArgs a) {
     const long long MSmask = (1ll << a.logMS) - 1;
     cplx<T> v[PPT];
 
-    // ---- global -> registers (all loads in flight), then -> LDS
-    static_for<PPT / 2>([&](auto ii) {
-        constexpr int it = ii;
-        const int e = (it * NT + tid) * 2;
-        cplx<T> p0, p1;
-        p0.x = 0; p0.y = 0; p1.x = 0; p1.y = 0;
-        if constexpr (ROW) {
-            const int c = e / L, r = e % L;
-            const long long rr = col0 + c;
-            if (rr < a.total) load_pair<T>(a, rr * a.ostride_in + r, p0, p1);
-        } else {
-            const int r = e / W, c = e % W;
-            const long long cc = col0 + c;
-            if (cc < a.total) {
-                const long long o = cc >> a.logMS, rem = cc & MSmask;
-                load_pair<T>(a, o * a.ostride_in + ((long long)r << a.logMS) + rem, p0, p1);
-            }
-        }
-        v[2 * it] = p0;
-        v[2 * it + 1] = p1;
-    });
+    // Split planes move 4 points (16 bytes per plane) per thread and step when the 4 points are contiguous in
+    // memory on both sides; everything else moves 2 points per step.
+    constexpr bool kQuadShape = (PPT % 4 == 0) && (ROW ? (L % 4 == 0) : (W % 4 == 0 && L % 4 == 0));
+    const bool quad = kQuadShape && a.split && (((a.ostride_in | a.ostride_out) & 3) == 0) &&
+                      (ROW || (a.logMS >= 2 && (TR || a.logS >= 2)));
     const T csign = a.inverse ? (T)-1 : (T)1;
-    static_for<PPT / 2>([&](auto ii) {
-        constexpr int it = ii;
-        const int e = (it * NT + tid) * 2;
-        cplx<T> p0 = v[2 * it], p1 = v[2 * it + 1];
-        p0.y *= csign;
-        p1.y *= csign;
-        if constexpr (ROW) {
-            const int c = e / L, r = e % L;
-            lds[lds_addr<L, W, ROW>(r, c)] = p0;
-            lds[lds_addr<L, W, ROW>(r + 1, c)] = p1;
-        } else {
-            const int r = e / W, c = e % W;
-            lds[lds_addr<L, W, ROW>(r, c)] = p0;
-            lds[lds_addr<L, W, ROW>(r, c + 1)] = p1;
-        }
-    });
+
+    // ---- global -> registers (all loads in flight), then -> LDS
+    auto load_phase = [&](auto vv) {
+        constexpr int V = vv;
+        static_for<PPT / V>([&](auto ii) {
+            constexpr int it = ii;
+            const int e = (it * NT + tid) * V;
+            cplx<T> p[V];
+            static_for<V>([&](auto k) { p[k].x = 0; p[k].y = 0; });
+            if constexpr (ROW) {
+                const int c = e / L, r = e % L;
+                const long long rr = col0 + c;
+                if (rr < a.total) load_vec<T, V>(a, rr * a.ostride_in + r, p);
+            } else {
+                const int r = e / W, c = e % W;
+                const long long cc = col0 + c;
+                if (cc < a.total) {
+                    const long long o = cc >> a.logMS, rem = cc & MSmask;
+                    load_vec<T, V>(a, o * a.ostride_in + ((long long)r << a.logMS) + rem, p);
+                }
+            }
+            static_for<V>([&](auto k) { v[V * it + k] = p[k]; });
+        });
+        static_for<PPT / V>([&](auto ii) {
+            constexpr int it = ii;
+            const int e = (it * NT + tid) * V;
+            static_for<V>([&](auto kk) {
+                constexpr int k = kk;
+                cplx<T> q = v[V * it + k];
+                q.y *= csign;
+                if constexpr (ROW) {
+                    const int c = e / L, r = e % L;
+                    lds[lds_addr<L, W, ROW>(r + k, c)] = q;
+                } else {
+                    const int r = e / W, c = e % W;
+                    lds[lds_addr<L, W, ROW>(r, c + k)] = q;
+                }
+            });
+        });
+    };
+    if constexpr (kQuadShape) {
+        if (quad) load_phase(IC<4>{}); else load_phase(IC<2>{});
+    } else {
+        load_phase(IC<2>{});
+    }
     __syncthreads();
 
     Stages<T, L, W, NT, ROW, TR, 1, RL>::run(lds, v, a, tid, col0);
@@ -227,42 +266,47 @@ __global__ void __launch_bounds__(NT) fft_tile_kernel(const TileArgs a) {
     // ---- LDS -> global (scaled, conjugated back for the inverse)
     const T sx = (T)a.scale;
     const T sy = a.inverse ? -sx : sx;
-    static_for<PPT / 2>([&](auto ii) {
-        constexpr int it = ii;
-        const int e = (it * NT + tid) * 2;
-        cplx<T> p0, p1;
-        long long g;
-        bool valid;
-        if constexpr (ROW) {
-            const int c = e / L, r = e % L;
-            const long long rr = col0 + c;
-            valid = rr < a.total;
-            g = rr * a.ostride_out + r;
-            p0 = lds[lds_addr<L, W, ROW>(r, c)];
-            p1 = lds[lds_addr<L, W, ROW>(r + 1, c)];
-        } else if constexpr (TR) {
-            // S == 1: out[o][l][q], q contiguous
-            const int c = e / L, q = e % L;
-            const long long cc = col0 + c;
-            valid = cc < a.total;
-            const long long o = cc >> a.logMS, rem = cc & MSmask;
-            g = o * a.ostride_out + rem * L + q;
-            p0 = lds[c * (L + 1) + q];
-            p1 = lds[c * (L + 1) + q + 1];
-        } else {
-            // out[o][l][q][j'], j' contiguous (S >= 2)
-            const int q = e / W, c = e % W;
-            const long long cc = col0 + c;
-            valid = cc < a.total;
-            const long long o = cc >> a.logMS, rem = cc & MSmask;
-            const long long l = rem >> a.logS, jp = rem & ((1ll << a.logS) - 1);
-            g = o * a.ostride_out + (((l * L) + q) << a.logS) + jp;
-            p0 = lds[lds_addr<L, W, ROW>(q, c)];
-            p1 = lds[lds_addr<L, W, ROW>(q, c + 1)];
-        }
-        p0.x *= sx; p0.y *= sy; p1.x *= sx; p1.y *= sy;
-        if (valid) store_pair<T>(a, g, p0, p1);
-    });
+    auto store_phase = [&](auto vv) {
+        constexpr int V = vv;
+        static_for<PPT / V>([&](auto ii) {
+            constexpr int it = ii;
+            const int e = (it * NT + tid) * V;
+            cplx<T> p[V];
+            long long g;
+            bool valid;
+            if constexpr (ROW) {
+                const int c = e / L, r = e % L;
+                const long long rr = col0 + c;
+                valid = rr < a.total;
+                g = rr * a.ostride_out + r;
+                static_for<V>([&](auto k) { p[k] = lds[lds_addr<L, W, ROW>(r + k, c)]; });
+            } else if constexpr (TR) {
+                // S == 1: out[o][l][q], q contiguous
+                const int c = e / L, q = e % L;
+                const long long cc = col0 + c;
+                valid = cc < a.total;
+                const long long o = cc >> a.logMS, rem = cc & MSmask;
+                g = o * a.ostride_out + rem * L + q;
+                static_for<V>([&](auto k) { p[k] = lds[c * (L + 1) + q + k]; });
+            } else {
+                // out[o][l][q][j'], j' contiguous (S >= V)
+                const int q = e / W, c = e % W;
+                const long long cc = col0 + c;
+                valid = cc < a.total;
+                const long long o = cc >> a.logMS, rem = cc & MSmask;
+                const long long l = rem >> a.logS, jp = rem & ((1ll << a.logS) - 1);
+                g = o * a.ostride_out + (((l * L) + q) << a.logS) + jp;
+                static_for<V>([&](auto k) { p[k] = lds[lds_addr<L, W, ROW>(q, c + k)]; });
+            }
+            static_for<V>([&](auto k) { p[k].x *= sx; p[k].y *= sy; });
+            if (valid) store_vec<T, V>(a, g, p);
+        });
+    };
+    if constexpr (kQuadShape) {
+        if (quad) store_phase(IC<4>{}); else store_phase(IC<2>{});
+    } else {
+        store_phase(IC<2>{});
+    }
 }
 
 }  // namespace mifft

@@ -48,7 +48,10 @@ if __name__ == "__main__":
     p = device_props()
     print(p.name.decode(), p.gcn_arch.decode(), "CUs", p.compute_units, flush=True)
     c64, c128, f32, f64 = numpy.complex64, numpy.complex128, numpy.float32, numpy.float64
-    if len(sys.argv) > 1 and sys.argv[1] == "nd":
+    if len(sys.argv) > 1 and sys.argv[1] == "split":
+        cases = [((1 << 20,), f32, 256), ((1 << 20,), c64, 256), ((1024, 1024), f32, 256), ((1 << 16,), f32, 4096), ((1 << 18,), f32, 1024),
+                 ((1024,), f32, 1 << 16), ((256, 256), f32, 4096), ((128, 128, 128), f32, 128)]
+    elif len(sys.argv) > 1 and sys.argv[1] == "nd":
         cases = [((1024, 1024), c64, 512), ((256, 256), c64, 8192), ((4096, 64), c64, 2048), ((128, 128, 128), c64, 256),
                  ((256, 256, 256), c128, 16), ((256, 256, 256), f64, 16), ((64, 64, 64), c128, 1024), ((1 << 20,), f32, 256),
                  ((1024, 1024), f32, 256)]
