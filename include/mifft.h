@@ -56,6 +56,10 @@ extern "C" {
 /* pass kinds */
 #define MIFFT_PASS_COL 0  /* strided pass: [outer][L][M*S] -> [outer][M][L][S]  (kernel.mako:805-1047) */
 #define MIFFT_PASS_ROW 1  /* contiguous pass: `outer` rows of L points, in place  (kernel.mako:725-803)  */
+#define MIFFT_PASS_ND  2  /* whole small 2-D/3-D transform in LDS: L = x, M = y, S = z (x contiguous), `outer`
+                            transforms back to back; tw_L / tw_lo / tw_hi = w(x)^k / w(y)^k / w(z)^k tables (NULL for an
+                            axis of length 1); x*y*z <= mifft_nd_max_points_for(precision).  In place capable.
+                            Replaces the reference's local kernel + one global chain per further axis (plan.py:111-123) */
 
 typedef void *mifft_stream_t; /* hipStream_t; NULL = the default stream */
 typedef void *mifft_event_t;  /* hipEvent_t */
@@ -136,6 +140,9 @@ int mifft_event_sync(mifft_event_t event);
 int mifft_event_elapsed_ms(float *ms, mifft_event_t start, mifft_event_t stop);
 
 /* ---- pass launchers (replace cuda.py Function.__call__, cuda.py:35-46) ----------------------------- */
+
+/* largest x*y*z a MIFFT_PASS_ND launch accepts for the precision */
+int mifft_nd_max_points_for(int32_t precision);
 
 /* 0 if a compiled kernel exists for (kind, precision, L, variant), else MIFFT_E_UNSUPPORTED.
  * Counterpart of Function.isExecutable (cuda.py:48-49) for AOT kernels. */

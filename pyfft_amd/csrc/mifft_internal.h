@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "fft_tile.hpp"
 #include "fft_fused2.hpp"
+#include "fft_nd.hpp"
 
 // Each returns 0 on success, MIFFT_E_UNSUPPORTED (-2) when no kernel is compiled for (L, tr, variant),
 // or a hipError_t.  With query_only != 0 nothing is launched.
@@ -11,6 +12,8 @@ int mifft_dispatch_col_f32(int L, int tr, int variant, const mifft::TileArgs* a,
 int mifft_dispatch_row_f32(int L, int variant, const mifft::TileArgs* a, hipStream_t s, int query_only);
 int mifft_dispatch_col_f64(int L, int tr, int variant, const mifft::TileArgs* a, hipStream_t s, int query_only);
 int mifft_dispatch_row_f64(int L, int variant, const mifft::TileArgs* a, hipStream_t s, int query_only);
+int mifft_nd_max_points(int f64);
+int mifft_nd_launch(int f64, const mifft::NdArgs* a, hipStream_t s);
 int mifft_fused2_f32_launch(int L0, int L1, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
 }
 

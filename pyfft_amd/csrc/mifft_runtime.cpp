@@ -38,11 +38,18 @@ int ilog2(long long v) {
 
 int validate(const mifft_pass* p) {
     if (!p) return set_err(MIFFT_E_INVALID, "null pass descriptor");
-    if (p->kind != MIFFT_PASS_COL && p->kind != MIFFT_PASS_ROW) return set_err(MIFFT_E_INVALID, "bad pass kind %d", p->kind);
+    if (p->kind != MIFFT_PASS_COL && p->kind != MIFFT_PASS_ROW && p->kind != MIFFT_PASS_ND) return set_err(MIFFT_E_INVALID, "bad pass kind %d", p->kind);
     if (p->precision != MIFFT_F32 && p->precision != MIFFT_F64) return set_err(MIFFT_E_INVALID, "bad precision %d", p->precision);
     if (p->layout != MIFFT_INTERLEAVED && p->layout != MIFFT_SPLIT) return set_err(MIFFT_E_INVALID, "bad layout %d", p->layout);
-    if (!is_pow2(p->L) || p->L < 2) return set_err(MIFFT_E_INVALID, "L=%d is not a power of two >= 2", p->L);
+    if (!is_pow2(p->L) || (p->L < 2 && p->kind != MIFFT_PASS_ND)) return set_err(MIFFT_E_INVALID, "L=%d is not a power of two >= 2", p->L);
     if (p->outer < 0) return set_err(MIFFT_E_INVALID, "negative outer count");
+    if (p->kind == MIFFT_PASS_ND) {
+        if (!is_pow2(p->M) || !is_pow2(p->S)) return set_err(MIFFT_E_INVALID, "ND pass: y and z must be powers of two");
+        const long long n = (long long)p->L * p->M * p->S;
+        if (n < 4 || n > mifft_nd_max_points(p->precision == MIFFT_F64)) return set_err(MIFFT_E_UNSUPPORTED, "ND pass: %lld points do not fit a tile", n);
+        if ((p->L > 1 && !p->tw_L) || (p->M > 1 && !p->tw_lo) || (p->S > 1 && !p->tw_hi)) return set_err(MIFFT_E_INVALID, "ND pass: twiddle table missing");
+        return 0;
+    }
     if (!p->tw_L) return set_err(MIFFT_E_INVALID, "tw_L table missing");
     if (p->kind == MIFFT_PASS_COL) {
         if (!is_pow2(p->M) || !is_pow2(p->S)) return set_err(MIFFT_E_INVALID, "M and S must be powers of two");
@@ -84,6 +91,55 @@ void fill_args(const mifft_pass* p, const void* in0, const void* in1, void* out0
     a.inverse = p->inverse ? 1 : 0;
     a.has_tw = (p->kind == MIFFT_PASS_COL && p->M > 1) ? 1 : 0;
     a.scale = p->scale;
+}
+
+// radix list of one axis for the in-LDS N-D kernel (each radix <= maxr, a power of two)
+int nd_radices(int L, int maxr, int* out) {
+    int n = 0;
+    while (L > 1) {
+        int r = maxr;
+        while (r > L) r >>= 1;
+        // avoid a trailing radix 2 after big radices: prefer e.g. 32 = 8 * 4 over 16 * 2
+        if (L > r && L / r == 2 && r >= 8) r >>= 1;
+        out[n++] = r;
+        L /= r;
+    }
+    return n;
+}
+
+int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0, void* out1, hipStream_t s) {
+    mifft::NdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in0 = in0; a.in1 = in1; a.out0 = out0; a.out1 = out1;
+    a.tw[0] = p->tw_L; a.tw[1] = p->tw_lo; a.tw[2] = p->tw_hi;
+    const long long dims[3] = {p->L, p->M, p->S};
+    a.total = p->outer * dims[0] * dims[1] * dims[2];
+    const bool f64 = p->precision == MIFFT_F64;
+    int logs = 0, ns = 0;
+    for (int ax = 0; ax < 3; ++ax) {
+        a.logL[ax] = ilog2(dims[ax]);
+        a.logS[ax] = logs;
+        logs += a.logL[ax];
+        int rad[16];
+        const int nr = nd_radices((int)dims[ax], f64 ? 8 : 16, rad);
+        int logNs = 0;
+        for (int i = 0; i < nr; ++i) {
+            if (ns >= mifft::kNdMaxStages) return set_err(MIFFT_E_UNSUPPORTED, "ND pass: too many stages");
+            a.st_axis[ns] = (unsigned char)ax;
+            a.st_radix[ns] = (unsigned char)rad[i];
+            a.st_logNs[ns] = (unsigned char)logNs;
+            logNs += ilog2(rad[i]);
+            ++ns;
+        }
+    }
+    a.nstages = ns;
+    a.split = p->layout == MIFFT_SPLIT ? 1 : 0;
+    a.inverse = p->inverse ? 1 : 0;
+    a.scale = p->scale;
+    const int rc = mifft_nd_launch(f64 ? 1 : 0, &a, s);
+    if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
+    if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
+    return 0;
 }
 
 int dispatch(const mifft_pass* p, const mifft::TileArgs* a, hipStream_t s, int query_only) {
@@ -190,7 +246,10 @@ int mifft_event_elapsed_ms(float* ms, mifft_event_t start, mifft_event_t stop) {
     return hip_check(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop), "hipEventElapsedTime");
 }
 
+int mifft_nd_max_points_for(int32_t precision) { return mifft_nd_max_points(precision == MIFFT_F64); }
+
 int mifft_pass_supported(int32_t kind, int32_t precision, int32_t L, int32_t variant) {
+    if (kind == MIFFT_PASS_ND) return (L >= 1 && L <= mifft_nd_max_points(precision == MIFFT_F64) && (L & (L - 1)) == 0) ? 0 : MIFFT_E_UNSUPPORTED;
     mifft_pass p;
     memset(&p, 0, sizeof(p));
     p.kind = kind;
@@ -221,6 +280,10 @@ int mifft_launch_pass(const mifft_pass* p, const void* in0, const void* in1, voi
         return set_err(MIFFT_E_INVALID, "a COL pass with M > 1 cannot run in place");
     if (p->outer == 0) return 0;
 
+    if (p->kind == MIFFT_PASS_ND) {
+        if ((p->outer * p->L * p->M * p->S) & 3) return set_err(MIFFT_E_INVALID, "ND pass: total points must be a multiple of 4");
+        return launch_nd(p, in0, in1, out0, out1, (hipStream_t)stream);
+    }
     mifft::TileArgs a;
     fill_args(p, in0, in1, out0, out1, &a);
     return dispatch(p, &a, (hipStream_t)stream, 0);

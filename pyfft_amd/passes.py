@@ -87,6 +87,8 @@ class PassSpec(object):
         self.curr_n = L * M
 
     def __repr__(self):
+        if self.kind == N.PASS_ND:
+            return "nd(x=%d,y=%d,z=%d)*" % (self.L, self.M, self.S)
         name = "row" if self.kind == N.PASS_ROW else "col"
         return "%s(L=%d,M=%d,S=%d)%s" % (name, self.L, self.M, self.S, "*" if self.in_place_possible else "")
 
@@ -112,6 +114,9 @@ def build_chain(x, y, z, precision):
     _fft1D, plan.py:111-171): X passes, then the Y chain, then the Z chain.  Axes of length 1 are
     skipped (plan.py:149,160,164)."""
     chain = []
+    # small 2-D / 3-D transforms: every axis inside LDS, one launch, one HBM round trip (csrc/fft_nd.hpp)
+    if (x > 1) + (y > 1) + (z > 1) >= 2 and 4 <= x * y * z <= N.lib.mifft_nd_max_points_for(precision):
+        return [PassSpec(N.PASS_ND, X_DIRECTION, x * y * z, x, y, z, 1, x * y * z, True)]
     if x > 1:
         if x <= row_max(precision):
             chain.append(PassSpec(N.PASS_ROW, X_DIRECTION, x, x, 1, 1, y * z, x, True))

@@ -127,6 +127,12 @@ class FFTPlan(object):
         self._tables = {}      # key -> device allocation
         self._table_ptrs = []  # per pass: (tw_L, tw_lo, tw_hi, shift)
         for k in self._kernels:
+            if k.kind == N.PASS_ND:
+                # one w(len)^k table per axis (x, y, z) in the tw_L / tw_lo / tw_hi slots
+                tabs = [self._device_table(("L", n), lambda L=n: _twiddle_table(L, L, 1, p.complex_dtype)) if n > 1 else None
+                        for n in (k.L, k.M, k.S)]
+                self._table_ptrs.append((tabs[0], tabs[1], tabs[2], 0))
+                continue
             twL = self._device_table(("L", k.L), lambda L=k.L: _twiddle_table(L, L, 1, p.complex_dtype))
             if k.M > 1:
                 n = k.curr_n
