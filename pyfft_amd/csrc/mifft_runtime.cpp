@@ -136,7 +136,7 @@ int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0,
     a.split = p->layout == MIFFT_SPLIT ? 1 : 0;
     a.inverse = p->inverse ? 1 : 0;
     a.scale = p->scale;
-    const int rc = mifft_nd_launch(f64 ? 1 : 0, &a, s);
+    const int rc = mifft_nd_launch(f64 ? 1 : 0, dims[0] * dims[1] * dims[2], &a, s);
     if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
     if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
     return 0;

@@ -51,7 +51,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "small":
         cases = [((16, 16), c64, 1 << 20), ((64, 64), c64, 1 << 16), ((16, 16, 16), c64, 1 << 16), ((8, 8, 64), c64, 1 << 16),
                  ((32, 16, 8), c64, 1 << 16), ((16, 16), c128, 1 << 19), ((16, 16), f32, 1 << 20), ((8, 8, 16), f64, 1 << 17),
-                 ((4, 1024), c64, 1 << 16), ((2, 2), c64, 1 << 24)]
+                 ((4, 1024), c64, 1 << 16), ((2, 2), c64, 1 << 24), ((128, 64), c64, 1 << 15), ((128, 128), c64, 1 << 14),
+                 ((16, 16, 64), c64, 1 << 14), ((16, 16, 32), c128, 1 << 14), ((64, 64), c128, 1 << 15)]
     elif len(sys.argv) > 1 and sys.argv[1] == "split":
         cases = [((1 << 20,), f32, 256), ((1 << 20,), c64, 256), ((1024, 1024), f32, 256), ((1 << 16,), f32, 4096), ((1 << 18,), f32, 1024),
                  ((1024,), f32, 1 << 16), ((256, 256), f32, 4096), ((128, 128, 128), f32, 128)]
