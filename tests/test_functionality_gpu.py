@@ -117,13 +117,14 @@ def test_wrong_shape(ctx, prec):                  # :135-139
 
 def test_mempool(ctx, prec):                      # CudaPlan.testMempool :147-150 (+ it is really used)
     pool = ctx.getMemoryPool()
-    plan = ctx.getPlan((8192,), dtype=prec[1], mempool=pool)
-    a = ctx.toGpu(numpy.ones(8192, dtype=prec[1]))
+    n = 16384                                     # two strided passes in both precisions -> needs a temp buffer
+    plan = ctx.getPlan((n,), dtype=prec[1], mempool=pool)
+    a = ctx.toGpu(numpy.ones(n, dtype=prec[1]))
     plan.execute(a)
     assert pool.calls == 1
     plan.execute(a, inverse=True)
     assert pool.calls == 1            # same batch: temp is reused (plan.py:179-192)
-    b = ctx.toGpu(numpy.ones(8192 * 2, dtype=prec[1]))
+    b = ctx.toGpu(numpy.ones(n * 2, dtype=prec[1]))
     plan.execute(b, batch=2)
     assert pool.calls == 2            # new batch: temp reallocated
 

@@ -48,7 +48,9 @@ if __name__ == "__main__":
     p = device_props()
     print(p.name.decode(), p.gcn_arch.decode(), "CUs", p.compute_units, flush=True)
     c64, c128, f32, f64 = numpy.complex64, numpy.complex128, numpy.float32, numpy.float64
-    if len(sys.argv) > 1 and sys.argv[1] == "small":
+    if len(sys.argv) > 1 and sys.argv[1] == "mid1d":
+        cases = [((1 << k,), c64, (1 << 28) >> k) for k in (10, 11, 12, 13, 14)] + [((1 << k,), c128, (1 << 27) >> k) for k in (11, 12, 13)]
+    elif len(sys.argv) > 1 and sys.argv[1] == "small":
         cases = [((16, 16), c64, 1 << 20), ((64, 64), c64, 1 << 16), ((16, 16, 16), c64, 1 << 16), ((8, 8, 64), c64, 1 << 16),
                  ((32, 16, 8), c64, 1 << 16), ((16, 16), c128, 1 << 19), ((16, 16), f32, 1 << 20), ((8, 8, 16), f64, 1 << 17),
                  ((4, 1024), c64, 1 << 16), ((2, 2), c64, 1 << 24), ((128, 64), c64, 1 << 15), ((128, 128), c64, 1 << 14),
