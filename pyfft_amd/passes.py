@@ -120,6 +120,11 @@ def build_chain(x, y, z, precision):
     if (ndims >= 2 and 4 <= x * y * z <= N.lib.mifft_nd_max_points_for(precision)) or \
             (ndims == 1 and precision == N.F32 and x * y * z == 8192):
         return [PassSpec(N.PASS_ND, X_DIRECTION, x * y * z, x, y, z, 1, x * y * z, True)]
+    # 3-D shapes too big for one tile but with a small (y, x) plane: x and y together in LDS per plane (the planes
+    # are just more batch items), then only z as a strided chain -- two HBM round trips instead of three
+    if ndims == 3 and x * y <= N.lib.mifft_nd_max_points_for(precision):
+        return [PassSpec(N.PASS_ND, X_DIRECTION, x * y, x, y, 1, z, x * y, True)] + \
+            col_chain(Z_DIRECTION, z, x * y, 1, precision)
     if x > 1:
         if x <= row_max(precision):
             chain.append(PassSpec(N.PASS_ROW, X_DIRECTION, x, x, 1, 1, y * z, x, True))

@@ -70,7 +70,7 @@ def test_launch_rejects_bad_descriptors_without_touching_the_gpu():
 
 SHAPES = [(2, 1, 1), (1024, 1, 1), (4096, 1, 1), (8192, 1, 1), (1 << 16, 1, 1), (1 << 20, 1, 1), (1 << 22, 1, 1),
           (1 << 24, 1, 1), (16, 16, 1), (1024, 1024, 1), (4, 2048, 1), (2048, 8, 1), (256, 256, 256), (16, 16, 16),
-          (64, 8, 8), (2, 4, 2), (1, 16, 1), (1, 1, 64), (1, 8, 8), (16, 1, 8)]
+          (64, 8, 8), (2, 4, 2), (1, 16, 1), (1, 1, 64), (1, 8, 8), (16, 1, 8), (128, 128, 128), (128, 32, 32), (64, 16, 2048)]
 
 
 @pytest.mark.parametrize("xyz", SHAPES, ids=str)
@@ -86,6 +86,16 @@ def test_gfx950_chain_is_a_valid_factorisation_and_matches_numpy(xyz):
         k = chain[0]
         assert (k.L, k.M, k.S) == (x, y, z) and k.in_place_possible and k.outer_stride == x * y * z
         assert x * y * z <= N.lib.mifft_nd_max_points_for(N.F32)
+        return
+    if chain and chain[0].kind == N.PASS_ND:
+        # (y, x) planes in LDS, then the z chain
+        k = chain[0]
+        assert (k.L, k.M, k.S) == (x, y, 1) and k.outer_per_batch == z and k.outer_stride == x * y
+        assert all(c.kind == N.PASS_COL and c.axis == P.Z_DIRECTION for c in chain[1:]) and len(chain) >= 2
+        prod = 1
+        for c in chain[1:]:
+            prod *= c.L
+        assert prod == z
         return
     per_axis = {}
     for k in chain:
