@@ -57,10 +57,26 @@ __device__ __forceinline__ void nd_stage(cplx<T>* lds, cplx<T>* v, const cplx<T>
         });
         if (logNs > 0) {
             const int ai = (jb & (Ns - 1)) << (logL - logNs - logR);
-            static_for<R - 1>([&](auto kk) {
-                constexpr int k = kk + 1;
-                v[b * R + k] = cmul<T>(v[b * R + k], tw[k * ai]);
-            });
+            if (R >= 4 && logL >= 6) {
+                // long axis: one look-up + power tree instead of R-1 look-ups all over a table that does not fit the
+                // L1 next to the data stream (same reasoning as fft_tile.hpp)
+                cplx<T> t[R];
+                t[1] = tw[ai];
+                static_for<R - 2>([&](auto kk) {
+                    constexpr int k = kk + 2;
+                    if constexpr ((k & 1) == 0) t[k] = cmul<T>(t[k / 2], t[k / 2]);
+                    else t[k] = cmul<T>(t[k - 1], t[1]);
+                });
+                static_for<R - 1>([&](auto kk) {
+                    constexpr int k = kk + 1;
+                    v[b * R + k] = cmul<T>(v[b * R + k], t[k]);
+                });
+            } else {
+                static_for<R - 1>([&](auto kk) {
+                    constexpr int k = kk + 1;
+                    v[b * R + k] = cmul<T>(v[b * R + k], tw[k * ai]);
+                });
+            }
         }
         Dft<R, T>::run(v + b * R);
     });
