@@ -15,6 +15,8 @@ extern "C" int mifft_dispatch_row_f32(int L, int variant, const mifft::TileArgs*
         MIFFT_ROW_CASE(float, 1024, 4, 256, 16, 16, 4)
         MIFFT_ROW_CASE(float, 2048, 2, 256, 16, 16, 8)
         MIFFT_ROW_CASE(float, 4096, 1, 256, 16, 16, 16)
+        MIFFT_ROW_CASE(float, 8192, 1, 512, 16, 16, 16, 2)
+        MIFFT_ROW_CASE(float, 16384, 1, 1024, 16, 16, 16, 4)
     }
     return -2;
 }

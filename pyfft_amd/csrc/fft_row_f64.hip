@@ -15,6 +15,7 @@ extern "C" int mifft_dispatch_row_f64(int L, int variant, const mifft::TileArgs*
         MIFFT_ROW_CASE(double, 1024, 2, 256, 8, 8, 4, 4)
         MIFFT_ROW_CASE(double, 2048, 1, 256, 8, 8, 8, 4)
         MIFFT_ROW_CASE(double, 4096, 1, 512, 8, 8, 8, 8)
+        MIFFT_ROW_CASE(double, 8192, 1, 1024, 8, 8, 8, 8, 2)
     }
     return -2;
 }

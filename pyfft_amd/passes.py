@@ -115,10 +115,8 @@ def build_chain(x, y, z, precision):
     skipped (plan.py:149,160,164)."""
     chain = []
     # small 2-D / 3-D transforms: every axis inside LDS, one launch, one HBM round trip (csrc/fft_nd.hpp)
-    # ... and the one 1-D size where the in-LDS path beats two strided passes (measured: fp32 N = 8192, 37.7 % vs 32.3 %)
     ndims = (x > 1) + (y > 1) + (z > 1)
-    if (ndims >= 2 and 4 <= x * y * z <= N.lib.mifft_nd_max_points_for(precision)) or \
-            (ndims == 1 and precision == N.F32 and x * y * z == 8192):
+    if ndims >= 2 and 4 <= x * y * z <= N.lib.mifft_nd_max_points_for(precision):
         return [PassSpec(N.PASS_ND, X_DIRECTION, x * y * z, x, y, z, 1, x * y * z, True)]
     # 3-D shapes too big for one tile but with a small (y, x) plane: x and y together in LDS per plane (the planes
     # are just more batch items), then only z as a strided chain -- two HBM round trips instead of three

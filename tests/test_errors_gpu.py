@@ -174,7 +174,7 @@ def test_fused_two_pass_kernel(ctx, monkeypatch, n, batch):
     assert oracle.difference(data, back, batch) < 1.1e-6
 
 
-@pytest.mark.parametrize("shape,batch", [((16384,), 2051), ((1 << 16,), 515), ((4096, 8), 1030)], ids=str)
+@pytest.mark.parametrize("shape,batch", [((32768,), 1027), ((1 << 16,), 515), ((4096, 8), 1030)], ids=str)
 def test_pipelined_chunks(ctx, monkeypatch, shape, batch):
     data = oracle.get_test_data(shape, numpy.complex64, batch, 777)
     want = _run_strategy(ctx, monkeypatch, "chain", shape, batch, data)
