@@ -220,7 +220,9 @@ class FFTPlan(object):
         forced = os.environ.get("PYFFT_AMD_STRATEGY", "auto")
         p = self._params
         item_bytes = p.size * p.complex_nbytes
-        chunk = max(1, self.PIPELINE_TARGET_BYTES // item_bytes)
+        target = int(os.environ.get("PYFFT_AMD_PIPE_MB", "0")) << 20 or self.PIPELINE_TARGET_BYTES   # development override
+        nstreams = int(os.environ.get("PYFFT_AMD_PIPE_STREAMS", "0")) or self.PIPELINE_STREAMS
+        chunk = max(1, target // item_bytes)
         strat = ("chain",)
         if self._temp_buffer_needed and forced in ("auto", "fused") and self._fused2_eligible():
             grid = 2 * self._context.compute_units
@@ -234,7 +236,7 @@ class FFTPlan(object):
         # any multi-pass plan gains from cache-sized chunks (the second pass re-reads what the first just wrote),
         # whether or not it needs a temp buffer
         if len(self._kernels) >= 2 and forced in ("auto", "pipelined") and batch >= 4 * chunk:
-            return ("pipelined", chunk, self.PIPELINE_STREAMS)
+            return ("pipelined", chunk, nstreams)
         return strat
 
     def _prepare(self, batch):

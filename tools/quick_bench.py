@@ -48,7 +48,11 @@ if __name__ == "__main__":
     p = device_props()
     print(p.name.decode(), p.gcn_arch.decode(), "CUs", p.compute_units, flush=True)
     c64, c128, f32, f64 = numpy.complex64, numpy.complex128, numpy.float32, numpy.float64
-    if len(sys.argv) > 1 and sys.argv[1] == "3d":
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg":
+        cases = [((1024, 1024), c64, 512), ((256, 256, 256), c128, 32), ((1 << 22,), c64, 128), ((1 << 16,), c64, 8192), ((1 << 18,), c64, 2048)]
+    elif len(sys.argv) > 1 and sys.argv[1] == "f64":
+        cases = [((1 << k,), c128, (1 << 27) >> k) for k in (14, 15, 16, 17, 18, 20, 22)] + [((1024, 1024), c128, 128), ((2048, 2048), c64, 64)]
+    elif len(sys.argv) > 1 and sys.argv[1] == "3d":
         cases = [((128, 128, 128), c64, 128), ((32, 32, 128), c64, 2048), ((16, 16, 128), c64, 8192), ((64, 64, 64), c128, 512),
                  ((256, 64, 64), c64, 256), ((128, 128, 128), f32, 128), ((128, 64, 64), c128, 128)]
     elif len(sys.argv) > 1 and sys.argv[1] == "mid1d":
