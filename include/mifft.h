@@ -75,6 +75,8 @@ typedef void *mifft_event_t;  /* hipEvent_t */
  *
  *   MIFFT_PASS_ROW  in/out viewed as [outer][L]:  out[o][q] = scale * sum_r in[o][r] * w(L)^(r*q)
  *
+ *   MIFFT_PASS_ND   in/out viewed as [outer][S][M][L] (z, y, x):  out[o] = scale * DFT3(in[o])
+ *
  * Matrix `o` starts at element o*outer_stride_{in,out} (elements of the complex type; for split layout
  * the same offset applies to both planes).  Sizes are powers of two except `outer`.
  */
@@ -149,8 +151,8 @@ int mifft_nd_max_points_for(int32_t precision);
 int mifft_pass_supported(int32_t kind, int32_t precision, int32_t L, int32_t variant);
 
 /* Enqueue one pass.  in1/out1 are the imaginary planes for MIFFT_SPLIT and must be NULL for
- * MIFFT_INTERLEAVED.  In-place (out == in) is allowed for MIFFT_PASS_ROW and for MIFFT_PASS_COL with
- * M == 1 (pyfft/kernel.py:144,238-241). */
+ * MIFFT_INTERLEAVED.  In-place (out == in) is allowed for MIFFT_PASS_ROW, MIFFT_PASS_ND and for
+ * MIFFT_PASS_COL with M == 1 (pyfft/kernel.py:144,238-241). */
 int mifft_launch_pass(const mifft_pass *pass, const void *in0, const void *in1, void *out0, void *out1,
                       mifft_stream_t stream);
 
@@ -161,13 +163,13 @@ int mifft_launch_chain(const mifft_pass *passes, int32_t npasses, void *const bu
                        mifft_stream_t stream);
 
 /*
- * Pipelined form of mifft_launch_chain for plans that need a temp buffer (counterpart of the batch loop the
+ * Pipelined form of mifft_launch_chain for any multi-pass plan (counterpart of the batch loop the
  * reference runs inside each kernel grid, pyfft/kernel.py:99-121, re-cut for the MI355X memory system):
  * the batch is processed in chunks of `chunk` items; chunk i runs the whole pass chain on side stream
  * i % nside with temp slot i % nside, so the inter-pass intermediate of a chunk is consumed while it is still
  * in the 256 MiB Infinity Cache and kernels of different chunks overlap each other's launch tails.
  *   - `passes` describe the FULL batch (outer = outer_per_item * batch); `item_elems` = elements per batch item
- *     (per plane for split layout);  bufs*[2] (temp) must hold nside * chunk items.
+ *     (per plane for split layout);  bufs*[2] (temp), when the schedule uses it, must hold nside * chunk items.
  *   - ordering: side streams wait for everything enqueued on `stream` so far; `stream` waits for all side
  *     streams before the call's work counts as done.  events[0..nside] are caller-owned scratch events.
  */
