@@ -321,8 +321,8 @@ def main():
         descs = plan._descriptors(batch, args.inplace, False)
         ptr = plan._context.pointer_of
         if split:
-            b0 = [ins[0].ptr, outs[0].ptr, ptr(plan._tempmemobj_re) if plan._tempmemobj_re is not None else None]
-            b1 = [ins[1].ptr, outs[1].ptr, ptr(plan._tempmemobj_im) if plan._tempmemobj_im is not None else None]
+            b0 = [ins[0].ptr, outs[0].ptr, ptr(plan._tempmemobj) if plan._tempmemobj is not None else None]
+            b1 = [ins[1].ptr, outs[1].ptr, None]
         else:
             b0 = [ins[0].ptr, outs[0].ptr, ptr(plan._tempmemobj) if plan._tempmemobj is not None else None]
             b1 = [None, None, None]

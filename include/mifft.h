@@ -53,6 +53,13 @@ extern "C" {
 #define MIFFT_INTERLEAVED 0
 #define MIFFT_SPLIT       1
 
+/* mifft_pass.flags (only meaningful with layout == MIFFT_SPLIT): the buffer read / written by this pass is
+ * interleaved although the plan's layout is split.  Used for the plan-owned temp buffer, which is always
+ * interleaved: 16 columns of one fp32 plane are only 64 bytes per row, so every side kept interleaved streams
+ * at the full rate (src/dst plane pointer of that side is ignored and may be NULL). */
+#define MIFFT_FLAG_SRC_INTERLEAVED 1
+#define MIFFT_FLAG_DST_INTERLEAVED 2
+
 /* pass kinds */
 #define MIFFT_PASS_COL 0  /* strided pass: [outer][L][M*S] -> [outer][M][L][S]  (kernel.mako:805-1047) */
 #define MIFFT_PASS_ROW 1  /* contiguous pass: `outer` rows of L points, in place  (kernel.mako:725-803)  */
@@ -100,7 +107,7 @@ typedef struct mifft_pass {
     int32_t tw_shift;
     int32_t src;         /* for mifft_launch_chain: index of the buffer read  (0 in, 1 out, 2 temp) */
     int32_t dst;         /* for mifft_launch_chain: index of the buffer written */
-    int32_t reserved;
+    int32_t flags;       /* MIFFT_FLAG_*: per-side layout overrides for a plan's internal temp buffer */
 } mifft_pass;
 
 typedef struct mifft_device_props {
@@ -185,6 +192,7 @@ int mifft_launch_chain_pipelined(const mifft_pass *passes, int32_t npasses, void
  * strided last pass (COL, M == 1, S == p0->L).  `counters` = caller-owned device buffer of at least
  * (2 + 2 * outer) uint32 (zeroed by this call on `stream`); after completion counters[1] != 0 reports a
  * dependency time-out (results invalid).  Returns MIFFT_E_UNSUPPORTED when the shape has no fused kernel.
+ * The ring is always interleaved (ring0; ring1 is ignored), also for split-plane in/out buffers.
  */
 int mifft_launch_fused2(const mifft_pass *p0, const mifft_pass *p1, const void *in0, const void *in1, void *out0,
                         void *out1, void *ring0, void *ring1, int32_t ring_slots, int32_t lag, void *counters,

@@ -21,6 +21,7 @@ E_NODEVICE = -3
 F32, F64 = 0, 1
 INTERLEAVED, SPLIT = 0, 1
 PASS_COL, PASS_ROW, PASS_ND = 0, 1, 2
+FLAG_SRC_INTERLEAVED, FLAG_DST_INTERLEAVED = 1, 2
 
 
 class MifftPass(ctypes.Structure):
@@ -44,7 +45,7 @@ class MifftPass(ctypes.Structure):
         ("tw_shift", ctypes.c_int32),
         ("src", ctypes.c_int32),
         ("dst", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("flags", ctypes.c_int32),
     ]
 
 

@@ -38,11 +38,13 @@ template <int A, bool TR> struct Col2Lds {
 
 // One tile = 16 adjacent columns starting at column rem0 (a multiple of 16) of matrix o_in; the result goes to
 // matrix o_out (same index for a plain launch; a scratch-ring slot in the fused two-pass kernel).
+// SPLIT / SPLIT_OUT: layout of the input / output side (they differ only when one side is a plan's internal,
+//     always interleaved, temp buffer).
 // WT: write the result with write-through (agent-coherent, "sc1") stores -- used by the fused kernel for the
 //     intermediate so that publishing it needs no release fence (interleaved fp32 only).
 // NTIN / NTOUT: non-temporal hint on the input loads / output stores (streamed-once data in the fused kernel).
 template <typename T, int A, bool TR, bool TW, bool SPLIT, bool WT = false, bool NTIN = false, bool NTOUT = false,
-          typename LdsPtr = cplx<T>*>
+          bool SPLIT_OUT = SPLIT, typename LdsPtr = cplx<T>*>
 __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_in, const long long o_out,
                                           const long long rem0, LdsPtr lds) {
     constexpr int L = A * 256;
@@ -225,7 +227,7 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
             cplx<T> r;
             r.x = x[qb0].x * sx;
             r.y = x[qb0].y * sy;
-            if constexpr (!SPLIT) {
+            if constexpr (!SPLIT_OUT) {
                 char* p = reinterpret_cast<char*>(reinterpret_cast<cplx<T>*>(a.out0) + gu);
                 if constexpr (WT) {
                     static_assert(!WT || sizeof(cplx<T>) == 8, "write-through path is fp32 interleaved only");
@@ -248,13 +250,13 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
 
 // TR: S == 1 (first pass of a long contiguous axis; the store is a transposition)
 // TW: multiply by the inter-pass twiddle w(L*M)^(l*q)
-template <typename T, int A, bool TR, bool TW, bool SPLIT>
+template <typename T, int A, bool TR, bool TW, bool SPLIT, bool SPLIT_OUT = SPLIT>
 __global__ void __launch_bounds__(256, 2) fft_col2_kernel(const TileArgs a) {
     __shared__ __attribute__((aligned(16))) cplx<T> lds[Col2Lds<A, TR>::ELEMS];
     const long long col0 = (long long)blockIdx.x * 16;
     const long long o = col0 >> a.logMS;
     const long long rem0 = col0 & ((1ll << a.logMS) - 1);
-    col2_tile<T, A, TR, TW, SPLIT>(a, o, o, rem0, lds);
+    col2_tile<T, A, TR, TW, SPLIT, false, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
 }
 
 }  // namespace mifft

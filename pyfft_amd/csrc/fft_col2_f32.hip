@@ -9,10 +9,15 @@ namespace {
 template <int A, bool TR, bool TW> int launch_l(const mifft::TileArgs* a, hipStream_t s) {
     const long long tiles = a->total / 16;
     if (tiles > 2147483647ll) return -1;
-    if (a->split)
-        hipLaunchKernelGGL((mifft::fft_col2_kernel<float, A, TR, TW, true>), dim3((unsigned)tiles), dim3(256), 0, s, *a);
+    const dim3 g((unsigned)tiles), b(256);
+    if (a->split && a->split_out)
+        hipLaunchKernelGGL((mifft::fft_col2_kernel<float, A, TR, TW, true, true>), g, b, 0, s, *a);
+    else if (a->split)
+        hipLaunchKernelGGL((mifft::fft_col2_kernel<float, A, TR, TW, true, false>), g, b, 0, s, *a);
+    else if (a->split_out)
+        hipLaunchKernelGGL((mifft::fft_col2_kernel<float, A, TR, TW, false, true>), g, b, 0, s, *a);
     else
-        hipLaunchKernelGGL((mifft::fft_col2_kernel<float, A, TR, TW, false>), dim3((unsigned)tiles), dim3(256), 0, s, *a);
+        hipLaunchKernelGGL((mifft::fft_col2_kernel<float, A, TR, TW, false, false>), g, b, 0, s, *a);
     return (int)hipGetLastError();
 }
 // Instances: the transposing first pass of a long axis (S == 1, always with the inter-pass twiddle) and the plain

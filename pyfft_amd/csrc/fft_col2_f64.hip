@@ -8,10 +8,15 @@ namespace {
 template <bool TR, bool TW> int launch_l(const mifft::TileArgs* a, hipStream_t s) {
     const long long tiles = a->total / 16;
     if (tiles > 2147483647ll) return -1;
-    if (a->split)
-        hipLaunchKernelGGL((mifft::fft_col2_kernel<double, 1, TR, TW, true>), dim3((unsigned)tiles), dim3(256), 0, s, *a);
+    const dim3 g((unsigned)tiles), b(256);
+    if (a->split && a->split_out)
+        hipLaunchKernelGGL((mifft::fft_col2_kernel<double, 1, TR, TW, true, true>), g, b, 0, s, *a);
+    else if (a->split)
+        hipLaunchKernelGGL((mifft::fft_col2_kernel<double, 1, TR, TW, true, false>), g, b, 0, s, *a);
+    else if (a->split_out)
+        hipLaunchKernelGGL((mifft::fft_col2_kernel<double, 1, TR, TW, false, true>), g, b, 0, s, *a);
     else
-        hipLaunchKernelGGL((mifft::fft_col2_kernel<double, 1, TR, TW, false>), dim3((unsigned)tiles), dim3(256), 0, s, *a);
+        hipLaunchKernelGGL((mifft::fft_col2_kernel<double, 1, TR, TW, false, false>), g, b, 0, s, *a);
     return (int)hipGetLastError();
 }
 }  // namespace

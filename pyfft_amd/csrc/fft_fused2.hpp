@@ -14,7 +14,8 @@
 // agent-coherent write-through stores, every storing wave drains vmcnt, the work-group barrier, one lane bumps
 // the counter (relaxed, agent scope); the consumer's one lane polls relaxed, ONE acquire fence, vmcnt drain,
 // barrier, then plain loads.  (A release fence per tile -- buffer_wbl2 -- made this kernel 2x slower than two
-// launches.)  The split-plane layout keeps the fence form: 4-byte write-through stores are too slow.
+// launches.)  The scratch ring is always interleaved, also for split-plane user buffers (SPLIT: the input of
+// pass 0 and the output of pass 1 are two scalar planes).
 // Every spin is bounded; on timeout an error word is set (the host checks it) instead of hanging the GPU.
 #pragma once
 #include "fft_col2.hpp"
@@ -51,17 +52,6 @@ template <bool ACQ> __device__ __forceinline__ void fused_wait_ge(unsigned* ctr,
     __syncthreads();
 }
 
-// full agent-scope publication (release fence) -- only used by the split-plane layout
-__device__ __forceinline__ void fused_publish(unsigned* ctr) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 // signal "this tile is done".  The data a later tile depends on was written with write-through stores (pass 0) or
 // is only a read-completion (pass 1), so no release fence is needed: every wave drains its own memory
 // operations, the work-group barrier joins them, one lane bumps the counter.
@@ -95,14 +85,14 @@ __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
             if (g >= f.batch || tile >= f.tiles0) continue;
             const unsigned t = g;
             if (t >= f.ring) fused_wait_ge<false>(rdone + (t - f.ring), f.tiles1, err);
-            col2_tile<T, A0, true, true, SPLIT, !SPLIT, NT, false>(f.p0, (long long)t, (long long)(t % f.ring), (long long)tile * 16, lds);
-            if constexpr (SPLIT) fused_publish(wdone + t); else fused_signal(wdone + t);
+            col2_tile<T, A0, true, true, SPLIT, true, NT, false, false>(f.p0, (long long)t, (long long)(t % f.ring), (long long)tile * 16, lds);
+            fused_signal(wdone + t);
         } else {
             if (g < f.lag) continue;
             const unsigned t = g - f.lag;
             if (t >= f.batch || tile >= f.tiles1) continue;
             fused_wait_ge<true>(wdone + t, f.tiles0, err);
-            col2_tile<T, A1, false, false, SPLIT, false, false, NT>(f.p1, (long long)(t % f.ring), (long long)t, (long long)tile * 16, lds);
+            col2_tile<T, A1, false, false, false, false, false, NT, SPLIT>(f.p1, (long long)(t % f.ring), (long long)t, (long long)tile * 16, lds);
             fused_signal(rdone + t);
         }
     }

@@ -27,7 +27,8 @@ struct NdArgs {
     unsigned char st_axis[kNdMaxStages];
     unsigned char st_radix[kNdMaxStages];  // 2, 4, 8 or 16
     unsigned char st_logNs[kNdMaxStages];  // log2 of the product of the axis' earlier radices
-    int split;
+    int split;      // input layout
+    int split_out;  // output layout
     int inverse;
     double scale;
 };
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(NT) fft_nd_kernel(const NdArgs a) {
 
     // view the I/O helpers of fft_tile.hpp through a TileArgs shell (pointers + layout only)
     TileArgs io;
-    io.in0 = a.in0; io.in1 = a.in1; io.out0 = a.out0; io.out1 = a.out1; io.split = a.split;
+    io.in0 = a.in0; io.in1 = a.in1; io.out0 = a.out0; io.out1 = a.out1; io.split = a.split; io.split_out = a.split_out;
 
     const T csign = a.inverse ? (T)-1 : (T)1;
     auto load_phase = [&](auto vv) {
@@ -162,7 +163,7 @@ __global__ void __launch_bounds__(NT) fft_nd_kernel(const NdArgs a) {
             if (g0 + e < a.total) store_vec<T, V>(io, g0 + e, p);
         });
     };
-    if (a.split) store_phase(IC<4>{}); else store_phase(IC<2>{});
+    if (a.split_out) store_phase(IC<4>{}); else store_phase(IC<2>{});
 }
 
 }  // namespace mifft

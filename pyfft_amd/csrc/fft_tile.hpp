@@ -33,7 +33,8 @@ struct TileArgs {
     int logMS;        // COL: log2(M*S)
     int logS;         // COL: log2(S)
     int tw_shift;
-    int split;
+    int split;      // input side: 1 = two scalar planes (in0 = re, in1 = im), 0 = interleaved in in0
+    int split_out;  // output side likewise (differs from `split` only for a plan's internal temp buffer)
     int inverse;
     int has_tw;  // COL: M > 1 -> multiply by the inter-pass twiddle w(L*M)^(l*q)
     double scale;
@@ -57,7 +58,7 @@ template <typename T> __device__ __forceinline__ void load_pair(const TileArgs& 
 template <typename T> __device__ __forceinline__ void store_pair(const TileArgs& a, long long g, cplx<T> p0,
                                                                  cplx<T> p1) {
     using V4 = T __attribute__((ext_vector_type(4)));
-    if (!a.split) {
+    if (!a.split_out) {
         V4 t;
         t.x = p0.x; t.y = p0.y; t.z = p1.x; t.w = p1.y;
         *reinterpret_cast<V4*>(reinterpret_cast<cplx<T>*>(a.out0) + g) = t;
@@ -231,8 +232,9 @@ __global__ void __launch_bounds__(NT) fft_tile_kernel(const TileArgs a) {
     // Split planes move 4 points (16 bytes per plane) per thread and step when the 4 points are contiguous in
     // memory on both sides; everything else moves 2 points per step.
     constexpr bool kQuadShape = (PPT % 4 == 0) && (ROW ? (L % 4 == 0) : (W % 4 == 0 && L % 4 == 0));
-    const bool quad = kQuadShape && a.split && (((a.ostride_in | a.ostride_out) & 3) == 0) &&
-                      (ROW || (a.logMS >= 2 && (TR || a.logS >= 2)));
+    const bool quad_ok = kQuadShape && (((a.ostride_in | a.ostride_out) & 3) == 0) &&
+                         (ROW || (a.logMS >= 2 && (TR || a.logS >= 2)));
+    const bool quad_in = quad_ok && a.split, quad_out = quad_ok && a.split_out;
     const T csign = a.inverse ? (T)-1 : (T)1;
 
     // ---- global -> registers (all loads in flight), then -> LDS
@@ -275,7 +277,7 @@ __global__ void __launch_bounds__(NT) fft_tile_kernel(const TileArgs a) {
         });
     };
     if constexpr (kQuadShape) {
-        if (quad) load_phase(IC<4>{}); else load_phase(IC<2>{});
+        if (quad_in) load_phase(IC<4>{}); else load_phase(IC<2>{});
     } else {
         load_phase(IC<2>{});
     }
@@ -323,7 +325,7 @@ __global__ void __launch_bounds__(NT) fft_tile_kernel(const TileArgs a) {
         });
     };
     if constexpr (kQuadShape) {
-        if (quad) store_phase(IC<4>{}); else store_phase(IC<2>{});
+        if (quad_out) store_phase(IC<4>{}); else store_phase(IC<2>{});
     } else {
         store_phase(IC<2>{});
     }

@@ -67,7 +67,8 @@ int validate(const mifft_pass* p) {
 
 void fill_args(const mifft_pass* p, const void* in0, const void* in1, void* out0, void* out1, mifft::TileArgs* pa) {
     mifft::TileArgs& a = *pa;
-    const bool split = p->layout == MIFFT_SPLIT;
+    const bool split = p->layout == MIFFT_SPLIT && !(p->flags & MIFFT_FLAG_SRC_INTERLEAVED);
+    const bool split_out = p->layout == MIFFT_SPLIT && !(p->flags & MIFFT_FLAG_DST_INTERLEAVED);
     a.in0 = in0;
     a.in1 = in1;
     a.out0 = out0;
@@ -88,6 +89,7 @@ void fill_args(const mifft_pass* p, const void* in0, const void* in1, void* out0
     }
     a.tw_shift = p->tw_shift;
     a.split = split ? 1 : 0;
+    a.split_out = split_out ? 1 : 0;
     a.inverse = p->inverse ? 1 : 0;
     a.has_tw = (p->kind == MIFFT_PASS_COL && p->M > 1) ? 1 : 0;
     a.scale = p->scale;
@@ -133,7 +135,8 @@ int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0,
         }
     }
     a.nstages = ns;
-    a.split = p->layout == MIFFT_SPLIT ? 1 : 0;
+    a.split = (p->layout == MIFFT_SPLIT && !(p->flags & MIFFT_FLAG_SRC_INTERLEAVED)) ? 1 : 0;
+    a.split_out = (p->layout == MIFFT_SPLIT && !(p->flags & MIFFT_FLAG_DST_INTERLEAVED)) ? 1 : 0;
     a.inverse = p->inverse ? 1 : 0;
     a.scale = p->scale;
     const int rc = mifft_nd_launch(f64 ? 1 : 0, dims[0] * dims[1] * dims[2], &a, s);
@@ -269,14 +272,18 @@ int mifft_launch_pass(const mifft_pass* p, const void* in0, const void* in1, voi
     int rc = validate(p);
     if (rc) return rc;
     if (!in0 || !out0) return set_err(MIFFT_E_INVALID, "null data buffer");
-    const bool split = p->layout == MIFFT_SPLIT;
-    if (split && (!in1 || !out1)) return set_err(MIFFT_E_INVALID, "split layout needs imaginary planes");
-    if (!split && (in1 || out1)) return set_err(MIFFT_E_INVALID, "interleaved layout takes no imaginary planes");
+    const bool split_in = p->layout == MIFFT_SPLIT && !(p->flags & MIFFT_FLAG_SRC_INTERLEAVED);
+    const bool split_out = p->layout == MIFFT_SPLIT && !(p->flags & MIFFT_FLAG_DST_INTERLEAVED);
+    const bool split = split_in;
+    if ((split_in && !in1) || (split_out && !out1)) return set_err(MIFFT_E_INVALID, "split layout needs imaginary planes");
+    if (p->layout != MIFFT_SPLIT && (in1 || out1)) return set_err(MIFFT_E_INVALID, "interleaved layout takes no imaginary planes");
+    if (!split_in) in1 = nullptr;
+    if (!split_out) out1 = nullptr;
     const uintptr_t align_mask = 15;
     if (((uintptr_t)in0 | (uintptr_t)out0 | (uintptr_t)in1 | (uintptr_t)out1) & align_mask)
         return set_err(MIFFT_E_INVALID, "data buffers must be 16-byte aligned");
     if ((p->outer_stride_in | p->outer_stride_out) & 1) return set_err(MIFFT_E_INVALID, "outer strides must be even");
-    if (p->kind == MIFFT_PASS_COL && p->M > 1 && (in0 == out0 || (split && in1 == out1)))
+    if (p->kind == MIFFT_PASS_COL && p->M > 1 && (in0 == out0 || (split && split_out && in1 == out1)))
         return set_err(MIFFT_E_INVALID, "a COL pass with M > 1 cannot run in place");
     if (p->outer == 0) return 0;
 
@@ -316,16 +323,17 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     auto ok_len = [](int L) { return L == 256 || L == 512 || L == 1024; };
     if (!ok_len(p0->L) || !ok_len(p1->L)) return set_err(MIFFT_E_UNSUPPORTED, "fused2: no kernel for %d x %d", p0->L, p1->L);
     const bool split = p0->layout == MIFFT_SPLIT;
-    if (!in0 || !out0 || !ring0 || !counters || (split && (!in1 || !out1 || !ring1))) return set_err(MIFFT_E_INVALID, "fused2: null buffer");
+    if (!in0 || !out0 || !ring0 || !counters || (split && (!in1 || !out1))) return set_err(MIFFT_E_INVALID, "fused2: null buffer");
+    (void)ring1;  // the ring is always interleaved
     if (ring_slots < 2 || lag < 1 || lag >= ring_slots || grid < 1) return set_err(MIFFT_E_INVALID, "fused2: need 1 <= lag < ring_slots, grid >= 1");
-    if (((uintptr_t)in0 | (uintptr_t)out0 | (uintptr_t)ring0 | (uintptr_t)in1 | (uintptr_t)out1 | (uintptr_t)ring1) & 15)
+    if (((uintptr_t)in0 | (uintptr_t)out0 | (uintptr_t)ring0 | (uintptr_t)in1 | (uintptr_t)out1) & 15)
         return set_err(MIFFT_E_INVALID, "data buffers must be 16-byte aligned");
     if (p0->outer == 0) return 0;
     if (p0->outer > 0x3fffffff) return set_err(MIFFT_E_INVALID, "fused2: batch too large");
     const int64_t n = (int64_t)p0->L * p1->L;
     mifft::FusedArgs f;
-    fill_args(p0, in0, in1, ring0, ring1, &f.p0);
-    fill_args(p1, ring0, ring1, out0, out1, &f.p1);
+    fill_args(p0, in0, in1, ring0, nullptr, &f.p0);
+    fill_args(p1, ring0, nullptr, out0, out1, &f.p1);
     f.p0.ostride_out = n;  // ring slot pitch
     f.p1.ostride_in = n;
     f.counters = (unsigned*)counters;
@@ -357,6 +365,12 @@ int mifft_launch_chain_pipelined(const mifft_pass* passes, int32_t npasses, void
     const bool f64 = passes[0].precision == MIFFT_F64;
     const bool split = passes[0].layout == MIFFT_SPLIT;
     const int64_t ebytes = (split ? 1 : 2) * (f64 ? 8 : 4);
+    bool tmp_interleaved = !split;  // the temp buffer is interleaved when the passes touching it say so
+    for (int i = 0; i < npasses; ++i) {
+        if (passes[i].src == 2 && (passes[i].flags & MIFFT_FLAG_SRC_INTERLEAVED)) tmp_interleaved = true;
+        if (passes[i].dst == 2 && (passes[i].flags & MIFFT_FLAG_DST_INTERLEAVED)) tmp_interleaved = true;
+    }
+    const int64_t tbytes = (tmp_interleaved ? 2 : 1) * (f64 ? 8 : 4);
     int rc = hip_check(hipEventRecord((hipEvent_t)events[0], (hipStream_t)stream), "hipEventRecord");
     if (rc) return rc;
     const int64_t nchunks = (batch + chunk - 1) / chunk;
@@ -369,7 +383,7 @@ int mifft_launch_chain_pipelined(const mifft_pass* passes, int32_t npasses, void
         const int64_t nb = (c + 1) * chunk <= batch ? chunk : batch - c * chunk;
         const int slot = (int)(c % nside);
         const int64_t off_io = c * chunk * item_elems * ebytes;
-        const int64_t off_tmp = (int64_t)slot * chunk * item_elems * ebytes;
+        const int64_t off_tmp = (int64_t)slot * chunk * item_elems * tbytes;
         for (int i = 0; i < npasses; ++i) {
             mifft_pass p = passes[i];
             p.outer = p.outer / batch * nb;

@@ -194,6 +194,13 @@ class FFTPlan(object):
             # in-place call: data_out aliases data_in, the schedule only uses indices 1 and 2
             d.src = src
             d.dst = dst
+            # the plan-owned temp buffer is always interleaved, also for split-plane plans (include/mifft.h)
+            d.flags = 0
+            if p.split:
+                if src == 2:
+                    d.flags |= N.FLAG_SRC_INTERLEAVED
+                if dst == 2:
+                    d.flags |= N.FLAG_DST_INTERLEAVED
         if len(self._desc_cache) > 64:
             self._desc_cache.clear()
         self._desc_cache[key] = arr
@@ -212,7 +219,7 @@ class FFTPlan(object):
     def _fused2_eligible(self):
         p = self._params
         k = self._kernels
-        return (p.precision == N.F32 and not p.split and len(k) == 2 and int(p.y) == 1 and int(p.z) == 1
+        return (p.precision == N.F32 and len(k) == 2 and int(p.y) == 1 and int(p.z) == 1
                 and k[0].kind == N.PASS_COL and k[1].kind == N.PASS_COL and k[0].S == 1 and k[0].M == k[1].L
                 and k[1].M == 1 and k[0].L in (256, 512, 1024) and k[1].L in (256, 512, 1024))
 
@@ -261,12 +268,9 @@ class FFTPlan(object):
             items = self._strategy[1] * self._strategy[2]  # chunk * streams
         else:
             items = batch
-        buffer_size = p.size * items * p.scalar_nbytes
-        if p.split:
-            self._tempmemobj_re = ctx.allocate(buffer_size)
-            self._tempmemobj_im = ctx.allocate(buffer_size)
-        else:
-            self._tempmemobj = ctx.allocate(buffer_size * 2)
+        # one interleaved buffer for both layouts (the reference allocates two scalar planes for split plans,
+        # plan.py:189-190; same total size)
+        self._tempmemobj = ctx.allocate(p.size * items * p.complex_nbytes)
 
     def _enqueue(self, batch, is_inplace, inverse, bufs0, bufs1):
         ctx = self._context
@@ -277,7 +281,9 @@ class FFTPlan(object):
             _, lag, ring, grid = strat
             d0, d1 = descs[0], descs[1]
             # the two-pass schedule is in -> temp -> out for both in-place and out-of-place calls
-            N.check(N.lib.mifft_launch_fused2(ctypes.byref(d0), ctypes.byref(d1), bufs0[d0.src], None, bufs0[d1.dst], None,
+            in1 = bufs1[d0.src] if bufs1 is not None else None
+            out1 = bufs1[d1.dst] if bufs1 is not None else None
+            N.check(N.lib.mifft_launch_fused2(ctypes.byref(d0), ctypes.byref(d1), bufs0[d0.src], in1, bufs0[d1.dst], out1,
                                               bufs0[2], None, ring, lag, ctx.pointer_of(self._counters), grid, stream),
                     "mifft_launch_fused2")
         elif strat[0] == "pipelined":
@@ -308,8 +314,8 @@ class FFTPlan(object):
                     is_inplace = True
                 else:
                     raise ValueError("partially aliased split buffers")
-            bufs0 = N.make_buf3(in_re, out_re, ptr(self._tempmemobj_re) if self._tempmemobj_re is not None else None)
-            bufs1 = N.make_buf3(in_im, out_im, ptr(self._tempmemobj_im) if self._tempmemobj_im is not None else None)
+            bufs0 = N.make_buf3(in_re, out_re, ptr(self._tempmemobj) if self._tempmemobj is not None else None)
+            bufs1 = N.make_buf3(in_im, out_im, None)
         else:
             d_in, d_out = (ptr(a) for a in args)
             if not is_inplace and d_in == d_out:

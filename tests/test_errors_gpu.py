@@ -184,3 +184,28 @@ def test_pipelined_chunks(ctx, monkeypatch, shape, batch):
     assert numpy.array_equal(want, got_ip)
     ref = oracle.numpy_fft(numpy.fft.fftn, data[:shape[0] * 2], 2)
     assert oracle.difference(ref, got[:shape[0] * 2], 2) < 1.1e-6
+
+
+@pytest.mark.parametrize("n,batch,strat", [(1 << 16, 520, "pipelined"), (1 << 20, 37, "fused"), (1 << 18, 80, "fused")], ids=str)
+def test_split_plane_strategies(ctx, monkeypatch, n, batch, strat):
+    """float32 split planes through the chunked / fused strategies (the plan's temp buffer is interleaved even
+    though the user buffers are planes): bit-identical to the plain chain, within tolerance of numpy."""
+    re, im = oracle.get_test_data((n,), numpy.float32, batch, 99)
+    outs = {}
+    for s in ("chain", strat):
+        monkeypatch.setenv("PYFFT_AMD_STRATEGY", s)
+        plan = ctx.getPlan((n,), dtype=numpy.float32)
+        assert plan.strategy(batch)[0] == {"fused": "fused2", "chain": "chain", "pipelined": "pipelined"}[s]
+        a, b = ctx.toGpu(re), ctx.toGpu(im)
+        c, d = ctx.allocate(re.shape, re.dtype), ctx.allocate(im.shape, im.dtype)
+        plan.execute(a, b, c, d, batch=batch)
+        assert numpy.array_equal(a.get(), re) and numpy.array_equal(b.get(), im)
+        outs[s] = (c.get(), d.get())
+        plan.execute(a, b, batch=batch)                  # in place
+        assert numpy.array_equal(a.get(), outs[s][0]) and numpy.array_equal(b.get(), outs[s][1])
+    assert numpy.array_equal(outs["chain"][0], outs[strat][0]) and numpy.array_equal(outs["chain"][1], outs[strat][1])
+    for item in (0, batch - 1):
+        sl = slice(item * n, (item + 1) * n)
+        ref = numpy.fft.fft(re[sl].astype(numpy.float64) + 1j * im[sl])
+        got = outs[strat][0][sl].astype(numpy.float64) + 1j * outs[strat][1][sl]
+        assert numpy.abs(ref - got).sum() / numpy.abs(ref).sum() < 1.1e-6
