@@ -149,7 +149,7 @@ def build_chain(x, y, z, precision):
     return chain
 
 
-def buffer_schedule(chain, is_inplace):
+def buffer_schedule(chain, is_inplace, via_temp=False):
     """Buffer ping-pong of FFTPlan._execute (plan.py:194-248): returns (temp_needed,
     [(src, dst), ...]) with 0 = data_in, 1 = data_out, 2 = temp.  Contract: an out-of-place
     call never writes data_in; an in-place call leaves the result in data_in (for which
@@ -158,6 +158,11 @@ def buffer_schedule(chain, is_inplace):
     odd = (len(chain) % 2 == 1)
     sched = []
     curr_read, curr_write = 0, 1
+    if via_temp and not temp_needed and len(chain) >= 2:
+        # every pass can run in place: go in -> temp, stay on the temp, last pass temp -> out
+        # (used for fp32 split-plane plans, whose temp is interleaved: only two sides touch the planes)
+        first = 1 if is_inplace else 0
+        return True, [(first, 2)] + [(2, 2)] * (len(chain) - 2) + [(2, 1)]
     if temp_needed:
         inplace_done = False
         if is_inplace:

@@ -123,6 +123,11 @@ class FFTPlan(object):
         p = self._params
         self._kernels = P.build_chain(int(p.x), int(p.y), int(p.z), p.precision)
         self._temp_buffer_needed = any(not k.in_place_possible for k in self._kernels)
+        # fp32 split planes: 16 columns of a plane are 64-byte segments, so multi-pass plans detour through an
+        # interleaved temp even when every pass could run in place (passes.buffer_schedule)
+        self._via_temp = (p.split and p.precision == N.F32 and len(self._kernels) >= 2 and not self._temp_buffer_needed)
+        if self._via_temp:
+            self._temp_buffer_needed = True
 
         self._tables = {}      # key -> device allocation
         self._table_ptrs = []  # per pass: (tw_L, tw_lo, tw_hi, shift)
@@ -170,7 +175,7 @@ class FFTPlan(object):
         if d is not None:
             return d
         p = self._params
-        _, sched = P.buffer_schedule(self._kernels, is_inplace)
+        _, sched = P.buffer_schedule(self._kernels, is_inplace, self._via_temp)
         arr = (N.MifftPass * max(1, len(self._kernels)))()
         last = len(self._kernels) - 1
         for i, (k, (src, dst), (twL, lo, hi, shift)) in enumerate(zip(self._kernels, sched, self._table_ptrs)):

@@ -211,3 +211,25 @@ def test_kernel_model_matches_oracle():
         x = rnd(outer * L * M * S)
         y = km.run_pass(x, False, L, M, S, outer, L * M * S, W, NT, rad)
         assert numpy.abs(y - oracle.global_pass(x, L, M, S, -1)).max() < 1e-9
+
+
+def test_via_temp_schedule_contract():
+    """fp32 split-plane plans whose passes could all run in place detour through the (interleaved) temp:
+    in -> temp, temp -> temp ..., temp -> out.  Same contract: out-of-place never writes data_in, the result
+    lands in data_out / data_in."""
+    from pyfft_amd import _native as N
+    from pyfft_amd import passes as P
+    for xyz in [(1024, 1024, 1), (256, 256, 256), (64, 64, 2048)]:
+        chain = P.build_chain(*xyz, N.F32)
+        assert all(k.in_place_possible for k in chain) and len(chain) >= 2
+        for inplace in (False, True):
+            temp, sched = P.buffer_schedule(chain, inplace, via_temp=True)
+            assert temp and len(sched) == len(chain)
+            assert sched[0] == ((1 if inplace else 0), 2) and sched[-1] == (2, 1)
+            assert all(sd == (2, 2) for sd in sched[1:-1])
+            assert all(w != 0 for _, w in sched)
+    # single-pass plans and plans that need the temp anyway are unchanged
+    for xyz in [(1024, 1, 1), (1 << 20, 1, 1), (16, 16, 1)]:
+        chain = P.build_chain(*xyz, N.F32)
+        for inplace in (False, True):
+            assert P.buffer_schedule(chain, inplace, via_temp=True) == P.buffer_schedule(chain, inplace)
