@@ -99,9 +99,7 @@ class FFTPlan(object):
         self._scale = float(scale)
         self._wait_for_finish = wait_for_finish
 
-        self._tempmemobj = None
-        self._tempmemobj_re = None
-        self._tempmemobj_im = None
+        self._tempmemobj = None      # always one interleaved buffer (see _prepare)
         self._last_batch_size = 0
         self._desc_cache = {}
         self._strategy = ("chain",)
@@ -259,7 +257,7 @@ class FFTPlan(object):
             return
         self._last_batch_size = batch
         self._strategy = self._select_strategy(batch)
-        self._tempmemobj = self._tempmemobj_re = self._tempmemobj_im = None
+        self._tempmemobj = None
         if self._strategy[0] == "pipelined" and self._side_streams is None:
             from .hip import Stream, Event
             self._side_streams = [Stream() for _ in range(self._strategy[2])]
