@@ -1,0 +1,198 @@
+// Contiguous-axis (ROW) transforms, register-edged form: one work-group owns W rows of L points (whole LDS-resident
+// transform; counterpart of pyfft/kernel.mako:725-803), TPR = NT / W threads per row, every thread keeps PPT = L / TPR
+// points of its row.
+// Unlike fft_tile.hpp the first radix stage takes its operands straight from HBM into registers and the last one
+// stores its results straight from registers to HBM, so a three-stage transform crosses LDS twice instead of four times
+// (the long rows are LDS-bound: one 70 / 139 KiB tile per CU).
+//
+// Stockham autosort indexing as in fft_tile.hpp: stage with radix R and Ns = product of the earlier radices reads
+// idx = j + k*L/R, multiplies by w(L)^(k * (j mod Ns) * L/(Ns*R)) and writes (j & ~(Ns-1))*R + (j & (Ns-1)) + k*Ns.
+// For the first stage (Ns = 1) the reads are x[j + k*L/R]: consecutive j across the lanes, so coalesced; for the last
+// stage (Ns = L/R) the writes are out[j + k*L/R], coalesced likewise.
+#pragma once
+#include <type_traits>
+#include "fft_tile.hpp"
+
+namespace mifft {
+
+// v[k] *= w(L)^(k*ai), k < R, with few look-ups (the table competes with the data stream for the L1) and few live
+// registers: powers 1..7 (or 1..R-1 for R <= 8) by a product tree from one look-up, every further block of 8 from its own
+// look-up w(L)^(8h*ai) times the first seven -- no power is further than 4 products from a table entry.
+template <typename T, int R> __device__ __forceinline__ void row2_twiddle(const cplx<T>* twL, int ai, cplx<T>* v) {
+    constexpr int Q = R < 8 ? R : 8;
+    cplx<T> t[Q];
+    t[1] = twL[ai];
+    static_for<Q - 2>([&](auto kk) {
+        constexpr int k = kk + 2;
+        if constexpr ((k & 1) == 0) t[k] = cmul<T>(t[k / 2], t[k / 2]);
+        else t[k] = cmul<T>(t[k - 1], t[1]);
+    });
+    static_for<Q - 1>([&](auto kk) {
+        constexpr int k = kk + 1;
+        v[k] = cmul<T>(v[k], t[k]);
+    });
+    static_for<R / 8 - (R >= 8 ? 1 : 0)>([&](auto hh) {
+        constexpr int h = (hh + 1) * 8;
+        const cplx<T> th = twL[h * ai];
+        v[h] = cmul<T>(v[h], th);
+        static_for<7>([&](auto kk) {
+            constexpr int k = kk + 1;
+            v[h + k] = cmul<T>(v[h + k], cmul<T>(th, t[k]));
+        });
+    });
+}
+
+__device__ __forceinline__ int row2_pad(int i) { return i + (i >> 4); }
+
+// TPR = threads per row; `tid` below is the thread's index within its row, `lds` the row's own LDS slab.
+// HALF: the exchange between two stages moves the real parts, then the imaginary parts, through an LDS slab of L scalars
+// instead of L complex numbers: twice the barriers, half the LDS, so twice the work-groups per CU for the longest rows.
+template <typename T, int L, int TPR, int Ns, bool FIRST, bool HALF, typename RL> struct Row2Stages;
+
+template <typename T, int L, int TPR, int Ns, bool FIRST, bool HALF, int R, int... Rest>
+struct Row2Stages<T, L, TPR, Ns, FIRST, HALF, RadixList<R, Rest...>> {
+    static constexpr int NT = TPR;
+    static constexpr int PPT = L / NT;
+    static constexpr int NB = PPT / R;
+    static constexpr int LR = L / R;
+    static constexpr bool LAST = sizeof...(Rest) == 0;
+    static_assert(NB >= 1 && NB * R == PPT, "radix must divide the points per thread");
+    static_assert(!(FIRST && LAST), "needs at least two stages");
+    using LdsT = typename std::conditional<HALF, T, cplx<T>>::type;
+
+    // operands of this stage: LDS -> v (component sel: 0 = whole complex number, 1 = real part, 2 = imaginary part)
+    // LDS addresses are one per-thread base + a compile-time offset (DS instructions carry a 16-bit immediate): with
+    // idx = base + c, c a multiple of a power of two that divides 16 or is divided by it and base % 16 + c % 16 < 16,
+    // pad(idx) = pad(base) + c + (c >> 4).  Computing pad() per access instead keeps one address VGPR per point alive.
+    template <int SEL> static __device__ __forceinline__ void fetch(const LdsT* lds, cplx<T>* v, int tid) {
+        static_for<NB>([&](auto bb) {
+            constexpr int b = bb;
+            const LdsT* p = lds + row2_pad(b * NT + tid);  // j = b * NT + tid < LR
+            static_for<R>([&](auto kk) {
+                constexpr int k = kk;
+                constexpr int off = k * LR + ((k * LR) >> 4);
+                if constexpr (SEL == 0) v[b * R + k] = p[off];
+                else if constexpr (SEL == 1) v[b * R + k].x = p[off];
+                else v[b * R + k].y = p[off];
+            });
+        });
+    }
+    // results of this stage: v -> LDS at the autosort position
+    template <int SEL> static __device__ __forceinline__ void spill(LdsT* lds, const cplx<T>* v, int tid) {
+        static_for<NB>([&](auto bb) {
+            constexpr int b = bb;
+            const int j = b * NT + tid;
+            const int idxD = (j & ~(Ns - 1)) * R + (j & (Ns - 1));
+            LdsT* p = lds + row2_pad(idxD);
+            static_for<R>([&](auto kk) {
+                constexpr int k = kk;
+                constexpr int off = k * Ns + ((k * Ns) >> 4);
+                if constexpr (SEL == 0) p[off] = v[b * R + k];
+                else if constexpr (SEL == 1) p[off] = v[b * R + k].x;
+                else p[off] = v[b * R + k].y;
+            });
+        });
+    }
+
+    // v holds the operands of this stage (from HBM for the first stage, from the exchange otherwise)
+    // Global addresses are (base pointer) + constant + (32-bit per-thread byte offset voff): with one row per
+    // work-group the base is wave-uniform and lives in SGPRs, so a load costs no address VGPRs beyond voff (with 64-bit
+    // per-load addresses the 32 loads of a thread alone pinned 64 VGPRs and halved the occupancy).
+    static __device__ __forceinline__ void run(LdsT* lds, cplx<T>* v, const TileArgs& a, int tid, const char* inb,
+                                               char* outb, unsigned voff, bool valid) {
+        const cplx<T>* twL = reinterpret_cast<const cplx<T>*>(a.tw_L);
+        if constexpr (FIRST) {
+            // all loads of the row in flight before the first butterfly
+            static_for<PPT>([&](auto i) { v[i].x = 0; v[i].y = 0; });
+            if (valid) {
+                static_for<NB>([&](auto bb) {
+                    constexpr int b = bb;
+                    static_for<R>([&](auto kk) {
+                        constexpr int k = kk;
+                        v[b * R + k] = *reinterpret_cast<const cplx<T>*>(
+                            inb + (size_t)(b * NT + k * LR) * sizeof(cplx<T>) + voff);
+                    });
+                });
+            }
+            if (a.inverse) static_for<PPT>([&](auto i) { v[i].y = -v[i].y; });
+        }
+        static_for<NB>([&](auto bb) {
+            constexpr int b = bb;
+            const int j = b * NT + tid;
+            if constexpr (!FIRST) {
+                const int ai = (j & (Ns - 1)) * (L / (Ns * R));
+                row2_twiddle<T, R>(twL, ai, v + b * R);
+            }
+            Dft<R, T>::run(v + b * R);
+        });
+        if constexpr (LAST) {
+            const T sx = (T)a.scale;
+            const T sy = a.inverse ? -sx : sx;
+            if (valid) {
+                static_for<NB>([&](auto bb) {
+                    constexpr int b = bb;  // Ns == LR: idxD = j = b * NT + tid
+                    static_for<R>([&](auto kk) {
+                        constexpr int k = kk;
+                        cplx<T> p = v[b * R + k];
+                        p.x *= sx;
+                        p.y *= sy;
+                        *reinterpret_cast<cplx<T>*>(outb + (size_t)(b * NT + k * Ns) * sizeof(cplx<T>) + voff) = p;
+                    });
+                });
+            }
+        } else {
+            using Next = Row2Stages<T, L, TPR, Ns * R, false, HALF, RadixList<Rest...>>;
+            if constexpr (!FIRST) __syncthreads();  // everybody has fetched its operands of this stage
+            if constexpr (!HALF) {
+                spill<0>(lds, v, tid);
+                __syncthreads();
+                Next::template fetch<0>(lds, v, tid);
+            } else {
+                spill<1>(lds, v, tid);
+                __syncthreads();
+                Next::template fetch<1>(lds, v, tid);  // the real-part registers are free again: reuse them
+                __syncthreads();
+                spill<2>(lds, v, tid);
+                __syncthreads();
+                Next::template fetch<2>(lds, v, tid);
+            }
+            Next::run(lds, v, a, tid, inb, outb, voff, valid);
+        }
+    }
+};
+
+// OCC: waves per SIMD the register allocation must leave room for (1 = whatever the kernel needs)
+template <typename T, int L, int W, int NT, bool HALF, int OCC, typename RL>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) fft_row2_kernel(const TileArgs a) {
+    constexpr int TPR = NT / W;
+    constexpr int PPT = L / TPR;
+    constexpr int LP = L + L / 16;
+    static_assert(TPR * W == NT && PPT * TPR == L && L >= 16, "bad row configuration");
+    using LdsT = typename std::conditional<HALF, T, cplx<T>>::type;
+    __shared__ __attribute__((aligned(16))) LdsT lds[W * LP];
+    const int c = W == 1 ? 0 : threadIdx.x / TPR, u = W == 1 ? threadIdx.x : threadIdx.x % TPR;
+    const long long row = (long long)blockIdx.x * W + c;
+    const bool valid = row < a.total;
+    const char* inb = reinterpret_cast<const char*>(reinterpret_cast<const cplx<T>*>(a.in0) + row * a.ostride_in);
+    char* outb = reinterpret_cast<char*>(reinterpret_cast<cplx<T>*>(a.out0) + row * a.ostride_out);
+    unsigned voff = (unsigned)u * (unsigned)sizeof(cplx<T>);
+    if constexpr (W > 1) {  // the row differs across the wave: fold the thread's offset into its own 64-bit base
+        inb += voff;
+        outb += voff;
+        voff = 0;
+    }
+    cplx<T> v[PPT];
+    Row2Stages<T, L, TPR, 1, true, HALF, RL>::run(lds + c * LP, v, a, u, inb, outb, voff, valid);
+}
+
+template <typename T, int L, int W, int NT, typename RL, bool HALF = false, int OCC = 1>
+static inline int launch_row2(const TileArgs* a, hipStream_t s, int query_only) {
+    if (query_only) return 0;
+    const long long tiles = (a->total + W - 1) / W;
+    if (tiles <= 0) return 0;
+    if (tiles > 2147483647ll) return -1;
+    hipLaunchKernelGGL((fft_row2_kernel<T, L, W, NT, HALF, OCC, RL>), dim3((unsigned)tiles), dim3(NT), 0, s, *a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mifft

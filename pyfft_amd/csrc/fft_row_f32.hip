@@ -1,7 +1,22 @@
-// fp32 contiguous-axis (ROW) tile kernels: W rows of L points per work-group, 16 points per thread.
+// fp32 contiguous-axis (ROW) kernels: register-edged form (fft_row2.hpp) for interleaved L >= 256, LDS-staged tile
+// kernels (fft_tile.hpp; W rows of L points per work-group, 16 points per thread) for short rows and split planes.
 #include "mifft_internal.h"
+#include "fft_row2.hpp"
 extern "C" int mifft_dispatch_row_f32(int L, int variant, const mifft::TileArgs* a, hipStream_t s, int query_only) {
     if (variant != 0) return -2;
+    // both sides interleaved: register-edged kernels (fft_row2.hpp).  Shapes chosen by measurement (1 GiB buffers,
+    // tools/row_probe.py): the half-exchange form wins where it raises the work-groups per CU (8192: 2 -> 3,
+    // 16384: 1 -> 2), the plain form everywhere else.
+    if (a && !a->split && !a->split_out) {
+        using namespace mifft;
+        if (L == 256) return launch_row2<float, 256, 8, 256, RadixList<8, 8, 4>>(a, s, query_only);
+        if (L == 512) return launch_row2<float, 512, 8, 256, RadixList<16, 2, 16>>(a, s, query_only);
+        if (L == 1024) return launch_row2<float, 1024, 4, 256, RadixList<16, 4, 16>>(a, s, query_only);
+        if (L == 2048) return launch_row2<float, 2048, 1, 128, RadixList<16, 8, 16>>(a, s, query_only);
+        if (L == 4096) return launch_row2<float, 4096, 1, 256, RadixList<16, 16, 16>>(a, s, query_only);
+        if (L == 8192) return launch_row2<float, 8192, 1, 256, RadixList<16, 16, 32>, true>(a, s, query_only);
+        if (L == 16384) return launch_row2<float, 16384, 1, 512, RadixList<4, 16, 16, 16>, true, 4>(a, s, query_only);
+    }
     switch (L) {
         MIFFT_ROW_CASE(float, 2, 2048, 256, 2)
         MIFFT_ROW_CASE(float, 4, 1024, 256, 4)

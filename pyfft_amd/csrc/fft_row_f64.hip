@@ -1,7 +1,18 @@
-// fp64 contiguous-axis (ROW) tile kernels: 8 points per thread.
+// fp64 contiguous-axis (ROW) kernels: register-edged form (fft_row2.hpp) for interleaved L >= 1024, LDS-staged tile
+// kernels (8 points per thread) otherwise.
 #include "mifft_internal.h"
+#include "fft_row2.hpp"
 extern "C" int mifft_dispatch_row_f64(int L, int variant, const mifft::TileArgs* a, hipStream_t s, int query_only) {
     if (variant != 0) return -2;
+    // both sides interleaved: register-edged kernels (fft_row2.hpp); L <= 512: the LDS-staged tile kernels below
+    // measure faster for 16-byte points.  8192: half-exchange form, 2 work-groups per CU instead of 1 (59 % -> 70 %).
+    if (a && !a->split && !a->split_out) {
+        using namespace mifft;
+        if (L == 1024) return launch_row2<double, 1024, 4, 256, RadixList<16, 4, 16>>(a, s, query_only);
+        if (L == 2048) return launch_row2<double, 2048, 1, 128, RadixList<16, 8, 16>>(a, s, query_only);
+        if (L == 4096) return launch_row2<double, 4096, 1, 256, RadixList<16, 16, 16>>(a, s, query_only);
+        if (L == 8192) return launch_row2<double, 8192, 1, 512, RadixList<2, 16, 16, 16>, true>(a, s, query_only);
+    }
     switch (L) {
         MIFFT_ROW_CASE(double, 2, 1024, 256, 2)
         MIFFT_ROW_CASE(double, 4, 512, 256, 4)

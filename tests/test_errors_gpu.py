@@ -122,6 +122,17 @@ def test_errors_batched(ctx, shape, batch, dtype):
     run_protocol(ctx, shape, dtype, batch - 1 if batch > 1 else 5, seed=78, check_oracle=False)
 
 
+@pytest.mark.parametrize("dtype,n", [(numpy.complex64, 1 << k) for k in range(8, 15)] +
+                         [(numpy.complex128, 1 << k) for k in range(10, 14)],
+                         ids=lambda v: str(v) if isinstance(v, int) else numpy.dtype(v).name)
+def test_register_edged_rows(ctx, dtype, n):
+    """Every register-edged ROW kernel (csrc/fft_row2.hpp: several rows per work-group, plain and half-exchange
+    forms) with a batch that leaves a ragged last tile, and as the first pass of a 2-D plan."""
+    run_protocol(ctx, (n,), dtype, 37, seed=n + 5)
+    if n <= 4096:
+        run_protocol(ctx, (128, n), dtype, 3, seed=n + 6)  # numpy shape (y, x): ROW over x = n, then a strided pass
+
+
 @pytest.mark.parametrize("dtype", [numpy.complex64, numpy.float32], ids=lambda d: numpy.dtype(d).name)
 def test_errors_large_1d(ctx, dtype):
     """N = 2^20 (BASELINE config 2 shape, small batch): the reference's largest 1-D test size
