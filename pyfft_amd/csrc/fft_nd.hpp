@@ -7,6 +7,11 @@
 // idxD = (jb & ~(Ns-1))*R + (jb & (Ns-1))), with the axis' elements S = (product of faster axes) apart; the
 // transforms of a tile and the slower axes are just more independent "outer" butterflies.  All sizes are runtime
 // (shifts), only the radix of a stage is a template parameter, so any power-of-two shape with x*y*z <= P works.
+//
+// Register edge: when the last stage of all writes runs of >= 128 bytes (the faster axes are contiguous under it), its
+// results go straight from registers to HBM (edge_out) instead of through LDS and a linear store: one LDS write + read
+// of the whole tile and a barrier less (+2...7 points of roofline).  The mirror image for the first stage measured
+// slower than the 16-byte linear load + LDS round it replaces (8-byte accesses in 128-byte runs) and is not built.
 #pragma once
 #include "fft_tile.hpp"
 
@@ -30,13 +35,17 @@ struct NdArgs {
     int split;      // input layout
     int split_out;  // output layout
     int inverse;
+    int edge_out;   // last stage writes its results straight to HBM (interleaved output only)
     double scale;
 };
 
 __device__ __forceinline__ int nd_pad(int i) { return i + (i >> 4); }
 
-template <typename T, int P, int NT, int R>
-__device__ __forceinline__ void nd_stage(cplx<T>* lds, cplx<T>* v, const cplx<T>* tw, int logL, int logS, int logNs, int tid) {
+// EDGE (last stage of all): results scaled (and conjugated back for the inverse) straight to HBM; `gout` = first byte of
+// the tile, `left` = points from the start of the tile to the end of the data (whole transforms are in or out).
+template <typename T, int P, int NT, int R, bool EDGE>
+__device__ __forceinline__ void nd_stage(cplx<T>* lds, cplx<T>* v, const cplx<T>* tw, int logL, int logS, int logNs, int tid,
+                                         char* gout, long long left, T sx, T sy) {
     constexpr int PPT = P / NT;
     constexpr int NB = PPT / R;
     constexpr int logR = R == 2 ? 1 : R == 4 ? 2 : R == 8 ? 3 : 4;
@@ -86,12 +95,25 @@ __device__ __forceinline__ void nd_stage(cplx<T>* lds, cplx<T>* v, const cplx<T>
         constexpr int b = bb;
         const int jb = jbs[b];
         const int idxD = ((jb & ~(Ns - 1)) << logR) + (jb & (Ns - 1));
-        static_for<R>([&](auto kk) {
-            constexpr int k = kk;
-            lds[nd_pad(base[b] + ((idxD + (k << logNs)) << logS))] = v[b * R + k];
-        });
+        if constexpr (EDGE) {
+            if (base[b] < left) {
+                static_for<R>([&](auto kk) {
+                    constexpr int k = kk;
+                    cplx<T> p = v[b * R + k];
+                    p.x *= sx;
+                    p.y *= sy;
+                    const unsigned idx = (unsigned)(base[b] + ((idxD + (k << logNs)) << logS));
+                    *reinterpret_cast<cplx<T>*>(gout + idx * (unsigned)sizeof(cplx<T>)) = p;
+                });
+            }
+        } else {
+            static_for<R>([&](auto kk) {
+                constexpr int k = kk;
+                lds[nd_pad(base[b] + ((idxD + (k << logNs)) << logS))] = v[b * R + k];
+            });
+        }
     });
-    __syncthreads();
+    if constexpr (!EDGE) __syncthreads();
 }
 
 template <typename T, int P, int NT>
@@ -132,22 +154,30 @@ __global__ void __launch_bounds__(NT) fft_nd_kernel(const NdArgs a) {
     if (a.split) load_phase(IC<4>{}); else load_phase(IC<2>{});
     __syncthreads();
 
+    const T sx = (T)a.scale;
+    const T sy = a.inverse ? -sx : sx;
+    const long long left = a.total - g0;
+    char* gout = reinterpret_cast<char*>(reinterpret_cast<cplx<T>*>(a.out0) + g0);
     for (int s = 0; s < a.nstages; ++s) {
         const int ax = a.st_axis[s];
         const cplx<T>* tw = reinterpret_cast<const cplx<T>*>(a.tw[ax]);
         const int logL = a.logL[ax], logS = a.logS[ax], logNs = a.st_logNs[s];
+        const bool edge = s + 1 == a.nstages && a.edge_out;
+#define MIFFT_ND_STAGE(R)                                                                          \
+    if (edge) nd_stage<T, P, NT, R, true>(lds, v, tw, logL, logS, logNs, tid, gout, left, sx, sy); \
+    else nd_stage<T, P, NT, R, false>(lds, v, tw, logL, logS, logNs, tid, gout, left, sx, sy);
         switch (a.st_radix[s]) {
-            case 2: nd_stage<T, P, NT, 2>(lds, v, tw, logL, logS, logNs, tid); break;
-            case 4: nd_stage<T, P, NT, 4>(lds, v, tw, logL, logS, logNs, tid); break;
-            case 8: nd_stage<T, P, NT, 8>(lds, v, tw, logL, logS, logNs, tid); break;
+            case 2: MIFFT_ND_STAGE(2) break;
+            case 4: MIFFT_ND_STAGE(4) break;
+            case 8: MIFFT_ND_STAGE(8) break;
             default:
-                if constexpr (PPT >= 16) nd_stage<T, P, NT, 16>(lds, v, tw, logL, logS, logNs, tid);
+                if constexpr (PPT >= 16) { MIFFT_ND_STAGE(16) }
                 break;
         }
+#undef MIFFT_ND_STAGE
     }
+    if (a.edge_out) return;
 
-    const T sx = (T)a.scale;
-    const T sy = a.inverse ? -sx : sx;
     auto store_phase = [&](auto vv) {
         constexpr int V = vv;
         static_for<PPT / V>([&](auto ii) {

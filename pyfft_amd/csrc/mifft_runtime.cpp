@@ -139,6 +139,12 @@ int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0,
     a.split_out = (p->layout == MIFFT_SPLIT && !(p->flags & MIFFT_FLAG_DST_INTERLEAVED)) ? 1 : 0;
     a.inverse = p->inverse ? 1 : 0;
     a.scale = p->scale;
+    // register edge: the last stage of all writes runs of (L / radix) * S points; straight to HBM when that is >= 128 bytes
+    if (ns >= 1) {
+        const int axn = a.st_axis[ns - 1];
+        const long long run_out = ((dims[axn] / a.st_radix[ns - 1]) << a.logS[axn]) * (f64 ? 16 : 8);
+        a.edge_out = (!a.split_out && run_out >= 128) ? 1 : 0;
+    }
     const int rc = mifft_nd_launch(f64 ? 1 : 0, dims[0] * dims[1] * dims[2], &a, s);
     if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
     if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
