@@ -30,10 +30,13 @@ template <int A, int E, typename T> __device__ __forceinline__ cplx<T> mul_w16A(
         return mul_w32<E, T>(v);  // A == 2: w(32)
 }
 
-template <int A, bool TR> struct Col2Lds {
+// ESZ = bytes per complex element: 8-byte points double-buffer the exchange (2 x 34 KiB); 16-byte points reuse one
+// 68 KiB buffer with one more barrier per round, so that two work-groups still share a CU.
+template <int A, bool TR, int ESZ = 8> struct Col2Lds {
     static constexpr int PITCH = TR ? 17 : 16;   // TR: [b0][c][qb1 + pad]; else [b0][qb1][c]
     static constexpr int BUF = 16 * 16 * PITCH;  // complex elements per exchange buffer
-    static constexpr int ELEMS = (A > 1 ? 2 : 1) * BUF;
+    static constexpr bool DOUBLE = A > 1 && ESZ <= 8;
+    static constexpr int ELEMS = (DOUBLE ? 2 : 1) * BUF;
 };
 
 // One tile = 16 adjacent columns starting at column rem0 (a multiple of 16) of matrix o_in; the result goes to
@@ -49,8 +52,9 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
                                           const long long rem0, LdsPtr lds) {
     constexpr int L = A * 256;
     constexpr int PPT = A * 16;
-    constexpr int PITCH = Col2Lds<A, TR>::PITCH;
-    constexpr int BUF = Col2Lds<A, TR>::BUF;
+    constexpr int PITCH = Col2Lds<A, TR, sizeof(cplx<T>)>::PITCH;
+    constexpr int BUF = Col2Lds<A, TR, sizeof(cplx<T>)>::BUF;
+    constexpr bool kDoubleBuf = Col2Lds<A, TR, sizeof(cplx<T>)>::DOUBLE;
 
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));  // same reason as below, for the per-thread (VGPR) address pieces
@@ -184,7 +188,8 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
 
     static_for<A>([&](auto rr) {
         constexpr int qa = rr;
-        LdsPtr buf = lds + (qa & 1) * BUF;
+        LdsPtr buf = lds + (kDoubleBuf ? (qa & 1) * BUF : 0);
+        if constexpr (!kDoubleBuf && qa > 0) __syncthreads();  // the previous round's reads are done
         static_for<16>([&](auto ss) {
             constexpr int qb1 = ss;
             if constexpr (TR)
@@ -252,7 +257,7 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
 // TW: multiply by the inter-pass twiddle w(L*M)^(l*q)
 template <typename T, int A, bool TR, bool TW, bool SPLIT, bool SPLIT_OUT = SPLIT>
 __global__ void __launch_bounds__(256, 2) fft_col2_kernel(const TileArgs a) {
-    __shared__ __attribute__((aligned(16))) cplx<T> lds[Col2Lds<A, TR>::ELEMS];
+    __shared__ __attribute__((aligned(16))) cplx<T> lds[Col2Lds<A, TR, sizeof(cplx<T>)>::ELEMS];
     const long long col0 = (long long)blockIdx.x * 16;
     const long long o = col0 >> a.logMS;
     const long long rem0 = col0 & ((1ll << a.logMS) - 1);

@@ -133,6 +133,14 @@ def test_register_edged_rows(ctx, dtype, n):
         run_protocol(ctx, (128, n), dtype, 3, seed=n + 6)  # numpy shape (y, x): ROW over x = n, then a strided pass
 
 
+@pytest.mark.parametrize("dtype", [numpy.complex128, numpy.float64], ids=lambda d: numpy.dtype(d).name)
+@pytest.mark.parametrize("shape,batch", [((1 << 18,), 3), ((1 << 17,), 5), ((512, 64), 9), ((512, 16, 2), 4)], ids=str)
+def test_fp64_two_phase_col_512(ctx, shape, batch, dtype):
+    """fp64 two-phase COL kernels at L = 512 (csrc/fft_col2_f64.hip: single exchange buffer): transposing first pass
+    with inter-pass twiddles, plain last pass, and strided y / z axes."""
+    run_protocol(ctx, shape, dtype, batch, seed=77 + batch)
+
+
 @pytest.mark.parametrize("dtype", [numpy.complex64, numpy.float32], ids=lambda d: numpy.dtype(d).name)
 def test_errors_large_1d(ctx, dtype):
     """N = 2^20 (BASELINE config 2 shape, small batch): the reference's largest 1-D test size
