@@ -1,0 +1,237 @@
+// Whole 2-D / 3-D transforms of one fixed shape, register-edged: the compile-time counterpart of fft_nd.hpp for the
+// common shapes (a tile of P points = P / (LX*LY*LZ) complete transforms per work-group).
+// Same data flow as fft_row2.hpp -- the points live in registers and cross LDS only to be re-distributed between two
+// radix stages, optionally as real parts then imaginary parts (HALF: 128 x 128 in fp32 takes 64 KiB instead of 128, two
+// work-groups per CU); the last stage stores straight to HBM; the first stage loads straight from HBM when its
+// butterflies read runs of >= 128 bytes (EDGE_IN), otherwise after a 16-byte linear load and one more exchange.
+// Every stage is described at compile time by (axis length LA, element stride SA, radix R, product Ns of the axis'
+// earlier radices), so that an LDS address is one per-thread base plus an immediate offset.  (With run-time geometry
+// the same structure needs ~190 VGPRs for the big tile and cannot keep two work-groups per CU; and even at equal
+// occupancy the fixed-shape form measures 46 % -> 58 % of roofline at 128 x 128.)
+//
+// Stage algebra = fft_nd.hpp / fft_tile.hpp (Stockham autosort): butterfly (o, jb, j) of an axis reads
+// base + (jb + k*LA/R)*SA, multiplies by w(LA)^(k * (jb mod Ns) * LA/(Ns*R)) and writes base + (idxD + k*Ns)*SA with
+// base = o*LA*SA + j, idxD = (jb & ~(Ns-1))*R + (jb & (Ns-1)).
+#pragma once
+#include "fft_row2.hpp"
+
+namespace mifft {
+
+template <int AX_, int LA_, int SA_, int Ns_, int R_> struct Nd2StageDesc {
+    static constexpr int AX = AX_, LA = LA_, SA = SA_, Ns = Ns_, R = R_;
+};
+template <typename... S> struct Nd2StageList {};
+
+// stage descriptors of one axis from its radix list
+template <int AX, int LA, int SA, int Ns, typename RL, typename Acc> struct Nd2AxisStages;
+template <int AX, int LA, int SA, int Ns, typename... Acc>
+struct Nd2AxisStages<AX, LA, SA, Ns, RadixList<>, Nd2StageList<Acc...>> {
+    using type = Nd2StageList<Acc...>;
+};
+template <int AX, int LA, int SA, int Ns, int R, int... Rest, typename... Acc>
+struct Nd2AxisStages<AX, LA, SA, Ns, RadixList<R, Rest...>, Nd2StageList<Acc...>> {
+    using type = typename Nd2AxisStages<AX, LA, SA, Ns * R, RadixList<Rest...>,
+                                        Nd2StageList<Acc..., Nd2StageDesc<AX, LA, SA, Ns, R>>>::type;
+};
+
+template <typename T, int P, int NT, bool HALF, typename D> struct Nd2Stage {
+    static constexpr int AX = D::AX, LA = D::LA, SA = D::SA, Ns = D::Ns, R = D::R;
+    static constexpr int PPT = P / NT, NB = PPT / R, LR = LA / R;
+    static_assert(NB >= 1 && NB * R == PPT, "radix must divide the points per thread");
+    // pad(base + c) == pad(base) + c + (c >> 4) for the offsets c used below: everything is a power of two, the
+    // per-thread part is smaller than the offset unit or a multiple of 16 above it (see fft_row2.hpp)
+    using LdsT = typename std::conditional<HALF, T, cplx<T>>::type;
+
+    static __device__ __forceinline__ void geom(int b, int tid, int& base, int& jb) {
+        const int bid = b * NT + tid;
+        const int j = bid % SA, t = bid / SA;
+        jb = t % LR;
+        base = (t / LR) * (LA * SA) + j;
+    }
+    static __device__ __forceinline__ int idxd(int jb) { return (jb & ~(Ns - 1)) * R + (jb & (Ns - 1)); }
+
+    template <int SEL> static __device__ __forceinline__ void fetch(const LdsT* lds, cplx<T>* v, int tid) {
+        static_for<NB>([&](auto bb) {
+            constexpr int b = bb;
+            int base, jb;
+            geom(b, tid, base, jb);
+            const LdsT* p = lds + row2_pad(base + jb * SA);
+            static_for<R>([&](auto kk) {
+                constexpr int k = kk;
+                constexpr int off = k * LR * SA + ((k * LR * SA) >> 4);
+                if constexpr (SEL == 0) v[b * R + k] = p[off];
+                else if constexpr (SEL == 1) v[b * R + k].x = p[off];
+                else v[b * R + k].y = p[off];
+            });
+        });
+    }
+    template <int SEL> static __device__ __forceinline__ void spill(LdsT* lds, const cplx<T>* v, int tid) {
+        static_for<NB>([&](auto bb) {
+            constexpr int b = bb;
+            int base, jb;
+            geom(b, tid, base, jb);
+            LdsT* p = lds + row2_pad(base + idxd(jb) * SA);
+            static_for<R>([&](auto kk) {
+                constexpr int k = kk;
+                constexpr int off = k * Ns * SA + ((k * Ns * SA) >> 4);
+                if constexpr (SEL == 0) p[off] = v[b * R + k];
+                else if constexpr (SEL == 1) p[off] = v[b * R + k].x;
+                else p[off] = v[b * R + k].y;
+            });
+        });
+    }
+    // operands straight from HBM: `inb` = first byte of the transform (wave-uniform)
+    // `left` = points from the start of the tile to the end of the data (whole transforms are in or out of range)
+    static __device__ __forceinline__ void load(const char* inb, cplx<T>* v, int tid, long long left) {
+        static_for<NB>([&](auto bb) {
+            constexpr int b = bb;
+            int base, jb;
+            geom(b, tid, base, jb);
+            const unsigned voff = (unsigned)(base + jb * SA) * (unsigned)sizeof(cplx<T>);
+            const bool ok = base < left;
+            static_for<R>([&](auto kk) {
+                constexpr int k = kk;
+                cplx<T> p;
+                p.x = 0; p.y = 0;
+                if (ok) p = *reinterpret_cast<const cplx<T>*>(inb + (size_t)(k * LR * SA) * sizeof(cplx<T>) + voff);
+                v[b * R + k] = p;
+            });
+        });
+    }
+    static __device__ __forceinline__ void store(char* outb, const cplx<T>* v, int tid, T sx, T sy, long long left) {
+        static_for<NB>([&](auto bb) {
+            constexpr int b = bb;
+            int base, jb;
+            geom(b, tid, base, jb);
+            const unsigned voff = (unsigned)(base + idxd(jb) * SA) * (unsigned)sizeof(cplx<T>);
+            if (base < left) {
+                static_for<R>([&](auto kk) {
+                    constexpr int k = kk;
+                    cplx<T> p = v[b * R + k];
+                    p.x *= sx;
+                    p.y *= sy;
+                    *reinterpret_cast<cplx<T>*>(outb + (size_t)(k * Ns * SA) * sizeof(cplx<T>) + voff) = p;
+                });
+            }
+        });
+    }
+    static __device__ __forceinline__ void compute(cplx<T>* v, const cplx<T>* tw, int tid) {
+        static_for<NB>([&](auto bb) {
+            constexpr int b = bb;
+            if constexpr (Ns > 1) {
+                int base, jb;
+                geom(b, tid, base, jb);
+                const int ai = (jb & (Ns - 1)) * (LA / (Ns * R));
+                row2_twiddle<T, R>(tw, ai, v + b * R);
+            }
+            Dft<R, T>::run(v + b * R);
+        });
+    }
+};
+
+template <typename T, int P, int NT, bool HALF, bool FIRST, typename SL> struct Nd2Chain;
+
+template <typename T, int P, int NT, bool HALF, bool FIRST, typename D, typename... Rest>
+struct Nd2Chain<T, P, NT, HALF, FIRST, Nd2StageList<D, Rest...>> {
+    using St = Nd2Stage<T, P, NT, HALF, D>;
+    using LdsT = typename St::LdsT;
+    static constexpr bool LAST = sizeof...(Rest) == 0;
+
+    // v holds the operands of this stage; tw[ax] = twiddle table of axis ax
+    static __device__ __forceinline__ void run(LdsT* lds, cplx<T>* v, const cplx<T>* const* tw, int tid, char* outb, T sx,
+                                               T sy, long long left) {
+        St::compute(v, tw[D::AX], tid);
+        if constexpr (LAST) {
+            St::store(outb, v, tid, sx, sy, left);
+        } else {
+            using NextChain = Nd2Chain<T, P, NT, HALF, false, Nd2StageList<Rest...>>;
+            using Next = typename NextChain::St;
+            if constexpr (!FIRST) __syncthreads();  // everybody has fetched its operands of this stage
+            if constexpr (!HALF) {
+                St::template spill<0>(lds, v, tid);
+                __syncthreads();
+                Next::template fetch<0>(lds, v, tid);
+            } else {
+                St::template spill<1>(lds, v, tid);
+                __syncthreads();
+                Next::template fetch<1>(lds, v, tid);  // the real-part registers are free again: reuse them
+                __syncthreads();
+                St::template spill<2>(lds, v, tid);
+                __syncthreads();
+                Next::template fetch<2>(lds, v, tid);
+            }
+            NextChain::run(lds, v, tw, tid, outb, sx, sy, left);
+        }
+    }
+};
+
+template <typename A, typename B> struct Nd2Concat;
+template <typename... A, typename... B> struct Nd2Concat<Nd2StageList<A...>, Nd2StageList<B...>> {
+    using type = Nd2StageList<A..., B...>;
+};
+template <typename SL> struct Nd2First;
+template <typename D, typename... Rest> struct Nd2First<Nd2StageList<D, Rest...>> { using type = D; };
+
+// A tile of P points = P / (LX*LY*LZ) whole (LZ, LY, LX) transforms (x contiguous) per work-group.  TileArgs: in0 / out0
+// interleaved, total = number of POINTS, tw_L / tw_lo / tw_hi = w(LX) / w(LY) / w(LZ) tables, inverse, scale.
+template <typename T, int LX, int LY, int LZ, int P, int NT, bool HALF, int OCC, bool EDGE_IN, typename RLX, typename RLY,
+          typename RLZ>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) fft_nd2_kernel(const TileArgs a) {
+    constexpr int PPT = P / NT;
+    static_assert(PPT * NT == P && P % (LX * LY * LZ) == 0 && PPT % 2 == 0, "bad tile");
+    static_assert(EDGE_IN || !HALF, "the linear-load form is built for full-complex exchanges only");
+    using SX = typename Nd2AxisStages<0, LX, 1, 1, RLX, Nd2StageList<>>::type;
+    using SY = typename Nd2AxisStages<1, LY, LX, 1, RLY, Nd2StageList<>>::type;
+    using SZ = typename Nd2AxisStages<2, LZ, LX * LY, 1, RLZ, Nd2StageList<>>::type;
+    using SL = typename Nd2Concat<typename Nd2Concat<SX, SY>::type, SZ>::type;
+    using First = Nd2Stage<T, P, NT, HALF, typename Nd2First<SL>::type>;
+    using LdsT = typename std::conditional<HALF, T, cplx<T>>::type;
+    __shared__ __attribute__((aligned(16))) LdsT lds[P + P / 16];
+    const int tid = threadIdx.x;
+    const long long g0 = (long long)blockIdx.x * P;
+    const long long left = a.total - g0;
+    const char* inb = reinterpret_cast<const char*>(reinterpret_cast<const cplx<T>*>(a.in0) + g0);
+    char* outb = reinterpret_cast<char*>(reinterpret_cast<cplx<T>*>(a.out0) + g0);
+    const cplx<T>* tw[3] = {reinterpret_cast<const cplx<T>*>(a.tw_L), reinterpret_cast<const cplx<T>*>(a.tw_lo),
+                            reinterpret_cast<const cplx<T>*>(a.tw_hi)};
+    const T sx = (T)a.scale;
+    const T sy = a.inverse ? -sx : sx;
+    cplx<T> v[PPT];
+    if constexpr (EDGE_IN) {
+        First::load(inb, v, tid, left);
+    } else {
+        // 16-byte linear load (thread: points 2*(it*NT + tid), +1), then one exchange into the first stage's order
+        using V4 = T __attribute__((ext_vector_type(4)));
+        static_for<PPT / 2>([&](auto ii) {
+            constexpr int it = ii;
+            const unsigned e = (unsigned)(it * NT + tid) * 2u;
+            V4 q = {0, 0, 0, 0};
+            if ((long long)e < left) q = *reinterpret_cast<const V4*>(inb + e * (unsigned)sizeof(cplx<T>));
+            v[2 * it].x = q.x; v[2 * it].y = q.y; v[2 * it + 1].x = q.z; v[2 * it + 1].y = q.w;
+        });
+        static_for<PPT / 2>([&](auto ii) {
+            constexpr int it = ii;
+            LdsT* p = lds + row2_pad((it * NT + tid) * 2);
+            p[0] = v[2 * it];
+            p[1] = v[2 * it + 1];
+        });
+        __syncthreads();
+        First::template fetch<0>(lds, v, tid);
+        __syncthreads();
+    }
+    if (a.inverse) static_for<PPT>([&](auto i) { v[i].y = -v[i].y; });
+    Nd2Chain<T, P, NT, HALF, true, SL>::run(lds, v, tw, tid, outb, sx, sy, left);
+}
+
+template <typename T, int LX, int LY, int LZ, int P, int NT, bool HALF, int OCC, bool EDGE_IN, typename RLX, typename RLY,
+          typename RLZ = RadixList<>>
+static inline int launch_nd2(const TileArgs* a, hipStream_t s) {
+    const long long tiles = (a->total + P - 1) / P;
+    if (tiles <= 0) return 0;
+    if (tiles > 2147483647ll) return -1;
+    hipLaunchKernelGGL((fft_nd2_kernel<T, LX, LY, LZ, P, NT, HALF, OCC, EDGE_IN, RLX, RLY, RLZ>), dim3((unsigned)tiles),
+                       dim3(NT), 0, s, *a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mifft

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 #include "../../include/mifft.h"
 #include "mifft_internal.h"
@@ -110,6 +111,22 @@ int nd_radices(int L, int maxr, int* out) {
 }
 
 int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0, void* out1, hipStream_t s) {
+    // fixed-shape kernels (fft_nd2.hpp) for the common interleaved fp32 shapes
+    if (p->precision == MIFFT_F32 && mifft_nd2_f32_supported((int)p->L, (int)p->M, (int)p->S) == 0 &&
+        (p->layout != MIFFT_SPLIT || ((p->flags & MIFFT_FLAG_SRC_INTERLEAVED) && (p->flags & MIFFT_FLAG_DST_INTERLEAVED))) &&
+        !getenv("MIFFT_NO_ND2")) {
+        mifft::TileArgs t;
+        memset(&t, 0, sizeof(t));
+        t.in0 = in0; t.out0 = out0;
+        t.tw_L = p->tw_L; t.tw_lo = p->tw_lo; t.tw_hi = p->tw_hi;
+        t.total = p->outer * p->L * p->M * p->S;
+        t.inverse = p->inverse ? 1 : 0;
+        t.scale = p->scale;
+        const int rc = mifft_nd2_f32_launch((int)p->L, (int)p->M, (int)p->S, &t, s);
+        if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
+        if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
+        return 0;
+    }
     mifft::NdArgs a;
     memset(&a, 0, sizeof(a));
     a.in0 = in0; a.in1 = in1; a.out0 = out0; a.out1 = out1;

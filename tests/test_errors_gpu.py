@@ -133,6 +133,16 @@ def test_register_edged_rows(ctx, dtype, n):
         run_protocol(ctx, (128, n), dtype, 3, seed=n + 6)  # numpy shape (y, x): ROW over x = n, then a strided pass
 
 
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.float32], ids=lambda d: numpy.dtype(d).name)
+@pytest.mark.parametrize("shape,batch", [((16, 16), 37), ((32, 32), 7), ((64, 64), 3), ((16, 128), 5), ((32, 128), 3),
+                                         ((64, 128), 3), ((128, 64), 2), ((128, 128), 3), ((16, 16, 16), 3),
+                                         ((8, 8, 64), 5), ((32, 32, 128), 2), ((16, 16, 128), 3)], ids=str)
+def test_fixed_shape_nd_kernels(ctx, shape, batch, dtype):
+    """Every fixed-shape N-D kernel (csrc/fft_nd2_f32.hip; numpy order, x last) with a batch that leaves a ragged last
+    tile, plus 3-D shapes whose (y, x) planes run on them; float32 (split planes) takes the run-time-shaped kernel."""
+    run_protocol(ctx, shape, dtype, batch, seed=31 + batch)
+
+
 @pytest.mark.parametrize("dtype", [numpy.complex128, numpy.float64], ids=lambda d: numpy.dtype(d).name)
 @pytest.mark.parametrize("shape,batch", [((1 << 18,), 3), ((1 << 17,), 5), ((512, 64), 9), ((512, 16, 2), 4)], ids=str)
 def test_fp64_two_phase_col_512(ctx, shape, batch, dtype):
