@@ -234,4 +234,58 @@ static inline int launch_nd2(const TileArgs* a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+// ---- automatic configuration of a shape --------------------------------------------------------------------------
+// Radix list of an axis of length L with radices <= MAXR: full MAXR factors plus one smaller remainder factor, the
+// remainder FIRST on the first axis (its first stage then reads the longest runs from HBM), LAST on the others (the last
+// stage of all then writes the longest runs).
+template <typename A, typename B> struct RadixCat;
+template <int... A, int... B> struct RadixCat<RadixList<A...>, RadixList<B...>> { using type = RadixList<A..., B...>; };
+template <int L, int MAXR> struct RadixFull {  // L = MAXR^k exactly
+    using type = typename RadixCat<RadixList<MAXR>, typename RadixFull<L / MAXR, MAXR>::type>::type;
+};
+template <int MAXR> struct RadixFull<1, MAXR> { using type = RadixList<>; };
+constexpr int nd2_rem(int L, int maxr) {  // the factor of L left over after all full MAXR factors
+    while (L >= maxr) L /= maxr;
+    return L;
+}
+template <int L, int MAXR, bool REM_FIRST> struct AutoRadix {
+    static constexpr int REM = nd2_rem(L, MAXR);
+    using Full = typename RadixFull<L / REM, MAXR>::type;
+    using Rem = typename std::conditional<(REM > 1), RadixList<REM>, RadixList<>>::type;
+    using type = typename std::conditional<REM_FIRST, typename RadixCat<Rem, Full>::type,
+                                           typename RadixCat<Full, Rem>::type>::type;
+};
+template <typename RL> struct RadixFirst { static constexpr int value = 1; };
+template <int R, int... Rest> struct RadixFirst<RadixList<R, Rest...>> { static constexpr int value = R; };
+
+// Tile and launch shape for an (X, Y, Z) transform of type T: the smallest tile of TILE0 / 2*TILE0 / 4*TILE0 points that
+// holds one transform (TILE0 = 4096 points fp32, 2048 fp64: 32 KiB of LDS, four work-groups per CU); the largest one in
+// half-exchange form with twice the points per thread, so that two work-groups still share a CU.
+template <typename T, int X, int Y, int Z> struct Nd2Auto {
+    static constexpr int N = X * Y * Z;
+    static constexpr int TILE0 = sizeof(T) == 4 ? 4096 : 2048;
+    static constexpr int PPT0 = sizeof(T) == 4 ? 16 : 8;
+    static_assert(N <= 4 * TILE0, "shape too large for one tile");
+    static constexpr bool BIG = N > 2 * TILE0;
+    static constexpr int P = N <= TILE0 ? TILE0 : N <= 2 * TILE0 ? 2 * TILE0 : 4 * TILE0;
+    static constexpr bool HALF = BIG;
+    static constexpr int PPT = BIG ? 2 * PPT0 : PPT0;
+    static constexpr int NT = P / PPT;
+    static constexpr int OCC = BIG ? 4 : 1;
+    static constexpr int MAXR = PPT0;  // 16 (fp32) / 8 (fp64): radix-32 butterflies cost too many registers
+    // first axis with more than one point takes the remainder factor first
+    static constexpr bool XF = X > 1, YF = !XF && Y > 1;
+    using RLX = typename AutoRadix<X, MAXR, true>::type;
+    using RLY = typename AutoRadix<Y, MAXR, YF>::type;
+    using RLZ = typename AutoRadix<Z, MAXR, false>::type;
+    // the first stage reads runs of (X / first radix) points: straight from HBM when that is >= 128 bytes
+    static constexpr bool EDGE_IN = BIG || (X > 1 && (X / RadixFirst<RLX>::value) * (int)sizeof(cplx<T>) >= 128);
+};
+
+template <typename T, int X, int Y, int Z> static inline int launch_nd2_auto(const TileArgs* a, hipStream_t s) {
+    using C = Nd2Auto<T, X, Y, Z>;
+    return launch_nd2<T, X, Y, Z, C::P, C::NT, C::HALF, C::OCC, C::EDGE_IN, typename C::RLX, typename C::RLY,
+                      typename C::RLZ>(a, s);
+}
+
 }  // namespace mifft

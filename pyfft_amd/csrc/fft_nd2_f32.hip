@@ -1,29 +1,30 @@
-// fp32 instances of the fixed-shape N-D kernel (fft_nd2.hpp) for the common small 2-D / 3-D shapes (the reference's
-// published table, doc/source/index.rst:357-373, has (16,16), (128,128), (16,16,16), and the planes of (32,32,128) and
-// (128,128,128)); every other shape runs on the run-time-shaped kernel of fft_nd.hpp.
+// fp32 instances of the fixed-shape N-D kernel (fft_nd2.hpp): every 2-D shape with both axes in 16...1024 that fits one
+// tile (x*y <= 16384) and the common small 3-D shapes -- the reference's published table (doc/source/index.rst:357-373)
+// has (16,16), (128,128), (16,16,16), (8,8,64) and the planes of (32,32,128) and (128,128,128).  Tile size, threads,
+// radices and edge mode are derived per shape by Nd2Auto; every other shape runs on the run-time-shaped kernel of
+// fft_nd.hpp.
 #include "mifft_internal.h"
 #include "fft_nd2.hpp"
 
 namespace {
 using namespace mifft;
-// (x, y, z) -> launcher
 int launch_shape(int x, int y, int z, const TileArgs* a, hipStream_t s, int query) {
-#define SHAPE(X, Y, Z, ...)                      \
-    if (x == X && y == Y && z == Z) {            \
-        if (query) return 0;                     \
-        return launch_nd2<float, X, Y, Z, __VA_ARGS__>(a, s); \
+#define SHAPE(X, Y, Z)                                          \
+    if (x == X && y == Y && z == Z) {                           \
+        if (query) return 0;                                    \
+        return launch_nd2_auto<float, X, Y, Z>(a, s);           \
     }
-    //    shape          P     NT  HALF OCC EDGE_IN  radices x, y, z
-    SHAPE(16, 16, 1,     4096, 256, false, 1, false, RadixList<16>, RadixList<16>)
-    SHAPE(32, 32, 1,     4096, 256, false, 1, true,  RadixList<2, 16>, RadixList<16, 2>)
-    SHAPE(64, 64, 1,     4096, 256, false, 1, true,  RadixList<4, 16>, RadixList<16, 4>)
-    SHAPE(128, 16, 1,    4096, 256, false, 1, true,  RadixList<8, 16>, RadixList<16>)
-    SHAPE(128, 32, 1,    4096, 256, false, 1, true,  RadixList<8, 16>, RadixList<16, 2>)
-    SHAPE(128, 64, 1,    8192, 512, false, 1, true,  RadixList<8, 16>, RadixList<16, 4>)
-    SHAPE(64, 128, 1,    8192, 512, false, 1, true,  RadixList<4, 16>, RadixList<16, 8>)
-    SHAPE(128, 128, 1,   16384, 512, true, 4, true,  RadixList<8, 16>, RadixList<16, 8>)
-    SHAPE(16, 16, 16,    4096, 256, false, 1, false, RadixList<16>, RadixList<16>, RadixList<16>)
-    SHAPE(64, 8, 8,      4096, 256, false, 1, true,  RadixList<4, 16>, RadixList<8>, RadixList<8>)
+    SHAPE(16, 16, 1) SHAPE(16, 32, 1) SHAPE(16, 64, 1) SHAPE(16, 128, 1)
+    SHAPE(16, 256, 1) SHAPE(16, 512, 1) SHAPE(16, 1024, 1) SHAPE(32, 16, 1)
+    SHAPE(32, 32, 1) SHAPE(32, 64, 1) SHAPE(32, 128, 1) SHAPE(32, 256, 1)
+    SHAPE(32, 512, 1) SHAPE(64, 16, 1) SHAPE(64, 32, 1) SHAPE(64, 64, 1)
+    SHAPE(64, 128, 1) SHAPE(64, 256, 1) SHAPE(128, 16, 1) SHAPE(128, 32, 1)
+    SHAPE(128, 64, 1) SHAPE(128, 128, 1) SHAPE(256, 16, 1) SHAPE(256, 32, 1)
+    SHAPE(256, 64, 1) SHAPE(512, 16, 1) SHAPE(512, 32, 1) SHAPE(1024, 16, 1)
+    SHAPE(8, 8, 1) SHAPE(16, 16, 16) SHAPE(64, 8, 8) SHAPE(8, 8, 8)
+    SHAPE(32, 32, 16) SHAPE(32, 32, 8) SHAPE(64, 16, 16) SHAPE(32, 16, 16)
+    SHAPE(16, 16, 8) SHAPE(16, 16, 32) SHAPE(16, 16, 64) SHAPE(32, 16, 8)
+    SHAPE(64, 64, 4)
 #undef SHAPE
     return -2;
 }

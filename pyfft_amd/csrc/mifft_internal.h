@@ -16,6 +16,8 @@ int mifft_nd_max_points(int f64);
 int mifft_nd_launch(int f64, long long n, const mifft::NdArgs* a, hipStream_t s);
 int mifft_nd2_f32_supported(int x, int y, int z);
 int mifft_nd2_f32_launch(int x, int y, int z, const mifft::TileArgs* a, hipStream_t s);
+int mifft_nd2_f64_supported(int x, int y, int z);
+int mifft_nd2_f64_launch(int x, int y, int z, const mifft::TileArgs* a, hipStream_t s);
 int mifft_fused2_f32_launch(int L0, int L1, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
 }
 

@@ -111,8 +111,11 @@ int nd_radices(int L, int maxr, int* out) {
 }
 
 int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0, void* out1, hipStream_t s) {
-    // fixed-shape kernels (fft_nd2.hpp) for the common interleaved fp32 shapes
-    if (p->precision == MIFFT_F32 && mifft_nd2_f32_supported((int)p->L, (int)p->M, (int)p->S) == 0 &&
+    // fixed-shape kernels (fft_nd2.hpp) for the common shapes, interleaved on both sides
+    const bool f64nd = p->precision == MIFFT_F64;
+    const int have_nd2 = f64nd ? mifft_nd2_f64_supported((int)p->L, (int)p->M, (int)p->S)
+                               : mifft_nd2_f32_supported((int)p->L, (int)p->M, (int)p->S);
+    if (have_nd2 == 0 &&
         (p->layout != MIFFT_SPLIT || ((p->flags & MIFFT_FLAG_SRC_INTERLEAVED) && (p->flags & MIFFT_FLAG_DST_INTERLEAVED))) &&
         !getenv("MIFFT_NO_ND2")) {
         mifft::TileArgs t;
@@ -122,7 +125,8 @@ int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0,
         t.total = p->outer * p->L * p->M * p->S;
         t.inverse = p->inverse ? 1 : 0;
         t.scale = p->scale;
-        const int rc = mifft_nd2_f32_launch((int)p->L, (int)p->M, (int)p->S, &t, s);
+        const int rc = f64nd ? mifft_nd2_f64_launch((int)p->L, (int)p->M, (int)p->S, &t, s)
+                             : mifft_nd2_f32_launch((int)p->L, (int)p->M, (int)p->S, &t, s);
         if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
         if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
         return 0;

@@ -133,13 +133,45 @@ def test_register_edged_rows(ctx, dtype, n):
         run_protocol(ctx, (128, n), dtype, 3, seed=n + 6)  # numpy shape (y, x): ROW over x = n, then a strided pass
 
 
-@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.float32], ids=lambda d: numpy.dtype(d).name)
-@pytest.mark.parametrize("shape,batch", [((16, 16), 37), ((32, 32), 7), ((64, 64), 3), ((16, 128), 5), ((32, 128), 3),
-                                         ((64, 128), 3), ((128, 64), 2), ((128, 128), 3), ((16, 16, 16), 3),
-                                         ((8, 8, 64), 5), ((32, 32, 128), 2), ((16, 16, 128), 3)], ids=str)
-def test_fixed_shape_nd_kernels(ctx, shape, batch, dtype):
-    """Every fixed-shape N-D kernel (csrc/fft_nd2_f32.hip; numpy order, x last) with a batch that leaves a ragged last
-    tile, plus 3-D shapes whose (y, x) planes run on them; float32 (split planes) takes the run-time-shaped kernel."""
+def _fixed_nd_shapes(lo, hi, maxn, extra):
+    """(x, y, z) shapes of csrc/fft_nd2_f32.hip / fft_nd2_f64.hip: every 2-D shape with both axes in lo...hi that fits
+    one tile, plus the listed 3-D ones."""
+    out = []
+    x = lo
+    while x <= hi:
+        y = lo
+        while y <= hi:
+            if x * y <= maxn:
+                out.append((x, y, 1))
+            y *= 2
+        x *= 2
+    return out + extra
+
+
+FIXED_ND_F32 = _fixed_nd_shapes(16, 1024, 16384, [(8, 8, 1), (16, 16, 16), (64, 8, 8), (8, 8, 8), (32, 32, 16), (32, 32, 8),
+                                                   (64, 16, 16), (32, 16, 16), (16, 16, 8), (16, 16, 32), (16, 16, 64),
+                                                   (32, 16, 8), (64, 64, 4)])
+FIXED_ND_F64 = _fixed_nd_shapes(16, 512, 8192, [(8, 8, 1), (16, 16, 16), (64, 8, 8), (8, 8, 8), (32, 16, 16), (16, 16, 8),
+                                                 (16, 16, 32), (32, 32, 8), (16, 8, 8)])
+
+
+@pytest.mark.parametrize("dtype,xyz", [(numpy.complex64, s) for s in FIXED_ND_F32] + [(numpy.complex128, s) for s in FIXED_ND_F64],
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else numpy.dtype(v).name)
+def test_fixed_shape_nd_kernels(ctx, dtype, xyz):
+    """Every fixed-shape N-D kernel (csrc/fft_nd2_*.hip) with a batch that leaves a ragged last tile."""
+    x, y, z = xyz
+    shape = (y, x) if z == 1 else (z, y, x)  # numpy order, x last
+    n = x * y * z
+    tile = 4096 if dtype == numpy.complex64 else 2048
+    batch = 3 if n >= tile else (tile // n) * 2 + 1
+    run_protocol(ctx, shape, dtype, batch, seed=n + batch, check_oracle=(n <= 4096))
+
+
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.float32, numpy.complex128], ids=lambda d: numpy.dtype(d).name)
+@pytest.mark.parametrize("shape,batch", [((32, 32, 128), 2), ((16, 16, 128), 3), ((64, 64, 64), 2), ((16, 16), 37)], ids=str)
+def test_fixed_shape_nd_planes(ctx, shape, batch, dtype):
+    """3-D shapes whose (y, x) planes run on the fixed-shape kernels before the strided z pass; float32 (split planes)
+    takes the run-time-shaped kernel."""
     run_protocol(ctx, shape, dtype, batch, seed=31 + batch)
 
 
