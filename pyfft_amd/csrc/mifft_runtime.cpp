@@ -112,12 +112,13 @@ int nd_radices(int L, int maxr, int* out) {
 
 int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0, void* out1, hipStream_t s) {
     // fixed-shape kernels (fft_nd2.hpp) for the common shapes, interleaved on both sides
+    static const bool no_nd2 = getenv("MIFFT_NO_ND2") != nullptr;  // development switch: run-time-shaped kernel only
     const bool f64nd = p->precision == MIFFT_F64;
     const int have_nd2 = f64nd ? mifft_nd2_f64_supported((int)p->L, (int)p->M, (int)p->S)
                                : mifft_nd2_f32_supported((int)p->L, (int)p->M, (int)p->S);
     if (have_nd2 == 0 &&
         (p->layout != MIFFT_SPLIT || ((p->flags & MIFFT_FLAG_SRC_INTERLEAVED) && (p->flags & MIFFT_FLAG_DST_INTERLEAVED))) &&
-        !getenv("MIFFT_NO_ND2")) {
+        !no_nd2) {
         mifft::TileArgs t;
         memset(&t, 0, sizeof(t));
         t.in0 = in0; t.out0 = out0;
