@@ -1,6 +1,8 @@
 """Seeded randomized sweep through the public API on the GPU: random power-of-two shapes (1-3 axes), ragged
 batches (tile tails), four dtypes, forward/inverse, in/out of place, normalize and scale -- every case against
 numpy.fft on the complex128-upcast input with the reference's thresholds (test/test_errors.py:20-23)."""
+import os
+
 import numpy
 import pytest
 
@@ -19,14 +21,20 @@ def _cases(seed, count, max_points):
             continue
         shape = tuple(1 << l for l in logs)
         size = int(numpy.prod(shape))
-        batch = int(rng.integers(1, max(2, min(70, (1 << 18) // size))))
+        batch = int(rng.integers(1, max(2, min(70, (1 << max(18, max_points + 1)) // size))))
         dtype = [numpy.complex64, numpy.float32, numpy.complex128, numpy.float64][int(rng.integers(0, 4))]
         out.append((shape, batch, dtype, bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2)),
                     float([1.0, 0.5, 3.0][int(rng.integers(0, 3))])))
     return out
 
 
-@pytest.mark.parametrize("case", _cases(20261002, 60, 17), ids=lambda c: "%s-b%d-%s-%s%s" % (
+# PYFFT_AMD_SWEEP=<count>[:<seed>[:<max log2 points>]] widens the sweep for a one-off soak run (default: 60 cases)
+_SWEEP = os.environ.get("PYFFT_AMD_SWEEP", "60:20261002").split(":")
+_COUNT, _SEED = int(_SWEEP[0]), int(_SWEEP[1]) if len(_SWEEP) > 1 else 20261002
+_MAXLOG = int(_SWEEP[2]) if len(_SWEEP) > 2 else 17
+
+
+@pytest.mark.parametrize("case", _cases(_SEED, _COUNT, _MAXLOG), ids=lambda c: "%s-b%d-%s-%s%s" % (
     "x".join(map(str, c[0])), c[1], numpy.dtype(c[2]).name, "inv" if c[3] else "fwd", "-ip" if c[4] else ""))
 def test_random_case(ctx, case):
     shape, batch, dtype, inverse, inplace, normalize, scale = case
