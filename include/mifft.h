@@ -93,7 +93,7 @@ typedef struct mifft_pass {
     int32_t layout;      /* MIFFT_INTERLEAVED | MIFFT_SPLIT (same for input and output) */
     int32_t inverse;     /* 0 forward (numpy.fft.fft sign), 1 inverse (unnormalised unless `scale`) */
     int32_t L;           /* transform length of this launch (the radix of the pass) */
-    int32_t variant;     /* kernel variant selector, 0 = library default */
+    int32_t variant;     /* kernel variant selector, 0 = library default (the only value a launch takes) */
     int64_t M;           /* not-yet-transformed extent of the axis after this pass (COL), 1 for ROW */
     int64_t S;           /* extent of everything faster than the digit being transformed (COL), 1 for ROW */
     int64_t outer;       /* number of independent matrices / rows */
@@ -154,7 +154,9 @@ int mifft_event_elapsed_ms(float *ms, mifft_event_t start, mifft_event_t stop);
 int mifft_nd_max_points_for(int32_t precision);
 
 /* 0 if a compiled kernel exists for (kind, precision, L, variant), else MIFFT_E_UNSUPPORTED.
- * Counterpart of Function.isExecutable (cuda.py:48-49) for AOT kernels. */
+ * Counterpart of Function.isExecutable (cuda.py:48-49) for AOT kernels.  variant 0: a kernel that takes either layout;
+ * MIFFT_VARIANT_INTERLEAVED_ONLY (ROW passes): also count kernels that need interleaved data on both sides. */
+#define MIFFT_VARIANT_INTERLEAVED_ONLY 2
 int mifft_pass_supported(int32_t kind, int32_t precision, int32_t L, int32_t variant);
 
 /* Enqueue one pass.  in1/out1 are the imaginary planes for MIFFT_SPLIT and must be NULL for

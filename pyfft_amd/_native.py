@@ -20,6 +20,7 @@ E_NODEVICE = -3
 
 F32, F64 = 0, 1
 INTERLEAVED, SPLIT = 0, 1
+VARIANT_INTERLEAVED_ONLY = 2
 PASS_COL, PASS_ROW, PASS_ND = 0, 1, 2
 FLAG_SRC_INTERLEAVED, FLAG_DST_INTERLEAVED = 1, 2
 

@@ -148,13 +148,20 @@ struct Row2Stages<T, L, TPR, Ns, FIRST, HALF, RadixList<R, Rest...>> {
                 __syncthreads();
                 Next::template fetch<0>(lds, v, tid);
             } else {
-                spill<1>(lds, v, tid);
+                // every step gets its own opaque copy of the thread index: otherwise the LDS base addresses of a
+                // layout are computed once and kept in VGPRs across the barriers and the other component's step
+                auto fresh = [&]() __attribute__((always_inline)) {
+                    int t = tid;
+                    asm volatile("" : "+v"(t));
+                    return t;
+                };
+                spill<1>(lds, v, fresh());
                 __syncthreads();
-                Next::template fetch<1>(lds, v, tid);  // the real-part registers are free again: reuse them
+                Next::template fetch<1>(lds, v, fresh());  // the real-part registers are free again: reuse them
                 __syncthreads();
-                spill<2>(lds, v, tid);
+                spill<2>(lds, v, fresh());
                 __syncthreads();
-                Next::template fetch<2>(lds, v, tid);
+                Next::template fetch<2>(lds, v, fresh());
             }
             Next::run(lds, v, a, tid, inb, outb, voff, valid);
         }

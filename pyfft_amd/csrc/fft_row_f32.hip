@@ -3,7 +3,14 @@
 #include "mifft_internal.h"
 #include "fft_row2.hpp"
 extern "C" int mifft_dispatch_row_f32(int L, int variant, const mifft::TileArgs* a, hipStream_t s, int query_only) {
-    if (variant != 0) return -2;
+    if (variant != 0 && variant != 2) return -2;
+    // L = 32768 exists in the register-edged half-exchange form only (128 KiB of LDS as scalars, one work-group per CU):
+    // interleaved data on both sides; a query with variant 2 (MIFFT_VARIANT_INTERLEAVED_ONLY) asks for exactly that
+    if (L == 32768) {
+        if (query_only) return variant == 2 ? 0 : -2;
+        if (!a || a->split || a->split_out) return -2;
+        return mifft::launch_row2<float, 32768, 1, 512, mifft::RadixList<32, 32, 32>, true, 2>(a, s, 0);
+    }
     // both sides interleaved: register-edged kernels (fft_row2.hpp).  Shapes chosen by measurement (1 GiB buffers,
     // tools/row_probe.py): the half-exchange form wins where it raises the work-groups per CU (8192: 2 -> 3,
     // 16384: 1 -> 2), the plain form everywhere else.

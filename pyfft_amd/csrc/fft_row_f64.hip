@@ -3,7 +3,13 @@
 #include "mifft_internal.h"
 #include "fft_row2.hpp"
 extern "C" int mifft_dispatch_row_f64(int L, int variant, const mifft::TileArgs* a, hipStream_t s, int query_only) {
-    if (variant != 0) return -2;
+    if (variant != 0 && variant != 2) return -2;
+    // L = 16384 exists in the register-edged half-exchange form only (interleaved on both sides; query with variant 2, MIFFT_VARIANT_INTERLEAVED_ONLY)
+    if (L == 16384) {
+        if (query_only) return variant == 2 ? 0 : -2;
+        if (!a || a->split || a->split_out) return -2;
+        return mifft::launch_row2<double, 16384, 1, 1024, mifft::RadixList<4, 16, 16, 16>, true, 4>(a, s, 0);
+    }
     // both sides interleaved: register-edged kernels (fft_row2.hpp); L <= 512: the LDS-staged tile kernels below
     // measure faster for 16-byte points.  8192: half-exchange form, 2 work-groups per CU instead of 1 (59 % -> 70 %).
     if (a && !a->split && !a->split_out) {

@@ -35,23 +35,25 @@ def is_pow2(n):
 _support_cache = {}
 
 
-def _max_len(kind, precision):
+def _max_len(kind, precision, variant=0):
     """Largest L the library has a compiled kernel for (Function.isExecutable counterpart,
     cuda.py:48-49)."""
-    key = (kind, precision)
+    key = (kind, precision, variant)
     if key not in _support_cache:
         best = 0
         L = 2
         while L <= (1 << 16):
-            if N.lib.mifft_pass_supported(kind, precision, L, 0) == 0:
+            if N.lib.mifft_pass_supported(kind, precision, L, 0) == 0 or \
+                    (variant and N.lib.mifft_pass_supported(kind, precision, L, variant) == 0):
                 best = L
             L *= 2
         _support_cache[key] = best
     return _support_cache[key]
 
 
-def row_max(precision):
-    return _max_len(N.PASS_ROW, precision)
+def row_max(precision, interleaved=False):
+    """Longest contiguous axis one ROW launch takes; the longest rows exist for interleaved data only."""
+    return _max_len(N.PASS_ROW, precision, N.VARIANT_INTERLEAVED_ONLY if interleaved else 0)
 
 
 def col_max(precision):
@@ -109,10 +111,11 @@ def col_chain(axis, n, radix_init, outer_per_batch, precision):
     return chain
 
 
-def build_chain(x, y, z, precision):
+def build_chain(x, y, z, precision, interleaved=False):
     """Kernel chain for a (z, y, x) array with x contiguous (FFTPlan._generateKernelCode and
     _fft1D, plan.py:111-171): X passes, then the Y chain, then the Z chain.  Axes of length 1 are
-    skipped (plan.py:149,160,164)."""
+    skipped (plan.py:149,160,164).  `interleaved`: the user's buffers are interleaved complex (some
+    kernels do not take split planes)."""
     chain = []
     # small 2-D / 3-D transforms: every axis inside LDS, one launch, one HBM round trip (csrc/fft_nd.hpp)
     ndims = (x > 1) + (y > 1) + (z > 1)
@@ -124,14 +127,14 @@ def build_chain(x, y, z, precision):
         return [PassSpec(N.PASS_ND, X_DIRECTION, x * y, x, y, 1, z, x * y, True)] + \
             col_chain(Z_DIRECTION, z, x * y, 1, precision)
     if x > 1:
-        if x <= row_max(precision):
+        if x <= row_max(precision, interleaved):
             chain.append(PassSpec(N.PASS_ROW, X_DIRECTION, x, x, 1, 1, y * z, x, True))
         else:
             chain.extend(col_chain(X_DIRECTION, x, 1, y * z, precision))
     if y > 1:
         if x == 1:
             # degenerate: the y axis is the contiguous one
-            sub = build_chain(y, 1, 1, precision)
+            sub = build_chain(y, 1, 1, precision, interleaved)
             for p in sub:
                 p.axis = Y_DIRECTION
                 p.outer_per_batch *= z
@@ -140,7 +143,7 @@ def build_chain(x, y, z, precision):
             chain.extend(col_chain(Y_DIRECTION, y, x, z, precision))
     if z > 1:
         if x * y == 1:
-            sub = build_chain(z, 1, 1, precision)
+            sub = build_chain(z, 1, 1, precision, interleaved)
             for p in sub:
                 p.axis = Z_DIRECTION
             chain.extend(sub)

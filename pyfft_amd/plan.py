@@ -119,7 +119,7 @@ class FFTPlan(object):
         """Select the pass chain and upload twiddle tables (plan.py:111-133; nothing is
         compiled here -- the kernels are ahead-of-time HIP)."""
         p = self._params
-        self._kernels = P.build_chain(int(p.x), int(p.y), int(p.z), p.precision)
+        self._kernels = P.build_chain(int(p.x), int(p.y), int(p.z), p.precision, interleaved=not p.split)
         self._temp_buffer_needed = any(not k.in_place_possible for k in self._kernels)
         # fp32 split planes: 16 columns of a plane are 64-byte segments, so multi-pass plans detour through an
         # interleaved temp even when every pass could run in place (passes.buffer_schedule)

@@ -122,8 +122,8 @@ def test_errors_batched(ctx, shape, batch, dtype):
     run_protocol(ctx, shape, dtype, batch - 1 if batch > 1 else 5, seed=78, check_oracle=False)
 
 
-@pytest.mark.parametrize("dtype,n", [(numpy.complex64, 1 << k) for k in range(8, 15)] +
-                         [(numpy.complex128, 1 << k) for k in range(10, 14)],
+@pytest.mark.parametrize("dtype,n", [(numpy.complex64, 1 << k) for k in range(8, 16)] +
+                         [(numpy.complex128, 1 << k) for k in range(10, 15)],
                          ids=lambda v: str(v) if isinstance(v, int) else numpy.dtype(v).name)
 def test_register_edged_rows(ctx, dtype, n):
     """Every register-edged ROW kernel (csrc/fft_row2.hpp: several rows per work-group, plain and half-exchange
@@ -235,7 +235,7 @@ def test_fused_two_pass_kernel(ctx, monkeypatch, n, batch):
     assert oracle.difference(data, back, batch) < 1.1e-6
 
 
-@pytest.mark.parametrize("shape,batch", [((32768,), 1027), ((1 << 16,), 515), ((4096, 8), 1030)], ids=str)
+@pytest.mark.parametrize("shape,batch", [((1 << 17,), 259), ((1 << 16,), 515), ((4096, 8), 1030)], ids=str)
 def test_pipelined_chunks(ctx, monkeypatch, shape, batch):
     data = oracle.get_test_data(shape, numpy.complex64, batch, 777)
     want = _run_strategy(ctx, monkeypatch, "chain", shape, batch, data)

@@ -117,7 +117,7 @@ def test_wrong_shape(ctx, prec):                  # :135-139
 
 def test_mempool(ctx, prec):                      # CudaPlan.testMempool :147-150 (+ it is really used)
     pool = ctx.getMemoryPool()
-    n = 32768                                     # two strided passes in both precisions -> needs a temp buffer
+    n = 1 << 17                                   # two strided passes in both precisions -> needs a temp buffer
     plan = ctx.getPlan((n,), dtype=prec[1], mempool=pool)
     a = ctx.toGpu(numpy.ones(n, dtype=prec[1]))
     plan.execute(a)

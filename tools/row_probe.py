@@ -12,5 +12,5 @@ if __name__ == "__main__":
         for k in range(lo, hi + 1):
             run((1 << k,), numpy.complex64, (1 << 27) >> k)
     if which in ("f64", "both"):
-        for k in range(lo, min(hi, 13) + 1):
+        for k in range(lo, min(hi, 14) + 1):
             run((1 << k,), numpy.complex128, (1 << 26) >> k)
