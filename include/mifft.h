@@ -150,8 +150,13 @@ int mifft_event_elapsed_ms(float *ms, mifft_event_t start, mifft_event_t stop);
 
 /* ---- pass launchers (replace cuda.py Function.__call__, cuda.py:35-46) ----------------------------- */
 
-/* largest x*y*z a MIFFT_PASS_ND launch accepts for the precision */
+/* largest x*y*z a MIFFT_PASS_ND launch accepts for ANY power-of-two shape and either layout of the precision */
 int mifft_nd_max_points_for(int32_t precision);
+
+/* 0 if one MIFFT_PASS_ND launch can transform the (z, y, x) shape, else MIFFT_E_UNSUPPORTED: every shape up to
+ * mifft_nd_max_points_for(); with variant MIFFT_VARIANT_INTERLEAVED_ONLY also the larger fixed shapes that exist for
+ * interleaved data on both sides only.  (No counterpart in the reference, whose kernels are generated per plan.) */
+int mifft_nd_shape_supported(int32_t precision, int32_t x, int32_t y, int32_t z, int32_t variant);
 
 /* 0 if a compiled kernel exists for (kind, precision, L, variant), else MIFFT_E_UNSUPPORTED.
  * Counterpart of Function.isExecutable (cuda.py:48-49) for AOT kernels.  variant 0: a kernel that takes either layout;

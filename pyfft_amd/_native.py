@@ -97,6 +97,7 @@ PROTOTYPES = {
     "mifft_event_sync": (ctypes.c_int, [_vp]),
     "mifft_event_elapsed_ms": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), _vp, _vp]),
     "mifft_nd_max_points_for": (ctypes.c_int, [_i32]),
+    "mifft_nd_shape_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32]),
     "mifft_pass_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
     "mifft_launch_pass": (ctypes.c_int, [_pass_p, _vp, _vp, _vp, _vp, _vp]),
     "mifft_launch_chain": (ctypes.c_int, [_pass_p, _i32, _vpp, _vpp, _vp]),

@@ -258,28 +258,34 @@ template <int L, int MAXR, bool REM_FIRST> struct AutoRadix {
 template <typename RL> struct RadixFirst { static constexpr int value = 1; };
 template <int R, int... Rest> struct RadixFirst<RadixList<R, Rest...>> { static constexpr int value = R; };
 
-// Tile and launch shape for an (X, Y, Z) transform of type T: the smallest tile of TILE0 / 2*TILE0 / 4*TILE0 points that
-// holds one transform (TILE0 = 4096 points fp32, 2048 fp64: 32 KiB of LDS, four work-groups per CU); the largest one in
-// half-exchange form with twice the points per thread, so that two work-groups still share a CU.
+// Tile and launch shape for an (X, Y, Z) transform of type T: the smallest tile of 1 / 2 / 4 / 8 x TILE0 points that holds
+// one transform (TILE0 = 4096 points fp32, 2048 fp64: 32 KiB of LDS, four work-groups per CU).  4 x TILE0 ("big") runs in
+// half-exchange form with twice the points per thread, so that two work-groups still share a CU; 8 x TILE0 ("huge":
+// 128 KiB of LDS even as scalars, one work-group per CU) still beats one HBM round trip per axis.
 template <typename T, int X, int Y, int Z> struct Nd2Auto {
     static constexpr int N = X * Y * Z;
-    static constexpr int TILE0 = sizeof(T) == 4 ? 4096 : 2048;
-    static constexpr int PPT0 = sizeof(T) == 4 ? 16 : 8;
-    static_assert(N <= 4 * TILE0, "shape too large for one tile");
-    static constexpr bool BIG = N > 2 * TILE0;
-    static constexpr int P = N <= TILE0 ? TILE0 : N <= 2 * TILE0 ? 2 * TILE0 : 4 * TILE0;
-    static constexpr bool HALF = BIG;
-    static constexpr int PPT = BIG ? 2 * PPT0 : PPT0;
+    static constexpr bool F32 = sizeof(T) == 4;
+    static constexpr int TILE0 = F32 ? 4096 : 2048;
+    static constexpr int PPT0 = F32 ? 16 : 8;
+    static_assert(N <= 8 * TILE0, "shape too large for one tile");
+    static constexpr bool HUGE = N > 4 * TILE0;
+    static constexpr bool BIG = !HUGE && N > 2 * TILE0;
+    static constexpr int P = N <= TILE0 ? TILE0 : N <= 2 * TILE0 ? 2 * TILE0 : N <= 4 * TILE0 ? 4 * TILE0 : 8 * TILE0;
+    static constexpr bool HALF = BIG || HUGE;
+    // points per thread: fp32 16 / 32 (big) / 64 (huge, 512 threads, ~240 VGPRs); fp64 8 / 16 (big) / 16 (huge, 1024 threads)
+    static constexpr int PPT = HUGE ? (F32 ? 64 : 16) : BIG ? 2 * PPT0 : PPT0;
     static constexpr int NT = P / PPT;
-    static constexpr int OCC = BIG ? 4 : 1;
-    static constexpr int MAXR = PPT0;  // 16 (fp32) / 8 (fp64): radix-32 butterflies cost too many registers
+    static constexpr int OCC = HUGE ? (F32 ? 2 : 4) : BIG ? 4 : 1;
+    // largest radix: 16 (fp32) / 8 (fp64) -- radix-32 butterflies cost too many registers at 128 VGPRs; the huge tiles
+    // have the registers (fp32: 32) or the points per thread (fp64: 16) for one more factor of two per stage
+    static constexpr int MAXR = HUGE ? (F32 ? 32 : 16) : PPT0;
     // first axis with more than one point takes the remainder factor first
     static constexpr bool XF = X > 1, YF = !XF && Y > 1;
     using RLX = typename AutoRadix<X, MAXR, true>::type;
     using RLY = typename AutoRadix<Y, MAXR, YF>::type;
     using RLZ = typename AutoRadix<Z, MAXR, false>::type;
     // the first stage reads runs of (X / first radix) points: straight from HBM when that is >= 128 bytes
-    static constexpr bool EDGE_IN = BIG || (X > 1 && (X / RadixFirst<RLX>::value) * (int)sizeof(cplx<T>) >= 128);
+    static constexpr bool EDGE_IN = HALF || (X > 1 && (X / RadixFirst<RLX>::value) * (int)sizeof(cplx<T>) >= 128);
 };
 
 template <typename T, int X, int Y, int Z> static inline int launch_nd2_auto(const TileArgs* a, hipStream_t s) {

@@ -25,6 +25,10 @@ int launch_shape(int x, int y, int z, const TileArgs* a, hipStream_t s, int quer
     SHAPE(32, 32, 16) SHAPE(32, 32, 8) SHAPE(64, 16, 16) SHAPE(32, 16, 16)
     SHAPE(16, 16, 8) SHAPE(16, 16, 32) SHAPE(16, 16, 64) SHAPE(32, 16, 8)
     SHAPE(64, 64, 4)
+    // one-tile shapes beyond the run-time-shaped kernel's largest tile (interleaved data only)
+    SHAPE(32, 1024, 1) SHAPE(64, 512, 1) SHAPE(128, 256, 1) SHAPE(256, 128, 1)
+    SHAPE(1024, 32, 1) SHAPE(32, 32, 32) SHAPE(64, 64, 8)
+    SHAPE(128, 16, 16)
 #undef SHAPE
     return -2;
 }

@@ -20,6 +20,9 @@ int launch_shape(int x, int y, int z, const TileArgs* a, hipStream_t s, int quer
     SHAPE(512, 16, 1) SHAPE(8, 8, 1) SHAPE(16, 16, 16) SHAPE(64, 8, 8)
     SHAPE(8, 8, 8) SHAPE(32, 16, 16) SHAPE(16, 16, 8) SHAPE(16, 16, 32)
     SHAPE(32, 32, 8) SHAPE(16, 8, 8)
+    // one-tile shapes beyond the run-time-shaped kernel's largest tile (interleaved data only)
+    SHAPE(32, 512, 1) SHAPE(64, 256, 1) SHAPE(128, 128, 1) SHAPE(256, 64, 1)
+    SHAPE(512, 32, 1) SHAPE(32, 32, 16) SHAPE(64, 16, 16) SHAPE(16, 16, 64)
 #undef SHAPE
     return -2;
 }

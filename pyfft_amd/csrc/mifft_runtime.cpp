@@ -47,7 +47,9 @@ int validate(const mifft_pass* p) {
     if (p->kind == MIFFT_PASS_ND) {
         if (!is_pow2(p->M) || !is_pow2(p->S)) return set_err(MIFFT_E_INVALID, "ND pass: y and z must be powers of two");
         const long long n = (long long)p->L * p->M * p->S;
-        if (n < 4 || n > mifft_nd_max_points(p->precision == MIFFT_F64)) return set_err(MIFFT_E_UNSUPPORTED, "ND pass: %lld points do not fit a tile", n);
+        const bool both_interleaved = p->layout != MIFFT_SPLIT || ((p->flags & MIFFT_FLAG_SRC_INTERLEAVED) && (p->flags & MIFFT_FLAG_DST_INTERLEAVED));
+        if (n < 4 || mifft_nd_shape_supported(p->precision, p->L, (int32_t)p->M, (int32_t)p->S, both_interleaved ? MIFFT_VARIANT_INTERLEAVED_ONLY : 0) != 0)
+            return set_err(MIFFT_E_UNSUPPORTED, "ND pass: no kernel for %d x %lld x %lld (%lld points)", p->L, (long long)p->M, (long long)p->S, n);
         if ((p->L > 1 && !p->tw_L) || (p->M > 1 && !p->tw_lo) || (p->S > 1 && !p->tw_hi)) return set_err(MIFFT_E_INVALID, "ND pass: twiddle table missing");
         return 0;
     }
@@ -278,6 +280,16 @@ int mifft_event_elapsed_ms(float* ms, mifft_event_t start, mifft_event_t stop) {
 }
 
 int mifft_nd_max_points_for(int32_t precision) { return mifft_nd_max_points(precision == MIFFT_F64); }
+
+int mifft_nd_shape_supported(int32_t precision, int32_t x, int32_t y, int32_t z, int32_t variant) {
+    if (precision != MIFFT_F32 && precision != MIFFT_F64) return MIFFT_E_UNSUPPORTED;
+    if (x < 1 || y < 1 || z < 1 || (x & (x - 1)) || (y & (y - 1)) || (z & (z - 1))) return MIFFT_E_UNSUPPORTED;
+    const long long n = (long long)x * y * z;
+    if (n <= mifft_nd_max_points(precision == MIFFT_F64)) return 0;
+    if (variant != MIFFT_VARIANT_INTERLEAVED_ONLY) return MIFFT_E_UNSUPPORTED;
+    const int rc = precision == MIFFT_F64 ? mifft_nd2_f64_supported(x, y, z) : mifft_nd2_f32_supported(x, y, z);
+    return rc == 0 ? 0 : MIFFT_E_UNSUPPORTED;
+}
 
 int mifft_pass_supported(int32_t kind, int32_t precision, int32_t L, int32_t variant) {
     if (kind == MIFFT_PASS_ND) return (L >= 1 && L <= mifft_nd_max_points(precision == MIFFT_F64) && (L & (L - 1)) == 0) ? 0 : MIFFT_E_UNSUPPORTED;

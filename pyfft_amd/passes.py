@@ -117,13 +117,18 @@ def build_chain(x, y, z, precision, interleaved=False):
     skipped (plan.py:149,160,164).  `interleaved`: the user's buffers are interleaved complex (some
     kernels do not take split planes)."""
     chain = []
-    # small 2-D / 3-D transforms: every axis inside LDS, one launch, one HBM round trip (csrc/fft_nd.hpp)
+    variant = N.VARIANT_INTERLEAVED_ONLY if interleaved else 0
+
+    def nd_ok(xx, yy, zz):
+        return N.lib.mifft_nd_shape_supported(precision, xx, yy, zz, variant) == 0
+
+    # small 2-D / 3-D transforms: every axis inside LDS, one launch, one HBM round trip (csrc/fft_nd.hpp, fft_nd2.hpp)
     ndims = (x > 1) + (y > 1) + (z > 1)
-    if ndims >= 2 and 4 <= x * y * z <= N.lib.mifft_nd_max_points_for(precision):
+    if ndims >= 2 and x * y * z >= 4 and nd_ok(x, y, z):
         return [PassSpec(N.PASS_ND, X_DIRECTION, x * y * z, x, y, z, 1, x * y * z, True)]
     # 3-D shapes too big for one tile but with a small (y, x) plane: x and y together in LDS per plane (the planes
     # are just more batch items), then only z as a strided chain -- two HBM round trips instead of three
-    if ndims == 3 and x * y <= N.lib.mifft_nd_max_points_for(precision):
+    if ndims == 3 and nd_ok(x, y, 1):
         return [PassSpec(N.PASS_ND, X_DIRECTION, x * y, x, y, 1, z, x * y, True)] + \
             col_chain(Z_DIRECTION, z, x * y, 1, precision)
     if x > 1:

@@ -150,9 +150,14 @@ def _fixed_nd_shapes(lo, hi, maxn, extra):
 
 FIXED_ND_F32 = _fixed_nd_shapes(16, 1024, 16384, [(8, 8, 1), (16, 16, 16), (64, 8, 8), (8, 8, 8), (32, 32, 16), (32, 32, 8),
                                                    (64, 16, 16), (32, 16, 16), (16, 16, 8), (16, 16, 32), (16, 16, 64),
-                                                   (32, 16, 8), (64, 64, 4)])
+                                                   (32, 16, 8), (64, 64, 4),
+                                                   # beyond the run-time-shaped kernel's largest tile (interleaved only)
+                                                   (32, 1024, 1), (64, 512, 1), (128, 256, 1), (256, 128, 1), (1024, 32, 1),
+                                                   (32, 32, 32), (64, 64, 8), (128, 16, 16)])
 FIXED_ND_F64 = _fixed_nd_shapes(16, 512, 8192, [(8, 8, 1), (16, 16, 16), (64, 8, 8), (8, 8, 8), (32, 16, 16), (16, 16, 8),
-                                                 (16, 16, 32), (32, 32, 8), (16, 8, 8)])
+                                                 (16, 16, 32), (32, 32, 8), (16, 8, 8),
+                                                 (32, 512, 1), (64, 256, 1), (128, 128, 1), (256, 64, 1), (512, 32, 1),
+                                                 (32, 32, 16), (64, 16, 16), (16, 16, 64)])
 
 
 @pytest.mark.parametrize("dtype,xyz", [(numpy.complex64, s) for s in FIXED_ND_F32] + [(numpy.complex128, s) for s in FIXED_ND_F64],
@@ -168,7 +173,8 @@ def test_fixed_shape_nd_kernels(ctx, dtype, xyz):
 
 
 @pytest.mark.parametrize("dtype", [numpy.complex64, numpy.float32, numpy.complex128], ids=lambda d: numpy.dtype(d).name)
-@pytest.mark.parametrize("shape,batch", [((32, 32, 128), 2), ((16, 16, 128), 3), ((64, 64, 64), 2), ((16, 16), 37)], ids=str)
+@pytest.mark.parametrize("shape,batch", [((32, 32, 128), 2), ((16, 16, 128), 3), ((64, 64, 64), 2), ((16, 16), 37),
+                                         ((32, 32, 32), 3), ((128, 128), 3), ((128, 128, 128), 1)], ids=str)
 def test_fixed_shape_nd_planes(ctx, shape, batch, dtype):
     """3-D shapes whose (y, x) planes run on the fixed-shape kernels before the strided z pass; float32 (split planes)
     takes the run-time-shaped kernel."""

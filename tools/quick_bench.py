@@ -69,6 +69,10 @@ if __name__ == "__main__":
         cases = [((1024, 1024), c64, 512), ((256, 256), c64, 8192), ((4096, 64), c64, 2048), ((128, 128, 128), c64, 256),
                  ((256, 256, 256), c128, 16), ((256, 256, 256), f64, 16), ((64, 64, 64), c128, 1024), ((1 << 20,), f32, 256),
                  ((1024, 1024), f32, 256)]
+    elif len(sys.argv) > 1 and sys.argv[1] == "huge":
+        cases = [((32, 32, 32), c64, 8192), ((256, 128), c64, 8192), ((128, 256), c64, 8192), ((32, 1024), c64, 8192), ((1024, 32), c64, 8192),
+                 ((128, 128), c128, 8192), ((64, 256), c128, 8192), ((32, 32, 16), c128, 8192), ((128, 128, 128), c128, 64),
+                 ((32, 32, 32), f32, 8192), ((128, 128), f64, 8192)]
     elif len(sys.argv) > 1 and sys.argv[1] == "1d":
         cases = [((1 << k,), c64, max(64, (1 << 31) >> (k + 3))) for k in (13, 14, 15, 16, 17, 18, 19, 20, 21, 22)]
     else:
