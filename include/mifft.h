@@ -65,7 +65,7 @@ extern "C" {
 #define MIFFT_PASS_ROW 1  /* contiguous pass: `outer` rows of L points, in place  (kernel.mako:725-803)  */
 #define MIFFT_PASS_ND  2  /* whole small 2-D/3-D transform in LDS: L = x, M = y, S = z (x contiguous), `outer`
                             transforms back to back; tw_L / tw_lo / tw_hi = w(x)^k / w(y)^k / w(z)^k tables (NULL for an
-                            axis of length 1); x*y*z <= mifft_nd_max_points_for(precision).  In place capable.
+                            axis of length 1); shape accepted by mifft_nd_shape_supported().  In place capable.
                             Replaces the reference's local kernel + one global chain per further axis (plan.py:111-123) */
 
 typedef void *mifft_stream_t; /* hipStream_t; NULL = the default stream */
@@ -88,7 +88,7 @@ typedef void *mifft_event_t;  /* hipEvent_t */
  * the same offset applies to both planes).  Sizes are powers of two except `outer`.
  */
 typedef struct mifft_pass {
-    int32_t kind;        /* MIFFT_PASS_COL | MIFFT_PASS_ROW */
+    int32_t kind;        /* MIFFT_PASS_COL | MIFFT_PASS_ROW | MIFFT_PASS_ND */
     int32_t precision;   /* MIFFT_F32 | MIFFT_F64 */
     int32_t layout;      /* MIFFT_INTERLEAVED | MIFFT_SPLIT (same for input and output) */
     int32_t inverse;     /* 0 forward (numpy.fft.fft sign), 1 inverse (unnormalised unless `scale`) */

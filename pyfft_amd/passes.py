@@ -4,9 +4,11 @@ pyfft/kernel_helpers.py in the reference).
 The reference factors a long or strided axis in base 128 (kernel_helpers.py:67-122) and an
 LDS-resident axis by a fixed table up to n = 2048 (kernel_helpers.py:10-65) because of 16 KiB
 of shared memory and 512-thread blocks.  MI355X has 160 KiB of LDS per CU and 1024-thread
-work-groups, so the factorisation here is different: a contiguous axis up to 4096 points is one
-ROW launch, a strided axis up to 1024 points is one COL launch, and longer axes are split into
-the fewest near-equal COL passes (every pass is a full HBM round trip, so fewer is better).
+work-groups, so the factorisation here is different: a contiguous axis up to 16384 points
+(32768 interleaved fp32; half of that in fp64) is one ROW launch, a whole 2-D/3-D shape of up to
+16384 points (more for the common shapes, see mifft_nd_shape_supported) is one ND launch, a
+strided axis up to 1024 points is one COL launch, and longer axes are split into the fewest
+near-equal COL passes (every pass is a full HBM round trip, so fewer is better).
 The pass algebra itself is the reference's (kernel.mako:805-1047):
 
     view in as [outer][R][M][S], out as [outer][M][R][S]
