@@ -16,5 +16,11 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def ctx():
     """HipContext: counterpart of the reference's helpers.CudaContext (test/helpers.py:29-74)."""
+    # torch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's): import it before libmifft.so is loaded so
+    # that one HIP runtime serves both and the torch-interop test can run (bench.py does the same)
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     from helpers import HipContext
     return HipContext()
