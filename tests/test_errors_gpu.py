@@ -189,6 +189,14 @@ def test_fp64_two_phase_col_512(ctx, shape, batch, dtype):
     run_protocol(ctx, shape, dtype, batch, seed=77 + batch)
 
 
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.float64], ids=lambda d: numpy.dtype(d).name)
+@pytest.mark.parametrize("shape", [(16, 1), (1, 16), (1, 1, 16), (8, 1, 8), (1, 64, 1), (4096, 1), (1, 2048, 4), (2, 1, 1)], ids=str)
+def test_unit_axes(ctx, shape, dtype):
+    """Axes of length 1 (the reference lists y == 1 / z == 1 plans as a TODO, TODO.txt:6-8; plan.py:149,160,164 skip
+    them): every placement of the unit axes gives the transform over the remaining ones."""
+    run_protocol(ctx, shape, dtype, 3, seed=5 + len(shape))
+
+
 @pytest.mark.parametrize("dtype", [numpy.complex64, numpy.float32], ids=lambda d: numpy.dtype(d).name)
 def test_errors_large_1d(ctx, dtype):
     """N = 2^20 (BASELINE config 2 shape, small batch): the reference's largest 1-D test size
