@@ -133,31 +133,20 @@ def test_register_edged_rows(ctx, dtype, n):
         run_protocol(ctx, (128, n), dtype, 3, seed=n + 6)  # numpy shape (y, x): ROW over x = n, then a strided pass
 
 
-def _fixed_nd_shapes(lo, hi, maxn, extra):
-    """(x, y, z) shapes of csrc/fft_nd2_f32.hip / fft_nd2_f64.hip: every 2-D shape with both axes in lo...hi that fits
-    one tile, plus the listed 3-D ones."""
-    out = []
-    x = lo
-    while x <= hi:
-        y = lo
-        while y <= hi:
-            if x * y <= maxn:
-                out.append((x, y, 1))
-            y *= 2
-        x *= 2
-    return out + extra
+def _fixed_nd_shapes(prec):
+    """(x, y, z) shapes of the generated tables csrc/fft_nd2_f32_*.hip / fft_nd2_f64_*.hip (tools/gen_nd2_tables.py is
+    their single source)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gen_nd2_tables.py")
+    spec = importlib.util.spec_from_file_location("gen_nd2_tables", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.shapes(prec)
 
 
-FIXED_ND_F32 = _fixed_nd_shapes(16, 1024, 16384, [(8, 8, 1), (16, 16, 16), (64, 8, 8), (8, 8, 8), (32, 32, 16), (32, 32, 8),
-                                                   (64, 16, 16), (32, 16, 16), (16, 16, 8), (16, 16, 32), (16, 16, 64),
-                                                   (32, 16, 8), (64, 64, 4),
-                                                   # beyond the run-time-shaped kernel's largest tile (interleaved only)
-                                                   (32, 1024, 1), (64, 512, 1), (128, 256, 1), (256, 128, 1), (1024, 32, 1),
-                                                   (32, 32, 32), (64, 64, 8), (128, 16, 16)])
-FIXED_ND_F64 = _fixed_nd_shapes(16, 512, 8192, [(8, 8, 1), (16, 16, 16), (64, 8, 8), (8, 8, 8), (32, 16, 16), (16, 16, 8),
-                                                 (16, 16, 32), (32, 32, 8), (16, 8, 8),
-                                                 (32, 512, 1), (64, 256, 1), (128, 128, 1), (256, 64, 1), (512, 32, 1),
-                                                 (32, 32, 16), (64, 16, 16), (16, 16, 64)])
+FIXED_ND_F32 = _fixed_nd_shapes("f32")
+FIXED_ND_F64 = _fixed_nd_shapes("f64")
 
 
 @pytest.mark.parametrize("dtype,xyz", [(numpy.complex64, s) for s in FIXED_ND_F32] + [(numpy.complex128, s) for s in FIXED_ND_F64],
@@ -169,7 +158,7 @@ def test_fixed_shape_nd_kernels(ctx, dtype, xyz):
     n = x * y * z
     tile = 4096 if dtype == numpy.complex64 else 2048
     batch = 3 if n >= tile else (tile // n) * 2 + 1
-    run_protocol(ctx, shape, dtype, batch, seed=n + batch, check_oracle=(n <= 4096))
+    run_protocol(ctx, shape, dtype, batch, seed=n + batch, check_oracle=(n <= 4096 and n * batch <= 16384))
 
 
 @pytest.mark.parametrize("dtype", [numpy.complex64, numpy.float32, numpy.complex128], ids=lambda d: numpy.dtype(d).name)
