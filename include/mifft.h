@@ -59,6 +59,11 @@ extern "C" {
  * at the full rate (src/dst plane pointer of that side is ignored and may be NULL). */
 #define MIFFT_FLAG_SRC_INTERLEAVED 1
 #define MIFFT_FLAG_DST_INTERLEAVED 2
+/* hints for multi-pass plans: the source of this pass is read once and not needed again (the plan's first pass) /
+   the destination is not re-read by the plan (its last pass): kernels that honour them use non-temporal accesses,
+   which leaves the Infinity Cache to the intermediate of the pipelined strategy.  Results are unaffected. */
+#define MIFFT_FLAG_STREAM_SRC 4
+#define MIFFT_FLAG_STREAM_DST 8
 
 /* pass kinds */
 #define MIFFT_PASS_COL 0  /* strided pass: [outer][L][M*S] -> [outer][M][L][S]  (kernel.mako:805-1047) */

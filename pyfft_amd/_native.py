@@ -23,6 +23,7 @@ INTERLEAVED, SPLIT = 0, 1
 VARIANT_INTERLEAVED_ONLY = 2
 PASS_COL, PASS_ROW, PASS_ND = 0, 1, 2
 FLAG_SRC_INTERLEAVED, FLAG_DST_INTERLEAVED = 1, 2
+FLAG_STREAM_SRC, FLAG_STREAM_DST = 4, 8
 
 
 class MifftPass(ctypes.Structure):

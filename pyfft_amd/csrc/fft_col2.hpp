@@ -261,7 +261,17 @@ __global__ void __launch_bounds__(256, 2) fft_col2_kernel(const TileArgs a) {
     const long long col0 = (long long)blockIdx.x * 16;
     const long long o = col0 >> a.logMS;
     const long long rem0 = col0 & ((1ll << a.logMS) - 1);
-    col2_tile<T, A, TR, TW, SPLIT, false, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
+    // streaming hints (MIFFT_FLAG_STREAM_*): a transposing pass is the first pass of a plan (its input is read once), a
+    // plain one the last pass of an axis (when it is the plan's last, nobody re-reads its output)
+    if constexpr (TR && !SPLIT) {
+        if (a.nt & 1) col2_tile<T, A, TR, TW, SPLIT, false, true, false, SPLIT_OUT>(a, o, o, rem0, lds);
+        else col2_tile<T, A, TR, TW, SPLIT, false, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
+    } else if constexpr (!TR && !SPLIT_OUT) {
+        if (a.nt & 2) col2_tile<T, A, TR, TW, SPLIT, false, false, true, SPLIT_OUT>(a, o, o, rem0, lds);
+        else col2_tile<T, A, TR, TW, SPLIT, false, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
+    } else {
+        col2_tile<T, A, TR, TW, SPLIT, false, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
+    }
 }
 
 }  // namespace mifft

@@ -82,6 +82,7 @@ template <typename T, int P, int NT, bool HALF, typename D> struct Nd2Stage {
     }
     // operands straight from HBM: `inb` = first byte of the transform (wave-uniform)
     // `left` = points from the start of the tile to the end of the data (whole transforms are in or out of range)
+    template <bool NTL = false>
     static __device__ __forceinline__ void load(const char* inb, cplx<T>* v, int tid, long long left) {
         static_for<NB>([&](auto bb) {
             constexpr int b = bb;
@@ -93,11 +94,16 @@ template <typename T, int P, int NT, bool HALF, typename D> struct Nd2Stage {
                 constexpr int k = kk;
                 cplx<T> p;
                 p.x = 0; p.y = 0;
-                if (ok) p = *reinterpret_cast<const cplx<T>*>(inb + (size_t)(k * LR * SA) * sizeof(cplx<T>) + voff);
+                if (ok) {
+                    const cplx<T>* q = reinterpret_cast<const cplx<T>*>(inb + (size_t)(k * LR * SA) * sizeof(cplx<T>) + voff);
+                    if constexpr (NTL) p = __builtin_nontemporal_load(q);
+                    else p = *q;
+                }
                 v[b * R + k] = p;
             });
         });
     }
+    template <bool NTS = false>
     static __device__ __forceinline__ void store(char* outb, const cplx<T>* v, int tid, T sx, T sy, long long left) {
         static_for<NB>([&](auto bb) {
             constexpr int b = bb;
@@ -110,7 +116,9 @@ template <typename T, int P, int NT, bool HALF, typename D> struct Nd2Stage {
                     cplx<T> p = v[b * R + k];
                     p.x *= sx;
                     p.y *= sy;
-                    *reinterpret_cast<cplx<T>*>(outb + (size_t)(k * Ns * SA) * sizeof(cplx<T>) + voff) = p;
+                    cplx<T>* q = reinterpret_cast<cplx<T>*>(outb + (size_t)(k * Ns * SA) * sizeof(cplx<T>) + voff);
+                    if constexpr (NTS) __builtin_nontemporal_store(p, q);
+                    else *q = p;
                 });
             }
         });
@@ -139,10 +147,11 @@ struct Nd2Chain<T, P, NT, HALF, FIRST, Nd2StageList<D, Rest...>> {
 
     // v holds the operands of this stage; tw[ax] = twiddle table of axis ax
     static __device__ __forceinline__ void run(LdsT* lds, cplx<T>* v, const cplx<T>* const* tw, int tid, char* outb, T sx,
-                                               T sy, long long left) {
+                                               T sy, long long left, bool nt_out) {
         St::compute(v, tw[D::AX], tid);
         if constexpr (LAST) {
-            St::store(outb, v, tid, sx, sy, left);
+            if (nt_out) St::template store<true>(outb, v, tid, sx, sy, left);  // MIFFT_FLAG_STREAM_DST
+            else St::template store<false>(outb, v, tid, sx, sy, left);
         } else {
             using NextChain = Nd2Chain<T, P, NT, HALF, false, Nd2StageList<Rest...>>;
             using Next = typename NextChain::St;
@@ -160,7 +169,7 @@ struct Nd2Chain<T, P, NT, HALF, FIRST, Nd2StageList<D, Rest...>> {
                 __syncthreads();
                 Next::template fetch<2>(lds, v, tid);
             }
-            NextChain::run(lds, v, tw, tid, outb, sx, sy, left);
+            NextChain::run(lds, v, tw, tid, outb, sx, sy, left, nt_out);
         }
     }
 };
@@ -198,7 +207,8 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) 
     const T sy = a.inverse ? -sx : sx;
     cplx<T> v[PPT];
     if constexpr (EDGE_IN) {
-        First::load(inb, v, tid, left);
+        if (a.nt & 1) First::template load<true>(inb, v, tid, left);  // MIFFT_FLAG_STREAM_SRC
+        else First::template load<false>(inb, v, tid, left);
     } else {
         // 16-byte linear load (thread: points 2*(it*NT + tid), +1), then one exchange into the first stage's order
         using V4 = T __attribute__((ext_vector_type(4)));
@@ -220,7 +230,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) 
         __syncthreads();
     }
     if (a.inverse) static_for<PPT>([&](auto i) { v[i].y = -v[i].y; });
-    Nd2Chain<T, P, NT, HALF, true, SL>::run(lds, v, tw, tid, outb, sx, sy, left);
+    Nd2Chain<T, P, NT, HALF, true, SL>::run(lds, v, tw, tid, outb, sx, sy, left, (a.nt & 2) != 0);
 }
 
 template <typename T, int LX, int LY, int LZ, int P, int NT, bool HALF, int OCC, bool EDGE_IN, typename RLX, typename RLY,

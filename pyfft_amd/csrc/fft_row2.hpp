@@ -105,14 +105,21 @@ struct Row2Stages<T, L, TPR, Ns, FIRST, HALF, RadixList<R, Rest...>> {
             // all loads of the row in flight before the first butterfly
             static_for<PPT>([&](auto i) { v[i].x = 0; v[i].y = 0; });
             if (valid) {
-                static_for<NB>([&](auto bb) {
-                    constexpr int b = bb;
-                    static_for<R>([&](auto kk) {
-                        constexpr int k = kk;
-                        v[b * R + k] = *reinterpret_cast<const cplx<T>*>(
-                            inb + (size_t)(b * NT + k * LR) * sizeof(cplx<T>) + voff);
+                auto loads = [&](auto ntc) __attribute__((always_inline)) {
+                    constexpr bool NTL = ntc;
+                    static_for<NB>([&](auto bb) {
+                        constexpr int b = bb;
+                        static_for<R>([&](auto kk) {
+                            constexpr int k = kk;
+                            const cplx<T>* p = reinterpret_cast<const cplx<T>*>(
+                                inb + (size_t)(b * NT + k * LR) * sizeof(cplx<T>) + voff);
+                            if constexpr (NTL) v[b * R + k] = __builtin_nontemporal_load(p);
+                            else v[b * R + k] = *p;
+                        });
                     });
-                });
+                };
+                // MIFFT_FLAG_STREAM_SRC: the input is read once (first pass of a multi-pass plan)
+                if (a.nt & 1) loads(IC<1>{}); else loads(IC<0>{});
             }
             if (a.inverse) static_for<PPT>([&](auto i) { v[i].y = -v[i].y; });
         }
@@ -129,16 +136,22 @@ struct Row2Stages<T, L, TPR, Ns, FIRST, HALF, RadixList<R, Rest...>> {
             const T sx = (T)a.scale;
             const T sy = a.inverse ? -sx : sx;
             if (valid) {
-                static_for<NB>([&](auto bb) {
-                    constexpr int b = bb;  // Ns == LR: idxD = j = b * NT + tid
-                    static_for<R>([&](auto kk) {
-                        constexpr int k = kk;
-                        cplx<T> p = v[b * R + k];
-                        p.x *= sx;
-                        p.y *= sy;
-                        *reinterpret_cast<cplx<T>*>(outb + (size_t)(b * NT + k * Ns) * sizeof(cplx<T>) + voff) = p;
+                auto stores = [&](auto ntc) __attribute__((always_inline)) {
+                    constexpr bool NTS = ntc;
+                    static_for<NB>([&](auto bb) {
+                        constexpr int b = bb;  // Ns == LR: idxD = j = b * NT + tid
+                        static_for<R>([&](auto kk) {
+                            constexpr int k = kk;
+                            cplx<T> p = v[b * R + k];
+                            p.x *= sx;
+                            p.y *= sy;
+                            cplx<T>* q = reinterpret_cast<cplx<T>*>(outb + (size_t)(b * NT + k * Ns) * sizeof(cplx<T>) + voff);
+                            if constexpr (NTS) __builtin_nontemporal_store(p, q);
+                            else *q = p;
+                        });
                     });
-                });
+                };
+                if (a.nt & 2) stores(IC<1>{}); else stores(IC<0>{});
             }
         } else {
             using Next = Row2Stages<T, L, TPR, Ns * R, false, HALF, RadixList<Rest...>>;

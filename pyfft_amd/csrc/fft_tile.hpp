@@ -37,6 +37,7 @@ struct TileArgs {
     int split_out;  // output side likewise (differs from `split` only for a plan's internal temp buffer)
     int inverse;
     int has_tw;  // COL: M > 1 -> multiply by the inter-pass twiddle w(L*M)^(l*q)
+    int nt;      // bit 0: non-temporal loads of the input, bit 1: non-temporal stores of the output (kernels may ignore)
     double scale;
 };
 

@@ -95,6 +95,7 @@ void fill_args(const mifft_pass* p, const void* in0, const void* in1, void* out0
     a.split_out = split_out ? 1 : 0;
     a.inverse = p->inverse ? 1 : 0;
     a.has_tw = (p->kind == MIFFT_PASS_COL && p->M > 1) ? 1 : 0;
+    a.nt = ((p->flags & MIFFT_FLAG_STREAM_SRC) ? 1 : 0) | ((p->flags & MIFFT_FLAG_STREAM_DST) ? 2 : 0);
     a.scale = p->scale;
 }
 
@@ -128,6 +129,7 @@ int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0,
         t.total = p->outer * p->L * p->M * p->S;
         t.inverse = p->inverse ? 1 : 0;
         t.scale = p->scale;
+        t.nt = ((p->flags & MIFFT_FLAG_STREAM_SRC) ? 1 : 0) | ((p->flags & MIFFT_FLAG_STREAM_DST) ? 2 : 0);
         const int rc = f64nd ? mifft_nd2_f64_launch((int)p->L, (int)p->M, (int)p->S, &t, s)
                              : mifft_nd2_f32_launch((int)p->L, (int)p->M, (int)p->S, &t, s);
         if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");

@@ -204,6 +204,12 @@ class FFTPlan(object):
                     d.flags |= N.FLAG_SRC_INTERLEAVED
                 if dst == 2:
                     d.flags |= N.FLAG_DST_INTERLEAVED
+            # multi-pass plans: the first pass reads the input once, nobody re-reads what the last pass writes
+            if last >= 1 and not os.environ.get("PYFFT_AMD_NO_STREAM_HINTS"):  # (development switch)
+                if i == 0:
+                    d.flags |= N.FLAG_STREAM_SRC
+                if i == last:
+                    d.flags |= N.FLAG_STREAM_DST
         if len(self._desc_cache) > 64:
             self._desc_cache.clear()
         self._desc_cache[key] = arr
