@@ -30,12 +30,13 @@ template <int A, int E, typename T> __device__ __forceinline__ cplx<T> mul_w16A(
         return mul_w32<E, T>(v);  // A == 2: w(32)
 }
 
-// ESZ = bytes per complex element: 8-byte points double-buffer the exchange (2 x 34 KiB); 16-byte points reuse one
-// 68 KiB buffer with one more barrier per round, so that two work-groups still share a CU.
+// ESZ = bytes per complex element.  L = 1024 in fp32 double-buffers the exchange (2 x 34 KiB: its 250-VGPR kernel fits two
+// work-groups per CU either way); L = 512 reuses one 34 KiB buffer with one more barrier per round, so that FOUR
+// work-groups share a CU (108 VGPRs; pipelined N = 2^18: 36.5 -> 38 %); 16-byte points reuse one 68 KiB buffer (two per CU).
 template <int A, bool TR, int ESZ = 8> struct Col2Lds {
     static constexpr int PITCH = TR ? 17 : 16;   // TR: [b0][c][qb1 + pad]; else [b0][qb1][c]
     static constexpr int BUF = 16 * 16 * PITCH;  // complex elements per exchange buffer
-    static constexpr bool DOUBLE = A > 1 && ESZ <= 8;
+    static constexpr bool DOUBLE = A > 2 && ESZ <= 8;
     static constexpr int ELEMS = (DOUBLE ? 2 : 1) * BUF;
 };
 
