@@ -9,7 +9,7 @@ extern "C" int mifft_dispatch_row_f32(int L, int variant, const mifft::TileArgs*
     if (L == 32768) {
         if (query_only) return variant == 2 ? 0 : -2;
         if (!a || a->split || a->split_out) return -2;
-        return mifft::launch_row2<float, 32768, 1, 512, mifft::RadixList<32, 32, 32>, true, 2>(a, s, 0);
+        return mifft::launch_row2<float, 32768, 1, 1024, mifft::RadixList<8, 16, 16, 16>, true, 4>(a, s, 0);
     }
     // both sides interleaved: register-edged kernels (fft_row2.hpp).  Shapes chosen by measurement (1 GiB buffers,
     // tools/row_probe.py): the half-exchange form wins where it raises the work-groups per CU (8192: 2 -> 3,
