@@ -43,11 +43,15 @@ struct TileArgs {
 
 template <int... Rs> struct RadixList {};
 
-template <typename T> __device__ __forceinline__ void load_pair(const TileArgs& a, long long g, cplx<T>& p0,
-                                                                cplx<T>& p1) {
+// NT: non-temporal access (MIFFT_FLAG_STREAM_SRC / _DST: data read once / not re-read by the plan), interleaved only
+template <typename T, bool NT = false> __device__ __forceinline__ void load_pair(const TileArgs& a, long long g, cplx<T>& p0,
+                                                                                 cplx<T>& p1) {
     using V4 = T __attribute__((ext_vector_type(4)));
     if (!a.split) {
-        V4 t = *reinterpret_cast<const V4*>(reinterpret_cast<const cplx<T>*>(a.in0) + g);
+        const V4* q = reinterpret_cast<const V4*>(reinterpret_cast<const cplx<T>*>(a.in0) + g);
+        V4 t;
+        if constexpr (NT) t = __builtin_nontemporal_load(q);
+        else t = *q;
         p0.x = t.x; p0.y = t.y; p1.x = t.z; p1.y = t.w;
     } else {
         cplx<T> re = *reinterpret_cast<const cplx<T>*>(reinterpret_cast<const T*>(a.in0) + g);
@@ -56,13 +60,15 @@ template <typename T> __device__ __forceinline__ void load_pair(const TileArgs& 
     }
 }
 
-template <typename T> __device__ __forceinline__ void store_pair(const TileArgs& a, long long g, cplx<T> p0,
-                                                                 cplx<T> p1) {
+template <typename T, bool NT = false> __device__ __forceinline__ void store_pair(const TileArgs& a, long long g, cplx<T> p0,
+                                                                                  cplx<T> p1) {
     using V4 = T __attribute__((ext_vector_type(4)));
     if (!a.split_out) {
         V4 t;
         t.x = p0.x; t.y = p0.y; t.z = p1.x; t.w = p1.y;
-        *reinterpret_cast<V4*>(reinterpret_cast<cplx<T>*>(a.out0) + g) = t;
+        V4* q = reinterpret_cast<V4*>(reinterpret_cast<cplx<T>*>(a.out0) + g);
+        if constexpr (NT) __builtin_nontemporal_store(t, q);
+        else *q = t;
     } else {
         cplx<T> re, im;
         re.x = p0.x; re.y = p1.x; im.x = p0.y; im.y = p1.y;
@@ -73,9 +79,9 @@ template <typename T> __device__ __forceinline__ void store_pair(const TileArgs&
 
 // V consecutive points (V = 2: one 16-byte access interleaved / one 8-byte access per plane when split;
 // V = 4: split planes only, one 16-byte access per plane)
-template <typename T, int V> __device__ __forceinline__ void load_vec(const TileArgs& a, long long g, cplx<T>* p) {
+template <typename T, int V, bool NT = false> __device__ __forceinline__ void load_vec(const TileArgs& a, long long g, cplx<T>* p) {
     if constexpr (V == 2) {
-        load_pair<T>(a, g, p[0], p[1]);
+        load_pair<T, NT>(a, g, p[0], p[1]);
     } else {
         using V4 = T __attribute__((ext_vector_type(4)));
         const V4 re = *reinterpret_cast<const V4*>(reinterpret_cast<const T*>(a.in0) + g);
@@ -84,9 +90,9 @@ template <typename T, int V> __device__ __forceinline__ void load_vec(const Tile
         p[2].x = re.z; p[2].y = im.z; p[3].x = re.w; p[3].y = im.w;
     }
 }
-template <typename T, int V> __device__ __forceinline__ void store_vec(const TileArgs& a, long long g, const cplx<T>* p) {
+template <typename T, int V, bool NT = false> __device__ __forceinline__ void store_vec(const TileArgs& a, long long g, const cplx<T>* p) {
     if constexpr (V == 2) {
-        store_pair<T>(a, g, p[0], p[1]);
+        store_pair<T, NT>(a, g, p[0], p[1]);
     } else {
         using V4 = T __attribute__((ext_vector_type(4)));
         V4 re, im;
@@ -239,8 +245,9 @@ __global__ void __launch_bounds__(NT) fft_tile_kernel(const TileArgs a) {
     const T csign = a.inverse ? (T)-1 : (T)1;
 
     // ---- global -> registers (all loads in flight), then -> LDS
-    auto load_phase = [&](auto vv) {
+    auto load_phase = [&](auto vv, auto ntc) {
         constexpr int V = vv;
+        constexpr bool NTL = (int)ntc != 0;
         static_for<PPT / V>([&](auto ii) {
             constexpr int it = ii;
             const int e = (it * NT + tid) * V;
@@ -249,13 +256,13 @@ __global__ void __launch_bounds__(NT) fft_tile_kernel(const TileArgs a) {
             if constexpr (ROW) {
                 const int c = e / L, r = e % L;
                 const long long rr = col0 + c;
-                if (rr < a.total) load_vec<T, V>(a, rr * a.ostride_in + r, p);
+                if (rr < a.total) load_vec<T, V, NTL>(a, rr * a.ostride_in + r, p);
             } else {
                 const int r = e / W, c = e % W;
                 const long long cc = col0 + c;
                 if (cc < a.total) {
                     const long long o = cc >> a.logMS, rem = cc & MSmask;
-                    load_vec<T, V>(a, o * a.ostride_in + ((long long)r << a.logMS) + rem, p);
+                    load_vec<T, V, NTL>(a, o * a.ostride_in + ((long long)r << a.logMS) + rem, p);
                 }
             }
             static_for<V>([&](auto k) { v[V * it + k] = p[k]; });
@@ -277,10 +284,14 @@ __global__ void __launch_bounds__(NT) fft_tile_kernel(const TileArgs a) {
             });
         });
     };
+    // (streaming hint only on the plain interleaved path)
     if constexpr (kQuadShape) {
-        if (quad_in) load_phase(IC<4>{}); else load_phase(IC<2>{});
+        if (quad_in) load_phase(IC<4>{}, IC<0>{});
+        else if (a.nt & 1) load_phase(IC<2>{}, IC<1>{});
+        else load_phase(IC<2>{}, IC<0>{});
     } else {
-        load_phase(IC<2>{});
+        if (a.nt & 1) load_phase(IC<2>{}, IC<1>{});
+        else load_phase(IC<2>{}, IC<0>{});
     }
     __syncthreads();
 
@@ -289,8 +300,9 @@ __global__ void __launch_bounds__(NT) fft_tile_kernel(const TileArgs a) {
     // ---- LDS -> global (scaled, conjugated back for the inverse)
     const T sx = (T)a.scale;
     const T sy = a.inverse ? -sx : sx;
-    auto store_phase = [&](auto vv) {
+    auto store_phase = [&](auto vv, auto ntc) {
         constexpr int V = vv;
+        constexpr bool NTS = (int)ntc != 0;
         static_for<PPT / V>([&](auto ii) {
             constexpr int it = ii;
             const int e = (it * NT + tid) * V;
@@ -322,13 +334,16 @@ __global__ void __launch_bounds__(NT) fft_tile_kernel(const TileArgs a) {
                 static_for<V>([&](auto k) { p[k] = lds[lds_addr<L, W, ROW>(q, c + k)]; });
             }
             static_for<V>([&](auto k) { p[k].x *= sx; p[k].y *= sy; });
-            if (valid) store_vec<T, V>(a, g, p);
+            if (valid) store_vec<T, V, NTS>(a, g, p);
         });
     };
     if constexpr (kQuadShape) {
-        if (quad_out) store_phase(IC<4>{}); else store_phase(IC<2>{});
+        if (quad_out) store_phase(IC<4>{}, IC<0>{});
+        else if (a.nt & 2) store_phase(IC<2>{}, IC<1>{});
+        else store_phase(IC<2>{}, IC<0>{});
     } else {
-        store_phase(IC<2>{});
+        if (a.nt & 2) store_phase(IC<2>{}, IC<1>{});
+        else store_phase(IC<2>{}, IC<0>{});
     }
 }
 

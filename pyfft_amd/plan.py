@@ -204,8 +204,11 @@ class FFTPlan(object):
                     d.flags |= N.FLAG_SRC_INTERLEAVED
                 if dst == 2:
                     d.flags |= N.FLAG_DST_INTERLEAVED
-            # multi-pass plans: the first pass reads the input once, nobody re-reads what the last pass writes
-            if last >= 1 and not os.environ.get("PYFFT_AMD_NO_STREAM_HINTS"):  # (development switch)
+            # multi-pass plans: the first pass reads the input once, nobody re-reads what the last pass writes.  Only
+            # while a transform's intermediate can stay in the 256 MiB Infinity Cache (256^3 fp64: 256 MiB per transform,
+            # measured 1 % slower with the hints)
+            if last >= 1 and p.size * p.complex_nbytes <= (64 << 20) and \
+                    not os.environ.get("PYFFT_AMD_NO_STREAM_HINTS"):  # (development switch)
                 if i == 0:
                     d.flags |= N.FLAG_STREAM_SRC
                 if i == last:
