@@ -246,10 +246,12 @@ class FFTPlan(object):
         if self._temp_buffer_needed and forced in ("auto", "fused") and self._fused2_eligible():
             grid = 2 * self._context.compute_units
             gsize = 2 * max(self._kernels[0].M // 16, self._kernels[1].S // 16)
-            lag = max(2, -(-9 * grid // (4 * gsize)))
-            ring = 2 * lag
+            # producers run `lag` transforms ahead of the consumers; ring = 2 * lag slots (1024 x 1024: lag 14, 224 MiB --
+            # the largest ring that still fits the 256 MiB Infinity Cache measured best: fused_probe.py wide)
             # measured on MI355X: the persistent kernel beats stream-pipelined chunks only for 1024 x 1024
             big = min(self._kernels[0].L, self._kernels[1].L) >= 1024
+            lag = max(2, -(-(14 if big else 9) * grid // (4 * gsize)))
+            ring = 2 * lag
             if batch >= 2 * ring and (big or forced == "fused"):
                 return ("fused2", lag, ring, grid)
         # any multi-pass plan gains from cache-sized chunks (the second pass re-reads what the first just wrote),

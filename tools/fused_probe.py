@@ -55,4 +55,7 @@ def probe(n, B, combos, iters=3, check=True):
         del scratch
 
 if __name__ == "__main__":
-    probe(1 << 20, 1024, [(7, 14, 512), (8, 16, 512), (9, 18, 512), (10, 20, 512), (8, 12, 512), (8, 24, 512), (8, 16, 384), (8, 16, 448), (6, 16, 384)])
+    combos = [(7, 14, 512), (8, 16, 512), (9, 18, 512), (10, 20, 512), (8, 12, 512), (8, 24, 512), (8, 16, 384), (8, 16, 448), (6, 16, 384)]
+    if len(sys.argv) > 1 and sys.argv[1] == "wide":
+        combos = [(l, r, 512) for l in (6, 8, 10, 12, 14, 18, 24) for r in (2 * l, 3 * l // 2)] + [(18, 36, 768), (12, 24, 768), (18, 36, 384)]
+    probe(1 << 20, 1024, combos)
