@@ -126,6 +126,17 @@ class FFTPlan(object):
         self._via_temp = (p.split and p.precision == N.F32 and len(self._kernels) >= 2 and not self._temp_buffer_needed)
         if self._via_temp:
             self._temp_buffer_needed = True
+        # 3-D transforms larger than the Infinity Cache: the leading x / y passes work plane by plane, so they can run
+        # slab by slab (a few z planes) through the pipelined launcher before the z passes run over whole transforms --
+        # the x -> y intermediate then stays on die.  (_slab_passes leading passes, every pass in place capable.)
+        self._slab_passes = 0
+        if int(p.z) > 1 and not self._temp_buffer_needed and p.size * p.complex_nbytes > self.PIPELINE_TARGET_BYTES:
+            k = 0
+            while k < len(self._kernels) and self._kernels[k].kind != N.PASS_ND and \
+                    self._kernels[k].axis in (P.X_DIRECTION, P.Y_DIRECTION):
+                k += 1
+            if 2 <= k < len(self._kernels):
+                self._slab_passes = k
 
         self._tables = {}      # key -> device allocation
         self._table_ptrs = []  # per pass: (tw_L, tw_lo, tw_hi, shift)
@@ -207,7 +218,7 @@ class FFTPlan(object):
             # multi-pass plans: the first pass reads the input once, nobody re-reads what the last pass writes.  Only
             # while a transform's intermediate can stay in the 256 MiB Infinity Cache (256^3 fp64: 256 MiB per transform,
             # measured 1 % slower with the hints)
-            if last >= 1 and p.size * p.complex_nbytes <= (64 << 20) and \
+            if last >= 1 and (p.size * p.complex_nbytes <= (64 << 20) or self._slab_passes) and \
                     not os.environ.get("PYFFT_AMD_NO_STREAM_HINTS"):  # (development switch)
                 if i == 0:
                     d.flags |= N.FLAG_STREAM_SRC
@@ -226,6 +237,7 @@ class FFTPlan(object):
     #              slot (mifft_launch_chain_pipelined)
     #   fused2     both passes of a long 1-D fp32 transform in one persistent launch (mifft_launch_fused2)
     PIPELINE_TARGET_BYTES = 64 << 20
+    SLAB_TARGET_BYTES = 128 << 20      # slabs of the leading passes of a big 3-D transform (C4: 24.7 % at 64 MiB, 25.5 % at 128)
     PIPELINE_STREAMS = 2
 
     def _fused2_eligible(self):
@@ -257,7 +269,14 @@ class FFTPlan(object):
         # any multi-pass plan gains from cache-sized chunks (the second pass re-reads what the first just wrote),
         # whether or not it needs a temp buffer
         if len(self._kernels) >= 2 and forced in ("auto", "pipelined") and batch >= 4 * chunk:
-            return ("pipelined", chunk, nstreams)
+            nslab = 0
+            if self._slab_passes and not os.environ.get("PYFFT_AMD_NO_SLABS"):   # (development switch)
+                plane_bytes = int(p.x) * int(p.y) * p.complex_nbytes
+                slab_target = int(os.environ.get("PYFFT_AMD_SLAB_MB", "0")) << 20 or \
+                    (self.SLAB_TARGET_BYTES // 2 if p.split else self.SLAB_TARGET_BYTES)   # split planes measured best at 64 MiB
+                planes = min(int(p.z), max(1, slab_target // plane_bytes))
+                nslab = int(p.z) // planes
+            return ("pipelined", chunk, nstreams, nslab)
         return strat
 
     def _prepare(self, batch):
@@ -301,10 +320,19 @@ class FFTPlan(object):
                                               bufs0[2], None, ring, lag, ctx.pointer_of(self._counters), grid, stream),
                     "mifft_launch_fused2")
         elif strat[0] == "pipelined":
-            _, chunk, nside = strat
+            _, chunk, nside, nslab = strat
             side = (ctypes.c_void_p * nside)(*[s.handle for s in self._side_streams])
             evs = (ctypes.c_void_p * (nside + 1))(*[e.handle for e in self._side_events])
-            N.check(N.lib.mifft_launch_chain_pipelined(descs, len(self._kernels), bufs0, bufs1, batch, chunk,
+            npass = len(self._kernels)
+            first = 0
+            if nslab > 1:
+                # leading x / y passes slab by slab: "batch" = batch * nslab slabs of size / nslab points, one per chunk
+                first = self._slab_passes
+                N.check(N.lib.mifft_launch_chain_pipelined(descs, first, bufs0, bufs1, batch * nslab, 1,
+                                                           self._params.size // nslab, stream, side, nside, evs),
+                        "mifft_launch_chain_pipelined")
+            rest = ctypes.cast(ctypes.byref(descs, first * ctypes.sizeof(N.MifftPass)), ctypes.POINTER(N.MifftPass))
+            N.check(N.lib.mifft_launch_chain_pipelined(rest, npass - first, bufs0, bufs1, batch, chunk,
                                                        self._params.size, stream, side, nside, evs),
                     "mifft_launch_chain_pipelined")
         else:
