@@ -37,7 +37,10 @@ template <int A, bool TR, int ESZ = 8> struct Col2Lds {
     static constexpr int PITCH = TR ? 17 : 16;   // TR: [b0][c][qb1 + pad]; else [b0][qb1][c]
     static constexpr int BUF = 16 * 16 * PITCH;  // complex elements per exchange buffer
     static constexpr bool DOUBLE = A > 2 && ESZ <= 8;
-    static constexpr int ELEMS = (DOUBLE ? 2 : 1) * BUF;
+    // 16-byte points: the exchange moves real parts, then imaginary parts, through BUF scalars (34 KiB instead of 68:
+    // four work-groups per CU instead of two for L = 256, at ~120 VGPRs)
+    static constexpr bool HALF = ESZ > 8;
+    static constexpr int ELEMS = HALF ? (BUF + 1) / 2 : (DOUBLE ? 2 : 1) * BUF;
 };
 
 // One tile = 16 adjacent columns starting at column rem0 (a multiple of 16) of matrix o_in; the result goes to
@@ -56,6 +59,7 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
     constexpr int PITCH = Col2Lds<A, TR, sizeof(cplx<T>)>::PITCH;
     constexpr int BUF = Col2Lds<A, TR, sizeof(cplx<T>)>::BUF;
     constexpr bool kDoubleBuf = Col2Lds<A, TR, sizeof(cplx<T>)>::DOUBLE;
+    constexpr bool kHalf = Col2Lds<A, TR, sizeof(cplx<T>)>::HALF;
 
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));  // same reason as below, for the per-thread (VGPR) address pieces
@@ -191,22 +195,49 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
         constexpr int qa = rr;
         LdsPtr buf = lds + (kDoubleBuf ? (qa & 1) * BUF : 0);
         if constexpr (!kDoubleBuf && qa > 0) __syncthreads();  // the previous round's reads are done
-        static_for<16>([&](auto ss) {
-            constexpr int qb1 = ss;
-            if constexpr (TR)
-                buf[(b0 * 16 + c) * PITCH + qb1] = v[qa * 16 + qb1];
-            else
-                buf[(b0 * 16 + qb1) * 16 + c] = v[qa * 16 + qb1];
-        });
-        __syncthreads();
         cplx<T> x[16];
-        static_for<16>([&](auto bb) {
-            constexpr int bi = bb;
-            if constexpr (TR)
-                x[bi] = buf[(bi * 16 + c2) * PITCH + u];
-            else
-                x[bi] = buf[(bi * 16 + u) * 16 + c2];
-        });
+        if constexpr (!kHalf) {
+            static_for<16>([&](auto ss) {
+                constexpr int qb1 = ss;
+                if constexpr (TR)
+                    buf[(b0 * 16 + c) * PITCH + qb1] = v[qa * 16 + qb1];
+                else
+                    buf[(b0 * 16 + qb1) * 16 + c] = v[qa * 16 + qb1];
+            });
+            __syncthreads();
+            static_for<16>([&](auto bb) {
+                constexpr int bi = bb;
+                if constexpr (TR)
+                    x[bi] = buf[(bi * 16 + c2) * PITCH + u];
+                else
+                    x[bi] = buf[(bi * 16 + u) * 16 + c2];
+            });
+        } else {
+            // one component at a time through the same slots viewed as scalars
+            T* sb = reinterpret_cast<T*>(&lds[0]);
+            static_for<2>([&](auto cc) {
+                constexpr int comp = cc;
+                if constexpr (comp == 1) __syncthreads();  // the real parts have been read
+                static_for<16>([&](auto ss) {
+                    constexpr int qb1 = ss;
+                    const T w = comp == 0 ? v[qa * 16 + qb1].x : v[qa * 16 + qb1].y;
+                    if constexpr (TR)
+                        sb[(b0 * 16 + c) * PITCH + qb1] = w;
+                    else
+                        sb[(b0 * 16 + qb1) * 16 + c] = w;
+                });
+                __syncthreads();
+                static_for<16>([&](auto bb) {
+                    constexpr int bi = bb;
+                    T w;
+                    if constexpr (TR)
+                        w = sb[(bi * 16 + c2) * PITCH + u];
+                    else
+                        w = sb[(bi * 16 + u) * 16 + c2];
+                    if constexpr (comp == 0) x[bi].x = w; else x[bi].y = w;
+                });
+            });
+        }
         Dft<16, T>::run(x);
         if constexpr (TW) {
             // w(L*M)^(l*q) for q = qb0*16A + qlow, qlow = qa*16 + u.  Four anchors (qb0 = 0, 4, 8, 12) come from
