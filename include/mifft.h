@@ -143,6 +143,12 @@ int mifft_memset(void *ptr, int value, size_t nbytes, mifft_stream_t stream);
 int mifft_memcpy_h2d(void *dst, const void *src, size_t nbytes, mifft_stream_t stream);
 int mifft_memcpy_d2h(void *dst, const void *src, size_t nbytes, mifft_stream_t stream);
 int mifft_memcpy_d2d(void *dst, const void *src, size_t nbytes, mifft_stream_t stream);
+/* pinned host memory + a copy that does NOT synchronise: how a plan reads a persistent kernel's error word without
+ * stalling the stream (the copy is enqueued behind the launch, the host looks at it once mifft_event_query says so) */
+int mifft_host_alloc(void **ptr, size_t nbytes);
+int mifft_host_free(void *ptr);
+int mifft_memcpy_d2h_async(void *dst, const void *src, size_t nbytes, mifft_stream_t stream);
+/* streams are BLOCKING streams (they order against the legacy null stream, like PyCUDA's: cuda.py:94-96) */
 int mifft_stream_create(mifft_stream_t *stream);
 int mifft_stream_destroy(mifft_stream_t stream);
 int mifft_stream_sync(mifft_stream_t stream);
@@ -151,6 +157,7 @@ int mifft_event_create(mifft_event_t *event);
 int mifft_event_destroy(mifft_event_t event);
 int mifft_event_record(mifft_event_t event, mifft_stream_t stream);
 int mifft_event_sync(mifft_event_t event);
+int mifft_event_query(mifft_event_t event); /* 0 = completed, 1 = not yet, else an error code */
 int mifft_event_elapsed_ms(float *ms, mifft_event_t start, mifft_event_t stop);
 
 /* ---- pass launchers (replace cuda.py Function.__call__, cuda.py:35-46) ----------------------------- */
@@ -209,6 +216,28 @@ int mifft_launch_chain_pipelined(const mifft_pass *passes, int32_t npasses, void
 int mifft_launch_fused2(const mifft_pass *p0, const mifft_pass *p1, const void *in0, const void *in1, void *out0,
                         void *out1, void *ring0, void *ring1, int32_t ring_slots, int32_t lag, void *counters,
                         int32_t grid, mifft_stream_t stream);
+
+/*
+ * XCD-cooperative form of the same two-pass axis for N = 1024 * 1024, fp32 (csrc/fft_xcd2.hpp): ONE persistent launch of
+ * 2 work-groups per CU in which the 64 work-groups resident on each XCD (chiplet) own one transform at a time and
+ * hand the inter-pass intermediate over through that XCD's own L2, so that every point crosses the L2 <-> fabric
+ * boundary once in and once out (the fused / chained forms: twice).  Same pass pair as mifft_launch_fused2.
+ *   scratch  caller-owned, MIFFT_XCD2_SCRATCH_BYTES, 256-byte aligned; contents are don't-care
+ *   control  caller-owned, MIFFT_XCD2_CONTROL_BYTES (zeroed by this call on `stream`).  After completion
+ *            ((uint32_t*)control)[1] != 0 means the results are INVALID: bit 0 = a bounded wait timed out, bit 1 = the
+ *            launch did not find exactly 64 resident work-groups per XCD (nothing was written; run another strategy).
+ *   flags    bit 0: issue the next transform's loads while the current one is being stored (default form)
+ *            bit 1 (development): `control` is MIFFT_XCD2_CONTROL_BYTES + MIFFT_XCD2_TRACE_BYTES long and receives, behind
+ *            the control words, 32 time stamps (100 MHz) per work-group for the per-XCD transform index (flags >> 8)
+ * Requires a device with 8 XCDs x 32 CUs (MI355X); MIFFT_E_UNSUPPORTED otherwise or for other lengths.
+ */
+#define MIFFT_XCD2_SCRATCH_BYTES (8u * 2u * 64u * 16u * 256u * 8u)
+#define MIFFT_XCD2_CONTROL_BYTES ((64u + 2u * 512u) * 4u)
+#define MIFFT_XCD2_PREFETCH 1
+#define MIFFT_XCD2_TRACE 2
+#define MIFFT_XCD2_TRACE_BYTES (512u * 32u * 8u)
+int mifft_launch_xcd2(const mifft_pass *p0, const mifft_pass *p1, const void *in0, const void *in1, void *out0,
+                      void *out1, void *scratch, void *control, int32_t flags, mifft_stream_t stream);
 
 /* Same as mifft_launch_chain but brackets the chain with two events on `stream` and, after
  * synchronising, reports the elapsed device time of `repeats` back-to-back chains. (bench/test helper) */

@@ -1,0 +1,36 @@
+"""Development switches, all in one place (nothing in the product path reads the environment directly).
+
+None of these is needed in production; they exist so that the measurements quoted in DESIGN.md can be reproduced
+(tools/*.py set them).  Unset = the plan's own choice.
+"""
+import os
+
+
+def forced_strategy():
+    """PYFFT_AMD_STRATEGY = auto | chain | pipelined | fused | xcd"""
+    return os.environ.get("PYFFT_AMD_STRATEGY", "auto")
+
+
+def pipeline_chunk_bytes(default):
+    return (int(os.environ.get("PYFFT_AMD_PIPE_MB", "0")) << 20) or default
+
+
+def pipeline_streams(default):
+    return int(os.environ.get("PYFFT_AMD_PIPE_STREAMS", "0")) or default
+
+
+def slab_bytes(default):
+    return (int(os.environ.get("PYFFT_AMD_SLAB_MB", "0")) << 20) or default
+
+
+def no_slabs():
+    return bool(os.environ.get("PYFFT_AMD_NO_SLABS"))
+
+
+def no_stream_hints():
+    return bool(os.environ.get("PYFFT_AMD_NO_STREAM_HINTS"))
+
+
+def xcd2_flags(default):
+    v = os.environ.get("PYFFT_AMD_XCD2_FLAGS")
+    return default if v is None else int(v)

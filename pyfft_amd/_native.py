@@ -24,6 +24,11 @@ VARIANT_INTERLEAVED_ONLY = 2
 PASS_COL, PASS_ROW, PASS_ND = 0, 1, 2
 FLAG_SRC_INTERLEAVED, FLAG_DST_INTERLEAVED = 1, 2
 FLAG_STREAM_SRC, FLAG_STREAM_DST = 4, 8
+XCD2_SCRATCH_BYTES = 8 * 2 * 64 * 16 * 256 * 8
+XCD2_CONTROL_BYTES = (64 + 2 * 512) * 4
+XCD2_PREFETCH = 1
+XCD2_TRACE = 2
+XCD2_TRACE_BYTES = 512 * 32 * 8
 
 
 class MifftPass(ctypes.Structure):
@@ -88,6 +93,9 @@ PROTOTYPES = {
     "mifft_memcpy_h2d": (ctypes.c_int, [_vp, _vp, _sz, _vp]),
     "mifft_memcpy_d2h": (ctypes.c_int, [_vp, _vp, _sz, _vp]),
     "mifft_memcpy_d2d": (ctypes.c_int, [_vp, _vp, _sz, _vp]),
+    "mifft_host_alloc": (ctypes.c_int, [_vpp, _sz]),
+    "mifft_host_free": (ctypes.c_int, [_vp]),
+    "mifft_memcpy_d2h_async": (ctypes.c_int, [_vp, _vp, _sz, _vp]),
     "mifft_stream_create": (ctypes.c_int, [_vpp]),
     "mifft_stream_destroy": (ctypes.c_int, [_vp]),
     "mifft_stream_sync": (ctypes.c_int, [_vp]),
@@ -96,6 +104,7 @@ PROTOTYPES = {
     "mifft_event_destroy": (ctypes.c_int, [_vp]),
     "mifft_event_record": (ctypes.c_int, [_vp, _vp]),
     "mifft_event_sync": (ctypes.c_int, [_vp]),
+    "mifft_event_query": (ctypes.c_int, [_vp]),
     "mifft_event_elapsed_ms": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), _vp, _vp]),
     "mifft_nd_max_points_for": (ctypes.c_int, [_i32]),
     "mifft_nd_shape_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32]),
@@ -105,6 +114,7 @@ PROTOTYPES = {
     "mifft_launch_chain_pipelined": (ctypes.c_int, [_pass_p, _i32, _vpp, _vpp, ctypes.c_int64, ctypes.c_int64,
                                                       ctypes.c_int64, _vp, _vpp, _i32, _vpp]),
     "mifft_launch_fused2": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
+    "mifft_launch_xcd2": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "mifft_time_chain": (ctypes.c_int, [_pass_p, _i32, _vpp, _vpp, _vp, _i32, ctypes.POINTER(ctypes.c_float)]),
 }
 

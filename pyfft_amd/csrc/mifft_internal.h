@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "fft_tile.hpp"
 #include "fft_fused2.hpp"
+#include "fft_xcd2.hpp"
 #include "fft_nd.hpp"
 
 // Each returns 0 on success, MIFFT_E_UNSUPPORTED (-2) when no kernel is compiled for (L, tr, variant),
@@ -19,6 +20,7 @@ int mifft_nd2_f32_launch(int x, int y, int z, const mifft::TileArgs* a, hipStrea
 int mifft_nd2_f64_supported(int x, int y, int z);
 int mifft_nd2_f64_launch(int x, int y, int z, const mifft::TileArgs* a, hipStream_t s);
 int mifft_fused2_f32_launch(int L0, int L1, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
+int mifft_xcd2_f32_launch(const mifft::Xcd2Args* f, int split, int prefetch, unsigned grid, hipStream_t s);
 }
 
 namespace mifft {

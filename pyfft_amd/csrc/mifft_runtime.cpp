@@ -256,10 +256,29 @@ int mifft_memcpy_d2d(void* dst, const void* src, size_t nbytes, mifft_stream_t s
 int mifft_stream_create(mifft_stream_t* stream) {
     if (!stream) return set_err(MIFFT_E_INVALID, "null argument");
     hipStream_t s;
-    int rc = hip_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+    // a BLOCKING stream, like PyCUDA's (cuda.py:94-96): null-stream copies (DeviceArray.get/set, the reference quick-start
+    // doc/source/index.rst:61-92) and a framework's default-stream kernels order against the plan's work without a sync
+    int rc = hip_check(hipStreamCreateWithFlags(&s, hipStreamDefault), "hipStreamCreate");
     if (rc) return rc;
     *stream = (mifft_stream_t)s;
     return 0;
+}
+int mifft_host_alloc(void** ptr, size_t nbytes) {
+    if (!ptr) return set_err(MIFFT_E_INVALID, "null argument");
+    return hip_check(hipHostMalloc(ptr, nbytes ? nbytes : 1, hipHostMallocDefault), "hipHostMalloc");
+}
+int mifft_host_free(void* ptr) { return hip_check(hipHostFree(ptr), "hipHostFree"); }
+int mifft_memcpy_d2h_async(void* dst, const void* src, size_t nbytes, mifft_stream_t stream) {
+    return hip_check(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, (hipStream_t)stream), "hipMemcpyAsync(d2h)");
+}
+int mifft_event_query(mifft_event_t event) {
+    const hipError_t e = hipEventQuery((hipEvent_t)event);
+    if (e == hipSuccess) return 0;
+    if (e == hipErrorNotReady) {
+        (void)hipGetLastError();
+        return 1;
+    }
+    return hip_check(e, "hipEventQuery");
 }
 int mifft_stream_destroy(mifft_stream_t stream) { return hip_check(hipStreamDestroy((hipStream_t)stream), "hipStreamDestroy"); }
 int mifft_stream_sync(mifft_stream_t stream) { return hip_check(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize"); }
@@ -388,6 +407,51 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     if (rc) return rc;
     rc = mifft_fused2_f32_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream);
     if (rc == MIFFT_E_UNSUPPORTED) return set_err(rc, "fused2: no kernel for %d x %d", p0->L, p1->L);
+    if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
+    return 0;
+}
+
+int mifft_launch_xcd2(const mifft_pass* p0, const mifft_pass* p1, const void* in0, const void* in1, void* out0, void* out1,
+                      void* scratch, void* control, int32_t flags, mifft_stream_t stream) {
+    int rc = validate(p0);
+    if (rc) return rc;
+    rc = validate(p1);
+    if (rc) return rc;
+    if (p0->precision != MIFFT_F32 || p1->precision != MIFFT_F32) return set_err(MIFFT_E_UNSUPPORTED, "xcd2: fp32 only");
+    if (p0->kind != MIFFT_PASS_COL || p1->kind != MIFFT_PASS_COL || p0->S != 1 || p0->M != p1->L || p1->M != 1 ||
+        p1->S != p0->L || p0->outer != p1->outer || p0->layout != p1->layout || p0->inverse != p1->inverse)
+        return set_err(MIFFT_E_INVALID, "xcd2: passes are not the two passes of one long contiguous axis");
+    if (p0->L != 1024 || p1->L != 1024) return set_err(MIFFT_E_UNSUPPORTED, "xcd2: no kernel for %d x %d", p0->L, p1->L);
+    const bool split = p0->layout == MIFFT_SPLIT;
+    if ((p0->flags & MIFFT_FLAG_SRC_INTERLEAVED) || (p1->flags & MIFFT_FLAG_DST_INTERLEAVED))
+        return set_err(MIFFT_E_INVALID, "xcd2: the user sides follow the plan layout");
+    if (!in0 || !out0 || !scratch || !control || (split && (!in1 || !out1))) return set_err(MIFFT_E_INVALID, "xcd2: null buffer");
+    if (((uintptr_t)in0 | (uintptr_t)out0 | (uintptr_t)in1 | (uintptr_t)out1) & 15)
+        return set_err(MIFFT_E_INVALID, "data buffers must be 16-byte aligned");
+    if ((uintptr_t)scratch & 255) return set_err(MIFFT_E_INVALID, "xcd2: scratch must be 256-byte aligned");
+    // in place is fine: every point of a transform is in registers before any of its output is stored
+    if (p0->outer == 0) return 0;
+    if (p0->outer > 0x0fffffff) return set_err(MIFFT_E_INVALID, "xcd2: batch too large");
+    int dev = 0;
+    rc = hip_check(hipGetDevice(&dev), "hipGetDevice");
+    if (rc) return rc;
+    int cus = 0;
+    rc = hip_check(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute");
+    if (rc) return rc;
+    if (cus != 256) return set_err(MIFFT_E_UNSUPPORTED, "xcd2: needs 8 XCDs x 32 CUs (device has %d CUs)", cus);
+    mifft::Xcd2Args f;
+    fill_args(p0, in0, in1, nullptr, nullptr, &f.p0);
+    fill_args(p1, nullptr, nullptr, out0, out1, &f.p1);
+    f.ctl = (unsigned*)control;
+    f.scratch = scratch;
+    f.batch = (unsigned)p0->outer;
+    // development trace (MIFFT_XCD2_TRACE): 32 time stamps per work-group behind the control words
+    f.trace = (flags & MIFFT_XCD2_TRACE) ? (unsigned long long*)((char*)control + MIFFT_XCD2_CONTROL_BYTES) : nullptr;
+    f.trace_iter = (unsigned)((flags >> 8) & 0xffff);
+    f.pace = (flags & 4) ? 1u : 0u;
+    rc = hip_check(hipMemsetAsync(control, 0, MIFFT_XCD2_CONTROL_BYTES, (hipStream_t)stream), "hipMemsetAsync");
+    if (rc) return rc;
+    rc = mifft_xcd2_f32_launch(&f, split ? 1 : 0, (flags & MIFFT_XCD2_PREFETCH) ? 1 : 0, 2u * (unsigned)cus, (hipStream_t)stream);
     if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
     return 0;
 }

@@ -176,6 +176,67 @@ class Event(object):
             pass
 
 
+class ErrorMailbox(object):
+    """Pinned host words that receive a persistent kernel's error word behind every launch (FFTPlan.check / finish):
+    an asynchronous 4-byte copy plus an event on the launch's stream, inspected by the host without synchronising."""
+
+    SLOTS = 64
+
+    def __init__(self):
+        p = ctypes.c_void_p()
+        N.check(N.lib.mifft_host_alloc(ctypes.byref(p), 4 * self.SLOTS), "mifft_host_alloc")
+        self._host = p.value
+        self._words = (ctypes.c_uint32 * self.SLOTS).from_address(p.value)
+        self._events = [None] * self.SLOTS
+        self._pending = []          # (slot, tag) in launch order
+        self._next = 0
+
+    def post(self, dev_ptr, stream, tag):
+        if len(self._pending) >= self.SLOTS:          # the ring is full: the oldest launch must have finished by now
+            self._events[self._pending[0][0]].synchronize()
+        slot = self._next
+        self._next = (slot + 1) % self.SLOTS
+        if self._events[slot] is None:
+            self._events[slot] = Event()
+        N.check(N.lib.mifft_memcpy_d2h_async(self._host + 4 * slot, dev_ptr, 4, _stream_handle(stream)), "mifft_memcpy_d2h_async")
+        self._events[slot].record(stream)
+        self._pending.append((slot, tag))
+
+    def collect(self, wait):
+        """[(tag, word)] of the finished launches whose word is non-zero; wait=True waits for every pending launch."""
+        errors, keep = [], []
+        for slot, tag in self._pending:
+            ev = self._events[slot]
+            if wait:
+                ev.synchronize()
+            elif keep or N.lib.mifft_event_query(ev.handle) != 0:
+                keep.append((slot, tag))       # (launch order: nothing behind an unfinished launch has finished)
+                continue
+            word = int(self._words[slot])
+            if word:
+                errors.append((tag, word))
+        self._pending = keep
+        return errors
+
+    def __del__(self):
+        try:
+            if getattr(self, "_host", None):
+                N.lib.mifft_host_free(self._host)
+                self._host = None
+        except Exception:
+            pass
+
+
+def _torch_current_stream(args):
+    """torch's current stream if one of the buffers is a torch device tensor, else None (f1: a plan built without
+    stream= runs where the producing framework runs, cuda.py:116-134 current-context semantics)."""
+    for a in args:
+        if hasattr(a, "data_ptr") and getattr(a, "is_cuda", False):
+            import torch
+            return torch.cuda.current_stream(a.device)
+    return None
+
+
 def device_count():
     n = ctypes.c_int()
     N.check(N.lib.mifft_device_count(ctypes.byref(n)), "mifft_device_count")
@@ -196,8 +257,17 @@ class Context(object):
     """Plan execution context (cuda.py:64-113): stream lifecycle, allocator, device limits."""
 
     def __init__(self, device, stream, mempool):
+        if device is not None:
+            # HIP has one primary context per device: a plan runs on the device that is current when it is used
+            # (cuda.py:121-128 takes the current context's device); a different index is refused rather than ignored
+            cur = ctypes.c_int()
+            N.check(N.lib.mifft_get_device(ctypes.byref(cur)), "mifft_get_device")
+            if int(device) != cur.value:
+                raise ValueError("pyfft_amd: context=%d but device %d is current; call mifft_set_device / "
+                                 "torch.cuda.set_device first" % (int(device), cur.value))
         self._device = device
         self._stream = stream
+        self._call_stream = stream
         self._recreate_stream = stream is None
         props = device_props(device)
         self.device_name = props.name.decode()
@@ -221,12 +291,21 @@ class Context(object):
 
     pointer_of = staticmethod(device_pointer)
 
-    def createQueue(self):
-        if self._recreate_stream and self._stream is None:
+    def createQueue(self, buffers=()):
+        """Stream of the coming execute(): the one given to Plan(); else torch's current stream when a buffer is a torch
+        tensor; else the plan's own (blocking) stream, created on first use (cuda.py:94-96)."""
+        if not self._recreate_stream:
+            return
+        ts = _torch_current_stream(buffers)
+        if ts is not None:
+            self._call_stream = ts
+            return
+        if self._stream is None:
             self._stream = Stream()
+        self._call_stream = self._stream
 
     def stream_handle(self):
-        return _stream_handle(self._stream)
+        return _stream_handle(self._call_stream)
 
     def wait(self):
         N.check(N.lib.mifft_stream_sync(self.stream_handle()), "mifft_stream_sync")
@@ -235,7 +314,9 @@ class Context(object):
         pass
 
     def getQueue(self):
-        return self._stream
+        if self._call_stream is None:
+            self.createQueue()
+        return self._call_stream
 
     def isCuda(self):
         return False
@@ -272,7 +353,6 @@ def Plan(*args, **kwds):
         wait_for_finish = True
         stream_obj = None
     else:
-        stream_obj = Stream()
         wait_for_finish = True
 
     if 'wait_for_finish' not in kwds or kwds['wait_for_finish'] is None:

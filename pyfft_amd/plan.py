@@ -8,10 +8,10 @@ whole pass list is enqueued by one native call (mifft_launch_chain) instead of a
 """
 
 import ctypes
-import os
 
 import numpy
 
+from . import _debug as D
 from . import _native as N
 from . import passes as P
 
@@ -104,6 +104,9 @@ class FFTPlan(object):
         self._desc_cache = {}
         self._strategy = ("chain",)
         self._counters = None
+        self._xcd2_scratch = None
+        self._xcd2_disabled = False
+        self._mailbox = None
         self._side_streams = None
         self._side_events = None
 
@@ -218,8 +221,7 @@ class FFTPlan(object):
             # multi-pass plans: the first pass reads the input once, nobody re-reads what the last pass writes.  Only
             # while a transform's intermediate can stay in the 256 MiB Infinity Cache (256^3 fp64: 256 MiB per transform,
             # measured 1 % slower with the hints)
-            if last >= 1 and (p.size * p.complex_nbytes <= (64 << 20) or self._slab_passes) and \
-                    not os.environ.get("PYFFT_AMD_NO_STREAM_HINTS"):  # (development switch)
+            if last >= 1 and (p.size * p.complex_nbytes <= (64 << 20) or self._slab_passes) and not D.no_stream_hints():
                 if i == 0:
                     d.flags |= N.FLAG_STREAM_SRC
                 if i == last:
@@ -236,9 +238,12 @@ class FFTPlan(object):
     #   pipelined  batch cut into Infinity-Cache-sized chunks, chunk i on side stream i % n with its own temp
     #              slot (mifft_launch_chain_pipelined)
     #   fused2     both passes of a long 1-D fp32 transform in one persistent launch (mifft_launch_fused2)
+    #   xcd2       1024 x 1024 fp32: one persistent launch, each transform stays on one XCD between its two HBM
+    #              crossings (mifft_launch_xcd2); needs no temp buffer, in place or out of place
     PIPELINE_TARGET_BYTES = 64 << 20
     SLAB_TARGET_BYTES = 128 << 20      # slabs of the leading passes of a big 3-D transform (C4: 24.7 % at 64 MiB, 25.5 % at 128)
     PIPELINE_STREAMS = 2
+    XCD2_MIN_BATCH = 64                # 8 transforms per XCD: below that the pipelined chunks win
 
     def _fused2_eligible(self):
         p = self._params
@@ -247,14 +252,21 @@ class FFTPlan(object):
                 and k[0].kind == N.PASS_COL and k[1].kind == N.PASS_COL and k[0].S == 1 and k[0].M == k[1].L
                 and k[1].M == 1 and k[0].L in (256, 512, 1024) and k[1].L in (256, 512, 1024))
 
+    def _xcd2_eligible(self):
+        k = self._kernels
+        return (self._fused2_eligible() and k[0].L == 1024 and k[1].L == 1024 and self._context.compute_units == 256
+                and not self._xcd2_disabled)
+
     def _select_strategy(self, batch):
-        forced = os.environ.get("PYFFT_AMD_STRATEGY", "auto")
+        forced = D.forced_strategy()
         p = self._params
         item_bytes = p.size * p.complex_nbytes
-        target = int(os.environ.get("PYFFT_AMD_PIPE_MB", "0")) << 20 or self.PIPELINE_TARGET_BYTES   # development override
-        nstreams = int(os.environ.get("PYFFT_AMD_PIPE_STREAMS", "0")) or self.PIPELINE_STREAMS
+        target = D.pipeline_chunk_bytes(self.PIPELINE_TARGET_BYTES)
+        nstreams = D.pipeline_streams(self.PIPELINE_STREAMS)
         chunk = max(1, target // item_bytes)
         strat = ("chain",)
+        if forced == "xcd" and self._xcd2_eligible() and batch >= self.XCD2_MIN_BATCH:   # not the default yet: DESIGN.md section 4
+            return ("xcd2", D.xcd2_flags(N.XCD2_PREFETCH))
         if self._temp_buffer_needed and forced in ("auto", "fused") and self._fused2_eligible():
             grid = 2 * self._context.compute_units
             gsize = 2 * max(self._kernels[0].M // 16, self._kernels[1].S // 16)
@@ -270,10 +282,9 @@ class FFTPlan(object):
         # whether or not it needs a temp buffer
         if len(self._kernels) >= 2 and forced in ("auto", "pipelined") and batch >= 4 * chunk:
             nslab = 0
-            if self._slab_passes and not os.environ.get("PYFFT_AMD_NO_SLABS"):   # (development switch)
+            if self._slab_passes and not D.no_slabs():
                 plane_bytes = int(p.x) * int(p.y) * p.complex_nbytes
-                slab_target = int(os.environ.get("PYFFT_AMD_SLAB_MB", "0")) << 20 or \
-                    (self.SLAB_TARGET_BYTES // 2 if p.split else self.SLAB_TARGET_BYTES)   # split planes measured best at 64 MiB
+                slab_target = D.slab_bytes(self.SLAB_TARGET_BYTES // 2 if p.split else self.SLAB_TARGET_BYTES)   # split planes measured best at 64 MiB
                 planes = min(int(p.z), max(1, slab_target // plane_bytes))
                 nslab = int(p.z) // planes
             return ("pipelined", chunk, nstreams, nslab)
@@ -292,6 +303,11 @@ class FFTPlan(object):
             from .hip import Stream, Event
             self._side_streams = [Stream() for _ in range(self._strategy[2])]
             self._side_events = [Event() for _ in range(self._strategy[2] + 1)]
+        if self._strategy[0] == "xcd2":
+            if self._xcd2_scratch is None:
+                self._xcd2_scratch = ctx.allocate_raw(N.XCD2_SCRATCH_BYTES)
+            self._counters = ctx.allocate_raw(N.XCD2_CONTROL_BYTES + N.XCD2_TRACE_BYTES)
+            return
         if not self._temp_buffer_needed:
             return
         if self._strategy[0] == "fused2":
@@ -310,7 +326,15 @@ class FFTPlan(object):
         descs = self._descriptors(batch, is_inplace, bool(inverse))
         stream = ctx.stream_handle()
         strat = self._strategy
-        if strat[0] == "fused2":
+        if strat[0] == "xcd2":
+            d0, d1 = descs[0], descs[1]
+            in1 = bufs1[d0.src] if bufs1 is not None else None
+            out1 = bufs1[d1.dst] if bufs1 is not None else None
+            N.check(N.lib.mifft_launch_xcd2(ctypes.byref(d0), ctypes.byref(d1), bufs0[d0.src], in1, bufs0[d1.dst], out1,
+                                            ctx.pointer_of(self._xcd2_scratch), ctx.pointer_of(self._counters),
+                                            strat[1], stream), "mifft_launch_xcd2")
+            self._post_error_word(stream)
+        elif strat[0] == "fused2":
             _, lag, ring, grid = strat
             d0, d1 = descs[0], descs[1]
             # the two-pass schedule is in -> temp -> out for both in-place and out-of-place calls
@@ -319,6 +343,7 @@ class FFTPlan(object):
             N.check(N.lib.mifft_launch_fused2(ctypes.byref(d0), ctypes.byref(d1), bufs0[d0.src], in1, bufs0[d1.dst], out1,
                                               bufs0[2], None, ring, lag, ctx.pointer_of(self._counters), grid, stream),
                     "mifft_launch_fused2")
+            self._post_error_word(stream)
         elif strat[0] == "pipelined":
             _, chunk, nside, nslab = strat
             side = (ctypes.c_void_p * nside)(*[s.handle for s in self._side_streams])
@@ -338,13 +363,38 @@ class FFTPlan(object):
         else:
             N.check(N.lib.mifft_launch_chain(descs, len(self._kernels), bufs0, bufs1, stream), "mifft_launch_chain")
 
-    def _check_fused(self):
-        """After a synchronisation: the fused kernel's dependency time-out word must be clear."""
-        if self._strategy[0] == "fused2":
-            flag = numpy.zeros(2, numpy.uint32)
-            N.check(N.lib.mifft_memcpy_d2h(flag.ctypes.data, self._context.pointer_of(self._counters), 8, None), "d2h")
-            if flag[1] != 0:
-                raise RuntimeError("pyfft_amd: fused kernel dependency time-out (results invalid)")
+    # ---- error word of the persistent kernels (fused2 / xcd2): word [1] of their control block --------------------
+    # Every launch is followed, on the same stream, by an asynchronous copy of that word into pinned host memory and an
+    # event.  check() looks at the copies whose event has completed (never blocks); finish() synchronises first.  execute()
+    # calls check() on entry, so an asynchronous caller learns of a time-out at its next call at the latest, and the
+    # waiting path / Stream users call finish().
+    def _post_error_word(self, stream):
+        if self._mailbox is None:
+            from .hip import ErrorMailbox
+            self._mailbox = ErrorMailbox()
+        self._mailbox.post(self._context.pointer_of(self._counters) + 4, stream, self._strategy[0])
+
+    def check(self):
+        """Raise if a completed asynchronous execute() reported invalid results (non-blocking)."""
+        if self._mailbox is not None:
+            self._handle_errors(self._mailbox.collect(False))
+
+    def finish(self):
+        """Wait for the plan's stream, then raise if any execute() since the last check reported invalid results."""
+        self._context.wait()
+        if self._mailbox is not None:
+            self._handle_errors(self._mailbox.collect(True))
+
+    def _handle_errors(self, errors):
+        for strategy, word in errors:
+            if strategy == "xcd2" and (word & 2):
+                # the launch did not find 64 resident work-groups per XCD (the device is shared): nothing was written;
+                # this plan stops using the strategy
+                self._xcd2_disabled = True
+                self._last_batch_size = 0
+                raise RuntimeError("pyfft_amd: XCD-cooperative launch found no full XCD residency; results of that execute() "
+                                   "are invalid -- the plan has switched strategy, run it again")
+            raise RuntimeError("pyfft_amd: %s kernel dependency time-out (results invalid)" % strategy)
 
     def _buffers(self, is_inplace, args):
         ptr = self._context.pointer_of
@@ -372,10 +422,11 @@ class FFTPlan(object):
         batch = int(batch)
         if batch < 1:
             raise ValueError("batch must be positive")
+        self.check()
         self._prepare(batch)
         is_inplace, bufs0, bufs1 = self._buffers(is_inplace, args)
 
-        ctx.createQueue()
+        ctx.createQueue(args)
         self._enqueue(batch, is_inplace, inverse, bufs0, bufs1)
 
         # global wait setting has lower priority than the local one (plan.py:250-253)
@@ -384,8 +435,7 @@ class FFTPlan(object):
             wait = wait_for_finish
 
         if wait:
-            ctx.wait()
-            self._check_fused()
+            self.finish()
         else:
             ctx.flush()
             return ctx.getQueue()
@@ -438,5 +488,5 @@ class FFTPlan(object):
             self._enqueue(batch, is_inplace, inverse, bufs0, bufs1)
         e1.record(ctx.getQueue())
         e1.synchronize()
-        self._check_fused()
+        self.finish()
         return e1.time_since(e0)
