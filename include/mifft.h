@@ -231,7 +231,7 @@ int mifft_launch_fused2(const mifft_pass *p0, const mifft_pass *p1, const void *
  *            the control words, 32 time stamps (100 MHz) per work-group for the per-XCD transform index (flags >> 8)
  * Requires a device with 8 XCDs x 32 CUs (MI355X); MIFFT_E_UNSUPPORTED otherwise or for other lengths.
  */
-#define MIFFT_XCD2_SCRATCH_BYTES (8u * 2u * 64u * 16u * 256u * 8u)
+#define MIFFT_XCD2_SCRATCH_BYTES (8u * 64u * 16u * 256u * 8u)
 #define MIFFT_XCD2_CONTROL_BYTES ((64u + 2u * 512u) * 4u)
 #define MIFFT_XCD2_PREFETCH 1
 #define MIFFT_XCD2_TRACE 2

@@ -34,7 +34,7 @@ struct Xcd2Args {
     TileArgs p1;     // pass 1: out0/out1 = user output, tw_L = w(1024), scale
     unsigned* ctl;   // control block, zeroed per launch: [0] arrivals [1] error [8..16) work-groups per XCD
                      //   [64 + 64x ..) ready[x][64]   [576 + 64x ..) rdone[x][64]
-    void* scratch;   // [8 XCDs][2][64 consumers][16 slots][256 threads] complex<float>: 4 MiB per XCD
+    void* scratch;   // [8 XCDs][64 consumers][16 slots][256 threads] complex<float>: 2 MiB per XCD
     unsigned batch;
     unsigned long long* trace;   // development: 32 time stamps (100 MHz) per work-group for transform index trace_iter, or null
     unsigned trace_iter;
@@ -52,8 +52,8 @@ __device__ __forceinline__ unsigned xcd2_xcc_id() {
 // Wave 0 waits until the 32 flag words flags(lane)[idx(lane)] (lanes 0..31; per-lane array, index and target) are all >= target.  Flags live in this XCD's
 // L2: written with plain (workgroup-scope) stores by work-groups of the same XCD, polled with sc1 (L1-bypassing)
 // loads.  Returns false after a time-out or when another work-group has already raised the error word.
-__device__ __forceinline__ bool xcd2_wait32(const unsigned* flags, unsigned idx, unsigned target, unsigned* err) {
-    const bool active = (threadIdx.x & 63u) < 32u;
+__device__ __forceinline__ bool xcd2_wait16(const unsigned* flags, unsigned idx, unsigned target, unsigned* err) {
+    const bool active = (threadIdx.x & 63u) < 16u;
     for (unsigned spins = 0;; ++spins) {
         bool ok = true;
         if (active) ok = __hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
@@ -176,7 +176,7 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
     unsigned* const err = f.ctl + 1;
     unsigned* const ready = f.ctl + 64 + 64 * x;
     unsigned* const rdone = f.ctl + 64 + 512 + 64 * x;
-    char* const sbase = reinterpret_cast<char*>(f.scratch) + (size_t)x * (2u * 64u * 16u * 256u * 8u);
+    char* const sbase = reinterpret_cast<char*>(f.scratch) + (size_t)x * (64u * 16u * 256u * 8u);
     const unsigned slot = r >> 2;              // b1 of my columns in every consumer's first-stage butterfly
     const long long rem0 = (long long)r * 16;  // my 16 columns, both passes
 
@@ -229,12 +229,9 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
         }
         xcd2_stage2<T>(v, twL0, hi4);
         stamp(1);
-        // ================= four rounds: slab qa of pass 0 out, first-stage butterfly ia of pass 1 in, software-pipelined so
-        // that every L2 latency (store acknowledgement, hand-off loads) runs under the next slab's butterflies:
-        //     compute(0) stores(0) | compute(1) SYNC(0) stores(1) loads(0) | compute(2) SYNC(1) stores(2) loads(1) | ...
-        // SYNC(k) = drain -> barrier -> publish {ready = g+k+1, rdone = g+k} -> ONE poll of 32 flag words: my 16 producers
-        // have published round k (lanes 0-15) and my 16 consumers of round k+1 have read round k-1, whose buffer parity
-        // stores(k+1) overwrites (lanes 16-31; at k = 3 this covers the NEXT transform's stores(0)).
+        // ================= four rounds: slab qa of pass 0 out, first-stage butterfly ia of pass 1 in.  The butterflies of
+        // the next slab run under the store acknowledgements, stage 1 of the previous arrival under the load latency:
+        //     compute(0) stores(0) | compute(1) A(0) loads(0) B(0) stores(1) | compute(2) A(1) loads(1) st1(y0) B(1) stores(2) | ...
         cplx<T> y[64];
         cplx<T> xs[16];   // the slab that has been computed but not yet stored
         auto compute = [&](auto kk) {
@@ -273,7 +270,7 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
         auto stores = [&](auto kk) {
             constexpr int k = kk;
             constexpr int qa = (ROT - k) & 3;
-            constexpr unsigned par = (unsigned)(k & 1);
+            constexpr unsigned par = 0u;
             static_for<16>([&](auto qq) {
                 constexpr int qb0 = qq;
                 char* p = sbase + ((size_t)((par * 64u + (unsigned)(qb0 * 4 + qa)) * 16u + slot_l) << (sh10 + 1));
@@ -284,7 +281,7 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
         auto loads = [&](auto kk) {
             constexpr int k = kk;
             constexpr int ia = (ROT + k) & 3;    // butterfly I receive in round k; my producers are r = j*4 + ia
-            constexpr unsigned par = (unsigned)(k & 1);
+            constexpr unsigned par = 0u;
             static_for<16>([&](auto jj) {
                 constexpr int j = jj;
                 const char* p = sbase + ((size_t)((par * 64u + r_l) * 16u + (unsigned)j) << (sh10 + 1));
@@ -293,20 +290,15 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
                 y[ia * 16 + j] = __builtin_bit_cast(cplx<T>, w);
             });
         };
-        auto sync_point = [&](auto kk) {
-            constexpr int k = kk;
-            constexpr unsigned ia = (unsigned)((ROT + k) & 3);        // my producers of round k
-            constexpr unsigned qn = (unsigned)((ROT - k - 1) & 3);    // my consumers of round k + 1
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // stores(k) acknowledged, loads(k-1) landed
+        // One 2 MiB buffer per XCD (what stays resident in the 4 MiB L2 next to the streams: profiles/r02_e_*), so every
+        // round has TWO rendezvous: A = my 16 producers have published round k (then loads(k)); B = my 16 consumers of
+        // round k+1 have read round k (then stores(k+1) may overwrite their blocks).
+        auto rendezvous = [&](unsigned* mine, unsigned value, const unsigned* theirs, unsigned sel) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A: stores(k) acknowledged; B: loads(k) landed
             __syncthreads();
-            if (tid == 0) {
-                __hip_atomic_store(ready + r, g + k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(rdone + r, g + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            if (tid == 0) __hip_atomic_store(mine + r, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (wave0) {
-                const unsigned lane = (unsigned)tid & 63u;
-                const bool hi = lane >= 16u;
-                const bool ok = xcd2_wait32(hi ? rdone : ready, lane16 * 4u + (hi ? qn : ia), hi ? g + k : g + k + 1u, err);
+                const bool ok = xcd2_wait16(theirs, lane16 * 4u + sel, value, err);
                 if (tid == 0) *s_ok = ok ? 1u : 0u;
             }
             __syncthreads();
@@ -322,36 +314,22 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
         };
         stamp(2);
         compute(IC<0>{});
-        stores(IC<0>{});
-        compute(IC<1>{});
-        sync_point(IC<0>{});
-        stamp(3);
-        stores(IC<1>{});
-        loads(IC<0>{});
-        compute(IC<2>{});
-        sync_point(IC<1>{});
-        stamp(4);
-        stores(IC<2>{});
-        loads(IC<1>{});
-        compute(IC<3>{});
-        stage1_y(IC<0>{});
-        sync_point(IC<2>{});
-        stamp(5);
-        stores(IC<3>{});
-        loads(IC<2>{});
-        stage1_y(IC<1>{});
-        sync_point(IC<3>{});
-        stamp(6);
-        loads(IC<3>{});
-        stage1_y(IC<2>{});
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(rdone + r, g + 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        stamp(7);
+        stores(IC<0>{});       // (my consumers of round 0 have read the previous transform: rendezvous B of its round 3)
+        static_for<4>([&](auto kk) {
+            constexpr int k = kk;
+            if constexpr (k < 3) compute(IC<k + 1>{});          // under the store acknowledgements
+            rendezvous(ready, g + k + 1u, ready, (unsigned)((ROT + k) & 3));
+            stamp(3 + 2 * k);
+            loads(IC<k>{});
+            if constexpr (k > 0) stage1_y(IC<k - 1>{});         // under the load latency
+            rendezvous(rdone, g + k + 1u, rdone, (unsigned)((ROT - k - 1) & 3));
+            stamp(4 + 2 * k);
+            if constexpr (k < 3) stores(IC<k + 1>{});
+        });
         stage1_y(IC<3>{});
         if (!alive) break;
         xcd2_stage2<T>(y, twL1, hi4);
-        stamp(8);
+        stamp(11);
 
         // ================= pass 1 phase 2 (thread = (c2 = lo4, u = hi4)): exchange, radix-16, store; prefetch the next transform
         const bool more = PREFETCH && (i + 1u < nx);
@@ -401,7 +379,7 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
             if (i + 1u < nx) static_for<4>([&](auto aa) { xcd2_load_slab<T, SPLIT, NT, aa>(f.p0, t + 8, rem0, voff_in, sh10, v); });
             else static_for<64>([&](auto kk) { v[kk] = cplx<T>{(T)0, (T)0}; });
         }
-        stamp(9);
+        stamp(12);
         __syncthreads();   // LDS is free for the next transform's pass 0
     }
 }

@@ -67,12 +67,12 @@ def trace(it):
     N.check(N.lib.mifft_memcpy_d2h(raw.ctypes.data, p._context.pointer_of(p._counters) + N.XCD2_CONTROL_BYTES, raw.nbytes, None))
     t = raw.reshape(512, 32).astype(numpy.float64) / 100.0      # us
     t = t[t[:, 0] > 0]
-    names = ["loads + stage 1,2", "(stamp)", "compute0 stores0 compute1 SYNC0", "stores1 loads0 compute2 SYNC1",
-             "stores2 loads1 compute3 st1(y0) SYNC2", "stores3 loads2 st1(y1) SYNC3", "loads3 st1(y2) drain", "st1(y3) + stage 2",
+    names = ["loads + stage 1,2", "(stamp)", "compute0 stores0 compute1 A0", "loads0 B0", "stores1 compute2 A1", "loads1 st1(y0) B1",
+             "stores2 compute3 A2", "loads2 st1(y1) B2", "stores3 A3", "loads3 st1(y2) B3", "st1(y3) + stage 2",
              "final rounds (HBM stores + prefetch)"]
-    d = numpy.diff(t[:, :10], axis=1)
+    d = numpy.diff(t[:, :13], axis=1)
     print("trace of per-XCD transform %d over %d work-groups: total %.2f us (min %.2f max %.2f)" % (
-        it, len(t), (t[:, 9] - t[:, 0]).mean(), (t[:, 9] - t[:, 0]).min(), (t[:, 9] - t[:, 0]).max()))
+        it, len(t), (t[:, 12] - t[:, 0]).mean(), (t[:, 12] - t[:, 0]).min(), (t[:, 12] - t[:, 0]).max()))
     for i, nm in enumerate(names):
         print("   %-40s mean %6.2f  min %6.2f  max %6.2f" % (nm, d[:, i].mean(), d[:, i].min(), d[:, i].max()))
     # spread of the XCDs' phases: start time of this transform per XCD (first 8 work-groups' stamp 0 differ by XCD)
