@@ -5,17 +5,25 @@
 
 Workload (BASELINE.json configs[1]): batched 1-D c2c fp32, N = 2^20, batch 4096 per GPU, out of
 place, synthetic N(0,1) data resident in HBM before the timed region.  One "step" = one
-plan.execute() over the whole per-GPU batch (every pass of the transform).  N > 1: one process per
-GPU (torch.distributed / RCCL only for the barrier and the max-over-ranks reduction -- the batch is
-sharded across ranks and the hot path has no collective), weak scaling.
+plan.execute() over the whole per-GPU batch (every pass of the transform).
 
-Prints ONE JSON line on rank 0.  `value` = nominal 5*N*log2(N) GFLOPS of the whole job
-(test/test_performance.py:24 in the reference); the line also carries transforms/s, the algorithmic
-HBM GB/s, the roofline object (HIP events on the plan's stream) and the CPU baseline.
+N > 1: one process per GPU; the batch is sharded across ranks and the hot path has no collective
+(torch.distributed / RCCL only for the barrier and the max-over-ranks reduction), weak scaling.
+Under a launcher (RANK / WORLD_SIZE set, e.g. `python -m torch.distributed.run ...`) this process is
+one rank.  Without one, `--gpus N` with N > 1 starts the N ranks itself, as children, BEFORE
+anything in this process touches torch or HIP, and relays rank 0's line.
+
+Prints ONE JSON line on rank 0.  `value` = nominal 5*N*log2(N) GFLOPS of the whole job over EXACTLY K
+timed steps (test/test_performance.py:24 in the reference); the line also carries transforms/s,
+the algorithmic HBM GB/s, the roofline object (HIP events on the plan's stream), the reference's
+timing protocol (out of place AND in place, median of >= 5 repeats: test/test_performance.py:22-30,
+cuda/test.cu:37-64) and the CPU baseline.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -50,6 +58,53 @@ def dist_env():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     return rank, local_rank, world
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """`--gpus N` without a launcher: start the N ranks as child processes (torch.distributed.run, rendezvous on
+    127.0.0.1) and relay their output.  Called before this process imports torch or touches HIP: a process that has
+    initialised the GPU must never be replaced or forked into another program."""
+    n = args.gpus
+    note = None
+    if not args.selftest_dist:
+        # counting devices does not initialise the GPU on this image; the children do the real work
+        import torch
+        visible = torch.cuda.device_count()
+        if visible < 1:
+            raise SystemExit("bench.py: no GPU visible")
+        if visible < n:
+            note = "requested %d GPUs, %d visible: ran %d ranks" % (n, visible, visible)
+            n = visible
+    child = [a for a in argv]
+    for i, a in enumerate(child):           # the children see the number of ranks that really run
+        if a == "--gpus" and i + 1 < len(child):
+            child[i + 1] = str(n)
+        elif a.startswith("--gpus="):
+            child[i] = "--gpus=%d" % n
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + child
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout.splitlines():
+        if line.startswith("{") and note:
+            try:
+                d = json.loads(line)
+                d["note"] = note
+                line = json.dumps(d)
+            except ValueError:
+                pass
+        print(line)
+    raise SystemExit(proc.returncode)
 
 
 def selftest_dist(args):
@@ -93,28 +148,63 @@ def fill_device(N, dst_ptr, nbytes, host_block):
     N.check(N.lib.mifft_device_sync(), "sync")
 
 
-def cpu_baseline(shape, dtype, host_items, flop_per_xform, budget_s=25.0):
-    """CPU figures on this box's host cores for the same transforms.
-    host_items: array [n, *shape] of the very data the GPU transforms."""
+_POOL_ITEMS = None
+
+
+def _pool_fft(i):
     import numpy
+    numpy.fft.fftn(_POOL_ITEMS[i % len(_POOL_ITEMS)])
+    return 0
+
+
+def cpu_baseline(shape, dtype, host_items, flop_per_xform, budget_s=24.0):
+    """CPU figures on this box's host cores for the same transforms.  Runs BEFORE this process
+    initialises the GPU (the process pool forks).  host_items: array [n, *shape] of the very data the GPU transforms.
+    The reference has no CPU implementation of its own: its CPU path is numpy.fft (test/test_errors.py:5-16,35), which is
+    therefore the `value` (kind "reference"), fanned over all cores with a process pool; scipy.fft with all cores and the
+    oracle's plain-C restatement of the reference chain (a scalar port, one core) are reported next to it."""
+    import numpy
+    global _POOL_ITEMS
     res = {}
     axes = tuple(range(1, host_items.ndim))
     cores = os.cpu_count() or 1
     n = host_items.shape[0]
-    # (1) numpy.fft (pocketfft, one thread) -- the reference's own CPU oracle (test/test_errors.py:35)
+    part = budget_s / 4.0
+    # (1) numpy.fft (pocketfft, one thread)
     t0 = time.perf_counter()
     done = 0
     for i in range(n):
         numpy.fft.fftn(host_items[i])
         done += 1
-        if time.perf_counter() - t0 > budget_s / 3:
+        if time.perf_counter() - t0 > part:
             break
     dt = time.perf_counter() - t0
-    res["numpy_fft_1core_gflops"] = flop_per_xform * done / dt / 1e9
-    res["numpy_fft_1core_xforms_per_s"] = done / dt
+    rate1 = done / dt
+    res["numpy_fft_1core_gflops"] = flop_per_xform * rate1 / 1e9
+    res["numpy_fft_1core_xforms_per_s"] = rate1
     res["numpy_sample_xforms"] = done
-    # (2) scipy.fft with all cores
-    best = None
+    # (2) numpy.fft over a process pool of all cores (BASELINE.md section 4)
+    pool_val = None
+    try:
+        import multiprocessing as mp
+        _POOL_ITEMS = host_items
+        workers = cores
+        tasks = max(workers, min(4 * workers, int(rate1 * workers * part * 0.5) or workers))
+        with mp.get_context("fork").Pool(workers) as pool:
+            pool.map(_pool_fft, range(workers), chunksize=1)          # start-up and first touch, untimed
+            t0 = time.perf_counter()
+            pool.map(_pool_fft, range(tasks), chunksize=1)
+            dt = time.perf_counter() - t0
+        pool_val = flop_per_xform * tasks / dt / 1e9
+        res["numpy_fft_pool_gflops"] = pool_val
+        res["numpy_fft_pool_xforms_per_s"] = tasks / dt
+        res["numpy_fft_pool_workers"] = workers
+        res["numpy_fft_pool_sample_xforms"] = tasks
+    except Exception as e:
+        res["numpy_pool_error"] = repr(e)
+    finally:
+        _POOL_ITEMS = None
+    # (3) scipy.fft with all cores (a stronger CPU figure than the reference's own path)
     try:
         import scipy.fft
         scipy.fft.fftn(host_items[:1], axes=axes, workers=cores)
@@ -123,15 +213,14 @@ def cpu_baseline(shape, dtype, host_items, flop_per_xform, budget_s=25.0):
         while True:
             scipy.fft.fftn(host_items, axes=axes, workers=cores)
             reps += 1
-            if time.perf_counter() - t0 > budget_s / 3 or reps >= 8:
+            if time.perf_counter() - t0 > part or reps >= 8:
                 break
         dt = time.perf_counter() - t0
         res["scipy_fft_allcores_gflops"] = flop_per_xform * n * reps / dt / 1e9
         res["scipy_fft_allcores_xforms_per_s"] = n * reps / dt
-        best = ("scipy.fft.fftn workers=%d" % cores, res["scipy_fft_allcores_gflops"], cores, n * reps)
     except Exception as e:  # scipy missing
         res["scipy_error"] = repr(e)
-    # (3) the oracle's plain-C restatement of the reference chain (scalar port, one core)
+    # (4) the oracle's plain-C restatement of the reference chain (scalar port, one core)
     try:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import c_oracle
@@ -143,22 +232,47 @@ def cpu_baseline(shape, dtype, host_items, flop_per_xform, budget_s=25.0):
             while k < n:
                 c_oracle.execute(host_items[k].reshape(-1), xyz, batch=1)
                 k += 1
-                if time.perf_counter() - t0 > budget_s / 3:
+                if time.perf_counter() - t0 > part:
                     break
             dt = time.perf_counter() - t0
             res["oracle_c_port_1core_gflops"] = flop_per_xform * k / dt / 1e9
             res["oracle_c_port_sample_xforms"] = k
     except Exception as e:
         res["oracle_port_error"] = repr(e)
-    if best is None:
-        best = ("numpy.fft.fftn (1 thread)", res["numpy_fft_1core_gflops"], 1, done)
-    out = {"value": best[1], "unit": "GFLOPS", "cores": best[2], "kind": "port",
-           "impl": best[0],
-           "sample": "%d transforms of the same %s %s data the GPU transforms (host copy), nominal 5*N*log2(N) flop" %
-                     (best[3], "x".join(map(str, shape)), dtype),
+    if pool_val is not None:
+        value, used, impl, sample = pool_val, cores, "numpy.fft.fftn, process pool of %d workers" % cores, res["numpy_fft_pool_sample_xforms"]
+    else:
+        value, used, impl, sample = res["numpy_fft_1core_gflops"], 1, "numpy.fft.fftn (1 thread)", done
+    out = {"value": value, "unit": "GFLOPS", "cores": used, "kind": "reference",
+           "impl": impl + " -- the reference's own CPU path (test/test_errors.py:35)",
+           "sample": "%d transforms drawn from %d items of the same %s %s data the GPU transforms (host copy), nominal 5*N*log2(N) flop" %
+                     (sample, n, "x".join(map(str, shape)), dtype),
            "host_cores": cores}
     out.update(res)
     return out
+
+
+def make_host_block(shape, dtname, batch, seed, rank):
+    import numpy
+    dtype = numpy.dtype(dtname)
+    cdtype = numpy.dtype(numpy.complex64 if dtype in (numpy.complex64, numpy.float32) else numpy.complex128)
+    size = int(numpy.prod(shape))
+    blk = min(batch, max(1, (512 << 20) // (size * cdtype.itemsize)), 64)
+    rng = numpy.random.default_rng(seed + rank)
+    fdt = numpy.float32 if cdtype == numpy.complex64 else numpy.float64
+    host_re = rng.standard_normal((blk,) + tuple(shape)).astype(fdt)
+    host_im = rng.standard_normal((blk,) + tuple(shape)).astype(fdt)
+    host_c = numpy.empty((blk,) + tuple(shape), cdtype)
+    host_c.real = host_re
+    host_c.imag = host_im
+    return blk, host_re, host_im, host_c
+
+
+def stats(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    med = xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+    return {"median": med, "min": xs[0], "max": xs[-1], "n": n}
 
 
 def main():
@@ -168,38 +282,27 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS.keys()))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (development only)")
-    ap.add_argument("--inplace", action="store_true")
+    ap.add_argument("--inplace", action="store_true", help="the K timed steps run in place (the default line times out of place)")
+    ap.add_argument("--repeats", type=int, default=5, help="repeats of the out-of-place / in-place protocol blocks (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--plain", action="store_true", help="only parity + warm-up + the K timed steps (no protocol repeats, per-pass timing or CPU baseline): profiler runs")
     ap.add_argument("--selftest-dist", action="store_true", help="CPU/gloo self-test of the multi-process harness")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even at world size 1 (test)")
     args = ap.parse_args()
 
+    if args.plain:
+        args.repeats = 0
+        args.no_cpu_baseline = True
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return self_launch(args, sys.argv[1:])       # never returns
     if args.selftest_dist:
         return selftest_dist(args)
 
     rank, local_rank, world = dist_env()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
 
     import numpy
-    torch = None
-    try:
-        import torch  # first, so that this process uses one HIP runtime for torch and libmifft
-    except Exception:
-        if world > 1:
-            raise
-    dist = None
-    if torch is not None and torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
-    if world > 1 or args.force_dist:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-
-    from pyfft_amd import _native as N
-    from pyfft_amd.hip import Plan, DeviceArray, Event, device_props
-    N.check(N.lib.mifft_set_device(local_rank), "set_device")
-    props = device_props(local_rank)
-
     shape, dtname, batch, seed = CONFIGS[args.config]
     if args.batch:
         batch = args.batch
@@ -212,23 +315,42 @@ def main():
     alg_bytes_per_xform = 2.0 * size * cdtype.itemsize          # read once + write once
     gstart, _ = shard_batch(batch * world, rank, world)          # this rank's slice of the global batch
 
-    # ---- synthetic data: one host block of <= 64 transforms, tiled across the batch on the device
-    blk = min(batch, max(1, (512 << 20) // (size * cdtype.itemsize)), 64)
-    rng = numpy.random.default_rng(seed + rank)
-    fdt = numpy.float32 if cdtype == numpy.complex64 else numpy.float64
-    host_re = rng.standard_normal((blk,) + tuple(shape)).astype(fdt)
-    host_im = rng.standard_normal((blk,) + tuple(shape)).astype(fdt)
+    # ---- synthetic data: one host block of <= 64 transforms (tiled across the batch on the device further down)
+    blk, host_re, host_im, host_c = make_host_block(shape, dtname, batch, seed, rank)
+
+    # ---- CPU baseline first: rank 0 at N = 1 only, before this process initialises the GPU (the pool forks)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(shape, dtname, host_c[:min(blk, 16)], flop_per_xform)
+
+    torch = None
+    try:
+        import torch  # first, so that this process uses one HIP runtime for torch and libmifft
+    except Exception:
+        if world > 1:
+            raise
+    dist = None
+    if torch is not None and torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    if world > 1 or args.force_dist:
+        import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:            # --force-dist at world 1 without a launcher
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ["MASTER_PORT"] = str(_free_port())
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from pyfft_amd import _native as N
+    from pyfft_amd.hip import Plan, DeviceArray, Event, device_props
+    N.check(N.lib.mifft_set_device(local_rank), "set_device")
+    props = device_props(local_rank)
+
     nel = size * batch
     if split:
         ins = [DeviceArray((nel,), dtype), DeviceArray((nel,), dtype)]
         outs = ins if args.inplace else [DeviceArray((nel,), dtype), DeviceArray((nel,), dtype)]
         fill_device(N, ins[0].ptr, ins[0].nbytes, host_re)
         fill_device(N, ins[1].ptr, ins[1].nbytes, host_im)
-        host_c = host_re.astype(numpy.complex128) + 1j * host_im
     else:
-        host_c = numpy.empty((blk,) + tuple(shape), cdtype)
-        host_c.real = host_re
-        host_c.imag = host_im
         ins = [DeviceArray((nel,), dtype)]
         outs = ins if args.inplace else [DeviceArray((nel,), dtype)]
         fill_device(N, ins[0].ptr, ins[0].nbytes, host_c)
@@ -237,17 +359,20 @@ def main():
     plan = Plan(shape if len(shape) > 1 else shape[0], dtype=dtype, wait_for_finish=False)
     stream = plan._context.getQueue()
 
-    def step():
+    def execute(inplace, inverse=False):
         if split:
-            if args.inplace:
-                plan.execute(ins[0], ins[1], batch=batch)
+            if inplace:
+                plan.execute(ins[0], ins[1], batch=batch, inverse=inverse)
             else:
-                plan.execute(ins[0], ins[1], outs[0], outs[1], batch=batch)
+                plan.execute(ins[0], ins[1], outs[0], outs[1], batch=batch, inverse=inverse)
         else:
-            if args.inplace:
-                plan.execute(ins[0], batch=batch)
+            if inplace:
+                plan.execute(ins[0], batch=batch, inverse=inverse)
             else:
-                plan.execute(ins[0], outs[0], batch=batch)
+                plan.execute(ins[0], outs[0], batch=batch, inverse=inverse)
+
+    def step():
+        execute(args.inplace)
 
     def sync_all():
         if torch is not None and torch.cuda.is_available():
@@ -263,7 +388,7 @@ def main():
     parity = None
     if not args.inplace:
         step()
-        stream.synchronize()
+        plan.finish()
         samples = sorted(set([0, 1 % batch, (blk - 1) % batch, blk % batch, batch // 2, batch - 1]))
         worst_diff, worst_max = 0.0, 0.0
         isz = dtype.itemsize
@@ -305,11 +430,39 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     dev_ms = ev1.time_since(ev0)          # HIP events on the stream the kernels are launched on
+    plan.finish()                          # raises if a persistent kernel reported a dependency time-out (results invalid)
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- the reference's timing protocol (untimed for `value`): out of place AND in place, median of >= 5 repeats of a
+    # block of back-to-back executes between two HIP events (test/test_performance.py:22-30 times 10 executes once;
+    # cuda/test.cu:37-64 times both forms).  In place alternates forward / inverse so that the values stay bounded.
+    protocol = None
+    if args.repeats > 0 and world == 1 and not args.inplace:
+        per = max(2, min(args.steps, 10))
+        per += per & 1
+        protocol = {"executes_per_repeat": per, "repeats": args.repeats}
+        for name, inpl in (("out_of_place", False), ("in_place", True)):
+            ms = []
+            for _ in range(args.repeats):
+                e0, e1 = Event(), Event()
+                e0.record(stream)
+                for j in range(per):
+                    execute(inpl, inverse=bool(inpl and (j & 1)))
+                e1.record(stream)
+                e1.synchronize()
+                ms.append(e1.time_since(e0) / per)
+            plan.finish()
+            st = stats(ms)
+            protocol[name] = {"ms_per_execute": st,
+                              "gflops_median": flop_per_xform * batch / (st["median"] * 1e-3) / 1e9,
+                              "frac_median": alg_bytes_per_xform * batch / (st["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "frac_min_max": [alg_bytes_per_xform * batch / (st["max"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                               alg_bytes_per_xform * batch / (st["min"] * 1e-3) / 1e9 / HBM_PEAK_GBS],
+                              "strategy": plan.strategy(batch)[0]}
 
     # ---- per-pass device time (separate, untimed-for-value measurement; HIP events between launches).
     # Only meaningful for the one-launch-per-pass strategy; the fused / pipelined strategies own a small scratch.
@@ -317,7 +470,7 @@ def main():
     strategy = plan.strategy(batch)
     npass = len(plan.pass_list())
     pass_ms = None
-    if strategy[0] == "chain":
+    if strategy[0] == "chain" and not args.plain:
         descs = plan._descriptors(batch, args.inplace, False)
         ptr = plan._context.pointer_of
         if split:
@@ -338,9 +491,14 @@ def main():
             e1.record(stream)
             e1.synchronize()
             pass_ms.append(e1.time_since(e0) / reps)
-    launches = {"chain": "%d launches per step" % npass,
-                "fused2": "1 persistent launch per step (both passes, lag %s, ring %s)" % (strategy[1:3] if len(strategy) > 2 else ("", "")),
-                "pipelined": "%d launches per chunk, chunks of %s items on %s streams" % ((npass,) + tuple(strategy[1:3]) if len(strategy) > 2 else (npass, "", ""))}[strategy[0]]
+    if strategy[0] == "chain":
+        launches = "%d launches per step" % npass
+    elif strategy[0] == "fused2":
+        launches = "1 persistent launch per step (both passes, lag %s, ring %s)" % tuple(strategy[1:3])
+    elif strategy[0] == "xcd2":
+        launches = "1 persistent launch per step (both passes, XCD-resident intermediate)"
+    else:
+        launches = "%d launches per chunk, chunks of %s items on %s streams" % ((npass,) + tuple(strategy[1:3]))
 
     total_xforms = batch * world * args.steps
     ms_per_step = elapsed * 1e3 / args.steps
@@ -349,11 +507,15 @@ def main():
     chain_ms = dev_ms / args.steps
     achieved = alg_bytes_per_xform * batch / (chain_ms * 1e-3) / 1e9
 
+    # HBM traffic of one step from the PMC counters: profiles/traffic_<config>.json, regenerated by tools/pmc_traffic.py
+    # (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very command; the file names its source run)
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
     if os.path.exists(tf) and not args.batch and not args.inplace:   # measured on the default workload only
         try:
-            traffic = json.load(open(tf)).get("hbm_bytes_per_step")
+            tj = json.load(open(tf))
+            if tj.get("strategy", strategy[0]) == strategy[0]:
+                traffic = tj.get("hbm_bytes_per_step")
         except Exception:
             traffic = None
 
@@ -384,13 +546,11 @@ def main():
                      "kernel": "%s: %s" % (strategy[0], launches),
                      "algorithmic_bytes_per_step": alg_bytes_per_xform * batch,
                      "chain_ms_hip_events": chain_ms, "pass_ms_hip_events": pass_ms},
+        "protocol": protocol,
         "parity": parity,
         "device": "%s (%s), %d CUs" % (props.name.decode(), props.gcn_arch.decode(), props.compute_units),
+        "cpu_baseline": cpu,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(shape, dtname, host_c[:min(blk, 16)], flop_per_xform)
-    elif rank == 0:
-        result["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
