@@ -131,6 +131,14 @@ typedef struct mifft_device_props {
 /* ---- library ------------------------------------------------------------------------------------- */
 int         mifft_abi_version(void);
 const char *mifft_last_error(void);
+/* development switches (all 0 in production; pyfft_amd/_debug.py maps environment variables onto them) */
+#define MIFFT_DEBUG_NO_ND2 0       /* run-time-shaped N-D kernel only */
+#define MIFFT_DEBUG_FUSED_NO_NT 1  /* fused two-pass kernel without non-temporal hints */
+#define MIFFT_DEBUG_NO_WAVE 2      /* no wave-autonomous small-transform kernels */
+#define MIFFT_DEBUG_FORCE_WAVE 3   /* wave-autonomous kernels wherever one exists, whatever the buffer size */
+#define MIFFT_DEBUG_KEYS 8
+int mifft_debug_set(int32_t key, int32_t value);
+int mifft_debug_get(int32_t key);
 
 /* ---- runtime shim (replaces cuda.py Context: allocate / stream lifecycle / device limits) ---------- */
 int mifft_device_count(int *count);

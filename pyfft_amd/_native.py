@@ -27,6 +27,7 @@ FLAG_STREAM_SRC, FLAG_STREAM_DST = 4, 8
 XCD2_SCRATCH_BYTES = 8 * 64 * 16 * 256 * 8
 XCD2_CONTROL_BYTES = (64 + 2 * 512) * 4
 XCD2_PREFETCH = 1
+DEBUG_NO_ND2, DEBUG_FUSED_NO_NT, DEBUG_NO_WAVE, DEBUG_FORCE_WAVE = 0, 1, 2, 3
 XCD2_TRACE = 2
 XCD2_TRACE_BYTES = 512 * 32 * 8
 
@@ -83,6 +84,8 @@ _buf3 = ctypes.c_void_p * 3
 PROTOTYPES = {
     "mifft_abi_version": (ctypes.c_int, []),
     "mifft_last_error": (ctypes.c_char_p, []),
+    "mifft_debug_set": (ctypes.c_int, [_i32, _i32]),
+    "mifft_debug_get": (ctypes.c_int, [_i32]),
     "mifft_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     "mifft_set_device": (ctypes.c_int, [ctypes.c_int]),
     "mifft_get_device": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
@@ -138,6 +141,15 @@ def _load():
 
 
 lib = _load()
+
+
+def _apply_debug():
+    from . import _debug
+    import sys
+    _debug.apply_native_switches(sys.modules[__name__])
+
+
+_apply_debug()
 
 
 def last_error():

@@ -1,5 +1,5 @@
 // fp32 instances of the fused two-pass kernel (fft_fused2.hpp).  -fno-slp-vectorize: see fft_col2_f32.hip.
-#include <cstdlib>
+#include "../../include/mifft.h"
 #include "mifft_internal.h"
 #include "fft_fused2.hpp"
 
@@ -7,7 +7,7 @@ namespace {
 template <int A0, int A1> int launch(const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s) {
     // non-temporal accesses on the streamed side (input of pass 1, output of pass 2) leave the Infinity Cache to the
     // intermediate ring: C2 35.0 -> 36.6 % (development switch to turn it off)
-    static const bool nt = getenv("MIFFT_FUSED_NO_NT") == nullptr;
+    const bool nt = mifft_debug_get(MIFFT_DEBUG_FUSED_NO_NT) == 0;
     if (split)
         hipLaunchKernelGGL((mifft::fft_fused2_kernel<float, A0, A1, true, false>), dim3(grid), dim3(256), 0, s, *f);
     else if (nt && A0 == 4 && A1 == 4)

@@ -5,6 +5,7 @@
 #include "fft_fused2.hpp"
 #include "fft_xcd2.hpp"
 #include "fft_nd.hpp"
+#include "fft_wave.hpp"
 
 // Each returns 0 on success, MIFFT_E_UNSUPPORTED (-2) when no kernel is compiled for (L, tr, variant),
 // or a hipError_t.  With query_only != 0 nothing is launched.
@@ -20,6 +21,9 @@ int mifft_nd2_f32_launch(int x, int y, int z, const mifft::TileArgs* a, hipStrea
 int mifft_nd2_f64_supported(int x, int y, int z);
 int mifft_nd2_f64_launch(int x, int y, int z, const mifft::TileArgs* a, hipStream_t s);
 int mifft_fused2_f32_launch(int L0, int L1, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
+int mifft_wave_supported(int f64, int N);
+int mifft_wave_launch(int f64, int N, const mifft::WaveArgs* a, int max_blocks, hipStream_t s);
+int mifft_wave_16x16_launch(const mifft::WaveArgs* a, int max_blocks, hipStream_t s);
 int mifft_xcd2_f32_launch(const mifft::Xcd2Args* f, int split, int prefetch, unsigned grid, hipStream_t s);
 }
 

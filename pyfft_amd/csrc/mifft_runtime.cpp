@@ -13,6 +13,7 @@
 namespace {
 
 thread_local char g_err[512] = "";
+int g_debug[MIFFT_DEBUG_KEYS] = {0};   // development switches (mifft_debug_set); all zero in production
 
 int set_err(int code, const char* fmt, ...) {
     va_list ap;
@@ -113,9 +114,39 @@ int nd_radices(int L, int maxr, int* out) {
     return n;
 }
 
+// grid cap of the grid-stride wave kernels: 8 work-groups of 4 waves per CU
+int wave_max_blocks() {
+    static int blocks = 0;
+    if (!blocks) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        blocks = cus * 8;
+    }
+    return blocks;
+}
+
+long long wave_bytes(const mifft_pass* p, const mifft::TileArgs* a) {   // bytes of one side of a dense ROW pass
+    return a->total * p->L * (p->precision == MIFFT_F64 ? 16ll : 8ll);
+}
+
 int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0, void* out1, hipStream_t s) {
     // fixed-shape kernels (fft_nd2.hpp) for the common shapes, interleaved on both sides
-    static const bool no_nd2 = getenv("MIFFT_NO_ND2") != nullptr;  // development switch: run-time-shaped kernel only
+    const bool no_nd2 = g_debug[MIFFT_DEBUG_NO_ND2] != 0;  // development switch: run-time-shaped kernel only
+    // the (16, 16) fp32 plane, interleaved: wave-autonomous kernel (no LDS, DPP exchange; csrc/fft_wave.hpp)
+    // -- measured slower than the fixed-shape LDS kernel at the reference's 32 MiB buffer (0.62 vs 0.68 of the roofline) and
+    // equal at 128 MiB (profiles/r02_h_small_n.log), so it only runs on request (MIFFT_DEBUG_FORCE_WAVE; parity-tested)
+    if (p->precision == MIFFT_F32 && p->L == 16 && p->M == 16 && p->S == 1 && g_debug[MIFFT_DEBUG_FORCE_WAVE] &&
+        (p->layout != MIFFT_SPLIT || ((p->flags & MIFFT_FLAG_SRC_INTERLEAVED) && (p->flags & MIFFT_FLAG_DST_INTERLEAVED)))) {
+        mifft::WaveArgs w;
+        w.in = in0; w.out = out0;
+        w.pieces = p->outer * 128;
+        w.inverse = p->inverse ? 1 : 0;
+        w.nt = ((p->flags & MIFFT_FLAG_STREAM_SRC) ? 1 : 0) | ((p->flags & MIFFT_FLAG_STREAM_DST) ? 2 : 0);
+        w.scale = p->scale;
+        const int rc = mifft_wave_16x16_launch(&w, wave_max_blocks(), s);
+        if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
+        return 0;
+    }
     const bool f64nd = p->precision == MIFFT_F64;
     const int have_nd2 = f64nd ? mifft_nd2_f64_supported((int)p->L, (int)p->M, (int)p->S)
                                : mifft_nd2_f32_supported((int)p->L, (int)p->M, (int)p->S);
@@ -180,6 +211,24 @@ int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0,
 int dispatch(const mifft_pass* p, const mifft::TileArgs* a, hipStream_t s, int query_only) {
     const int tr = (p->kind == MIFFT_PASS_COL && p->S == 1) ? 1 : 0;
     int rc;
+    // short dense interleaved rows: wave-autonomous kernel (no LDS, DPP exchange; csrc/fft_wave.hpp)
+    // up to 128 MiB per side (both sides then fit the 256 MiB Infinity Cache: 0.72-0.84 of the roofline against 0.57-0.69
+    // for the LDS-staged kernels at the reference's 32 MiB buffer, 0.90-0.99 against 0.83-0.90 at 128 MiB); larger
+    // buffers are HBM-bound and the LDS kernels are 0-5 points ahead (profiles/r02_h_small_n.log)
+    if (!query_only && p->kind == MIFFT_PASS_ROW && a && !a->split && !a->split_out && a->ostride_in == p->L &&
+        a->ostride_out == p->L && !g_debug[MIFFT_DEBUG_NO_WAVE] && mifft_wave_supported(p->precision == MIFFT_F64, p->L) == 0 &&
+        (g_debug[MIFFT_DEBUG_FORCE_WAVE] ||
+         (wave_bytes(p, a) <= (128ll << 20) && !(p->precision == MIFFT_F32 && p->L == 32 && wave_bytes(p, a) < (64ll << 20))))) {
+        mifft::WaveArgs w;
+        w.in = a->in0; w.out = a->out0;
+        w.pieces = a->total * p->L * (p->precision == MIFFT_F64 ? 16 : 8) / 16;
+        w.inverse = a->inverse;
+        w.nt = a->nt;
+        w.scale = a->scale;
+        rc = mifft_wave_launch(p->precision == MIFFT_F64, p->L, &w, wave_max_blocks(), s);
+        if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
+        return 0;
+    }
     if (p->kind == MIFFT_PASS_COL)
         rc = p->precision == MIFFT_F32 ? mifft_dispatch_col_f32(p->L, tr, p->variant, a, s, query_only)
                                        : mifft_dispatch_col_f64(p->L, tr, p->variant, a, s, query_only);
@@ -198,6 +247,12 @@ int dispatch(const mifft_pass* p, const mifft::TileArgs* a, hipStream_t s, int q
 extern "C" {
 
 int mifft_abi_version(void) { return MIFFT_ABI_VERSION; }
+int mifft_debug_set(int32_t key, int32_t value) {
+    if (key < 0 || key >= MIFFT_DEBUG_KEYS) return set_err(MIFFT_E_INVALID, "bad debug key %d", key);
+    g_debug[key] = value;
+    return 0;
+}
+int mifft_debug_get(int32_t key) { return (key >= 0 && key < MIFFT_DEBUG_KEYS) ? g_debug[key] : 0; }
 const char* mifft_last_error(void) { return g_err; }
 
 int mifft_device_count(int* count) {

@@ -25,6 +25,9 @@ from .plan import FFTPlan
 def device_pointer(obj):
     """Device address of a buffer-like object (counterpart of the GPUArray -> gpudata unwrapping
     in Function.__call__, cuda.py:36-39)."""
+    t = type(obj)
+    if t is DeviceArray or t is DeviceAllocation:      # (the common case first: execute() is launch-bound for small plans)
+        return obj.ptr
     if obj is None:
         return None
     if isinstance(obj, (int, numpy.integer)) and not isinstance(obj, bool):
@@ -231,6 +234,8 @@ def _torch_current_stream(args):
     """torch's current stream if one of the buffers is a torch device tensor, else None (f1: a plan built without
     stream= runs where the producing framework runs, cuda.py:116-134 current-context semantics)."""
     for a in args:
+        if type(a) is DeviceArray:
+            continue
         if hasattr(a, "data_ptr") and getattr(a, "is_cuda", False):
             import torch
             return torch.cuda.current_stream(a.device)

@@ -107,6 +107,8 @@ class FFTPlan(object):
         self._xcd2_scratch = None
         self._xcd2_disabled = False
         self._mailbox = None
+        self._last_call_key = None
+        self._last_call = None
         self._side_streams = None
         self._side_events = None
 
@@ -297,6 +299,7 @@ class FFTPlan(object):
         if self._last_batch_size == batch:
             return
         self._last_batch_size = batch
+        self._last_call_key = None
         self._strategy = self._select_strategy(batch)
         self._tempmemobj = None
         if self._strategy[0] == "pipelined" and self._side_streams is None:
@@ -422,9 +425,18 @@ class FFTPlan(object):
         batch = int(batch)
         if batch < 1:
             raise ValueError("batch must be positive")
-        self.check()
-        self._prepare(batch)
-        is_inplace, bufs0, bufs1 = self._buffers(is_inplace, args)
+        if self._mailbox is not None:
+            self.check()
+        if self._last_batch_size != batch:
+            self._prepare(batch)
+        # small transforms are launch-bound (a 32 MiB execute is ~12 us of device time): the pointer triples of the last
+        # call are kept, so that repeated executes on the same buffers skip rebuilding them
+        ptr = ctx.pointer_of
+        key = (is_inplace,) + tuple(ptr(a) for a in args)
+        if key != self._last_call_key:
+            self._last_call = self._buffers(is_inplace, args)
+            self._last_call_key = key
+        is_inplace, bufs0, bufs1 = self._last_call
 
         ctx.createQueue(args)
         self._enqueue(batch, is_inplace, inverse, bufs0, bufs1)
