@@ -233,3 +233,17 @@ def test_via_temp_schedule_contract():
         chain = P.build_chain(*xyz, N.F32)
         for inplace in (False, True):
             assert P.buffer_schedule(chain, inplace, via_temp=True) == P.buffer_schedule(chain, inplace)
+
+
+def test_integration_stub_matches_the_bindings():
+    """The reference-side ctypes stub shown in INTEGRATION.md declares struct mifft_pass field for field as
+    pyfft_amd/_native.py does (which test_struct_layout_matches_header ties to include/mifft.h)."""
+    import re
+    from pyfft_amd import _native as N
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = text[text.index("class MifftPass(ctypes.Structure):"):]
+    block = block[:block.index("_lib.mifft_last_error")]
+    fields = re.findall(r'\("(\w+)", ctypes\.(c_\w+)\)', block)
+    import ctypes
+    got = [(name, getattr(ctypes, ct)) for name, ct in fields]      # (c_int32 is an alias of c_int: compare the types)
+    assert got == list(N.MifftPass._fields_)
