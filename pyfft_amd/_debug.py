@@ -39,6 +39,7 @@ def xcd2_flags(default):
 def apply_native_switches(native):
     """Environment -> libmifft's development switches (mifft_debug_set); called once when the library is loaded."""
     for env, key in (("MIFFT_NO_ND2", native.DEBUG_NO_ND2), ("MIFFT_FUSED_NO_NT", native.DEBUG_FUSED_NO_NT),
-                     ("MIFFT_NO_WAVE", native.DEBUG_NO_WAVE), ("MIFFT_FORCE_WAVE", native.DEBUG_FORCE_WAVE)):
+                     ("MIFFT_NO_WAVE", native.DEBUG_NO_WAVE), ("MIFFT_FORCE_WAVE", native.DEBUG_FORCE_WAVE),
+                     ("MIFFT_PERSIST", native.DEBUG_PERSIST)):
         if os.environ.get(env):
             native.lib.mifft_debug_set(key, 1)

@@ -98,30 +98,61 @@ struct Row2Stages<T, L, TPR, Ns, FIRST, HALF, RadixList<R, Rest...>> {
     // Global addresses are (base pointer) + constant + (32-bit per-thread byte offset voff): with one row per
     // work-group the base is wave-uniform and lives in SGPRs, so a load costs no address VGPRs beyond voff (with 64-bit
     // per-load addresses the 32 loads of a thread alone pinned 64 VGPRs and halved the occupancy).
+    // operands of the FIRST stage for registers [I0, I0 + CNT): v[b*R + k] = in[b*NT + k*LR (+ tid)], straight from HBM
+    template <int I0, int CNT, bool NTL>
+    static __device__ __forceinline__ void load_regs(cplx<T>* v, const char* inb, unsigned voff) {
+        static_assert(FIRST, "first-stage addressing");
+        static_for<CNT>([&](auto ii) {
+            constexpr int i = I0 + ii, b = i / R, k = i % R;
+            const cplx<T>* p = reinterpret_cast<const cplx<T>*>(inb + (size_t)(b * NT + k * LR) * sizeof(cplx<T>) + voff);
+            if constexpr (NTL) v[i] = __builtin_nontemporal_load(p);
+            else v[i] = *p;
+        });
+    }
+
+    // PRELOADED: v already holds the row (persistent form: loaded behind the previous row's stores).
+    // FirstStage / (next_inb, next_valid): persistent form only -- the LAST stage issues the NEXT row's first-stage loads into
+    // the registers of every butterfly right behind that butterfly's stores, so that they fly under the remaining
+    // butterflies and stores of this row (one row fills the CU: there is no second work-group to overlap with).
+    template <bool PRELOADED = false, typename FirstStage = void>
     static __device__ __forceinline__ void run(LdsT* lds, cplx<T>* v, const TileArgs& a, int tid, const char* inb,
-                                               char* outb, unsigned voff, bool valid) {
+                                               char* outb, unsigned voff, bool valid, const char* next_inb = nullptr,
+                                               bool next_valid = false) {
         const cplx<T>* twL = reinterpret_cast<const cplx<T>*>(a.tw_L);
         if constexpr (FIRST) {
-            // all loads of the row in flight before the first butterfly
-            static_for<PPT>([&](auto i) { v[i].x = 0; v[i].y = 0; });
-            if (valid) {
-                auto loads = [&](auto ntc) __attribute__((always_inline)) {
-                    constexpr bool NTL = ntc;
-                    static_for<NB>([&](auto bb) {
-                        constexpr int b = bb;
-                        static_for<R>([&](auto kk) {
-                            constexpr int k = kk;
-                            const cplx<T>* p = reinterpret_cast<const cplx<T>*>(
-                                inb + (size_t)(b * NT + k * LR) * sizeof(cplx<T>) + voff);
-                            if constexpr (NTL) v[b * R + k] = __builtin_nontemporal_load(p);
-                            else v[b * R + k] = *p;
-                        });
-                    });
-                };
-                // MIFFT_FLAG_STREAM_SRC: the input is read once (first pass of a multi-pass plan)
-                if (a.nt & 1) loads(IC<1>{}); else loads(IC<0>{});
+            if constexpr (!PRELOADED) {
+                // all loads of the row in flight before the first butterfly
+                static_for<PPT>([&](auto i) { v[i].x = 0; v[i].y = 0; });
+                if (valid) {
+                    // MIFFT_FLAG_STREAM_SRC: the input is read once (first pass of a multi-pass plan)
+                    if (a.nt & 1) load_regs<0, PPT, true>(v, inb, voff);
+                    else load_regs<0, PPT, false>(v, inb, voff);
+                }
             }
             if (a.inverse) static_for<PPT>([&](auto i) { v[i].y = -v[i].y; });
+        }
+        if constexpr (LAST && !std::is_void<FirstStage>::value) {
+            // persistent form (plain accesses): butterfly by butterfly -- twiddle, radix-R, stores, then the next row's
+            // first-stage loads into the same registers
+            const T sx = (T)a.scale;
+            const T sy = a.inverse ? -sx : sx;
+            static_for<NB>([&](auto bb) {
+                constexpr int b = bb;
+                const int j = b * NT + tid;
+                const int ai = (j & (Ns - 1)) * (L / (Ns * R));
+                row2_twiddle<T, R>(twL, ai, v + b * R);
+                Dft<R, T>::run(v + b * R);
+                static_for<R>([&](auto kk) {
+                    constexpr int k = kk;
+                    cplx<T> p = v[b * R + k];
+                    p.x *= sx;
+                    p.y *= sy;
+                    *reinterpret_cast<cplx<T>*>(outb + (size_t)(b * NT + k * Ns) * sizeof(cplx<T>) + voff) = p;
+                });
+                if (next_valid) FirstStage::template load_regs<b * R, R, false>(v, next_inb, voff);
+                else static_for<R>([&](auto kk) { v[b * R + kk] = cplx<T>{(T)0, (T)0}; });   // ends the live range
+            });
+            return;
         }
         static_for<NB>([&](auto bb) {
             constexpr int b = bb;
@@ -176,7 +207,7 @@ struct Row2Stages<T, L, TPR, Ns, FIRST, HALF, RadixList<R, Rest...>> {
                 __syncthreads();
                 Next::template fetch<2>(lds, v, fresh());
             }
-            Next::run(lds, v, a, tid, inb, outb, voff, valid);
+            Next::template run<PRELOADED, FirstStage>(lds, v, a, tid, inb, outb, voff, valid, next_inb, next_valid);
         }
     }
 };
@@ -203,6 +234,56 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) 
     }
     cplx<T> v[PPT];
     Row2Stages<T, L, TPR, 1, true, HALF, RL>::run(lds + c * LP, v, a, u, inb, outb, voff, valid);
+}
+
+// Persistent form for the rows that fill a CU (W == 1, one work-group per CU or two): the work-group walks rows
+// blockIdx.x, blockIdx.x + gridDim.x, ...; the first-stage loads of the next row are issued from the last stage of the
+// current one (Row2Stages::run, FirstStage).
+template <typename T, int L, int NT, bool HALF, int OCC, typename RL>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) fft_row2p_kernel(const TileArgs a) {
+    constexpr int PPT = L / NT;
+    constexpr int LP = L + L / 16;
+    using LdsT = typename std::conditional<HALF, T, cplx<T>>::type;
+    using First = Row2Stages<T, L, NT, 1, true, HALF, RL>;
+    __shared__ __attribute__((aligned(16))) LdsT lds[LP];
+    const unsigned voff = (unsigned)threadIdx.x * (unsigned)sizeof(cplx<T>);
+    long long row = blockIdx.x;
+    if (row >= a.total) return;
+    cplx<T> v[PPT];
+    {
+        const char* inb = reinterpret_cast<const char*>(reinterpret_cast<const cplx<T>*>(a.in0) + row * a.ostride_in);
+        First::template load_regs<0, PPT, false>(v, inb, voff);
+    }
+    for (;;) {
+        const long long next = row + gridDim.x;
+        // (the strides are laundered per row so that the ~PPT row offsets are not hoisted out of the loop as SGPR pairs)
+        long long sin = a.ostride_in, sout = a.ostride_out;
+        asm volatile("" : "+s"(sin), "+s"(sout));
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const char* inb = reinterpret_cast<const char*>(reinterpret_cast<const cplx<T>*>(a.in0) + row * sin);
+        char* outb = reinterpret_cast<char*>(reinterpret_cast<cplx<T>*>(a.out0) + row * sout);
+        const char* nin = reinterpret_cast<const char*>(reinterpret_cast<const cplx<T>*>(a.in0) + next * sin);
+        First::template run<true, First>(lds, v, a, tid, inb, outb, (unsigned)tid * (unsigned)sizeof(cplx<T>), true, nin, next < a.total);
+        if (next >= a.total) break;
+        row = next;
+        __syncthreads();   // the last exchange's LDS reads are over before the next row's first spill
+    }
+}
+
+// blocks_per_cu: resident work-groups per CU of this configuration (LDS- or register-bound); the grid is that many per CU
+template <typename T, int L, int NT, typename RL, bool HALF, int OCC>
+static inline int launch_row2p(const TileArgs* a, hipStream_t s, int blocks_per_cu) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    }
+    long long grid = (long long)cus * blocks_per_cu;
+    if (grid > a->total) grid = a->total;
+    if (grid <= 0) return 0;
+    hipLaunchKernelGGL((fft_row2p_kernel<T, L, NT, HALF, OCC, RL>), dim3((unsigned)grid), dim3(NT), 0, s, *a);
+    return (int)hipGetLastError();
 }
 
 template <typename T, int L, int W, int NT, typename RL, bool HALF = false, int OCC = 1>

@@ -2,6 +2,7 @@
 // kernels (fft_tile.hpp; W rows of L points per work-group, 16 points per thread) for short rows and split planes.
 #include "mifft_internal.h"
 #include "fft_row2.hpp"
+#include "../../include/mifft.h"
 extern "C" int mifft_dispatch_row_f32(int L, int variant, const mifft::TileArgs* a, hipStream_t s, int query_only) {
     if (variant != 0 && variant != 2) return -2;
     // L = 32768 exists in the register-edged half-exchange form only (128 KiB of LDS as scalars, one work-group per CU):
@@ -9,6 +10,8 @@ extern "C" int mifft_dispatch_row_f32(int L, int variant, const mifft::TileArgs*
     if (L == 32768) {
         if (query_only) return variant == 2 ? 0 : -2;
         if (!a || a->split || a->split_out) return -2;
+        if (mifft_debug_get(MIFFT_DEBUG_PERSIST))   // development: persistent + prefetching form (fft_row2.hpp)
+            return mifft::launch_row2p<float, 32768, 1024, mifft::RadixList<8, 16, 16, 16>, true, 4>(a, s, 1);
         return mifft::launch_row2<float, 32768, 1, 1024, mifft::RadixList<8, 16, 16, 16>, true, 4>(a, s, 0);
     }
     // both sides interleaved: register-edged kernels (fft_row2.hpp).  Shapes chosen by measurement (1 GiB buffers,
@@ -21,6 +24,14 @@ extern "C" int mifft_dispatch_row_f32(int L, int variant, const mifft::TileArgs*
         if (L == 1024) return launch_row2<float, 1024, 4, 256, RadixList<16, 4, 16>>(a, s, query_only);
         if (L == 2048) return launch_row2<float, 2048, 1, 128, RadixList<16, 8, 16>>(a, s, query_only);
         if (L == 4096) return launch_row2<float, 4096, 1, 256, RadixList<16, 16, 16>>(a, s, query_only);
+        // development: persistent form of the long rows (the next row's loads are issued from the last stage of the current
+        // one).  Measured at 1 GiB buffers (tools/row_probe.py): 4096 71.4 -> 73.5 %, 8192 66.1 -> 64.0 %, 16384 63.8 -> 56.3 %,
+        // 32768 47.1 -> 47.2 %: the rows that fill a CU are bound by their LDS exchanges, not by exposed load latency
+        if (!query_only && mifft_debug_get(MIFFT_DEBUG_PERSIST)) {
+            if (L == 4096) return launch_row2p<float, 4096, 256, RadixList<16, 16, 16>, false, 1>(a, s, 4);
+            if (L == 8192) return launch_row2p<float, 8192, 256, RadixList<16, 16, 32>, true, 1>(a, s, 3);
+            if (L == 16384) return launch_row2p<float, 16384, 512, RadixList<4, 16, 16, 16>, true, 4>(a, s, 2);
+        }
         if (L == 8192) return launch_row2<float, 8192, 1, 256, RadixList<16, 16, 32>, true>(a, s, query_only);
         if (L == 16384) return launch_row2<float, 16384, 1, 512, RadixList<4, 16, 16, 16>, true, 4>(a, s, query_only);
     }
