@@ -137,6 +137,7 @@ const char *mifft_last_error(void);
 #define MIFFT_DEBUG_NO_WAVE 2      /* no wave-autonomous small-transform kernels */
 #define MIFFT_DEBUG_FORCE_WAVE 3   /* wave-autonomous kernels wherever one exists, whatever the buffer size */
 #define MIFFT_DEBUG_PERSIST 4      /* persistent (prefetching) form of the long fp32 rows (measured: no gain) */
+#define MIFFT_DEBUG_ALT_ROWS 5     /* alternative stage lists of the longest fp32 rows (A/B measurements) */
 #define MIFFT_DEBUG_KEYS 8
 int mifft_debug_set(int32_t key, int32_t value);
 int mifft_debug_get(int32_t key);

@@ -27,7 +27,7 @@ FLAG_STREAM_SRC, FLAG_STREAM_DST = 4, 8
 XCD2_SCRATCH_BYTES = 8 * 64 * 16 * 256 * 8
 XCD2_CONTROL_BYTES = (64 + 2 * 512) * 4
 XCD2_PREFETCH = 1
-DEBUG_NO_ND2, DEBUG_FUSED_NO_NT, DEBUG_NO_WAVE, DEBUG_FORCE_WAVE, DEBUG_PERSIST = 0, 1, 2, 3, 4
+DEBUG_NO_ND2, DEBUG_FUSED_NO_NT, DEBUG_NO_WAVE, DEBUG_FORCE_WAVE, DEBUG_PERSIST, DEBUG_ALT_ROWS = 0, 1, 2, 3, 4, 5
 XCD2_TRACE = 2
 XCD2_TRACE_BYTES = 512 * 32 * 8
 

@@ -12,7 +12,11 @@ extern "C" int mifft_dispatch_row_f32(int L, int variant, const mifft::TileArgs*
         if (!a || a->split || a->split_out) return -2;
         if (mifft_debug_get(MIFFT_DEBUG_PERSIST))   // development: persistent + prefetching form (fft_row2.hpp)
             return mifft::launch_row2p<float, 32768, 1024, mifft::RadixList<8, 16, 16, 16>, true, 4>(a, s, 1);
-        return mifft::launch_row2<float, 32768, 1, 1024, mifft::RadixList<8, 16, 16, 16>, true, 4>(a, s, 0);
+        switch (mifft_debug_get(MIFFT_DEBUG_ALT_ROWS)) {   // development: A/B of the stage lists
+            case 1: return mifft::launch_row2<float, 32768, 1, 1024, mifft::RadixList<8, 16, 16, 16>, true, 4>(a, s, 0);
+            case 2: return mifft::launch_row2<float, 32768, 1, 512, mifft::RadixList<32, 32, 32>, true, 2>(a, s, 0);
+        }
+        return mifft::launch_row2<float, 32768, 1, 1024, mifft::RadixList<32, 32, 32>, true, 4>(a, s, 0);
     }
     // both sides interleaved: register-edged kernels (fft_row2.hpp).  Shapes chosen by measurement (1 GiB buffers,
     // tools/row_probe.py): the half-exchange form wins where it raises the work-groups per CU (8192: 2 -> 3,
@@ -33,6 +37,12 @@ extern "C" int mifft_dispatch_row_f32(int L, int variant, const mifft::TileArgs*
             if (L == 16384) return launch_row2p<float, 16384, 512, RadixList<4, 16, 16, 16>, true, 4>(a, s, 2);
         }
         if (L == 8192) return launch_row2<float, 8192, 1, 256, RadixList<16, 16, 32>, true>(a, s, query_only);
+        if (L == 16384 && !query_only) {
+            switch (mifft_debug_get(MIFFT_DEBUG_ALT_ROWS)) {   // development: A/B of the stage lists
+                case 2: return launch_row2<float, 16384, 1, 512, RadixList<16, 32, 32>, true, 4>(a, s, 0);
+                case 3: return launch_row2<float, 16384, 1, 512, RadixList<32, 16, 32>, true, 4>(a, s, 0);
+            }
+        }
         if (L == 16384) return launch_row2<float, 16384, 1, 512, RadixList<4, 16, 16, 16>, true, 4>(a, s, query_only);
     }
     switch (L) {

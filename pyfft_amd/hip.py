@@ -337,6 +337,9 @@ def Plan(*args, **kwds):
     execute() is asynchronous by default and returns the stream.  `context`: accepted for
     signature parity (a device index or None: HIP has one primary context per device).
     `mempool`: any object with an allocate(nbytes) method returning a buffer-like object.
+    `fast_math`: accepted for signature parity and ignored -- the reference passes -use_fast_math to nvcc for its on-device
+    sincos (cuda.py:56-57); here twiddles come from float64-evaluated tables, so there is nothing to relax (results meet the
+    reference's thresholds either way).
     """
     mempool = kwds.pop('mempool', None)
     context_obj = kwds.pop('context', None)

@@ -160,34 +160,35 @@ def build_chain(x, y, z, precision, interleaved=False):
 
 
 def buffer_schedule(chain, is_inplace, via_temp=False):
-    """Buffer ping-pong of FFTPlan._execute (plan.py:194-248): returns (temp_needed,
-    [(src, dst), ...]) with 0 = data_in, 1 = data_out, 2 = temp.  Contract: an out-of-place
-    call never writes data_in; an in-place call leaves the result in data_in (for which
-    data_out aliases data_in, so index 1 is the user's buffer in both cases)."""
+    """Which buffer every pass reads and writes: returns (temp_needed, [(src, dst), ...]) with 0 = data_in,
+    1 = data_out, 2 = the plan's temp buffer.  Contract of FFTPlan._execute (plan.py:194-248): an out-of-place call never
+    writes data_in, the result ends in data_out (which aliases data_in for an in-place call, so index 1 is the user's
+    buffer in both cases), and a pass that cannot run in place never reads and writes the same buffer.
+
+    The chain alternates between data_out and temp, and the LAST pass must land on data_out: so pass i (of n) writes data_out
+    exactly when an even number of buffer switches follows it.  An in-place call starts ON data_out; with an odd number of
+    passes one pass has to stay where it is, and that is the first one that can run in place (plan.py:214-221)."""
+    n = len(chain)
     temp_needed = any(not p.in_place_possible for p in chain)
-    odd = (len(chain) % 2 == 1)
-    sched = []
-    curr_read, curr_write = 0, 1
-    if via_temp and not temp_needed and len(chain) >= 2:
+    start = 1 if is_inplace else 0
+    if via_temp and not temp_needed and n >= 2:
         # every pass can run in place: go in -> temp, stay on the temp, last pass temp -> out
         # (used for fp32 split-plane plans, whose temp is interleaved: only two sides touch the planes)
-        first = 1 if is_inplace else 0
-        return True, [(first, 2)] + [(2, 2)] * (len(chain) - 2) + [(2, 1)]
-    if temp_needed:
-        inplace_done = False
-        if is_inplace:
-            curr_read, curr_write = 1, 2
+        return True, [(start, 2)] + [(2, 2)] * (n - 2) + [(2, 1)]
+    if not temp_needed:
+        return False, [(0 if i == 0 else 1, 1) for i in range(n)]
+    stays = None
+    if is_inplace and n % 2 == 1:
+        stays = next((i for i, p in enumerate(chain) if p.in_place_possible), None)
+    sched, here = [], start
+    for i in range(n):
+        if i == stays:
+            there = here
+        elif is_inplace:
+            there = 2 if here == 1 else 1
         else:
-            curr_write = 1 if odd else 2
-        for p in chain:
-            if is_inplace and odd and not inplace_done and p.in_place_possible:
-                curr_write = curr_read
-                inplace_done = True
-            sched.append((curr_read, curr_write))
-            curr_read = 1 if curr_write == 1 else 2
-            curr_write = 2 if curr_write == 1 else 1
-    else:
-        for p in chain:
-            sched.append((curr_read, curr_write))
-            curr_read, curr_write = 1, 1
+            switches_after = n - 1 - i          # every later pass switches buffers
+            there = 1 if switches_after % 2 == 0 else 2
+        sched.append((here, there))
+        here = there
     return temp_needed, sched

@@ -8,7 +8,8 @@ from pyfft_amd.hip import Plan, DeviceArray, Event
 from pyfft_amd import _native as N
 
 
-def run(L, dtype, persist):
+def run(L, dtype, persist, alt=0):
+    N.check(N.lib.mifft_debug_set(N.DEBUG_ALT_ROWS, alt))
     N.check(N.lib.mifft_debug_set(N.DEBUG_PERSIST, 1 if persist else 0))
     isz = numpy.dtype(dtype).itemsize
     batch = (1 << 30) // (L * isz)
@@ -40,9 +41,20 @@ def run(L, dtype, persist):
         e1.synchronize()
         best = min(best, e1.time_since(e0) / 5)
     N.check(N.lib.mifft_debug_set(N.DEBUG_PERSIST, 0))
+    N.check(N.lib.mifft_debug_set(N.DEBUG_ALT_ROWS, 0))
     return 2.0 * L * batch * isz / (best * 1e-3) / 8e12, err
 
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "alt":
+    for L in (16384, 32768):
+        res = {}
+        for rep in range(4):                      # interleaved repeats: the pool drifts by a few per cent within a run
+            for alt in (0, 1, 2, 3):
+                f, e = run(L, numpy.complex64, False, alt)
+                res.setdefault(alt, []).append(f)
+        for alt in sorted(res):
+            print("L=%d stage-list variant %d: median %.3f  all %s" % (L, alt, sorted(res[alt])[len(res[alt]) // 2], ["%.3f" % x for x in res[alt]]), flush=True)
+    sys.exit(0)
 if __name__ == "__main__":
     print("%-8s %-10s | plain frac (err)      | persistent frac (err)" % ("L", "dtype"))
     for L, dtype in ((4096, numpy.complex64), (8192, numpy.complex64), (16384, numpy.complex64), (32768, numpy.complex64),
