@@ -33,16 +33,32 @@ struct FusedArgs {
     unsigned tiles1;     // 16-column tiles per transform in pass 1 (= L0 / 16)
 };
 
+// Deferred publish of a pass-0 tile: its write-through stores drain under the first poll of the NEXT item's dependency, and
+// the counter is bumped BEFORE this work-group starts to wait.  (Publishing only after the wait has ended deadlocks: work-group
+// X owes a tile of transform T and waits for U while Y owes a tile of U and waits for T -- measured as dependency time-outs.)
+struct FusedPending {
+    unsigned* ctr;   // wdone counter still to be bumped, or nullptr
+};
+
 // wait until *ctr >= target (one lane polls, bounded); ACQ: also make other work-groups' published data visible
-template <bool ACQ> __device__ __forceinline__ void fused_wait_ge(unsigned* ctr, unsigned target, unsigned* err) {
+template <bool ACQ> __device__ __forceinline__ void fused_wait_ge(unsigned* ctr, unsigned target, unsigned* err, FusedPending& pend) {
+    unsigned seen = 0;
+    if (threadIdx.x == 0) seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // first poll, in flight
+    if (pend.ctr != nullptr) {   // (uniform) the owed tile: every wave drains its stores, the barrier joins them, lane 0 publishes
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(pend.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pend.ctr = nullptr;
+    }
     if (threadIdx.x == 0) {
         unsigned spins = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        while (seen < target) {
             __builtin_amdgcn_s_sleep(32);
             if (++spins > (1u << 22)) {  // ~ seconds: never hang the GPU
                 __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
+            seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if constexpr (ACQ) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -52,11 +68,20 @@ template <bool ACQ> __device__ __forceinline__ void fused_wait_ge(unsigned* ctr,
     __syncthreads();
 }
 
-// signal "this tile is done".  The data a later tile depends on was written with write-through stores (pass 0) or
-// is only a read-completion (pass 1), so no release fence is needed: every wave drains its own memory
-// operations, the work-group barrier joins them, one lane bumps the counter.
-__device__ __forceinline__ void fused_signal(unsigned* ctr) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+// publish now: every wave drains its own memory operations, the work-group barrier joins them, one lane bumps the counter.
+// (The data a later tile depends on was written with write-through stores, so no release fence is needed.)
+__device__ __forceinline__ void fused_flush(FusedPending& pend) {
+    if (pend.ctr != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(pend.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pend.ctr = nullptr;
+    }
+}
+
+// "this tile has finished READING" (pass 1 and its ring slot): every load has been consumed by the time the tile's last
+// butterflies ran, so the stores of the result are not waited for.
+__device__ __forceinline__ void fused_signal_read(unsigned* ctr) {
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -74,9 +99,17 @@ __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
     const unsigned gsize = 2u * (f.tiles0 > f.tiles1 ? f.tiles0 : f.tiles1);
     const unsigned total = (f.batch + f.lag) * gsize;
 
+    // the ticket of the NEXT item is drawn while the current one is being worked on (the returning atomic takes 1-3 us under
+    // load: MI355X_MICROARCH.md, dequeue row), so its latency is off the critical path
+    FusedPending pend = {nullptr};
+    unsigned ahead = 0;
+    if (threadIdx.x == 0) ahead = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
         __syncthreads();  // the previous item's LDS traffic and its s_item read are over
-        if (threadIdx.x == 0) s_item = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            s_item = ahead;
+            if (ahead < total) ahead = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();
         const unsigned item = s_item;
         if (item >= total) break;
@@ -84,18 +117,25 @@ __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
         if ((k & 1u) == 0u) {
             if (g >= f.batch || tile >= f.tiles0) continue;
             const unsigned t = g;
-            if (t >= f.ring) fused_wait_ge<false>(rdone + (t - f.ring), f.tiles1, err);
+            if (t >= f.ring) {
+                fused_wait_ge<false>(rdone + (t - f.ring), f.tiles1, err, pend);
+            } else {
+                fused_flush(pend);
+            }
             col2_tile<T, A0, true, true, SPLIT, true, NT, false, false>(f.p0, (long long)t, (long long)(t % f.ring), (long long)tile * 16, lds);
-            fused_signal(wdone + t);
+            pend.ctr = wdone + t;       // published behind the next item's dependency wait (or at the end)
         } else {
             if (g < f.lag) continue;
             const unsigned t = g - f.lag;
             if (t >= f.batch || tile >= f.tiles1) continue;
-            fused_wait_ge<true>(wdone + t, f.tiles0, err);
-            col2_tile<T, A1, false, false, false, false, false, NT, SPLIT>(f.p1, (long long)(t % f.ring), (long long)t, (long long)tile * 16, lds);
-            fused_signal(rdone + t);
+            // no acquire fence: the ring is read with L1-bypassing (sc1) loads (every byte of it was stored write-through and
+            // drained before the counter moved: cdna_hip_programming.md Guideline 16, consumer form with sc1 loads)
+            fused_wait_ge<false>(wdone + t, f.tiles0, err, pend);
+            col2_tile<T, A1, false, false, false, false, false, NT, SPLIT, cplx<T>*, true>(f.p1, (long long)(t % f.ring), (long long)t, (long long)tile * 16, lds);
+            fused_signal_read(rdone + t);
         }
     }
+    fused_flush(pend);
 }
 
 }  // namespace mifft
