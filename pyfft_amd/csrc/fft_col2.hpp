@@ -50,10 +50,8 @@ template <int A, bool TR, int ESZ = 8> struct Col2Lds {
 // WT: write the result with write-through (agent-coherent, "sc1") stores -- used by the fused kernel for the
 //     intermediate so that publishing it needs no release fence (interleaved fp32 only).
 // NTIN / NTOUT: non-temporal hint on the input loads / output stores (streamed-once data in the fused kernel).
-// SC1IN: read the input with agent-coherent (L1-bypassing, "sc1") loads -- the consumer side of the fused kernel's hand-off,
-//     which then needs no acquire fence (every handed-off byte was stored write-through and is loaded this way; fp32 interleaved only).
 template <typename T, int A, bool TR, bool TW, bool SPLIT, bool WT = false, bool NTIN = false, bool NTOUT = false,
-          bool SPLIT_OUT = SPLIT, typename LdsPtr = cplx<T>*, bool SC1IN = false>
+          bool SPLIT_OUT = SPLIT, typename LdsPtr = cplx<T>*>
 __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_in, const long long o_out,
                                           const long long rem0, LdsPtr lds) {
     constexpr int L = A * 256;
@@ -87,11 +85,7 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
             static_for<PPT>([&](auto kk) {
                 constexpr int k = kk, ia = k >> 4, b1 = k & 15;
                 const char* p = src + (((long long)(b1 * 16 * A + ia * 16) << logMS) * (long long)sizeof(cplx<T>));
-                if constexpr (SC1IN) {
-                    static_assert(!SC1IN || sizeof(cplx<T>) == 8, "coherent-load path is fp32 interleaved only");
-                    v[k] = __builtin_bit_cast(cplx<T>, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p + vb),
-                                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                } else if constexpr (NTIN)
+                if constexpr (NTIN)
                     v[k] = __builtin_nontemporal_load(reinterpret_cast<const cplx<T>*>(p + vb));
                 else
                     v[k] = *reinterpret_cast<const cplx<T>*>(p + vb);

@@ -128,10 +128,10 @@ __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
             if (g < f.lag) continue;
             const unsigned t = g - f.lag;
             if (t >= f.batch || tile >= f.tiles1) continue;
-            // no acquire fence: the ring is read with L1-bypassing (sc1) loads (every byte of it was stored write-through and
-            // drained before the counter moved: cdna_hip_programming.md Guideline 16, consumer form with sc1 loads)
-            fused_wait_ge<false>(wdone + t, f.tiles0, err, pend);
-            col2_tile<T, A1, false, false, false, false, false, NT, SPLIT, cplx<T>*, true>(f.p1, (long long)(t % f.ring), (long long)t, (long long)tile * 16, lds);
+            // (reading the ring with sc1 loads instead of the acquire fence measured the same -- 22.52 ms -- and 8-byte sc1 loads
+            // at two work-groups per CU are outside the hand-off forms MI355X_MICROARCH.md lists as validated: the fence stays)
+            fused_wait_ge<true>(wdone + t, f.tiles0, err, pend);
+            col2_tile<T, A1, false, false, false, false, false, NT, SPLIT>(f.p1, (long long)(t % f.ring), (long long)t, (long long)tile * 16, lds);
             fused_signal_read(rdone + t);
         }
     }
