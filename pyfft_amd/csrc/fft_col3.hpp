@@ -1,18 +1,20 @@
-// Strided-axis (COL) kernel for L = 2048 in fp32: the two-phase col2 data flow (fft_col2.hpp) at 512 threads, so that
-// N = 2^21 and 2^22 need two HBM round trips instead of three (counterpart of the reference's four-pass chain for 2^22,
-// pyfft/kernel_helpers.py:67-122).
+// Strided-axis (COL) kernels for L = 2048 in fp32 and L = 1024 in fp64: the two-phase col2 data flow (fft_col2.hpp) at 512
+// threads, so that fp32 N = 2^21 / 2^22 and fp64 N = 2^19 / 2^20 need two HBM round trips instead of three (counterpart of
+// the reference's four-pass chain for 2^22, pyfft/kernel_helpers.py:67-122).
 //
-// 2048 = 2 * 1024 by decimation in TIME: the even rows and the odd rows of a 16-column tile are two independent
-// 1024-point col2 transforms (64 points per thread, radix 16 * 4 * 16, one LDS exchange each), and
-//     X[q'] = E[q'] + w(2048)^q' * O[q'],    X[q' + 1024] = E[q'] - w(2048)^q' * O[q'].
+// L = 2 * L' (L' = 256 * A: 1024 in fp32, A = 4; 512 in fp64, A = 2) by decimation in TIME: the even rows and the odd rows
+// of a 16-column tile are two independent L'-point col2 transforms (16 * A points per thread, radix 16 * A * 16, one LDS
+// exchange each), and
+//     X[q'] = E[q'] + w(L)^q' * O[q'],    X[q' + L'] = E[q'] - w(L)^q' * O[q'].
 // Lanes 0-31 of every wave work on the even rows, lanes 32-63 on the odd rows, with the same col2 thread index in both
 // halves: the two operands of one output pair then sit in lanes l and l ^ 32 of one wave and the combination is one
-// v_permlane32_swap per register (gfx950) -- no LDS, no barrier.  The halves have their own LDS exchange buffers
-// (2 x 34 KiB).  One work-group (8 waves, ~200 VGPRs) per CU.
+// v_permlane32_swap per 32-bit register (gfx950) -- no LDS, no barrier.  The halves have their own LDS exchange buffers
+// (2 x 34 KiB; 16-byte points go through them one component at a time, as in col2).  One work-group (8 waves, ~190 VGPRs)
+// per CU.
 //
 // Pass algebra as in fft_col2.hpp (SURVEY.md 3.3 / pyfft/kernel.mako:805-1047):
-//     out[l][q][j] = scale * w(L*M)^(l*q) * sum_r in[r][l][j] * w(L)^(r*q),   L = 2048
-// with r = 2*r' + h, r' = b1*64 + a*16 + b0 and q = h'*1024 + qb0*64 + qa*16 + qb1.
+//     out[l][q][j] = scale * w(L*M)^(l*q) * sum_r in[r][l][j] * w(L)^(r*q)
+// with r = 2*r' + h, r' = b1*16A + a*16 + b0 and q = h'*L' + qb0*16A + qa*16 + qb1.
 #pragma once
 #include "fft_col2.hpp"
 
@@ -25,19 +27,34 @@ __device__ __forceinline__ float col3_other_half(float x, bool upper) {
     return __builtin_bit_cast(float, upper ? r[0] : r[1]);
 }
 
-template <bool TR> struct Col3Lds {
+__device__ __forceinline__ double col3_other_half(double x, bool upper) {
+    typedef int i2 __attribute__((ext_vector_type(2)));
+    const i2 v = __builtin_bit_cast(i2, x);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(v[0], v[0], false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(v[1], v[1], false, false);
+    i2 o;
+    o[0] = upper ? r0[0] : r0[1];
+    o[1] = upper ? r1[0] : r1[1];
+    return __builtin_bit_cast(double, o);
+}
+
+// LDS of one work-group in units of T: two halves of BUF slots; 8-byte points store a whole point per slot (2 T),
+// 16-byte points one component at a time (1 T per slot)
+template <typename T, bool TR> struct Col3Lds {
     static constexpr int PITCH = TR ? 17 : 16;
-    static constexpr int BUF = 16 * 16 * PITCH;   // complex elements per half
-    static constexpr int ELEMS = 2 * BUF;
+    static constexpr int BUF = 16 * 16 * PITCH;   // slots per half
+    static constexpr bool HALF = sizeof(T) > 4;
+    static constexpr int SCALARS = 2 * BUF * (HALF ? 1 : 2);
 };
 
-template <typename T, bool TR, bool TW, bool SPLIT, bool NTIN, bool NTOUT, bool SPLIT_OUT>
+template <typename T, int A, bool TR, bool TW, bool SPLIT, bool NTIN, bool NTOUT, bool SPLIT_OUT>
 __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_in, const long long o_out, const long long rem0,
-                                          cplx<T>* lds) {
-    static_assert(sizeof(T) == 4, "fp32 only (the lane-half exchange moves 32-bit registers)");
-    constexpr int L = 2048;
-    constexpr int PITCH = Col3Lds<TR>::PITCH;
-    constexpr int BUF = Col3Lds<TR>::BUF;
+                                          T* lds) {
+    constexpr int L = 512 * A;          // 2 * L'
+    constexpr int PPT = 16 * A;
+    constexpr int PITCH = Col3Lds<T, TR>::PITCH;
+    constexpr int BUF = Col3Lds<T, TR>::BUF;
+    constexpr bool kHalf = Col3Lds<T, TR>::HALF;
 
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
@@ -48,21 +65,22 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
     const int c = tl & 15, b0 = tl >> 4;
     int logMS = a.logMS, logS = a.logS;
     asm volatile("" : "+s"(logMS), "+s"(logS));
-    const cplx<T>* twL = reinterpret_cast<const cplx<T>*>(a.tw_L);   // w(2048)^k
+    const cplx<T>* twL = reinterpret_cast<const cplx<T>*>(a.tw_L);   // w(L)^k
     const T csign = a.inverse ? (T)-1 : (T)1;
-    cplx<T>* const ldsh = lds + h * BUF;
+    cplx<T>* const ldsh = reinterpret_cast<cplx<T>*>(lds) + h * BUF;   // whole points (8-byte points)
+    T* const ldss = lds + h * BUF;                                      // one component at a time (16-byte points)
 
-    // ---- phase 1: v[a*16 + b1] = in[2*(b1*64 + a*16 + b0) + h][column c]
-    cplx<T> v[64];
+    // ---- phase 1: v[a*16 + b1] = in[2*(b1*16A + a*16 + b0) + h][column c]
+    cplx<T> v[PPT];
     {
         const long long ubase = o_in * a.ostride_in + rem0;
         const unsigned voff = ((unsigned)(2 * b0 + h) << logMS) + (unsigned)c;
         if constexpr (!SPLIT) {
             const char* src = reinterpret_cast<const char*>(reinterpret_cast<const cplx<T>*>(a.in0) + ubase);
             const unsigned vb = voff * (unsigned)sizeof(cplx<T>);
-            static_for<64>([&](auto kk) {
+            static_for<PPT>([&](auto kk) {
                 constexpr int k = kk, ia = k >> 4, b1 = k & 15;
-                const char* p = src + (((long long)(2 * (b1 * 64 + ia * 16)) << logMS) * (long long)sizeof(cplx<T>));
+                const char* p = src + (((long long)(2 * (b1 * 16 * A + ia * 16)) << logMS) * (long long)sizeof(cplx<T>));
                 if constexpr (NTIN) v[k] = __builtin_nontemporal_load(reinterpret_cast<const cplx<T>*>(p + vb));
                 else v[k] = *reinterpret_cast<const cplx<T>*>(p + vb);
             });
@@ -70,17 +88,17 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
             const char* sre = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.in0) + ubase);
             const char* sim = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.in1) + ubase);
             const unsigned vb = voff * (unsigned)sizeof(T);
-            static_for<64>([&](auto kk) {
+            static_for<PPT>([&](auto kk) {
                 constexpr int k = kk, ia = k >> 4, b1 = k & 15;
-                const long long off = ((long long)(2 * (b1 * 64 + ia * 16)) << logMS) * (long long)sizeof(T);
+                const long long off = ((long long)(2 * (b1 * 16 * A + ia * 16)) << logMS) * (long long)sizeof(T);
                 v[k].x = *reinterpret_cast<const T*>(sre + off + vb);
                 v[k].y = *reinterpret_cast<const T*>(sim + off + vb);
             });
         }
     }
-    static_for<64>([&](auto kk) { v[kk].y *= csign; });
+    static_for<PPT>([&](auto kk) { v[kk].y *= csign; });
 
-    // ---- stage 1 (radix-16 over b1) and stage 2 (radix-4 over a) of the 1024-point half: w(1024)^j = w(2048)^(2j)
+    // ---- stage 1 (radix-16 over b1) and stage 2 (radix-A over a) of the L'-point half: w(L')^j = w(L)^(2j)
     {
         const cplx<T> s1 = twL[2 * b0], s2 = twL[4 * b0], s4 = twL[8 * b0], s8 = twL[16 * b0];
         const cplx<T> s3 = cmul<T>(s1, s2), s5 = cmul<T>(s4, s1), s6 = cmul<T>(s4, s2), s7 = cmul<T>(s4, s3);
@@ -102,31 +120,31 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
             else if constexpr (k == 14) return cmul<T>(s8, s6);
             else return cmul<T>(s8, s7);
         };
-        static_for<4>([&](auto aa) {
+        static_for<A>([&](auto aa) {
             constexpr int ia = aa;
             Dft<16, T>::run(v + ia * 16);
             static_for<15>([&](auto q2) {
                 constexpr int qb1 = q2 + 1;
                 cplx<T> t = v[ia * 16 + qb1];
-                if constexpr (ia > 0) t = mul_w64<ia * qb1, T>(t);
+                if constexpr (ia > 0) t = mul_w16A<A, ia * qb1, T>(t);
                 v[ia * 16 + qb1] = cmul<T>(t, tw(IC<qb1>{}));
             });
             __builtin_amdgcn_sched_barrier(0);
         });
     }
     {
-        cplx<T> twA[3];
-        static_for<3>([&](auto qq) {
+        cplx<T> twA[A - 1];
+        static_for<A - 1>([&](auto qq) {
             constexpr int qa = qq + 1;
-            twA[qq] = twL[32 * b0 * qa];          // w(64)^(b0*qa)
+            twA[qq] = twL[32 * b0 * qa];          // w(16A)^(b0*qa) = w(L)^(32*b0*qa)
         });
         static_for<16>([&](auto bb) {
             constexpr int qb1 = bb;
-            cplx<T> t[4];
-            static_for<4>([&](auto aa) { t[aa] = v[aa * 16 + qb1]; });
-            Dft<4, T>::run(t);
+            cplx<T> t[A];
+            static_for<A>([&](auto aa) { t[aa] = v[aa * 16 + qb1]; });
+            Dft<A, T>::run(t);
             v[qb1] = t[0];
-            static_for<3>([&](auto qq) {
+            static_for<A - 1>([&](auto qq) {
                 constexpr int qa = qq + 1;
                 v[qa * 16 + qb1] = cmul<T>(t[qa], twA[qq]);
             });
@@ -148,29 +166,50 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
     const cplx<T>* twhi = reinterpret_cast<const cplx<T>*>(a.tw_hi);
     const int tw_shift = a.tw_shift;
     const unsigned lomask = (1u << tw_shift) - 1u;
-    // q = h*1024 + qb0*64 + qa*16 + u
+    // q = h*L' + qb0*16A + qa*16 + u
     const long long oubase = TR ? (a.ostride_out * o_out + rem0 * L) : (a.ostride_out * o_out + ((l0 * L) << logS) + jp0);
-    const unsigned ovoff = TR ? ((unsigned)c2 * L + (unsigned)u + 1024u * (unsigned)h)
-                              : ((((unsigned)dl * L + (unsigned)u + 1024u * (unsigned)h) << logS) + djp);
+    const unsigned ovoff = TR ? ((unsigned)c2 * L + (unsigned)u + (unsigned)(L / 2) * (unsigned)h)
+                              : ((((unsigned)dl * L + (unsigned)u + (unsigned)(L / 2) * (unsigned)h) << logS) + djp);
 
-    static_for<4>([&](auto rr) {
+    static_for<A>([&](auto rr) {
         constexpr int qa = rr;
         if constexpr (qa > 0) __syncthreads();   // the previous round's reads are done
         cplx<T> x[16];
-        static_for<16>([&](auto ss) {
-            constexpr int qb1 = ss;
-            if constexpr (TR) ldsh[(b0 * 16 + c) * PITCH + qb1] = v[qa * 16 + qb1];
-            else ldsh[(b0 * 16 + qb1) * 16 + c] = v[qa * 16 + qb1];
-        });
-        __syncthreads();
-        static_for<16>([&](auto bb) {
-            constexpr int bi = bb;
-            if constexpr (TR) x[bi] = ldsh[(bi * 16 + c2) * PITCH + u];
-            else x[bi] = ldsh[(bi * 16 + u) * 16 + c2];
-        });
+        if constexpr (!kHalf) {
+            static_for<16>([&](auto ss) {
+                constexpr int qb1 = ss;
+                if constexpr (TR) ldsh[(b0 * 16 + c) * PITCH + qb1] = v[qa * 16 + qb1];
+                else ldsh[(b0 * 16 + qb1) * 16 + c] = v[qa * 16 + qb1];
+            });
+            __syncthreads();
+            static_for<16>([&](auto bb) {
+                constexpr int bi = bb;
+                if constexpr (TR) x[bi] = ldsh[(bi * 16 + c2) * PITCH + u];
+                else x[bi] = ldsh[(bi * 16 + u) * 16 + c2];
+            });
+        } else {
+            static_for<2>([&](auto cc) {
+                constexpr int comp = cc;
+                if constexpr (comp == 1) __syncthreads();  // the real parts have been read
+                static_for<16>([&](auto ss) {
+                    constexpr int qb1 = ss;
+                    const T w = comp == 0 ? v[qa * 16 + qb1].x : v[qa * 16 + qb1].y;
+                    if constexpr (TR) ldss[(b0 * 16 + c) * PITCH + qb1] = w;
+                    else ldss[(b0 * 16 + qb1) * 16 + c] = w;
+                });
+                __syncthreads();
+                static_for<16>([&](auto bb) {
+                    constexpr int bi = bb;
+                    T w;
+                    if constexpr (TR) w = ldss[(bi * 16 + c2) * PITCH + u];
+                    else w = ldss[(bi * 16 + u) * 16 + c2];
+                    if constexpr (comp == 0) x[bi].x = w; else x[bi].y = w;
+                });
+            });
+        }
         Dft<16, T>::run(x);
-        // x[qb0] = E[q'] (lower lanes) or O[q'] (upper lanes), q' = qb0*64 + qa*16 + u.  The odd half is multiplied by
-        // w(2048)^q' = w(2048)^(qa*16 + u) [one look-up] * w(32)^qb0 [constants]; then X = other + (upper ? -own : own).
+        // x[qb0] = E[q'] (lower lanes) or O[q'] (upper lanes), q' = qb0*16A + qa*16 + u.  The odd half is multiplied by
+        // w(L)^q' = w(L)^(qa*16 + u) [one look-up] * w(32)^qb0 [constants: L / 16A = 32]; then X = other + (upper ? -own : own).
         {
             const cplx<T> w0 = twL[qa * 16 + u];
             static_for<16>([&](auto qq) {
@@ -188,10 +227,10 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
         }
         if constexpr (TW) {
             auto look = [&](unsigned e) { return cmul<T>(twlo[e & lomask], twhi[e >> tw_shift]); };
-            const cplx<T> sstep = look(l * 64u);
+            const cplx<T> sstep = look(l * (16u * A));
             static_for<4>([&](auto jj) {
                 constexpr int j = jj;
-                cplx<T> cur = look(l * ((unsigned)(qa * 16 + 256 * j) + (unsigned)u + 1024u * (unsigned)h));
+                cplx<T> cur = look(l * ((unsigned)(qa * 16 + 64 * A * j) + (unsigned)u + (unsigned)(L / 2) * (unsigned)h));
                 static_for<4>([&](auto ii) {
                     constexpr int qb0 = 4 * j + ii;
                     x[qb0] = cmul<T>(x[qb0], cur);
@@ -201,7 +240,7 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
         }
         static_for<16>([&](auto qq) {
             constexpr int qb0 = qq;
-            const long long gu = TR ? (oubase + qb0 * 64 + 16 * qa) : (oubase + ((long long)(qb0 * 64 + 16 * qa) << logS));
+            const long long gu = TR ? (oubase + qb0 * 16 * A + 16 * qa) : (oubase + ((long long)(qb0 * 16 * A + 16 * qa) << logS));
             cplx<T> r;
             r.x = x[qb0].x * sx;
             r.y = x[qb0].y * sy;
@@ -219,20 +258,20 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
     });
 }
 
-template <typename T, bool TR, bool TW, bool SPLIT, bool SPLIT_OUT>
+template <typename T, int A, bool TR, bool TW, bool SPLIT, bool SPLIT_OUT>
 __global__ void __launch_bounds__(512, 2) fft_col3_kernel(const TileArgs a) {
-    __shared__ __attribute__((aligned(16))) cplx<T> lds[Col3Lds<TR>::ELEMS];
+    __shared__ __attribute__((aligned(16))) T lds[Col3Lds<T, TR>::SCALARS];
     const long long col0 = (long long)blockIdx.x * 16;
     const long long o = col0 >> a.logMS;
     const long long rem0 = col0 & ((1ll << a.logMS) - 1);
     if constexpr (TR && !SPLIT) {
-        if (a.nt & 1) col3_tile<T, TR, TW, SPLIT, true, false, SPLIT_OUT>(a, o, o, rem0, lds);
-        else col3_tile<T, TR, TW, SPLIT, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
+        if (a.nt & 1) col3_tile<T, A, TR, TW, SPLIT, true, false, SPLIT_OUT>(a, o, o, rem0, lds);
+        else col3_tile<T, A, TR, TW, SPLIT, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
     } else if constexpr (!TR && !SPLIT_OUT) {
-        if (a.nt & 2) col3_tile<T, TR, TW, SPLIT, false, true, SPLIT_OUT>(a, o, o, rem0, lds);
-        else col3_tile<T, TR, TW, SPLIT, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
+        if (a.nt & 2) col3_tile<T, A, TR, TW, SPLIT, false, true, SPLIT_OUT>(a, o, o, rem0, lds);
+        else col3_tile<T, A, TR, TW, SPLIT, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
     } else {
-        col3_tile<T, TR, TW, SPLIT, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
+        col3_tile<T, A, TR, TW, SPLIT, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
     }
 }
 

@@ -8,13 +8,13 @@ template <bool TR, bool TW> int launch(const mifft::TileArgs* a, hipStream_t s) 
     if (tiles > 2147483647ll) return -1;
     const dim3 g((unsigned)tiles), b(512);
     if (a->split && a->split_out)
-        hipLaunchKernelGGL((mifft::fft_col3_kernel<float, TR, TW, true, true>), g, b, 0, s, *a);
+        hipLaunchKernelGGL((mifft::fft_col3_kernel<float, 4, TR, TW, true, true>), g, b, 0, s, *a);
     else if (a->split)
-        hipLaunchKernelGGL((mifft::fft_col3_kernel<float, TR, TW, true, false>), g, b, 0, s, *a);
+        hipLaunchKernelGGL((mifft::fft_col3_kernel<float, 4, TR, TW, true, false>), g, b, 0, s, *a);
     else if (a->split_out)
-        hipLaunchKernelGGL((mifft::fft_col3_kernel<float, TR, TW, false, true>), g, b, 0, s, *a);
+        hipLaunchKernelGGL((mifft::fft_col3_kernel<float, 4, TR, TW, false, true>), g, b, 0, s, *a);
     else
-        hipLaunchKernelGGL((mifft::fft_col3_kernel<float, TR, TW, false, false>), g, b, 0, s, *a);
+        hipLaunchKernelGGL((mifft::fft_col3_kernel<float, 4, TR, TW, false, false>), g, b, 0, s, *a);
     return (int)hipGetLastError();
 }
 }  // namespace

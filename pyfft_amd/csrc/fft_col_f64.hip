@@ -2,11 +2,15 @@
 #include "mifft_internal.h"
 extern "C" int mifft_col2_f64_eligible(int L, int tr, const mifft::TileArgs* a);
 extern "C" int mifft_col2_f64_launch(int L, int tr, const mifft::TileArgs* a, hipStream_t s);
+// the 512-thread two-phase kernel for L = 1024 (fft_col3_f64.hip)
+extern "C" int mifft_col3_f64_eligible(int L, int tr, const mifft::TileArgs* a);
+extern "C" int mifft_col3_f64_launch(int tr, const mifft::TileArgs* a, hipStream_t s);
 
 // variant 0: library default (two-phase kernel for L = 256 when eligible); variant 1: always the generic tile kernel
 extern "C" int mifft_dispatch_col_f64(int L, int tr, int variant, const mifft::TileArgs* a, hipStream_t s, int query_only) {
     if (variant != 0 && variant != 1) return -2;
     if (variant == 0 && !query_only && mifft_col2_f64_eligible(L, tr, a)) return mifft_col2_f64_launch(L, tr, a, s);
+    if (variant == 0 && !query_only && mifft_col3_f64_eligible(L, tr, a)) return mifft_col3_f64_launch(tr, a, s);
     switch (L) {
         MIFFT_COL_CASE(double, 2, 1024, 256, 2)
         MIFFT_COL_CASE(double, 4, 512, 256, 4)
