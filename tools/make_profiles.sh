@@ -1,12 +1,14 @@
 #!/bin/bash
 # Regenerates the round's evidence under profiles/ ON THE GPU BOX (run through gpurun from the repo root):
 #     gpurun --timeout 3000 -- 'bash tools/make_profiles.sh r02'
-# Everything is written to gpurun_out/<tag>/ first (scratch, merged back by gpurun) and the summaries that are judged are
-# copied to profiles/<tag>_*.  rocprofv3 gets the program directly after `--` (no env/bash hop), counters in their own runs.
+# Everything is written to gpurun_out/<tag>/ (scratch, merged back by gpurun); the summaries that are judged are gathered in
+# gpurun_out/<tag>/to_profiles/ under their final names -- back in the build container:
+#     cp gpurun_out/r02/to_profiles/* profiles/  rocprofv3 gets the program directly after `--` (no env/bash hop), counters in their own runs.
 set -u
 TAG=${1:-r02}
 OUT=gpurun_out/$TAG
-mkdir -p $OUT profiles
+mkdir -p $OUT/to_profiles profiles
+P=$OUT/to_profiles
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 
 # 1. the bench lines: default line (c2) and every other BASELINE configuration
@@ -14,19 +16,20 @@ timeout 600 python3 bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
 for c in c1 c3 c4 c4s c5; do
     timeout 600 python3 bench.py --config $c --steps 10 --warmup 2 > $OUT/bench_$c.json 2> $OUT/bench_$c.err
 done
-for c in c1 c2 c3 c4 c4s c5; do cp $OUT/bench_$c.json profiles/${TAG}_bench_$c.json; done
+for c in c1 c2 c3 c4 c4s c5; do cp $OUT/bench_$c.json $P/${TAG}_bench_$c.json; done
 
 # 2. kernel stats + PMC traffic of the same command, per configuration (writes profiles/traffic_<c>.json and
 #    profiles/<tag>_<c>_kernel_stats.csv)
 timeout 2400 python3 tools/pmc_traffic.py --tag $TAG c2 c3 c4 c4s c5 > $OUT/pmc_traffic.log 2>&1
-cp $OUT/pmc_traffic.log profiles/${TAG}_pmc_traffic.log
+cp $OUT/pmc_traffic.log $P/${TAG}_pmc_traffic.log
+cp profiles/traffic_*.json profiles/${TAG}_*_kernel_stats.csv $P/ 2>/dev/null
 
 # 3. the reference's published shapes (test/test_performance.py method) and the vendor yardstick (cuda/test.cu counterpart)
-timeout 900 python3 tools/perf_table.py > $OUT/perf_table.log 2>&1 && cp $OUT/perf_table.log profiles/${TAG}_perf_table_reference_shapes.log
-[ -x tools/rocfft_compare ] && timeout 600 ./tools/rocfft_compare > $OUT/rocfft.log 2>&1 && cp $OUT/rocfft.log profiles/${TAG}_rocfft_comparator.log
+timeout 900 python3 tools/perf_table.py > $OUT/perf_table.log 2>&1 && cp $OUT/perf_table.log $P/${TAG}_perf_table_reference_shapes.log
+[ -x tools/rocfft_compare ] && timeout 600 ./tools/rocfft_compare > $OUT/rocfft.log 2>&1 && cp $OUT/rocfft.log $P/${TAG}_rocfft_comparator.log
 
 # 4. memory-system ceilings and the XCD probes behind DESIGN.md section 4
-[ -x tools/membench ] && timeout 300 ./tools/membench > $OUT/membench.log 2>&1 && cp $OUT/membench.log profiles/${TAG}_fabric_ceiling_membench.log
-[ -x tools/xcd_probe ] && timeout 300 ./tools/xcd_probe > $OUT/xcd_probe.log 2>&1 && cp $OUT/xcd_probe.log profiles/${TAG}_xcd_probe.log
-timeout 600 python3 tools/xcd2_probe.py 512 5 > $OUT/xcd2_probe.log 2>&1 && cp $OUT/xcd2_probe.log profiles/${TAG}_xcd2_strategy_trace.log
+[ -x tools/membench ] && timeout 300 ./tools/membench > $OUT/membench.log 2>&1 && cp $OUT/membench.log $P/${TAG}_fabric_ceiling_membench.log
+[ -x tools/xcd_probe ] && timeout 300 ./tools/xcd_probe > $OUT/xcd_probe.log 2>&1 && cp $OUT/xcd_probe.log $P/${TAG}_xcd_probe.log
+timeout 600 python3 tools/xcd2_probe.py 512 5 > $OUT/xcd2_probe.log 2>&1 && cp $OUT/xcd2_probe.log $P/${TAG}_xcd2_strategy_trace.log
 echo done
