@@ -249,6 +249,34 @@ int mifft_launch_fused2(const mifft_pass *p0, const mifft_pass *p1, const void *
 int mifft_launch_xcd2(const mifft_pass *p0, const mifft_pass *p1, const void *in0, const void *in1, void *out0,
                       void *out1, void *scratch, void *control, int32_t flags, mifft_stream_t stream);
 
+/*
+ * ---- extensions the reference lists as TODO (TODO.txt:6-8): tiles of a bigger array, sizes that are not powers of two ----
+ * Both are built from the power-of-two plans plus two streaming helpers (pyfft_amd/generic.py):
+ *   mifft_aux_copy      general strided complex copy over an index space of up to 6 dimensions (dims[0] fastest): gathers the
+ *                       tiles of a parent array, or the lines of one axis, into dense rows and scatters them back.  Element
+ *                       = one complex number of `precision`; either side may be two scalar planes.  Optional, in this order:
+ *                       zero fill for dims[0] indices >= src_valid0 (0 = no padding), conjugation of the input, a complex
+ *                       multiplier mult[i0] (device table of dims[0] entries; the chirp of Bluestein's algorithm), a real
+ *                       scale, conjugation of the output.  Strides are in elements.
+ *   mifft_aux_mul_rows  a[r][j] *= b[j] for `rows` dense rows of n complex numbers (interleaved).
+ */
+typedef struct mifft_copy {
+    int32_t precision;          /* MIFFT_F32 | MIFFT_F64 */
+    int32_t ndim;               /* 1 .. 6 */
+    int64_t dims[6];
+    int64_t src_stride[6];
+    int64_t dst_stride[6];
+    int64_t src_valid0;         /* source extent along dims[0]; larger indices read as zero (0: all valid) */
+    int32_t src_split;          /* source is two scalar planes (src0 = re, src1 = im) */
+    int32_t dst_split;
+    int32_t conj_in;
+    int32_t conj_out;
+    const void *mult;           /* device: dims[0] complex multipliers, or NULL */
+    double  scale;
+} mifft_copy;
+int mifft_aux_copy(const mifft_copy *copy, const void *src0, const void *src1, void *dst0, void *dst1, mifft_stream_t stream);
+int mifft_aux_mul_rows(int32_t precision, void *a, const void *b, int64_t rows, int64_t n, mifft_stream_t stream);
+
 /* Same as mifft_launch_chain but brackets the chain with two events on `stream` and, after
  * synchronising, reports the elapsed device time of `repeats` back-to-back chains. (bench/test helper) */
 int mifft_time_chain(const mifft_pass *passes, int32_t npasses, void *const bufs0[3], void *const bufs1[3],

@@ -57,6 +57,24 @@ class MifftPass(ctypes.Structure):
     ]
 
 
+class MifftCopy(ctypes.Structure):
+    """struct mifft_copy (include/mifft.h)."""
+    _fields_ = [
+        ("precision", ctypes.c_int32),
+        ("ndim", ctypes.c_int32),
+        ("dims", ctypes.c_int64 * 6),
+        ("src_stride", ctypes.c_int64 * 6),
+        ("dst_stride", ctypes.c_int64 * 6),
+        ("src_valid0", ctypes.c_int64),
+        ("src_split", ctypes.c_int32),
+        ("dst_split", ctypes.c_int32),
+        ("conj_in", ctypes.c_int32),
+        ("conj_out", ctypes.c_int32),
+        ("mult", ctypes.c_void_p),
+        ("scale", ctypes.c_double),
+    ]
+
+
 class MifftDeviceProps(ctypes.Structure):
     """struct mifft_device_props (include/mifft.h)."""
     _fields_ = [
@@ -118,6 +136,8 @@ PROTOTYPES = {
                                                       ctypes.c_int64, _vp, _vpp, _i32, _vpp]),
     "mifft_launch_fused2": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "mifft_launch_xcd2": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "mifft_aux_copy": (ctypes.c_int, [ctypes.POINTER(MifftCopy), _vp, _vp, _vp, _vp, _vp]),
+    "mifft_aux_mul_rows": (ctypes.c_int, [_i32, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp]),
     "mifft_time_chain": (ctypes.c_int, [_pass_p, _i32, _vpp, _vpp, _vp, _i32, ctypes.POINTER(ctypes.c_float)]),
 }
 

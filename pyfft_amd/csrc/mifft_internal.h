@@ -1,6 +1,7 @@
 // Internal glue between the C-ABI runtime (mifft_runtime.cpp) and the per-precision kernel tables.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "../../include/mifft.h"
 #include "fft_tile.hpp"
 #include "fft_fused2.hpp"
 #include "fft_xcd2.hpp"
@@ -21,6 +22,8 @@ int mifft_nd2_f32_launch(int x, int y, int z, const mifft::TileArgs* a, hipStrea
 int mifft_nd2_f64_supported(int x, int y, int z);
 int mifft_nd2_f64_launch(int x, int y, int z, const mifft::TileArgs* a, hipStream_t s);
 int mifft_fused2_f32_launch(int L0, int L1, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
+int mifft_aux_copy_launch(const struct mifft_copy* c, const void* s0, const void* s1, void* d0, void* d1, hipStream_t s);
+int mifft_aux_mul_rows_launch(int f64, void* a, const void* b, long long rows, long long n, hipStream_t s);
 int mifft_wave_supported(int f64, int N);
 int mifft_wave_launch(int f64, int N, const mifft::WaveArgs* a, int max_blocks, hipStream_t s);
 int mifft_wave_16x16_launch(const mifft::WaveArgs* a, int max_blocks, hipStream_t s);

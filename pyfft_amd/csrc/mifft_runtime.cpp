@@ -566,6 +566,24 @@ int mifft_launch_chain_pipelined(const mifft_pass* passes, int32_t npasses, void
     return 0;
 }
 
+int mifft_aux_copy(const mifft_copy* c, const void* src0, const void* src1, void* dst0, void* dst1, mifft_stream_t stream) {
+    if (!c || c->ndim < 1 || c->ndim > 6) return set_err(MIFFT_E_INVALID, "aux_copy: bad descriptor");
+    if (c->precision != MIFFT_F32 && c->precision != MIFFT_F64) return set_err(MIFFT_E_INVALID, "aux_copy: bad precision");
+    for (int d = 0; d < c->ndim; ++d)
+        if (c->dims[d] < 1) return set_err(MIFFT_E_INVALID, "aux_copy: dims[%d] = %lld", d, (long long)c->dims[d]);
+    if (!src0 || !dst0 || (c->src_split && !src1) || (c->dst_split && !dst1)) return set_err(MIFFT_E_INVALID, "aux_copy: null buffer");
+    const int rc = mifft_aux_copy_launch(c, src0, src1, dst0, dst1, (hipStream_t)stream);
+    if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
+    return 0;
+}
+
+int mifft_aux_mul_rows(int32_t precision, void* a, const void* b, int64_t rows, int64_t n, mifft_stream_t stream) {
+    if (!a || !b || rows < 0 || n < 1) return set_err(MIFFT_E_INVALID, "aux_mul_rows: bad arguments");
+    const int rc = mifft_aux_mul_rows_launch(precision == MIFFT_F64, a, b, rows, n, (hipStream_t)stream);
+    if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
+    return 0;
+}
+
 int mifft_time_chain(const mifft_pass* passes, int32_t npasses, void* const bufs0[3], void* const bufs1[3], mifft_stream_t stream,
                      int32_t repeats, float* ms_total) {
     if (!ms_total || repeats < 1) return set_err(MIFFT_E_INVALID, "bad timing arguments");

@@ -1,0 +1,280 @@
+"""GenericFFTPlan: the two extensions the reference lists as TODO and never had (TODO.txt:6-8, doc/source/index.rst:231):
+
+  * "2D/3D tiled batch support (... to transform several tiles of big 2D/3D array in one pass)":
+        Plan(tile_shape, parent_shape=parent)   transforms every non-overlapping tile of `parent`
+  * "support for non-power-of-2 sized arrays":
+        Plan(shape, any_size=True)              any axis length >= 1 (Bluestein's algorithm per such axis)
+
+Both are OPT-IN keyword arguments: without them `Plan()` behaves exactly like the reference (a size that is not a power of
+two is a ValueError, plan.py:23-24).  Neither is a hot path: they are built from the power-of-two plans (plan.py) plus two
+streaming helper kernels of the C ABI (`mifft_aux_copy`, `mifft_aux_mul_rows`):
+
+    gather   user buffers (interleaved or split planes, dense or tiles of a parent array) -> dense interleaved work array
+    per axis  * power of two: the lines of the axis gathered into dense rows, one batched ROW plan, scattered back
+                (the contiguous axis runs in place on the work array)
+              * any other length n: Bluestein -- rows a[j] = x[j] * c[j] zero-padded to m = 2^k >= 2n - 1 with the chirp
+                c[j] = exp(-i pi j^2 / n), A = FFT_m(a), A *= FFT_m(b) (b = conj chirp, wrapped; computed once on the
+                host in float64), y = IFFT_m(A), X[k] = y[k] * c[k]
+    scatter  work array -> user output, with the plan's scale rule (kernel.py:23-37) and the conjugation trick for the
+             inverse transform
+
+Cost: two streaming passes around every axis (six to ten HBM round trips per non-power-of-two axis); results match
+numpy.fft within the tolerances stated in tests/test_round2_gpu.py.
+"""
+
+import ctypes
+
+import numpy
+
+from . import _native as N
+from .plan import FFTPlan, normalize_shape
+
+
+def _is_pow2(n):
+    return n >= 1 and (n & (n - 1)) == 0
+
+
+def _chirp(n, complex_dtype):
+    """c[j] = exp(-i*pi*j^2/n), j < n, with the phase reduced exactly (j^2 mod 2n) and evaluated in float64"""
+    j = numpy.arange(n, dtype=numpy.int64)
+    ph = (j * j) % (2 * n)
+    ang = -numpy.pi * ph.astype(numpy.float64) / float(n)
+    return (numpy.cos(ang) + 1j * numpy.sin(ang))
+
+
+class _Axis(object):
+    __slots__ = ("n", "m", "plan", "chirp", "bhat", "pow2")
+
+
+class _SubContext(object):
+    """What the inner power-of-two plans see: the outer plan's context with the stream choice frozen (the outer execute()
+    has already picked the stream of this call; an inner plan must not pick another one)."""
+
+    def __init__(self, ctx):
+        self._ctx = ctx
+        self.compute_units = ctx.compute_units
+        self.allocate = ctx.allocate
+        self.allocate_raw = ctx.allocate_raw
+        self.upload = ctx.upload
+        self.pointer_of = ctx.pointer_of
+
+    def createQueue(self, buffers=()):
+        pass
+
+    def stream_handle(self):
+        return self._ctx.stream_handle()
+
+    def wait(self):
+        self._ctx.wait()
+
+    def flush(self):
+        pass
+
+    def getQueue(self):
+        return self._ctx.getQueue()
+
+
+class GenericFFTPlan(object):
+    """Same call interface as FFTPlan (execute bound by layout, normalize / scale, wait_for_finish, batch)."""
+
+    def __init__(self, context, shape, dtype=numpy.complex64, normalize=True, wait_for_finish=None, fast_math=True,
+                 scale=1.0, parent_shape=None, any_size=False):
+        self._dim, xyz = normalize_shape(shape)
+        for v in xyz:
+            if not isinstance(v, (int, numpy.integer)) or isinstance(v, bool) or v < 1:
+                raise ValueError("Wrong shape")
+        self._xyz = tuple(int(v) for v in xyz)
+        if not any_size and not all(_is_pow2(v) for v in self._xyz):
+            raise ValueError("Array dimensions must be powers of two")
+        self._size = self._xyz[0] * self._xyz[1] * self._xyz[2]
+        if self._size < 2:
+            raise ValueError("Array must have at least two elements")
+        try:
+            dt = numpy.dtype(dtype)
+        except TypeError:
+            raise ValueError("Data type " + str(dtype) + " is not supported")
+        if dt in (numpy.dtype(numpy.complex64), numpy.dtype(numpy.float32)):
+            self._precision, self._cdtype = N.F32, numpy.dtype(numpy.complex64)
+        elif dt in (numpy.dtype(numpy.complex128), numpy.dtype(numpy.float64)):
+            self._precision, self._cdtype = N.F64, numpy.dtype(numpy.complex128)
+        else:
+            raise ValueError("Data type " + str(dtype) + " is not supported")
+        self._split = dt.kind == "f"
+        self._context = context
+        self._normalize = normalize
+        self._scale = float(scale)
+        self._wait_for_finish = wait_for_finish
+
+        # tiles of a parent array: parent dims (x, y, z) must be multiples of the tile's
+        if parent_shape is not None:
+            pdim, pxyz = normalize_shape(parent_shape)
+            if pdim != self._dim:
+                raise ValueError("parent_shape must have as many axes as the tile shape")
+            self._parent = tuple(int(v) for v in pxyz)
+            for p, t in zip(self._parent, self._xyz):
+                if p < t or p % t:
+                    raise ValueError("every parent axis must be a multiple of the tile axis")
+            self._counts = tuple(p // t for p, t in zip(self._parent, self._xyz))
+        else:
+            self._parent = self._xyz
+            self._counts = (1, 1, 1)
+        self._ntiles = self._counts[0] * self._counts[1] * self._counts[2]
+
+        # one batched 1-D power-of-two plan per distinct row length; they share this plan's context (= stream)
+        self._sub = _SubContext(context)
+        self._rowplans = {}
+        # every axis a power of two (tiles of a parent array): ONE N-D plan on the dense work array
+        self._ndplan = None
+        if all(_is_pow2(v) for v in self._xyz):
+            self._ndplan = FFTPlan(self._sub, shape, dtype=self._cdtype, normalize=True, wait_for_finish=False)
+        self._tables = []
+        self._axes = []
+        for n in self._xyz:
+            ax = _Axis()
+            ax.n = n
+            ax.pow2 = _is_pow2(n)
+            ax.m = n if ax.pow2 else 1 << int(numpy.ceil(numpy.log2(2 * n - 1)))
+            ax.plan = self._rowplan(ax.m) if ax.m > 1 else None
+            ax.chirp = ax.bhat = None
+            if not ax.pow2:
+                c = _chirp(n, self._cdtype)
+                b = numpy.zeros(ax.m, numpy.complex128)
+                b[:n] = numpy.conj(c)
+                b[ax.m - n + 1:] = numpy.conj(c[1:][::-1])
+                ax.chirp = self._upload(c.astype(self._cdtype))
+                ax.bhat = self._upload(numpy.fft.fft(b).astype(self._cdtype))
+            self._axes.append(ax)
+        self._work = None
+        self._rows = None
+        self._last_batch = 0
+        if self._split:
+            self.execute = self._executeSplit
+        else:
+            self.execute = self._executeInterleaved
+
+    # ------------------------------------------------------------------------------------------------
+    def _rowplan(self, m):
+        if m not in self._rowplans:
+            self._rowplans[m] = FFTPlan(self._sub, (m,), dtype=self._cdtype, normalize=True, wait_for_finish=False)
+        return self._rowplans[m]
+
+    def _upload(self, host):
+        host = numpy.ascontiguousarray(host)
+        mem = self._context.allocate_raw(host.nbytes)
+        self._context.upload(mem, host)
+        self._tables.append(mem)
+        return self._context.pointer_of(mem)
+
+    def _copy(self, dims, sstride, dstride, src0, src1, dst0, dst1, src_valid0=0, conj_in=False, conj_out=False, mult=None,
+              scale=1.0, src_split=False, dst_split=False):
+        c = N.MifftCopy()
+        c.precision = self._precision
+        c.ndim = len(dims)
+        for i, (d, s, t) in enumerate(zip(dims, sstride, dstride)):
+            c.dims[i], c.src_stride[i], c.dst_stride[i] = int(d), int(s), int(t)
+        c.src_valid0 = int(src_valid0)
+        c.src_split, c.dst_split = int(bool(src_split)), int(bool(dst_split))
+        c.conj_in, c.conj_out = int(bool(conj_in)), int(bool(conj_out))
+        c.mult = mult
+        c.scale = float(scale)
+        N.check(N.lib.mifft_aux_copy(ctypes.byref(c), src0, src1, dst0, dst1, self._context.stream_handle()), "mifft_aux_copy")
+
+    def _user_dims_strides(self, items):
+        """index space (x, y, z, cx, cy, item*cz) of `items` parent arrays and its strides in the user's buffers / the dense
+        work array [item][cz][cy][cx][z][y][x]"""
+        tx, ty, tz = self._xyz
+        px, py, pz = self._parent
+        cx, cy, cz = self._counts
+        dims = (tx, ty, tz, cx, cy, items * cz)
+        user = (1, px, px * py, tx, ty * px, tz * px * py)
+        tile = tx * ty * tz
+        work = (1, tx, tx * ty, tile, tile * cx, tile * cx * cy)
+        return dims, user, work
+
+    def _prepare(self, batch):
+        if batch == self._last_batch:
+            return
+        self._last_batch = batch
+        isz = self._cdtype.itemsize
+        nt = batch * self._ntiles
+        self._work = self._context.allocate(nt * self._size * isz)
+        worst = max((self._size // ax.n) * ax.m for ax in self._axes)
+        self._rows = self._context.allocate(nt * worst * isz)
+
+    def _execute(self, wait_for_finish, inverse, batch, ins, outs):
+        ctx = self._context
+        batch = int(batch)
+        if batch < 1:
+            raise ValueError("batch must be positive")
+        self._prepare(batch)
+        ptr = ctx.pointer_of
+        ctx.createQueue(ins + outs)
+        nt = batch * self._ntiles
+        work, rows = ptr(self._work), ptr(self._rows)
+        in0, in1 = ptr(ins[0]), (ptr(ins[1]) if self._split else None)
+        out0, out1 = ptr(outs[0]), (ptr(outs[1]) if self._split else None)
+        inverse = bool(inverse)
+
+        # the transform is forward on conj(input), conjugated at the end, for the inverse direction
+        dims, user, dense = self._user_dims_strides(batch)
+        self._copy(dims, user, dense, in0, in1, work, None, conj_in=inverse, src_split=self._split)
+
+        inner = 1
+        if self._ndplan is not None:
+            self._ndplan.execute(work, batch=nt, wait_for_finish=False)
+        for a, ax in enumerate(self._axes):           # x, y, z
+            n, m = ax.n, ax.m
+            if n > 1 and self._ndplan is None:
+                outer = nt * self._size // (n * inner)
+                lines = (n, inner, outer)              # index space of the axis' lines in the work array
+                wstride = (inner, 1, n * inner)
+                rstride = (1, m, m * inner)            # dense rows [outer][inner][m]
+                if ax.pow2 and inner == 1:
+                    ax.plan.execute(work, batch=outer, wait_for_finish=False)
+                elif ax.pow2:
+                    self._copy(lines, wstride, rstride, work, None, rows, None)
+                    ax.plan.execute(rows, batch=outer * inner, wait_for_finish=False)
+                    self._copy(lines, rstride, wstride, rows, None, work, None)
+                else:
+                    self._copy((m, inner, outer), wstride, rstride, work, None, rows, None, src_valid0=n, mult=ax.chirp)
+                    ax.plan.execute(rows, batch=outer * inner, wait_for_finish=False)
+                    N.check(N.lib.mifft_aux_mul_rows(self._precision, rows, ax.bhat, outer * inner, m, ctx.stream_handle()),
+                            "mifft_aux_mul_rows")
+                    ax.plan.execute(rows, batch=outer * inner, inverse=True, wait_for_finish=False)   # normalised: 1/m
+                    self._copy(lines, rstride, wstride, rows, None, work, None, mult=ax.chirp)
+            inner *= n
+
+        # the scale rule of _FFTKernel.getScaleCoeffFunc (kernel.py:23-37)
+        if not inverse:
+            factor = self._scale
+        else:
+            factor = 1.0 / ((self._size if self._normalize else 1.0) * self._scale)
+        self._copy(dims, dense, user, work, None, out0, out1, conj_out=inverse, scale=factor, dst_split=self._split)
+
+        wait = self._wait_for_finish
+        if wait_for_finish is not None:
+            wait = wait_for_finish
+        if wait:
+            ctx.wait()
+        else:
+            ctx.flush()
+            return ctx.getQueue()
+
+    def finish(self):
+        self._context.wait()
+
+    def check(self):
+        pass
+
+    def _executeInterleaved(self, data_in, data_out=None, inverse=False, batch=1, wait_for_finish=None):
+        if data_out is None:
+            data_out = data_in
+        return self._execute(wait_for_finish, inverse, batch, [data_in], [data_out])
+
+    def _executeSplit(self, data_in_re, data_in_im, data_out_re=None, data_out_im=None, inverse=False, batch=1,
+                      wait_for_finish=None):
+        if data_out_re is None and data_out_im is None:
+            data_out_re, data_out_im = data_in_re, data_in_im
+        elif data_out_re is None or data_out_im is None:
+            raise ValueError("both output planes must be given")
+        return self._execute(wait_for_finish, inverse, batch, [data_in_re, data_in_im], [data_out_re, data_out_im])

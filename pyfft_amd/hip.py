@@ -337,6 +337,8 @@ def Plan(*args, **kwds):
     execute() is asynchronous by default and returns the stream.  `context`: accepted for
     signature parity (a device index or None: HIP has one primary context per device).
     `mempool`: any object with an allocate(nbytes) method returning a buffer-like object.
+    `parent_shape=`, `any_size=True`: opt-in extensions (tiles of a bigger array; sizes that are not powers of two), see
+    pyfft_amd/generic.py.  Without them a size that is not a power of two is a ValueError, as in the reference.
     `fast_math`: accepted for signature parity and ignored -- the reference passes -use_fast_math to nvcc for its on-device
     sincos (cuda.py:56-57); here twiddles come from float64-evaluated tables, so there is nothing to relax (results meet the
     reference's thresholds either way).
@@ -344,9 +346,14 @@ def Plan(*args, **kwds):
     mempool = kwds.pop('mempool', None)
     context_obj = kwds.pop('context', None)
     stream_obj = kwds.pop('stream', None)
+    # opt-in extensions the reference lists as TODO (TODO.txt:6-8; pyfft_amd/generic.py): tiles of a parent array, any size
+    parent_shape = kwds.pop('parent_shape', None)
+    any_size = bool(kwds.pop('any_size', False))
+    generic = parent_shape is not None or any_size
 
     # argument errors first (ValueError, as in the reference), then the device
-    FFTPlan.validate(*args, **kwds)
+    if not generic:
+        FFTPlan.validate(*args, **kwds)
     if device_count() < 1:
         raise RuntimeError("pyfft_amd: no HIP device visible (there is no CPU fallback)")
 
@@ -366,5 +373,11 @@ def Plan(*args, **kwds):
     if 'wait_for_finish' not in kwds or kwds['wait_for_finish'] is None:
         kwds['wait_for_finish'] = wait_for_finish
 
+    if generic:
+        from .generic import GenericFFTPlan
+        if device_count() < 1:
+            raise RuntimeError("pyfft_amd: no HIP device visible (there is no CPU fallback)")
+        context = Context(device, stream_obj, mempool)
+        return GenericFFTPlan(context, *args, parent_shape=parent_shape, any_size=any_size, **kwds)
     context = Context(device, stream_obj, mempool)
     return FFTPlan(context, *args, **kwds)

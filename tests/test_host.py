@@ -247,3 +247,41 @@ def test_integration_stub_matches_the_bindings():
     import ctypes
     got = [(name, getattr(ctypes, ct)) for name, ct in fields]      # (c_int32 is an alias of c_int: compare the types)
     assert got == list(N.MifftPass._fields_)
+
+
+def test_bluestein_tables_reproduce_the_dft_on_the_host():
+    """pyfft_amd/generic.py's chirp and filter tables, pushed through numpy FFTs the way the plan pushes them through the
+    power-of-two kernels, give the DFT of any length (the device only adds rounding)."""
+    from pyfft_amd import generic
+    rng = numpy.random.default_rng(5)
+    for n in (3, 5, 12, 100, 1023):
+        m = 1 << int(numpy.ceil(numpy.log2(2 * n - 1)))
+        c = generic._chirp(n, numpy.complex128)
+        assert numpy.allclose(c, numpy.exp(-1j * numpy.pi * (numpy.arange(n) ** 2 % (2 * n)) / n), atol=1e-15)
+        b = numpy.zeros(m, numpy.complex128)
+        b[:n] = numpy.conj(c)
+        b[m - n + 1:] = numpy.conj(c[1:][::-1])
+        x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        a = numpy.zeros(m, numpy.complex128)
+        a[:n] = x * c
+        y = numpy.fft.ifft(numpy.fft.fft(a) * numpy.fft.fft(b))
+        assert numpy.allclose(y[:n] * c, numpy.fft.fft(x), rtol=0, atol=1e-10 * numpy.abs(x).sum())
+
+
+def test_generic_plan_index_spaces():
+    """The gather / scatter index space of a tiled batch addresses every element of the parent arrays exactly once."""
+    from pyfft_amd.generic import GenericFFTPlan
+    plan = GenericFFTPlan.__new__(GenericFFTPlan)
+    plan._xyz, plan._parent, plan._counts = (4, 2, 2), (8, 6, 4), (2, 3, 2)
+    dims, user, work = plan._user_dims_strides(3)
+    idx = numpy.indices(dims[::-1]).reshape(6, -1)[::-1]          # idx[d] = index along dims[d]
+    uoff = sum(i * s for i, s in zip(idx, user))
+    woff = sum(i * s for i, s in zip(idx, work))
+    total = 3 * 8 * 6 * 4
+    assert sorted(uoff.tolist()) == list(range(total)) and sorted(woff.tolist()) == list(range(total))
+    # a work-array tile is one dense (z, y, x) block of the parent
+    par = numpy.arange(total).reshape(3, 4, 6, 8)
+    w = numpy.empty(total, numpy.int64)
+    w[woff] = par.ravel()[uoff]
+    tiles = w.reshape(3 * 2, 3, 2, 2, 2, 4)                      # [item*cz][cy][cx][z][y][x]
+    assert numpy.array_equal(tiles[1 * 2 + 1, 2, 1], par[1, 2:4, 4:6, 4:8])
