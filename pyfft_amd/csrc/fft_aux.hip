@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include "../../include/mifft.h"
 #include "fft_butterfly.hpp"
+#include <cstdint>
 
 namespace {
 
@@ -53,6 +54,30 @@ template <typename T> __global__ void __launch_bounds__(256) aux_copy_kernel(con
     }
 }
 
+// Dense-run form: both sides contiguous along dims[0] (stride 1), interleaved, no multiplier and no padding -- the tile
+// gather / scatter.  One thread moves V consecutive elements (16 bytes for fp32) and the index arithmetic is 32-bit.
+template <typename T, int V> __global__ void __launch_bounds__(256) aux_copy_runs_kernel(const CopyArgs a, unsigned d0v, unsigned totalv) {
+    using C = mifft::cplx<T>;
+    typedef T VT __attribute__((ext_vector_type(2 * V)));
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned id = blockIdx.x * blockDim.x + threadIdx.x; id < totalv; id += stride) {
+        unsigned rest = id / d0v;
+        const unsigned i0 = (id - rest * d0v) * V;
+        long long so = i0, dof = i0;
+        for (int d = 1; d < a.ndim; ++d) {
+            const unsigned dim = (unsigned)a.dims[d];
+            const unsigned q = rest / dim, i = rest - q * dim;
+            rest = q;
+            so += (long long)i * a.ss[d];
+            dof += (long long)i * a.ds[d];
+        }
+        VT v = *reinterpret_cast<const VT*>(reinterpret_cast<const C*>(a.s0) + so);
+        const T sc = (T)a.scale;
+        for (int k = 0; k < 2 * V; ++k) v[k] *= ((k & 1) && (a.conj_in != a.conj_out)) ? -sc : sc;
+        *reinterpret_cast<VT*>(reinterpret_cast<C*>(a.d0) + dof) = v;
+    }
+}
+
 template <typename T> __global__ void __launch_bounds__(256) aux_mul_rows_kernel(mifft::cplx<T>* a, const mifft::cplx<T>* b, long long total, long long n) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += stride)
@@ -84,6 +109,18 @@ extern "C" int mifft_aux_copy_launch(const mifft_copy* c, const void* s0, const 
     a.conj_in = c->conj_in; a.conj_out = c->conj_out;
     a.scale = c->scale;
     if (a.total <= 0) return 0;
+    // dense runs along dims[0] on both sides: the vector form (every offset then is a multiple of V elements)
+    const int V = c->precision == MIFFT_F64 ? 1 : 2;
+    bool runs = !c->src_split && !c->dst_split && !c->mult && a.src_valid0 >= a.dims[0] && a.ss[0] == 1 && a.ds[0] == 1 &&
+                a.dims[0] % V == 0 && a.total / V < 0x7fffffffll &&
+                (((uintptr_t)s0 | (uintptr_t)d0) & 15) == 0;
+    for (int d = 1; d < a.ndim && runs; ++d) runs = a.ss[d] % V == 0 && a.ds[d] % V == 0 && a.dims[d] < 0x7fffffffll;
+    if (runs) {
+        const unsigned d0v = (unsigned)(a.dims[0] / V), totalv = (unsigned)(a.total / V);
+        if (c->precision == MIFFT_F64) hipLaunchKernelGGL((aux_copy_runs_kernel<double, 1>), dim3(grid_for(totalv)), dim3(256), 0, s, a, d0v, totalv);
+        else hipLaunchKernelGGL((aux_copy_runs_kernel<float, 2>), dim3(grid_for(totalv)), dim3(256), 0, s, a, d0v, totalv);
+        return (int)hipGetLastError();
+    }
     if (c->precision == MIFFT_F64) hipLaunchKernelGGL(aux_copy_kernel<double>, dim3(grid_for(a.total)), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(aux_copy_kernel<float>, dim3(grid_for(a.total)), dim3(256), 0, s, a);
     return (int)hipGetLastError();
