@@ -475,6 +475,21 @@ class FFTPlan(object):
         return self._execute(wait_for_finish, is_inplace, inverse, batch,
                              data_in_re, data_in_im, data_out_re, data_out_im)
 
+    def close(self):
+        """Wait for outstanding work and release the plan's device resources now (temp buffer, counters, scratch, side
+        streams and events) instead of at garbage collection.  The plan stays usable: everything is re-created on demand."""
+        try:
+            self.finish()
+        finally:
+            self._tempmemobj = None
+            self._counters = None
+            self._xcd2_scratch = None
+            self._side_streams = None
+            self._side_events = None
+            self._mailbox = None
+            self._last_batch_size = 0
+            self._last_call_key = None
+
     # ------------------------------------------------------------------------------------
     # introspection helpers used by bench.py / tests (not part of the reference API)
     def pass_list(self):
