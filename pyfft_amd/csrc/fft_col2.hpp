@@ -30,6 +30,35 @@ template <int A, int E, typename T> __device__ __forceinline__ cplx<T> mul_w16A(
         return mul_w32<E, T>(v);  // A == 2: w(32)
 }
 
+// The 15 table twiddles s^k of a first stage, s = w(L)^i0: four look-ups (k = 1, 2, 4, 8) plus products of at most three of
+// them, the high ones formed on demand (saves ~14 VGPRs against 15 look-ups held across the stage).  `step` = table entries per
+// unit of i0 (1 when the table is w(L') of the sub-transform, 2 when it is w(2L')).  Shared by fft_col3.hpp and fft_xcd2.hpp;
+// col2_tile below spells the same arithmetic out in place.
+template <typename T> struct ColStageTw {
+    cplx<T> s1, s2, s3, s4, s5, s6, s7, s8;
+    __device__ __forceinline__ void init(const cplx<T>* twL, int i0, int step = 1) {
+        s1 = twL[step * i0]; s2 = twL[2 * step * i0]; s4 = twL[4 * step * i0]; s8 = twL[8 * step * i0];
+        s3 = cmul<T>(s1, s2); s5 = cmul<T>(s4, s1); s6 = cmul<T>(s4, s2); s7 = cmul<T>(s4, s3);
+    }
+    template <int k> __device__ __forceinline__ cplx<T> get() const {
+        if constexpr (k == 1) return s1;
+        else if constexpr (k == 2) return s2;
+        else if constexpr (k == 3) return s3;
+        else if constexpr (k == 4) return s4;
+        else if constexpr (k == 5) return s5;
+        else if constexpr (k == 6) return s6;
+        else if constexpr (k == 7) return s7;
+        else if constexpr (k == 8) return s8;
+        else if constexpr (k == 9) return cmul<T>(s8, s1);
+        else if constexpr (k == 10) return cmul<T>(s8, s2);
+        else if constexpr (k == 11) return cmul<T>(s8, s3);
+        else if constexpr (k == 12) return cmul<T>(s8, s4);
+        else if constexpr (k == 13) return cmul<T>(s8, s5);
+        else if constexpr (k == 14) return cmul<T>(s8, s6);
+        else return cmul<T>(s8, s7);
+    }
+};
+
 // ESZ = bytes per complex element.  L = 1024 in fp32 double-buffers the exchange (2 x 34 KiB: its 250-VGPR kernel fits two
 // work-groups per CU either way); L = 512 reuses one 34 KiB buffer with one more barrier per round, so that FOUR
 // work-groups share a CU (108 VGPRs; pipelined N = 2^18: 36.5 -> 38 %); 16-byte points reuse one 68 KiB buffer (two per CU).

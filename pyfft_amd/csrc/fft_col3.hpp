@@ -100,26 +100,8 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
 
     // ---- stage 1 (radix-16 over b1) and stage 2 (radix-A over a) of the L'-point half: w(L')^j = w(L)^(2j)
     {
-        const cplx<T> s1 = twL[2 * b0], s2 = twL[4 * b0], s4 = twL[8 * b0], s8 = twL[16 * b0];
-        const cplx<T> s3 = cmul<T>(s1, s2), s5 = cmul<T>(s4, s1), s6 = cmul<T>(s4, s2), s7 = cmul<T>(s4, s3);
-        auto tw = [&](auto kk) -> cplx<T> {
-            constexpr int k = kk;
-            if constexpr (k == 1) return s1;
-            else if constexpr (k == 2) return s2;
-            else if constexpr (k == 3) return s3;
-            else if constexpr (k == 4) return s4;
-            else if constexpr (k == 5) return s5;
-            else if constexpr (k == 6) return s6;
-            else if constexpr (k == 7) return s7;
-            else if constexpr (k == 8) return s8;
-            else if constexpr (k == 9) return cmul<T>(s8, s1);
-            else if constexpr (k == 10) return cmul<T>(s8, s2);
-            else if constexpr (k == 11) return cmul<T>(s8, s3);
-            else if constexpr (k == 12) return cmul<T>(s8, s4);
-            else if constexpr (k == 13) return cmul<T>(s8, s5);
-            else if constexpr (k == 14) return cmul<T>(s8, s6);
-            else return cmul<T>(s8, s7);
-        };
+        ColStageTw<T> tw;
+        tw.init(twL, b0, 2);          // s = w(L')^b0 = w(L)^(2*b0)
         static_for<A>([&](auto aa) {
             constexpr int ia = aa;
             Dft<16, T>::run(v + ia * 16);
@@ -127,7 +109,7 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
                 constexpr int qb1 = q2 + 1;
                 cplx<T> t = v[ia * 16 + qb1];
                 if constexpr (ia > 0) t = mul_w16A<A, ia * qb1, T>(t);
-                v[ia * 16 + qb1] = cmul<T>(t, tw(IC<qb1>{}));
+                v[ia * 16 + qb1] = cmul<T>(t, tw.template get<qb1>());
             });
             __builtin_amdgcn_sched_barrier(0);
         });

@@ -69,34 +69,8 @@ __device__ __forceinline__ bool xcd2_wait16(const unsigned* flags, unsigned idx,
     }
 }
 
-// the 15 stage-1 table twiddles s^k, s = w(L)^b0 (identical to col2_tile's)
-template <typename T> struct Xcd2Tw {
-    cplx<T> s1, s2, s3, s4, s5, s6, s7, s8;
-    __device__ __forceinline__ void init(const cplx<T>* twL, int b0) {
-        s1 = twL[b0]; s2 = twL[2 * b0]; s4 = twL[4 * b0]; s8 = twL[8 * b0];
-        s3 = cmul<T>(s1, s2); s5 = cmul<T>(s4, s1); s6 = cmul<T>(s4, s2); s7 = cmul<T>(s4, s3);
-    }
-    template <int k> __device__ __forceinline__ cplx<T> get() const {
-        if constexpr (k == 1) return s1;
-        else if constexpr (k == 2) return s2;
-        else if constexpr (k == 3) return s3;
-        else if constexpr (k == 4) return s4;
-        else if constexpr (k == 5) return s5;
-        else if constexpr (k == 6) return s6;
-        else if constexpr (k == 7) return s7;
-        else if constexpr (k == 8) return s8;
-        else if constexpr (k == 9) return cmul<T>(s8, s1);
-        else if constexpr (k == 10) return cmul<T>(s8, s2);
-        else if constexpr (k == 11) return cmul<T>(s8, s3);
-        else if constexpr (k == 12) return cmul<T>(s8, s4);
-        else if constexpr (k == 13) return cmul<T>(s8, s5);
-        else if constexpr (k == 14) return cmul<T>(s8, s6);
-        else return cmul<T>(s8, s7);
-    }
-};
-
 // stage 1 of one first-stage butterfly ia: radix-16 over b1, twiddle w(1024)^(b0*qb1) * w(64)^(ia*qb1)
-template <typename T, int ia> __device__ __forceinline__ void xcd2_stage1(cplx<T>* v, const Xcd2Tw<T>& tw) {
+template <typename T, int ia> __device__ __forceinline__ void xcd2_stage1(cplx<T>* v, const ColStageTw<T>& tw) {
     Dft<16, T>::run(v + ia * 16);
     static_for<15>([&](auto q2) {
         constexpr int qb1 = q2 + 1;
@@ -223,7 +197,7 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
             v[k].y *= csign;
         });
         {
-            Xcd2Tw<T> tw;
+            ColStageTw<T> tw;
             tw.init(twL0, hi4);
             static_for<4>([&](auto aa) { xcd2_stage1<T, aa>(v, tw); });
         }
@@ -308,7 +282,7 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
             constexpr int ia = (ROT + kk) & 3;
             // pass 1 stage 1 (thread = (c = lo4, b0 = hi4)); the table twiddles are looked up again per butterfly (L1 hits)
             // rather than held across the rounds (16 registers)
-            Xcd2Tw<T> tw1;
+            ColStageTw<T> tw1;
             tw1.init(twL1, hi4);
             xcd2_stage1<T, ia>(y, tw1);
         };
