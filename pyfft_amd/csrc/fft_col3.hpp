@@ -44,7 +44,10 @@ template <typename T, bool TR> struct Col3Lds {
     static constexpr int PITCH = TR ? 17 : 16;
     static constexpr int BUF = 16 * 16 * PITCH;   // slots per half
     static constexpr bool HALF = sizeof(T) > 4;
-    static constexpr int SCALARS = 2 * BUF * (HALF ? 1 : 2);
+    // 8-byte points double-buffer the exchange by slab parity (the work-group owns its CU anyway: 2 x 68 KiB of the 160), which
+    // drops the "previous round's reads are done" barrier; 16-byte points already take two barriers per component
+    static constexpr bool DOUBLE = !HALF;
+    static constexpr int SCALARS = 2 * BUF * (HALF ? 1 : 2) * (DOUBLE ? 2 : 1);
 };
 
 template <typename T, int A, bool TR, bool TW, bool SPLIT, bool NTIN, bool NTOUT, bool SPLIT_OUT>
@@ -155,19 +158,21 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
 
     static_for<A>([&](auto rr) {
         constexpr int qa = rr;
-        if constexpr (qa > 0) __syncthreads();   // the previous round's reads are done
+        constexpr bool kDouble = Col3Lds<T, TR>::DOUBLE;
+        if constexpr (qa > 0 && !kDouble) __syncthreads();   // the previous round's reads are done
         cplx<T> x[16];
         if constexpr (!kHalf) {
+            cplx<T>* const buf = ldsh + (kDouble ? (qa & 1) * 2 * BUF : 0);   // (the two halves of a parity are adjacent)
             static_for<16>([&](auto ss) {
                 constexpr int qb1 = ss;
-                if constexpr (TR) ldsh[(b0 * 16 + c) * PITCH + qb1] = v[qa * 16 + qb1];
-                else ldsh[(b0 * 16 + qb1) * 16 + c] = v[qa * 16 + qb1];
+                if constexpr (TR) buf[(b0 * 16 + c) * PITCH + qb1] = v[qa * 16 + qb1];
+                else buf[(b0 * 16 + qb1) * 16 + c] = v[qa * 16 + qb1];
             });
             __syncthreads();
             static_for<16>([&](auto bb) {
                 constexpr int bi = bb;
-                if constexpr (TR) x[bi] = ldsh[(bi * 16 + c2) * PITCH + u];
-                else x[bi] = ldsh[(bi * 16 + u) * 16 + c2];
+                if constexpr (TR) x[bi] = buf[(bi * 16 + c2) * PITCH + u];
+                else x[bi] = buf[(bi * 16 + u) * 16 + c2];
             });
         } else {
             static_for<2>([&](auto cc) {
