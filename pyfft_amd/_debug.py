@@ -31,6 +31,14 @@ def no_stream_hints():
     return bool(os.environ.get("PYFFT_AMD_NO_STREAM_HINTS"))
 
 
+def fused3_lag_ring(lag, ring):
+    """PYFFT_AMD_FUSED3 = lag,ring (development sweep of the 2048 x 2048 fused kernel)"""
+    v = os.environ.get("PYFFT_AMD_FUSED3")
+    if v:
+        lag, ring = (int(t) for t in v.split(","))
+    return lag, ring
+
+
 def xcd2_flags(default):
     v = os.environ.get("PYFFT_AMD_XCD2_FLAGS")
     return default if v is None else int(v)

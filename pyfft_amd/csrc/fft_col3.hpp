@@ -50,7 +50,8 @@ template <typename T, bool TR> struct Col3Lds {
     static constexpr int SCALARS = 2 * BUF * (HALF ? 1 : 2) * (DOUBLE ? 2 : 1);
 };
 
-template <typename T, int A, bool TR, bool TW, bool SPLIT, bool NTIN, bool NTOUT, bool SPLIT_OUT>
+// WT: write the result with write-through (agent-coherent) stores: the intermediate of the fused two-pass kernel (fp32 only)
+template <typename T, int A, bool TR, bool TW, bool SPLIT, bool NTIN, bool NTOUT, bool SPLIT_OUT, bool WT = false>
 __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_in, const long long o_out, const long long rem0,
                                           T* lds) {
     constexpr int L = 512 * A;          // 2 * L'
@@ -233,8 +234,15 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
             r.y = x[qb0].y * sy;
             if constexpr (!SPLIT_OUT) {
                 char* p = reinterpret_cast<char*>(reinterpret_cast<cplx<T>*>(a.out0) + gu);
-                if constexpr (NTOUT) __builtin_nontemporal_store(r, reinterpret_cast<cplx<T>*>(p + ovoff * (unsigned)sizeof(cplx<T>)));
-                else *reinterpret_cast<cplx<T>*>(p + ovoff * (unsigned)sizeof(cplx<T>)) = r;
+                if constexpr (WT) {
+                    static_assert(!WT || sizeof(cplx<T>) == 8, "write-through path is fp32 interleaved only");
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p + ovoff * (unsigned)sizeof(cplx<T>)),
+                                       __builtin_bit_cast(unsigned long long, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if constexpr (NTOUT) {
+                    __builtin_nontemporal_store(r, reinterpret_cast<cplx<T>*>(p + ovoff * (unsigned)sizeof(cplx<T>)));
+                } else {
+                    *reinterpret_cast<cplx<T>*>(p + ovoff * (unsigned)sizeof(cplx<T>)) = r;
+                }
             } else {
                 char* pr = reinterpret_cast<char*>(reinterpret_cast<T*>(a.out0) + gu);
                 char* pi = reinterpret_cast<char*>(reinterpret_cast<T*>(a.out1) + gu);

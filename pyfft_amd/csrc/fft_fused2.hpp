@@ -19,6 +19,7 @@
 // Every spin is bounded; on timeout an error word is set (the host checks it) instead of hanging the GPU.
 #pragma once
 #include "fft_col2.hpp"
+#include "fft_col3.hpp"
 
 namespace mifft {
 
@@ -132,6 +133,53 @@ __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
             // at two work-groups per CU are outside the hand-off forms MI355X_MICROARCH.md lists as validated: the fence stays)
             fused_wait_ge<true>(wdone + t, f.tiles0, err, pend);
             col2_tile<T, A1, false, false, false, false, false, NT, SPLIT>(f.p1, (long long)(t % f.ring), (long long)t, (long long)tile * 16, lds);
+            fused_signal_read(rdone + t);
+        }
+    }
+    fused_flush(pend);
+}
+
+// The same work list with the 512-thread L = 2048 tiles of fft_col3.hpp: N = 2^22 = 2048 x 2048 (BASELINE config 5).  One
+// work-group per CU; the ring holds 7 transforms of 32 MiB.
+template <typename T, bool SPLIT, bool NT>
+__global__ void __launch_bounds__(512, 2) fft_fused3_kernel(const FusedArgs f) {
+    constexpr int E0 = Col3Lds<T, true>::SCALARS, E1 = Col3Lds<T, false>::SCALARS;
+    __shared__ __attribute__((aligned(16))) T lds[E0 > E1 ? E0 : E1];
+    __shared__ unsigned s_item;
+
+    unsigned* const next = f.counters;
+    unsigned* const err = f.counters + 1;
+    unsigned* const wdone = f.counters + 2;
+    unsigned* const rdone = wdone + f.batch;
+    const unsigned gsize = 2u * (f.tiles0 > f.tiles1 ? f.tiles0 : f.tiles1);
+    const unsigned total = (f.batch + f.lag) * gsize;
+
+    FusedPending pend = {nullptr};
+    unsigned ahead = 0;
+    if (threadIdx.x == 0) ahead = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_item = ahead;
+            if (ahead < total) ahead = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const unsigned item = s_item;
+        if (item >= total) break;
+        const unsigned g = item / gsize, k = item % gsize, tile = k >> 1;
+        if ((k & 1u) == 0u) {
+            if (g >= f.batch || tile >= f.tiles0) continue;
+            const unsigned t = g;
+            if (t >= f.ring) fused_wait_ge<false>(rdone + (t - f.ring), f.tiles1, err, pend);
+            else fused_flush(pend);
+            col3_tile<T, 4, true, true, SPLIT, NT, false, false, true>(f.p0, (long long)t, (long long)(t % f.ring), (long long)tile * 16, lds);
+            pend.ctr = wdone + t;
+        } else {
+            if (g < f.lag) continue;
+            const unsigned t = g - f.lag;
+            if (t >= f.batch || tile >= f.tiles1) continue;
+            fused_wait_ge<true>(wdone + t, f.tiles0, err, pend);
+            col3_tile<T, 4, false, false, false, false, NT, SPLIT>(f.p1, (long long)(t % f.ring), (long long)t, (long long)tile * 16, lds);
             fused_signal_read(rdone + t);
         }
     }

@@ -19,6 +19,11 @@ template <int A0, int A1> int launch(const mifft::FusedArgs* f, int split, unsig
 }  // namespace
 
 extern "C" int mifft_fused2_f32_launch(int L0, int L1, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s) {
+    if (L0 == 2048 && L1 == 2048) {   // 512-thread tiles (fft_col3.hpp)
+        if (split) hipLaunchKernelGGL((mifft::fft_fused3_kernel<float, true, false>), dim3(grid), dim3(512), 0, s, *f);
+        else hipLaunchKernelGGL((mifft::fft_fused3_kernel<float, false, true>), dim3(grid), dim3(512), 0, s, *f);
+        return (int)hipGetLastError();
+    }
     const int key = (L0 / 256) * 10 + (L1 / 256);
     switch (key) {
         case 11: return launch<1, 1>(f, split, grid, s);

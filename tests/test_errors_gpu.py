@@ -221,7 +221,7 @@ def _run_strategy(ctx, monkeypatch, strat, shape, batch, data, inplace=False, in
     return b.get()
 
 
-@pytest.mark.parametrize("n,batch", [(1 << 16, 160), (1 << 17, 96), (1 << 18, 80), (1 << 19, 40), (1 << 20, 61)], ids=str)
+@pytest.mark.parametrize("n,batch", [(1 << 16, 160), (1 << 17, 96), (1 << 18, 80), (1 << 19, 40), (1 << 20, 61), (1 << 22, 17)], ids=str)
 def test_fused_two_pass_kernel(ctx, monkeypatch, n, batch):
     data = oracle.get_test_data((n,), numpy.complex64, batch, 4242)
     want = _run_strategy(ctx, monkeypatch, "chain", (n,), batch, data)
@@ -250,7 +250,7 @@ def test_pipelined_chunks(ctx, monkeypatch, shape, batch):
     assert oracle.difference(ref, got[:shape[0] * 2], 2) < 1.1e-6
 
 
-@pytest.mark.parametrize("n,batch,strat", [(1 << 16, 520, "pipelined"), (1 << 20, 61, "fused"), (1 << 18, 80, "fused")], ids=str)
+@pytest.mark.parametrize("n,batch,strat", [(1 << 16, 520, "pipelined"), (1 << 20, 61, "fused"), (1 << 18, 80, "fused"), (1 << 22, 15, "fused")], ids=str)
 def test_split_plane_strategies(ctx, monkeypatch, n, batch, strat):
     """float32 split planes through the chunked / fused strategies (the plan's temp buffer is interleaved even
     though the user buffers are planes): bit-identical to the plain chain, within tolerance of numpy."""
