@@ -50,7 +50,17 @@ template <typename T, bool TR> struct Col3Lds {
     static constexpr int SCALARS = 2 * BUF * (HALF ? 1 : 2) * (DOUBLE ? 2 : 1);
 };
 
-// WT: write the result with write-through (agent-coherent) stores: the intermediate of the fused two-pass kernel (fp32 only)
+// 16-byte agent-scope write-through store (the 8-byte form is what __hip_atomic_store(relaxed, agent) compiles to; clang has no
+// 16-byte atomic store, so the same encoding is spelled out).  The s_nop is the wait state gfx9 needs between a store of more
+// than 64 bits and a VALU write of its data registers: the compiler's hazard recogniser does not look inside inline assembly
+// (without it the first row of every pass-0 tile came out with a later value's real part in 4 lanes of 16).
+__device__ __forceinline__ void col3_store_wt16(void* p, const cplx<double>& r) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4 v = __builtin_bit_cast(u4, r);
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+}
+
+// WT: write the result with write-through (agent-coherent) stores: the intermediate of the fused two-pass kernel (interleaved)
 template <typename T, int A, bool TR, bool TW, bool SPLIT, bool NTIN, bool NTOUT, bool SPLIT_OUT, bool WT = false>
 __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_in, const long long o_out, const long long rem0,
                                           T* lds) {
@@ -235,9 +245,11 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
             if constexpr (!SPLIT_OUT) {
                 char* p = reinterpret_cast<char*>(reinterpret_cast<cplx<T>*>(a.out0) + gu);
                 if constexpr (WT) {
-                    static_assert(!WT || sizeof(cplx<T>) == 8, "write-through path is fp32 interleaved only");
-                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p + ovoff * (unsigned)sizeof(cplx<T>)),
-                                       __builtin_bit_cast(unsigned long long, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if constexpr (sizeof(cplx<T>) == 8)
+                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(p + ovoff * (unsigned)sizeof(cplx<T>)),
+                                           __builtin_bit_cast(unsigned long long, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        col3_store_wt16(p + ovoff * (unsigned)sizeof(cplx<T>), r);
                 } else if constexpr (NTOUT) {
                     __builtin_nontemporal_store(r, reinterpret_cast<cplx<T>*>(p + ovoff * (unsigned)sizeof(cplx<T>)));
                 } else {

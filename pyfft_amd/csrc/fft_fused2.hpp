@@ -139,9 +139,9 @@ __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
     fused_flush(pend);
 }
 
-// The same work list with the 512-thread L = 2048 tiles of fft_col3.hpp: N = 2^22 = 2048 x 2048 (BASELINE config 5).  One
-// work-group per CU; the ring holds 7 transforms of 32 MiB.
-template <typename T, bool SPLIT, bool NT>
+// The same work list with the 512-thread tiles of fft_col3.hpp: fp32 N = 2^22 = 2048 x 2048 (BASELINE config 5; A = 4, one
+// work-group per CU, the ring holds 7 transforms of 32 MiB) and fp64 N = 2^20 = 1024 x 1024 (A = 2, 14 transforms of 16 MiB).
+template <typename T, int A, bool SPLIT, bool NT>
 __global__ void __launch_bounds__(512, 2) fft_fused3_kernel(const FusedArgs f) {
     constexpr int E0 = Col3Lds<T, true>::SCALARS, E1 = Col3Lds<T, false>::SCALARS;
     __shared__ __attribute__((aligned(16))) T lds[E0 > E1 ? E0 : E1];
@@ -172,14 +172,14 @@ __global__ void __launch_bounds__(512, 2) fft_fused3_kernel(const FusedArgs f) {
             const unsigned t = g;
             if (t >= f.ring) fused_wait_ge<false>(rdone + (t - f.ring), f.tiles1, err, pend);
             else fused_flush(pend);
-            col3_tile<T, 4, true, true, SPLIT, NT, false, false, true>(f.p0, (long long)t, (long long)(t % f.ring), (long long)tile * 16, lds);
+            col3_tile<T, A, true, true, SPLIT, NT, false, false, true>(f.p0, (long long)t, (long long)(t % f.ring), (long long)tile * 16, lds);
             pend.ctr = wdone + t;
         } else {
             if (g < f.lag) continue;
             const unsigned t = g - f.lag;
             if (t >= f.batch || tile >= f.tiles1) continue;
             fused_wait_ge<true>(wdone + t, f.tiles0, err, pend);
-            col3_tile<T, 4, false, false, false, false, NT, SPLIT>(f.p1, (long long)(t % f.ring), (long long)t, (long long)tile * 16, lds);
+            col3_tile<T, A, false, false, false, false, NT, SPLIT>(f.p1, (long long)(t % f.ring), (long long)t, (long long)tile * 16, lds);
             fused_signal_read(rdone + t);
         }
     }

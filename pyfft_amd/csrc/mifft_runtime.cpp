@@ -432,13 +432,14 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     if (rc) return rc;
     rc = validate(p1);
     if (rc) return rc;
-    if (p0->precision != MIFFT_F32 || p1->precision != MIFFT_F32) return set_err(MIFFT_E_UNSUPPORTED, "fused2: fp32 only");
+    if (p0->precision != p1->precision) return set_err(MIFFT_E_INVALID, "fused2: passes of two precisions");
+    const bool f64 = p0->precision == MIFFT_F64;
     if (p0->kind != MIFFT_PASS_COL || p1->kind != MIFFT_PASS_COL || p0->S != 1 || p0->M != p1->L || p1->M != 1 ||
         p1->S != p0->L || p0->outer != p1->outer || p0->layout != p1->layout || p0->inverse != p1->inverse)
         return set_err(MIFFT_E_INVALID, "fused2: passes are not the two passes of one long contiguous axis");
     auto ok_len = [](int L) { return L == 256 || L == 512 || L == 1024; };
     const bool big = p0->L == 2048 && p1->L == 2048;   // 512-thread tiles (fft_col3.hpp)
-    if (!big && (!ok_len(p0->L) || !ok_len(p1->L))) return set_err(MIFFT_E_UNSUPPORTED, "fused2: no kernel for %d x %d", p0->L, p1->L);
+    if (f64 ? (p0->L != 1024 || p1->L != 1024) : (!big && (!ok_len(p0->L) || !ok_len(p1->L)))) return set_err(MIFFT_E_UNSUPPORTED, "fused2: no kernel for %d x %d", p0->L, p1->L);
     const bool split = p0->layout == MIFFT_SPLIT;
     if (!in0 || !out0 || !ring0 || !counters || (split && (!in1 || !out1))) return set_err(MIFFT_E_INVALID, "fused2: null buffer");
     (void)ring1;  // the ring is always interleaved
@@ -461,7 +462,8 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     f.tiles1 = (unsigned)(p1->S / 16);
     rc = hip_check(hipMemsetAsync(counters, 0, (size_t)(2 + 2 * p0->outer) * 4, (hipStream_t)stream), "hipMemsetAsync");
     if (rc) return rc;
-    rc = mifft_fused2_f32_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream);
+    rc = f64 ? mifft_fused3_f64_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)
+             : mifft_fused2_f32_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream);
     if (rc == MIFFT_E_UNSUPPORTED) return set_err(rc, "fused2: no kernel for %d x %d", p0->L, p1->L);
     if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
     return 0;

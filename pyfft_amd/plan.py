@@ -250,14 +250,17 @@ class FFTPlan(object):
     def _fused2_eligible(self):
         p = self._params
         k = self._kernels
-        return (p.precision == N.F32 and len(k) == 2 and int(p.y) == 1 and int(p.z) == 1
-                and k[0].kind == N.PASS_COL and k[1].kind == N.PASS_COL and k[0].S == 1 and k[0].M == k[1].L
-                and k[1].M == 1 and ((k[0].L in (256, 512, 1024) and k[1].L in (256, 512, 1024)) or
-                                     (k[0].L == 2048 and k[1].L == 2048)))
+        if not (len(k) == 2 and int(p.y) == 1 and int(p.z) == 1 and k[0].kind == N.PASS_COL and k[1].kind == N.PASS_COL
+                and k[0].S == 1 and k[0].M == k[1].L and k[1].M == 1):
+            return False
+        if p.precision == N.F64:
+            return k[0].L == 1024 and k[1].L == 1024
+        return (k[0].L in (256, 512, 1024) and k[1].L in (256, 512, 1024)) or (k[0].L == 2048 and k[1].L == 2048)
 
     def _xcd2_eligible(self):
         k = self._kernels
-        return (self._fused2_eligible() and k[0].L == 1024 and k[1].L == 1024 and self._context.compute_units == 256
+        return (self._fused2_eligible() and self._params.precision == N.F32 and k[0].L == 1024 and k[1].L == 1024
+                and self._context.compute_units == 256
                 and not self._xcd2_disabled)
 
     def _select_strategy(self, batch):
@@ -271,7 +274,7 @@ class FFTPlan(object):
         if forced == "xcd" and self._xcd2_eligible() and batch >= self.XCD2_MIN_BATCH:   # not the default yet: DESIGN.md section 4
             return ("xcd2", D.xcd2_flags(N.XCD2_PREFETCH))
         if self._temp_buffer_needed and forced in ("auto", "fused") and self._fused2_eligible():
-            huge = self._kernels[0].L == 2048               # 512-thread tiles: one work-group per CU
+            huge = self._kernels[0].L == 2048 or p.precision == N.F64   # 512-thread tiles: one work-group per CU
             grid = (1 if huge else 2) * self._context.compute_units
             gsize = 2 * max(self._kernels[0].M // 16, self._kernels[1].S // 16)
             # producers run `lag` transforms ahead of the consumers; ring = 2 * lag slots (1024 x 1024: lag 14, 224 MiB --
@@ -281,8 +284,11 @@ class FFTPlan(object):
             lag = max(2, -(-(14 if big else 9) * grid // (4 * gsize)))
             ring = 2 * lag
             if huge:
-                # 2048 x 2048: 32 MiB per transform; the ring that fits the Infinity Cache is 7 slots (224 MiB)
-                lag, ring = D.fused3_lag_ring(3, 7)
+                # fp32 2048 x 2048: 32 MiB per transform, fp64 1024 x 1024: 16 MiB; the ring that fits the Infinity Cache is
+                # 224 MiB, and the consumers follow the producers by three machine-waves of tiles
+                slots = (224 << 20) // item_bytes
+                lag, ring = D.fused3_lag_ring(3 * slots // 7, slots)
+                big = True
             if batch >= 2 * ring and (big or forced == "fused"):
                 return ("fused2", lag, ring, grid)
         # any multi-pass plan gains from cache-sized chunks (the second pass re-reads what the first just wrote),

@@ -238,6 +238,38 @@ def test_fused_two_pass_kernel(ctx, monkeypatch, n, batch):
     assert oracle.difference(data, back, batch) < 1.1e-6
 
 
+def test_fused_two_pass_kernel_fp64(ctx, monkeypatch):
+    """fp64 N = 2^20 (1024 x 1024 on the 512-thread tiles): the fused kernel gives the bits of the two-launch chain."""
+    n, batch = 1 << 20, 31
+    data = oracle.get_test_data((n,), numpy.complex128, batch, 4243)
+    outs = {}
+    for strat in ("chain", "fused"):
+        monkeypatch.setenv("PYFFT_AMD_STRATEGY", strat)
+        plan = ctx.getPlan((n,), dtype=numpy.complex128)
+        assert plan.strategy(batch)[0] == {"fused": "fused2", "chain": "chain"}[strat]
+        a = ctx.toGpu(data)
+        b = ctx.allocate(data.shape, data.dtype)
+        plan.execute(a, b, batch=batch)
+        assert numpy.array_equal(a.get(), data)
+        outs[strat] = b.get()
+        plan.execute(a, batch=batch)
+        assert numpy.array_equal(a.get(), outs[strat])
+    assert numpy.array_equal(outs["chain"], outs["fused"])
+    ref = oracle.numpy_fft(numpy.fft.fft, data[:2 * n], 2)
+    assert oracle.difference(ref, outs["fused"][:2 * n], 2) < 1e-14
+    # split planes
+    re, im = oracle.get_test_data((n,), numpy.float64, batch, 4244)
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "fused")
+    plan = ctx.getPlan((n,), dtype=numpy.float64)
+    assert plan.strategy(batch)[0] == "fused2"
+    a, b = ctx.toGpu(re), ctx.toGpu(im)
+    plan.execute(a, b, batch=batch)
+    sl = slice((batch - 1) * n, batch * n)
+    ref = numpy.fft.fft(re[sl] + 1j * im[sl])
+    got = a.get()[sl] + 1j * b.get()[sl]
+    assert numpy.abs(ref - got).sum() / numpy.abs(ref).sum() < 1e-14
+
+
 @pytest.mark.parametrize("shape,batch", [((1 << 17,), 259), ((1 << 16,), 515), ((4096, 8), 1030)], ids=str)
 def test_pipelined_chunks(ctx, monkeypatch, shape, batch):
     data = oracle.get_test_data(shape, numpy.complex64, batch, 777)

@@ -48,7 +48,10 @@ if __name__ == "__main__":
     p = device_props()
     print(p.name.decode(), p.gcn_arch.decode(), "CUs", p.compute_units, flush=True)
     c64, c128, f32, f64 = numpy.complex64, numpy.complex128, numpy.float32, numpy.float64
-    if len(sys.argv) > 1 and sys.argv[1] == "cfg":
+    if len(sys.argv) > 4 and sys.argv[1] == "one":      # one SHAPE(1048576 or 1024x1024) DTYPE BATCH [inplace]
+        cases = []
+        run(tuple(int(t) for t in sys.argv[2].split("x")), numpy.dtype(sys.argv[3]).type, int(sys.argv[4]), inplace="inplace" in sys.argv[5:])
+    elif len(sys.argv) > 1 and sys.argv[1] == "cfg":
         cases = [((1024, 1024), c64, 512), ((256, 256, 256), c128, 32), ((1 << 22,), c64, 128), ((1 << 16,), c64, 8192), ((1 << 18,), c64, 2048)]
     elif len(sys.argv) > 1 and sys.argv[1] == "f64":
         cases = [((1 << k,), c128, (1 << 27) >> k) for k in (14, 15, 16, 17, 18, 20, 22)] + [((1024, 1024), c128, 128), ((2048, 2048), c64, 64)]
