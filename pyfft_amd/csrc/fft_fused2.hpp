@@ -139,9 +139,10 @@ __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
     fused_flush(pend);
 }
 
-// The same work list with the 512-thread tiles of fft_col3.hpp: fp32 N = 2^22 = 2048 x 2048 (BASELINE config 5; A = 4, one
-// work-group per CU, the ring holds 7 transforms of 32 MiB) and fp64 N = 2^20 = 1024 x 1024 (A = 2, 14 transforms of 16 MiB).
-template <typename T, int A, bool SPLIT, bool NT>
+// The same work list with the 512-thread tiles of fft_col3.hpp (L = 512 * A): fp32 N = 2^22 = 2048 x 2048 (BASELINE config 5;
+// one work-group per CU, the ring holds 7 transforms of 32 MiB), fp32 N = 2^21 = 2048 x 1024 and fp64 N = 2^20 = 1024 x 1024
+// (14 transforms of 16 MiB).  A group is tiles0 + tiles1 items with the two kinds interleaved in their ratio (1:1 or 1:2).
+template <typename T, int A0, int A1, bool SPLIT, bool NT>
 __global__ void __launch_bounds__(512, 2) fft_fused3_kernel(const FusedArgs f) {
     constexpr int E0 = Col3Lds<T, true>::SCALARS, E1 = Col3Lds<T, false>::SCALARS;
     __shared__ __attribute__((aligned(16))) T lds[E0 > E1 ? E0 : E1];
@@ -151,7 +152,10 @@ __global__ void __launch_bounds__(512, 2) fft_fused3_kernel(const FusedArgs f) {
     unsigned* const err = f.counters + 1;
     unsigned* const wdone = f.counters + 2;
     unsigned* const rdone = wdone + f.batch;
-    const unsigned gsize = 2u * (f.tiles0 > f.tiles1 ? f.tiles0 : f.tiles1);
+    constexpr unsigned per0 = A0 > A1 ? 1u : (unsigned)(A1 / A0);   // tiles0 : tiles1 = L1 : L0 = A1 : A0
+    constexpr unsigned per1 = A1 > A0 ? 1u : (unsigned)(A0 / A1);
+    constexpr unsigned period = per0 + per1;
+    const unsigned gsize = f.tiles0 + f.tiles1;
     const unsigned total = (f.batch + f.lag) * gsize;
 
     FusedPending pend = {nullptr};
@@ -166,20 +170,21 @@ __global__ void __launch_bounds__(512, 2) fft_fused3_kernel(const FusedArgs f) {
         __syncthreads();
         const unsigned item = s_item;
         if (item >= total) break;
-        const unsigned g = item / gsize, k = item % gsize, tile = k >> 1;
-        if ((k & 1u) == 0u) {
-            if (g >= f.batch || tile >= f.tiles0) continue;
+        const unsigned g = item / gsize, k = item % gsize, j = k / period, m = k % period;
+        if (m < per0) {
+            const unsigned tile = j * per0 + m;
+            if (g >= f.batch) continue;
             const unsigned t = g;
             if (t >= f.ring) fused_wait_ge<false>(rdone + (t - f.ring), f.tiles1, err, pend);
             else fused_flush(pend);
-            col3_tile<T, A, true, true, SPLIT, NT, false, false, true>(f.p0, (long long)t, (long long)(t % f.ring), (long long)tile * 16, lds);
+            col3_tile<T, A0, true, true, SPLIT, NT, false, false, true>(f.p0, (long long)t, (long long)(t % f.ring), (long long)tile * 16, lds);
             pend.ctr = wdone + t;
         } else {
+            const unsigned tile = j * per1 + (m - per0);
             if (g < f.lag) continue;
             const unsigned t = g - f.lag;
-            if (t >= f.batch || tile >= f.tiles1) continue;
             fused_wait_ge<true>(wdone + t, f.tiles0, err, pend);
-            col3_tile<T, A, false, false, false, false, NT, SPLIT>(f.p1, (long long)(t % f.ring), (long long)t, (long long)tile * 16, lds);
+            col3_tile<T, A1, false, false, false, false, NT, SPLIT>(f.p1, (long long)(t % f.ring), (long long)t, (long long)tile * 16, lds);
             fused_signal_read(rdone + t);
         }
     }

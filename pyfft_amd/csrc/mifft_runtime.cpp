@@ -438,7 +438,7 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
         p1->S != p0->L || p0->outer != p1->outer || p0->layout != p1->layout || p0->inverse != p1->inverse)
         return set_err(MIFFT_E_INVALID, "fused2: passes are not the two passes of one long contiguous axis");
     auto ok_len = [](int L) { return L == 256 || L == 512 || L == 1024; };
-    const bool big = p0->L == 2048 && p1->L == 2048;   // 512-thread tiles (fft_col3.hpp)
+    const bool big = p0->L == 2048 && (p1->L == 2048 || p1->L == 1024);   // 512-thread tiles (fft_col3.hpp)
     if (f64 ? (p0->L != 1024 || p1->L != 1024) : (!big && (!ok_len(p0->L) || !ok_len(p1->L)))) return set_err(MIFFT_E_UNSUPPORTED, "fused2: no kernel for %d x %d", p0->L, p1->L);
     const bool split = p0->layout == MIFFT_SPLIT;
     if (!in0 || !out0 || !ring0 || !counters || (split && (!in1 || !out1))) return set_err(MIFFT_E_INVALID, "fused2: null buffer");

@@ -221,14 +221,19 @@ def _run_strategy(ctx, monkeypatch, strat, shape, batch, data, inplace=False, in
     return b.get()
 
 
-@pytest.mark.parametrize("n,batch", [(1 << 16, 160), (1 << 17, 96), (1 << 18, 80), (1 << 19, 40), (1 << 20, 61), (1 << 22, 17)], ids=str)
+@pytest.mark.parametrize("n,batch", [(1 << 16, 160), (1 << 17, 96), (1 << 18, 80), (1 << 19, 40), (1 << 20, 61), (1 << 21, 29), (1 << 22, 17)], ids=str)
 def test_fused_two_pass_kernel(ctx, monkeypatch, n, batch):
     data = oracle.get_test_data((n,), numpy.complex64, batch, 4242)
     want = _run_strategy(ctx, monkeypatch, "chain", (n,), batch, data)
     got = _run_strategy(ctx, monkeypatch, "fused", (n,), batch, data)
-    assert numpy.array_equal(want, got), "fused kernel differs from the two-launch chain"
+    if n == 1 << 21:
+        # 2048 x 1024: the fused kernel runs the 1024-point pass on the 512-thread tiles (2 x 512 by decimation in time), the
+        # chain on the 256-thread ones (radix 16 x 4 x 16): the same transform in another operation order
+        assert oracle.difference(want, got, batch) < 5e-7
+    else:
+        assert numpy.array_equal(want, got), "fused kernel differs from the two-launch chain"
     got_ip = _run_strategy(ctx, monkeypatch, "fused", (n,), batch, data, inplace=True)
-    assert numpy.array_equal(want, got_ip), "fused in-place differs"
+    assert numpy.array_equal(got, got_ip), "fused in-place differs"
     for item in (0, batch // 2, batch - 1):
         ref = numpy.fft.fft(data[item * n:(item + 1) * n].astype(numpy.complex128))
         g = got[item * n:(item + 1) * n]
@@ -282,7 +287,7 @@ def test_pipelined_chunks(ctx, monkeypatch, shape, batch):
     assert oracle.difference(ref, got[:shape[0] * 2], 2) < 1.1e-6
 
 
-@pytest.mark.parametrize("n,batch,strat", [(1 << 16, 520, "pipelined"), (1 << 20, 61, "fused"), (1 << 18, 80, "fused"), (1 << 22, 15, "fused")], ids=str)
+@pytest.mark.parametrize("n,batch,strat", [(1 << 16, 520, "pipelined"), (1 << 20, 61, "fused"), (1 << 18, 80, "fused"), (1 << 22, 15, "fused"), (1 << 21, 30, "fused")], ids=str)
 def test_split_plane_strategies(ctx, monkeypatch, n, batch, strat):
     """float32 split planes through the chunked / fused strategies (the plan's temp buffer is interleaved even
     though the user buffers are planes): bit-identical to the plain chain, within tolerance of numpy."""
@@ -299,7 +304,8 @@ def test_split_plane_strategies(ctx, monkeypatch, n, batch, strat):
         outs[s] = (c.get(), d.get())
         plan.execute(a, b, batch=batch)                  # in place
         assert numpy.array_equal(a.get(), outs[s][0]) and numpy.array_equal(b.get(), outs[s][1])
-    assert numpy.array_equal(outs["chain"][0], outs[strat][0]) and numpy.array_equal(outs["chain"][1], outs[strat][1])
+    if n != 1 << 21:   # (2048 x 1024 fused: another operation order than the chain, see test_fused_two_pass_kernel)
+        assert numpy.array_equal(outs["chain"][0], outs[strat][0]) and numpy.array_equal(outs["chain"][1], outs[strat][1])
     for item in (0, batch - 1):
         sl = slice(item * n, (item + 1) * n)
         ref = numpy.fft.fft(re[sl].astype(numpy.float64) + 1j * im[sl])
