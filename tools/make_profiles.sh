@@ -32,4 +32,9 @@ timeout 900 python3 tools/perf_table.py > $OUT/perf_table.log 2>&1 && cp $OUT/pe
 [ -x tools/membench ] && timeout 300 ./tools/membench > $OUT/membench.log 2>&1 && cp $OUT/membench.log $P/${TAG}_fabric_ceiling_membench.log
 [ -x tools/xcd_probe ] && timeout 300 ./tools/xcd_probe > $OUT/xcd_probe.log 2>&1 && cp $OUT/xcd_probe.log $P/${TAG}_xcd_probe.log
 timeout 600 python3 tools/xcd2_probe.py 512 5 > $OUT/xcd2_probe.log 2>&1 && cp $OUT/xcd2_probe.log $P/${TAG}_xcd2_strategy_trace.log
+
+# 5. the long 1-D sizes in both precisions (two-pass kernels; fused persistent forms at 2^20 / 2^21 / 2^22)
+timeout 900 python3 tools/quick_bench.py 1d > $OUT/long_1d.log 2>&1
+timeout 900 python3 tools/quick_bench.py f64 >> $OUT/long_1d.log 2>&1
+cp $OUT/long_1d.log $P/${TAG}_long_1d_sizes.log
 echo done
