@@ -30,6 +30,49 @@ template <typename T> __device__ __forceinline__ cplx<T> cmul(cplx<T> a, cplx<T>
     r.y = a.x * b.y + a.y * b.x;
     return r;
 }
+// fp32: the packed-math form, two instructions instead of four (v_pk_mul_f32 / v_pk_fma_f32 with operand-half selection and a
+// negated low half).  The compiler does not find it: from the vector expression it folds the broadcasts of a.x / a.y but builds
+// (-b.y, b.x) with a v_xor and a v_mov, and its SLP vectoriser packs the four products into two half-used instructions.
+//     t = (a.x * b.x, a.x * b.y);   r = (-a.y * b.y + t.x, a.y * b.x + t.y)
+template <> __device__ __forceinline__ cplx<float> cmul<float>(cplx<float> a, cplx<float> b) {
+    cplx<float> t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+// v * w for a COMPILE-TIME w: the constant sits in an SGPR pair (packed instructions take no literal), so a constant rotation
+// is two packed instructions and two scalar moves instead of four vector ones
+__device__ __forceinline__ cplx<float> cmul_const(cplx<float> v, cplx<float> w) {
+    cplx<float> t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(v), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(v), "s"(w), "v"(t));
+    return r;
+}
+// a + (-i) b and a + i b in one instruction each (the rotation is an operand-half swap plus one negated half)
+__device__ __forceinline__ cplx<float> cadd_mi(cplx<float> a, cplx<float> b) {
+    cplx<float> r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cplx<float> cadd_pi(cplx<float> a, cplx<float> b) {
+    cplx<float> r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (-i) v = (v.y, -v.x) and i v = (-v.y, v.x): one packed multiply by (1, -1) / (-1, 1) with the halves of v swapped
+__device__ __forceinline__ cplx<float> crot_mi(cplx<float> v) {
+    cplx<float> r;
+    const cplx<float> c = {1.0f, -1.0f};
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(v), "s"(c));
+    return r;
+}
+__device__ __forceinline__ cplx<float> crot_pi(cplx<float> v) {
+    cplx<float> r;
+    const cplx<float> c = {-1.0f, 1.0f};
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(v), "s"(c));
+    return r;
+}
+
 template <typename T> __device__ __forceinline__ cplx<T> cconj(cplx<T> a) {
     cplx<T> r;
     r.x = a.x;
@@ -58,7 +101,14 @@ constexpr double sin32(int e) { return cos32(e - 8); }  // sin(2*pi*e/32)
 template <int E, typename T> __device__ __forceinline__ cplx<T> mul_w32(cplx<T> v) {
     constexpr int e = E & 31;
     cplx<T> r;
-    if constexpr (e == 0) {
+    if constexpr (sizeof(T) == 4 && (e & 7) != 0) {   // fp32, a real multiplication: packed form
+        const cplx<float> w = {(float)cos32(e), (float)(-sin32(e))};
+        return cmul_const(v, w);
+    } else if constexpr (sizeof(T) == 4 && e == 8) {
+        return crot_mi(v);
+    } else if constexpr (sizeof(T) == 4 && e == 24) {
+        return crot_pi(v);
+    } else if constexpr (e == 0) {
         r = v;
     } else if constexpr (e == 8) {  // -i
         r.x = v.y;
@@ -118,6 +168,13 @@ template <int E, typename T> __device__ __forceinline__ cplx<T> mul_w64(cplx<T> 
     constexpr int e = E & 63;
     if constexpr ((e & 1) == 0) {
         return mul_w32<e / 2, T>(v);
+    } else if constexpr (sizeof(T) == 4) {
+        constexpr int n = e >> 4, m = e & 15;   // w(64)^e = (-i)^n (cos t - i sin t), t = 2 pi m / 64
+        constexpr double c = kCos64[m], sn = kCos64[16 - m];
+        constexpr double wr = n == 0 ? c : n == 1 ? -sn : n == 2 ? -c : sn;
+        constexpr double wi = n == 0 ? -sn : n == 1 ? -c : n == 2 ? sn : c;
+        const cplx<float> w = {(float)wr, (float)wi};
+        return cmul_const(v, w);
     } else {
         constexpr int n = e >> 4, m = e & 15;
         constexpr T c = (T)kCos64[m];
@@ -147,11 +204,16 @@ template <typename T> struct Dft<4, T> {
     static __device__ __forceinline__ void run(cplx<T>* v) {
         cplx<T> s0 = v[0] + v[2], d0 = v[0] - v[2];
         cplx<T> s1 = v[1] + v[3], d1 = v[1] - v[3];
-        cplx<T> md1 = mul_w32<8, T>(d1);  // -i * d1
         v[0] = s0 + s1;
-        v[1] = d0 + md1;
         v[2] = s0 - s1;
-        v[3] = d0 - md1;
+        if constexpr (sizeof(T) == 4) {
+            v[1] = cadd_mi(d0, d1);   // d0 - i d1
+            v[3] = cadd_pi(d0, d1);   // d0 + i d1
+        } else {
+            cplx<T> md1 = mul_w32<8, T>(d1);  // -i * d1
+            v[1] = d0 + md1;
+            v[3] = d0 - md1;
+        }
     }
 };
 

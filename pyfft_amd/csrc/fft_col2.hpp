@@ -210,6 +210,9 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
     const unsigned l = (unsigned)l0 + dl;  // row index of this thread's column in the inter-pass twiddle
     const T sx = (T)a.scale;
     const T sy = a.inverse ? -sx : sx;
+    cplx<T> sxy;
+    sxy.x = sx;
+    sxy.y = sy;
     const cplx<T>* twlo = reinterpret_cast<const cplx<T>*>(a.tw_lo);
     const cplx<T>* twhi = reinterpret_cast<const cplx<T>*>(a.tw_hi);
     const int tw_shift = a.tw_shift;
@@ -290,9 +293,7 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
             // uniform part of the output element index
             const long long gu = TR ? (oubase + qb0 * 16 * A + 16 * qa)
                                     : (oubase + ((long long)(qb0 * 16 * A + 16 * qa) << logS));
-            cplx<T> r;
-            r.x = x[qb0].x * sx;
-            r.y = x[qb0].y * sy;
+            const cplx<T> r = x[qb0] * sxy;   // (one packed multiply in fp32)
             if constexpr (!SPLIT_OUT) {
                 char* p = reinterpret_cast<char*>(reinterpret_cast<cplx<T>*>(a.out0) + gu);
                 if constexpr (WT) {

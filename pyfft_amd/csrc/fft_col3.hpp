@@ -20,22 +20,36 @@
 
 namespace mifft {
 
-// the value the lane 32 away holds
-__device__ __forceinline__ float col3_other_half(float x, bool upper) {
-    const int v = __builtin_bit_cast(int, x);
-    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // r[0] = (lo, lo), r[1] = (hi, hi)
-    return __builtin_bit_cast(float, upper ? r[0] : r[1]);
+// The radix-2 across the lane halves.  In: every lane's own value (lanes 0-31: E[q'], lanes 32-63: w * O[q'] of the thread 32
+// lanes below).  Out: lanes 0-31 X[q'] = E + w O, lanes 32-63 X[q' + L'] = E - w O.  v_permlane32_swap exchanges the upper half
+// of its first operand with the lower half of its second, so swapping the REAL register with the IMAGINARY one leaves lane l
+// with (E.re, wO.re) and lane l + 32 with (E.im, wO.im): every lane forms the sum and the difference of ONE component, and a
+// second swap of (sum, difference) puts (X.re, X.im) into lane l and (X'.re, X'.im) into lane l + 32.  Four instructions per
+// point, no copies and no selects.
+__device__ __forceinline__ void col3_swap(float& p, float& q) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, p), __builtin_bit_cast(int, q), false, false);
+    p = __builtin_bit_cast(float, (int)r[0]);
+    q = __builtin_bit_cast(float, (int)r[1]);
 }
-
-__device__ __forceinline__ double col3_other_half(double x, bool upper) {
+__device__ __forceinline__ void col3_swap(double& p, double& q) {
     typedef int i2 __attribute__((ext_vector_type(2)));
-    const i2 v = __builtin_bit_cast(i2, x);
-    const auto r0 = __builtin_amdgcn_permlane32_swap(v[0], v[0], false, false);
-    const auto r1 = __builtin_amdgcn_permlane32_swap(v[1], v[1], false, false);
-    i2 o;
-    o[0] = upper ? r0[0] : r0[1];
-    o[1] = upper ? r1[0] : r1[1];
-    return __builtin_bit_cast(double, o);
+    i2 a = __builtin_bit_cast(i2, p), b = __builtin_bit_cast(i2, q);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+    a[0] = r0[0]; b[0] = r0[1];
+    a[1] = r1[0]; b[1] = r1[1];
+    p = __builtin_bit_cast(double, a);
+    q = __builtin_bit_cast(double, b);
+}
+template <typename T> __device__ __forceinline__ cplx<T> col3_combine(cplx<T> own) {
+    T p = own.x, q = own.y;
+    col3_swap(p, q);
+    T sum = p + q, dif = p - q;
+    col3_swap(sum, dif);
+    cplx<T> r;
+    r.x = sum;
+    r.y = dif;
+    return r;
 }
 
 // LDS of one work-group in units of T: two halves of BUF slots; 8-byte points store a whole point per slot (2 T),
@@ -158,6 +172,9 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
     const unsigned l = (unsigned)l0 + dl;
     const T sx = (T)a.scale;
     const T sy = a.inverse ? -sx : sx;
+    cplx<T> sxy;   // one packed multiply per point in fp32
+    sxy.x = sx;
+    sxy.y = sy;
     const cplx<T>* twlo = reinterpret_cast<const cplx<T>*>(a.tw_lo);
     const cplx<T>* twhi = reinterpret_cast<const cplx<T>*>(a.tw_hi);
     const int tw_shift = a.tw_shift;
@@ -207,7 +224,7 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
         }
         Dft<16, T>::run(x);
         // x[qb0] = E[q'] (lower lanes) or O[q'] (upper lanes), q' = qb0*16A + qa*16 + u.  The odd half is multiplied by
-        // w(L)^q' = w(L)^(qa*16 + u) [one look-up] * w(32)^qb0 [constants: L / 16A = 32]; then X = other + (upper ? -own : own).
+        // w(L)^q' = w(L)^(qa*16 + u) [one look-up] * w(32)^qb0 [constants: L / 16A = 32]; then the radix-2 across the halves.
         {
             const cplx<T> w0 = twL[qa * 16 + u];
             static_for<16>([&](auto qq) {
@@ -216,11 +233,7 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
                 cplx<T> own;
                 own.x = upper ? t.x : x[qb0].x;
                 own.y = upper ? t.y : x[qb0].y;
-                cplx<T> oth;
-                oth.x = col3_other_half(own.x, upper);
-                oth.y = col3_other_half(own.y, upper);
-                x[qb0].x = upper ? oth.x - own.x : oth.x + own.x;
-                x[qb0].y = upper ? oth.y - own.y : oth.y + own.y;
+                x[qb0] = col3_combine<T>(own);
             });
         }
         if constexpr (TW) {
@@ -239,9 +252,7 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
         static_for<16>([&](auto qq) {
             constexpr int qb0 = qq;
             const long long gu = TR ? (oubase + qb0 * 16 * A + 16 * qa) : (oubase + ((long long)(qb0 * 16 * A + 16 * qa) << logS));
-            cplx<T> r;
-            r.x = x[qb0].x * sx;
-            r.y = x[qb0].y * sy;
+            const cplx<T> r = x[qb0] * sxy;
             if constexpr (!SPLIT_OUT) {
                 char* p = reinterpret_cast<char*>(reinterpret_cast<cplx<T>*>(a.out0) + gu);
                 if constexpr (WT) {
