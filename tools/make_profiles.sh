@@ -11,18 +11,18 @@ mkdir -p $OUT/to_profiles profiles
 P=$OUT/to_profiles
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 
-# 1. the bench lines: default line (c2) and every other BASELINE configuration
+# 1. kernel stats + PMC traffic of the same command, per configuration (writes profiles/traffic_<c>.json and
+#    profiles/<tag>_<c>_kernel_stats.csv)
+timeout 2400 python3 tools/pmc_traffic.py --tag $TAG c2 c3 c4 c4s c5 > $OUT/pmc_traffic.log 2>&1
+cp $OUT/pmc_traffic.log $P/${TAG}_pmc_traffic.log
+cp profiles/traffic_*.json profiles/${TAG}_*_kernel_stats.csv $P/ 2>/dev/null
+
+# 2. the bench lines (after the traffic files exist, so that every line carries roofline.traffic): default line (c2) and every other BASELINE configuration
 timeout 600 python3 bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
 for c in c1 c3 c4 c4s c5; do
     timeout 600 python3 bench.py --config $c --steps 10 --warmup 2 > $OUT/bench_$c.json 2> $OUT/bench_$c.err
 done
 for c in c1 c2 c3 c4 c4s c5; do cp $OUT/bench_$c.json $P/${TAG}_bench_$c.json; done
-
-# 2. kernel stats + PMC traffic of the same command, per configuration (writes profiles/traffic_<c>.json and
-#    profiles/<tag>_<c>_kernel_stats.csv)
-timeout 2400 python3 tools/pmc_traffic.py --tag $TAG c2 c3 c4 c4s c5 > $OUT/pmc_traffic.log 2>&1
-cp $OUT/pmc_traffic.log $P/${TAG}_pmc_traffic.log
-cp profiles/traffic_*.json profiles/${TAG}_*_kernel_stats.csv $P/ 2>/dev/null
 
 # 3. the reference's published shapes (test/test_performance.py method) and the vendor yardstick (cuda/test.cu counterpart)
 timeout 900 python3 tools/perf_table.py > $OUT/perf_table.log 2>&1 && cp $OUT/perf_table.log $P/${TAG}_perf_table_reference_shapes.log
@@ -37,4 +37,8 @@ timeout 600 python3 tools/xcd2_probe.py 512 5 > $OUT/xcd2_probe.log 2>&1 && cp $
 timeout 900 python3 tools/quick_bench.py 1d > $OUT/long_1d.log 2>&1
 timeout 900 python3 tools/quick_bench.py f64 >> $OUT/long_1d.log 2>&1
 cp $OUT/long_1d.log $P/${TAG}_long_1d_sizes.log
+
+# 6. SQ counters of the long fp32 rows (occupancy / LDS pressure)
+timeout 900 python3 tools/row_counters.py 32768 complex64 8192 16384 complex64 16384 8192 complex64 32768 > $OUT/row_counters.log 2>&1
+cp $OUT/row_counters.log $P/${TAG}_i_row_sq_counters.log
 echo done
