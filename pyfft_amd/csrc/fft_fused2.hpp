@@ -97,7 +97,12 @@ __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
     unsigned* const err = f.counters + 1;
     unsigned* const wdone = f.counters + 2;
     unsigned* const rdone = wdone + f.batch;
-    const unsigned gsize = 2u * (f.tiles0 > f.tiles1 ? f.tiles0 : f.tiles1);
+    // a group = the tiles0 pass-0 tiles of transform g and the tiles1 pass-1 tiles of transform g - lag, interleaved in their
+    // ratio (tiles0 : tiles1 = L1 : L0 = A1 : A0), so that no ticket is an empty item
+    constexpr unsigned per0 = A0 > A1 ? 1u : (unsigned)(A1 / A0);
+    constexpr unsigned per1 = A1 > A0 ? 1u : (unsigned)(A0 / A1);
+    constexpr unsigned period = per0 + per1;
+    const unsigned gsize = f.tiles0 + f.tiles1;
     const unsigned total = (f.batch + f.lag) * gsize;
 
     // the ticket of the NEXT item is drawn while the current one is being worked on (the returning atomic takes 1-3 us under
@@ -114,9 +119,13 @@ __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
         __syncthreads();
         const unsigned item = s_item;
         if (item >= total) break;
-        const unsigned g = item / gsize, k = item % gsize, tile = k >> 1;
-        if ((k & 1u) == 0u) {
-            if (g >= f.batch || tile >= f.tiles0) continue;
+        const unsigned g = item / gsize, k = item % gsize, j = k / period, m = k % period;
+        if (m < per0) {
+            const unsigned tile = j * per0 + m;
+            if (g >= f.batch) {          // (the drain of the last `lag` transforms) nothing to do, but never sit on a publish
+                fused_flush(pend);
+                continue;
+            }
             const unsigned t = g;
             if (t >= f.ring) {
                 fused_wait_ge<false>(rdone + (t - f.ring), f.tiles1, err, pend);
@@ -126,9 +135,12 @@ __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
             col2_tile<T, A0, true, true, SPLIT, true, NT, false, false>(f.p0, (long long)t, (long long)(t % f.ring), (long long)tile * 16, lds);
             pend.ctr = wdone + t;       // published behind the next item's dependency wait (or at the end)
         } else {
-            if (g < f.lag) continue;
+            const unsigned tile = j * per1 + (m - per0);
+            if (g < f.lag) {            // (the fill of the first `lag` transforms)
+                fused_flush(pend);
+                continue;
+            }
             const unsigned t = g - f.lag;
-            if (t >= f.batch || tile >= f.tiles1) continue;
             // (reading the ring with sc1 loads instead of the acquire fence measured the same -- 22.52 ms -- and 8-byte sc1 loads
             // at two work-groups per CU are outside the hand-off forms MI355X_MICROARCH.md lists as validated: the fence stays)
             fused_wait_ge<true>(wdone + t, f.tiles0, err, pend);
@@ -173,7 +185,10 @@ __global__ void __launch_bounds__(512, 2) fft_fused3_kernel(const FusedArgs f) {
         const unsigned g = item / gsize, k = item % gsize, j = k / period, m = k % period;
         if (m < per0) {
             const unsigned tile = j * per0 + m;
-            if (g >= f.batch) continue;
+            if (g >= f.batch) {
+                fused_flush(pend);
+                continue;
+            }
             const unsigned t = g;
             if (t >= f.ring) fused_wait_ge<false>(rdone + (t - f.ring), f.tiles1, err, pend);
             else fused_flush(pend);
@@ -181,7 +196,10 @@ __global__ void __launch_bounds__(512, 2) fft_fused3_kernel(const FusedArgs f) {
             pend.ctr = wdone + t;
         } else {
             const unsigned tile = j * per1 + (m - per0);
-            if (g < f.lag) continue;
+            if (g < f.lag) {
+                fused_flush(pend);
+                continue;
+            }
             const unsigned t = g - f.lag;
             fused_wait_ge<true>(wdone + t, f.tiles0, err, pend);
             col3_tile<T, A1, false, false, false, false, NT, SPLIT>(f.p1, (long long)(t % f.ring), (long long)t, (long long)tile * 16, lds);
