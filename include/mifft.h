@@ -219,10 +219,12 @@ int mifft_launch_chain_pipelined(const mifft_pass *passes, int32_t npasses, void
  * by `lag` transforms, with the intermediate in a scratch ring of `ring_slots` transforms (ring_slots > lag) that
  * stays in the Infinity Cache.  p0 must be the transposing first pass (COL, S == 1, M == p1->L), p1 the plain
  * strided last pass (COL, M == 1, S == p0->L).  `counters` = caller-owned device buffer of at least
- * (2 + 2 * outer) uint32 (zeroed by this call on `stream`); after completion counters[1] != 0 reports a
+ * MIFFT_FUSED2_COUNTER_BYTES(outer) bytes (zeroed by this call on `stream`; one 256-byte line per counter, see fft_fused2.hpp); after completion counters[1] != 0 reports a
  * dependency time-out (results invalid).  Returns MIFFT_E_UNSUPPORTED when the shape has no fused kernel.
  * The ring is always interleaved (ring0; ring1 is ignored), also for split-plane in/out buffers.
  */
+#define MIFFT_FUSED2_COUNTER_STRIDE 64u /* uint32 words between two counters */
+#define MIFFT_FUSED2_COUNTER_BYTES(outer) ((size_t)MIFFT_FUSED2_COUNTER_STRIDE * 4u * (1u + 2u * (size_t)(outer)))
 int mifft_launch_fused2(const mifft_pass *p0, const mifft_pass *p1, const void *in0, const void *in1, void *out0,
                         void *out1, void *ring0, void *ring1, int32_t ring_slots, int32_t lag, void *counters,
                         int32_t grid, mifft_stream_t stream);

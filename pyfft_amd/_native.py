@@ -26,6 +26,14 @@ FLAG_SRC_INTERLEAVED, FLAG_DST_INTERLEAVED = 1, 2
 FLAG_STREAM_SRC, FLAG_STREAM_DST = 4, 8
 XCD2_SCRATCH_BYTES = 8 * 64 * 16 * 256 * 8
 XCD2_CONTROL_BYTES = (64 + 2 * 512) * 4
+FUSED2_COUNTER_STRIDE = 64          # MIFFT_FUSED2_COUNTER_STRIDE (uint32 words between two counters)
+
+
+def fused2_counter_bytes(outer):
+    """MIFFT_FUSED2_COUNTER_BYTES(outer)"""
+    return FUSED2_COUNTER_STRIDE * 4 * (1 + 2 * int(outer))
+
+
 XCD2_PREFETCH = 1
 DEBUG_NO_ND2, DEBUG_FUSED_NO_NT, DEBUG_NO_WAVE, DEBUG_FORCE_WAVE, DEBUG_PERSIST, DEBUG_ALT_ROWS = 0, 1, 2, 3, 4, 5
 XCD2_TRACE = 2

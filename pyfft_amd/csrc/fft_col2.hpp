@@ -79,10 +79,16 @@ template <int A, bool TR, int ESZ = 8> struct Col2Lds {
 // WT: write the result with write-through (agent-coherent, "sc1") stores -- used by the fused kernel for the
 //     intermediate so that publishing it needs no release fence (interleaved fp32 only).
 // NTIN / NTOUT: non-temporal hint on the input loads / output stores (streamed-once data in the fused kernel).
+// `hook` is called once, by every thread, between the second register stage and the exchange rounds -- the middle of the tile:
+// the fused kernel issues the early poll of its next item's dependency there.
+struct TileNoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+
 template <typename T, int A, bool TR, bool TW, bool SPLIT, bool WT = false, bool NTIN = false, bool NTOUT = false,
-          bool SPLIT_OUT = SPLIT, typename LdsPtr = cplx<T>*>
+          bool SPLIT_OUT = SPLIT, typename LdsPtr = cplx<T>*, typename Hook = TileNoHook>
 __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_in, const long long o_out,
-                                          const long long rem0, LdsPtr lds) {
+                                          const long long rem0, LdsPtr lds, Hook hook = Hook()) {
     constexpr int L = A * 256;
     constexpr int PPT = A * 16;
     constexpr int PITCH = Col2Lds<A, TR, sizeof(cplx<T>)>::PITCH;
@@ -195,6 +201,7 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
         });
     }
     __builtin_amdgcn_sched_barrier(0);
+    hook();
 
     // ---- exchange + stage 3, one qa slab per round
     // phase-2 thread roles: non-TR (u = tid>>4, c2 = tid&15): lanes along the columns (128-byte row segments)

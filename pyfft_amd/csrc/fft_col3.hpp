@@ -75,9 +75,9 @@ __device__ __forceinline__ void col3_store_wt16(void* p, const cplx<double>& r) 
 }
 
 // WT: write the result with write-through (agent-coherent) stores: the intermediate of the fused two-pass kernel (interleaved)
-template <typename T, int A, bool TR, bool TW, bool SPLIT, bool NTIN, bool NTOUT, bool SPLIT_OUT, bool WT = false>
+template <typename T, int A, bool TR, bool TW, bool SPLIT, bool NTIN, bool NTOUT, bool SPLIT_OUT, bool WT = false, typename Hook = TileNoHook>
 __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_in, const long long o_out, const long long rem0,
-                                          T* lds) {
+                                          T* lds, Hook hook = Hook()) {
     constexpr int L = 512 * A;          // 2 * L'
     constexpr int PPT = 16 * A;
     constexpr int PITCH = Col3Lds<T, TR>::PITCH;
@@ -161,6 +161,7 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
         });
     }
     __builtin_amdgcn_sched_barrier(0);
+    hook();   // (fft_col2.hpp: the middle of the tile)
 
     // ---- per slab: exchange + radix-16 of each half, then the radix-2 across the lane halves
     const int u = TR ? (tl & 15) : (tl >> 4);

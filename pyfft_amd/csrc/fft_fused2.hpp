@@ -23,10 +23,13 @@
 
 namespace mifft {
 
+constexpr unsigned kFusedCS = 64u;   // words between two counters (= MIFFT_FUSED2_COUNTER_STRIDE)
+
 struct FusedArgs {
     TileArgs p0;         // pass 0: in = user input,  out = scratch ring (matrix index = ring slot)
     TileArgs p1;         // pass 1: in = scratch ring, out = user output
-    unsigned* counters;  // [0] ticket, [1] error, [2 .. 2+batch) wdone, [2+batch .. 2+2*batch) rdone  (zeroed per launch)
+    unsigned* counters;  // [0] ticket, [1] error, then one counter per CS = 64 words (256 bytes): wdone[t] at CS * (1 + t),
+                         // rdone[t] at CS * (1 + batch + t)  (zeroed per launch)
     unsigned batch;      // number of transforms
     unsigned lag;        // pass 1 of transform t is queued with pass 0 of transform t + lag
     unsigned ring;       // scratch ring slots (transforms); ring > lag
@@ -41,10 +44,11 @@ struct FusedPending {
     unsigned* ctr;   // wdone counter still to be bumped, or nullptr
 };
 
-// wait until *ctr >= target (one lane polls, bounded); ACQ: also make other work-groups' published data visible
-template <bool ACQ> __device__ __forceinline__ void fused_wait_ge(unsigned* ctr, unsigned target, unsigned* err, FusedPending& pend) {
-    unsigned seen = 0;
-    if (threadIdx.x == 0) seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // first poll, in flight
+// wait until *ctr >= target (one lane polls, bounded); ACQ: also make other work-groups' published data visible.
+// `seen` is lane 0's EARLY poll of the same counter, issued from the middle of the previous tile (FusedHook below): an agent-scope load takes 1-3 us
+// under load, and with the poll on the critical path of every item the kernel lost 16 % (C2: 22.5 ms; with no waits at all --
+// wrong results, same traffic -- 18.9 ms).  The counters only grow, so a stale value can only under-estimate.
+template <bool ACQ> __device__ __forceinline__ void fused_wait_ge(unsigned* ctr, unsigned target, unsigned seen, unsigned* err, FusedPending& pend) {
     if (pend.ctr != nullptr) {   // (uniform) the owed tile: every wave drains its stores, the barrier joins them, lane 0 publishes
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -53,13 +57,14 @@ template <bool ACQ> __device__ __forceinline__ void fused_wait_ge(unsigned* ctr,
     }
     if (threadIdx.x == 0) {
         unsigned spins = 0;
-        while (seen < target) {
+        while (seen < target) {          // (the early value was not enough: look again, then sleep between polls)
+            seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (seen >= target) break;
             __builtin_amdgcn_s_sleep(32);
             if (++spins > (1u << 22)) {  // ~ seconds: never hang the GPU
                 __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
-            seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if constexpr (ACQ) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -87,126 +92,156 @@ __device__ __forceinline__ void fused_signal_read(unsigned* ctr) {
     if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename T, int A0, int A1, bool SPLIT, bool NT>
-__global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
-    constexpr int E0 = Col2Lds<A0, true>::ELEMS, E1 = Col2Lds<A1, false>::ELEMS;
-    __shared__ __attribute__((aligned(16))) cplx<T> lds[E0 > E1 ? E0 : E1];
-    __shared__ unsigned s_item;
+// Lane 0's view of the work list: the ticket of the next item (drawn at the top of this one) and the early poll of that item's
+// dependency counter (issued from the middle of this tile, TileHook below).  Both returning atomics are consumed at the top of
+// the next item, so neither latency is on the critical path.
+struct FusedQueue {
+    unsigned t1, seen1;
+};
 
+struct FusedItem {
+    unsigned pass;     // 0, 1, or 2 = nothing to do (fill / drain of the pipeline)
+    unsigned t;        // transform
+    unsigned tile;
+    unsigned* dep;     // counter this item waits for (nullptr: none)
+    unsigned target;
+};
+
+template <unsigned PER0, unsigned PER1>
+__device__ __forceinline__ FusedItem fused_decode(const FusedArgs& f, unsigned item, unsigned gsize, unsigned* wdone, unsigned* rdone) {
+    constexpr unsigned period = PER0 + PER1;
+    const unsigned g = item / gsize, k = item % gsize, j = k / period, m = k % period;
+    FusedItem it;
+    it.dep = nullptr;
+    it.target = 0;
+    if (m < PER0) {
+        it.pass = g < f.batch ? 0u : 2u;
+        it.t = g;
+        it.tile = j * PER0 + m;
+        if (it.pass == 0u && g >= f.ring) {
+            it.dep = rdone + kFusedCS * (g - f.ring);   // the ring slot it overwrites has been read
+            it.target = f.tiles1;
+        }
+    } else {
+        it.pass = g >= f.lag ? 1u : 2u;
+        it.t = g - f.lag;
+        it.tile = j * PER1 + (m - PER0);
+        if (it.pass == 1u) {
+            it.dep = wdone + kFusedCS * it.t;           // every pass-0 tile of the transform has published
+            it.target = f.tiles0;
+        }
+    }
+    return it;
+}
+
+// lane 0 only: hand out this item's ticket and its early poll, draw the next ticket
+__device__ __forceinline__ unsigned fused_advance(FusedQueue& q, unsigned& seen, unsigned total, unsigned* next) {
+    const unsigned item = q.t1;
+    seen = q.seen1;
+    q.seen1 = 0u;     // "not polled yet" (the hook of this item's tile sets it)
+    if (item < total) q.t1 = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return item;
+}
+
+// The early poll.  A dependency is typically 20-50 us old when its consumer arrives (measured: 2 % younger than 10 us), so a
+// poll from the middle of the previous tile (~8 us earlier) almost always sees it; one item earlier it fails three times in four.
+template <unsigned PER0, unsigned PER1> struct FusedHook {
+    const FusedArgs& f;
+    FusedQueue& q;
+    unsigned total, gsize;
+    unsigned *wdone, *rdone;
+    __device__ __forceinline__ void operator()() const {
+        if (threadIdx.x == 0 && q.t1 < total) {
+            const FusedItem nx = fused_decode<PER0, PER1>(f, q.t1, gsize, wdone, rdone);
+            if (nx.dep != nullptr) q.seen1 = __hip_atomic_load(nx.dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+};
+
+// one persistent work-group: TILE0(t, slot, tile, hook) / TILE1(slot, t, tile, hook) run one tile of pass 0 / pass 1
+template <unsigned PER0, unsigned PER1, bool EARLY, typename TILE0, typename TILE1>
+__device__ __forceinline__ void fused_loop(const FusedArgs& f, unsigned* s_item, TILE0&& tile0, TILE1&& tile1) {
     unsigned* const next = f.counters;
     unsigned* const err = f.counters + 1;
-    unsigned* const wdone = f.counters + 2;
-    unsigned* const rdone = wdone + f.batch;
+    // One counter per 256-byte line: the counters of the few transforms in flight are polled and bumped by all 512 work-groups,
+    // and packed 32 to a line they shared one memory channel's atomic unit (C2 with no polls at all -- wrong results, same
+    // traffic -- ran 15 % faster; hiding the poll LATENCY changed nothing: it is the rate of same-line agent-scope accesses).
+    unsigned* const wdone = f.counters + kFusedCS;
+    unsigned* const rdone = wdone + kFusedCS * f.batch;
     // a group = the tiles0 pass-0 tiles of transform g and the tiles1 pass-1 tiles of transform g - lag, interleaved in their
-    // ratio (tiles0 : tiles1 = L1 : L0 = A1 : A0), so that no ticket is an empty item
-    constexpr unsigned per0 = A0 > A1 ? 1u : (unsigned)(A1 / A0);
-    constexpr unsigned per1 = A1 > A0 ? 1u : (unsigned)(A0 / A1);
-    constexpr unsigned period = per0 + per1;
+    // ratio (tiles0 : tiles1 = PER0 : PER1), so that no ticket is an empty item
     const unsigned gsize = f.tiles0 + f.tiles1;
     const unsigned total = (f.batch + f.lag) * gsize;
 
-    // the ticket of the NEXT item is drawn while the current one is being worked on (the returning atomic takes 1-3 us under
-    // load: MI355X_MICROARCH.md, dequeue row), so its latency is off the critical path
     FusedPending pend = {nullptr};
-    unsigned ahead = 0;
-    if (threadIdx.x == 0) ahead = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    FusedQueue q = {0u, 0u};
+    if (threadIdx.x == 0) q.t1 = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const FusedHook<PER0, PER1> hook = {f, q, total, gsize, wdone, rdone};
     for (;;) {
         __syncthreads();  // the previous item's LDS traffic and its s_item read are over
-        if (threadIdx.x == 0) {
-            s_item = ahead;
-            if (ahead < total) ahead = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        unsigned seen = 0;
+        if (threadIdx.x == 0) *s_item = fused_advance(q, seen, total, next);
         __syncthreads();
-        const unsigned item = s_item;
+        const unsigned item = *s_item;
         if (item >= total) break;
-        const unsigned g = item / gsize, k = item % gsize, j = k / period, m = k % period;
-        if (m < per0) {
-            const unsigned tile = j * per0 + m;
-            if (g >= f.batch) {          // (the drain of the last `lag` transforms) nothing to do, but never sit on a publish
-                fused_flush(pend);
-                continue;
-            }
-            const unsigned t = g;
-            if (t >= f.ring) {
-                fused_wait_ge<false>(rdone + (t - f.ring), f.tiles1, err, pend);
-            } else {
-                fused_flush(pend);
-            }
-            col2_tile<T, A0, true, true, SPLIT, true, NT, false, false>(f.p0, (long long)t, (long long)(t % f.ring), (long long)tile * 16, lds);
-            pend.ctr = wdone + t;       // published behind the next item's dependency wait (or at the end)
+        const FusedItem it = fused_decode<PER0, PER1>(f, item, gsize, wdone, rdone);
+        if (it.pass == 2u) {             // fill / drain of the pipeline: nothing to do, but never sit on a publish
+            fused_flush(pend);
+            continue;
+        }
+        if (it.pass == 0u) {
+            if (it.dep != nullptr) fused_wait_ge<false>(it.dep, it.target, seen, err, pend);
+            else fused_flush(pend);
+            if constexpr (EARLY) tile0(it.t, it.t % f.ring, it.tile, hook);
+            else tile0(it.t, it.t % f.ring, it.tile, TileNoHook());
+            pend.ctr = wdone + kFusedCS * it.t;     // published behind the next item's dependency wait (or at the end)
         } else {
-            const unsigned tile = j * per1 + (m - per0);
-            if (g < f.lag) {            // (the fill of the first `lag` transforms)
-                fused_flush(pend);
-                continue;
-            }
-            const unsigned t = g - f.lag;
-            // (reading the ring with sc1 loads instead of the acquire fence measured the same -- 22.52 ms -- and 8-byte sc1 loads
-            // at two work-groups per CU are outside the hand-off forms MI355X_MICROARCH.md lists as validated: the fence stays)
-            fused_wait_ge<true>(wdone + t, f.tiles0, err, pend);
-            col2_tile<T, A1, false, false, false, false, false, NT, SPLIT>(f.p1, (long long)(t % f.ring), (long long)t, (long long)tile * 16, lds);
-            fused_signal_read(rdone + t);
+            // (reading the ring with sc1 loads instead of the acquire fence measured the same, and 8-byte sc1 loads at two
+            // work-groups per CU are outside the hand-off forms MI355X_MICROARCH.md lists as validated: the fence stays)
+            fused_wait_ge<true>(it.dep, it.target, seen, err, pend);
+            if constexpr (EARLY) tile1(it.t % f.ring, it.t, it.tile, hook);
+            else tile1(it.t % f.ring, it.t, it.tile, TileNoHook());
+            fused_signal_read(rdone + kFusedCS * it.t);
         }
     }
     fused_flush(pend);
 }
 
+template <typename T, int A0, int A1, bool SPLIT, bool NT>
+__global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
+    constexpr int E0 = Col2Lds<A0, true>::ELEMS, E1 = Col2Lds<A1, false>::ELEMS;
+    __shared__ __attribute__((aligned(16))) cplx<T> lds[E0 > E1 ? E0 : E1];
+    __shared__ unsigned s_item;
+    constexpr unsigned per0 = A0 > A1 ? 1u : (unsigned)(A1 / A0);   // tiles0 : tiles1 = L1 : L0 = A1 : A0
+    constexpr unsigned per1 = A1 > A0 ? 1u : (unsigned)(A0 / A1);
+    fused_loop<per0, per1, !SPLIT>(   // early poll: C2 19.49 -> 19.32 ms; split planes 26.7 -> 25.6 ms WITHOUT it
+        f, &s_item,
+        [&](unsigned t, unsigned slot, unsigned tile, auto hook) {
+            col2_tile<T, A0, true, true, SPLIT, true, NT, false, false>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);
+        },
+        [&](unsigned slot, unsigned t, unsigned tile, auto hook) {
+            col2_tile<T, A1, false, false, false, false, false, NT, SPLIT>(f.p1, (long long)slot, (long long)t, (long long)tile * 16, lds, hook);
+        });
+}
+
 // The same work list with the 512-thread tiles of fft_col3.hpp (L = 512 * A): fp32 N = 2^22 = 2048 x 2048 (BASELINE config 5;
 // one work-group per CU, the ring holds 7 transforms of 32 MiB), fp32 N = 2^21 = 2048 x 1024 and fp64 N = 2^20 = 1024 x 1024
-// (14 transforms of 16 MiB).  A group is tiles0 + tiles1 items with the two kinds interleaved in their ratio (1:1 or 1:2).
+// (14 transforms of 16 MiB).
 template <typename T, int A0, int A1, bool SPLIT, bool NT>
 __global__ void __launch_bounds__(512, 2) fft_fused3_kernel(const FusedArgs f) {
     constexpr int E0 = Col3Lds<T, true>::SCALARS, E1 = Col3Lds<T, false>::SCALARS;
     __shared__ __attribute__((aligned(16))) T lds[E0 > E1 ? E0 : E1];
     __shared__ unsigned s_item;
-
-    unsigned* const next = f.counters;
-    unsigned* const err = f.counters + 1;
-    unsigned* const wdone = f.counters + 2;
-    unsigned* const rdone = wdone + f.batch;
-    constexpr unsigned per0 = A0 > A1 ? 1u : (unsigned)(A1 / A0);   // tiles0 : tiles1 = L1 : L0 = A1 : A0
+    constexpr unsigned per0 = A0 > A1 ? 1u : (unsigned)(A1 / A0);
     constexpr unsigned per1 = A1 > A0 ? 1u : (unsigned)(A0 / A1);
-    constexpr unsigned period = per0 + per1;
-    const unsigned gsize = f.tiles0 + f.tiles1;
-    const unsigned total = (f.batch + f.lag) * gsize;
-
-    FusedPending pend = {nullptr};
-    unsigned ahead = 0;
-    if (threadIdx.x == 0) ahead = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (;;) {
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            s_item = ahead;
-            if (ahead < total) ahead = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        const unsigned item = s_item;
-        if (item >= total) break;
-        const unsigned g = item / gsize, k = item % gsize, j = k / period, m = k % period;
-        if (m < per0) {
-            const unsigned tile = j * per0 + m;
-            if (g >= f.batch) {
-                fused_flush(pend);
-                continue;
-            }
-            const unsigned t = g;
-            if (t >= f.ring) fused_wait_ge<false>(rdone + (t - f.ring), f.tiles1, err, pend);
-            else fused_flush(pend);
-            col3_tile<T, A0, true, true, SPLIT, NT, false, false, true>(f.p0, (long long)t, (long long)(t % f.ring), (long long)tile * 16, lds);
-            pend.ctr = wdone + t;
-        } else {
-            const unsigned tile = j * per1 + (m - per0);
-            if (g < f.lag) {
-                fused_flush(pend);
-                continue;
-            }
-            const unsigned t = g - f.lag;
-            fused_wait_ge<true>(wdone + t, f.tiles0, err, pend);
-            col3_tile<T, A1, false, false, false, false, NT, SPLIT>(f.p1, (long long)(t % f.ring), (long long)t, (long long)tile * 16, lds);
-            fused_signal_read(rdone + t);
-        }
-    }
-    fused_flush(pend);
+    fused_loop<per0, per1, false>(   // no early poll: the fp64 tiles have no register to spare for it, the fp32 ones measured equal
+        f, &s_item,
+        [&](unsigned t, unsigned slot, unsigned tile, auto hook) {
+            col3_tile<T, A0, true, true, SPLIT, NT, false, false, true>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);
+        },
+        [&](unsigned slot, unsigned t, unsigned tile, auto hook) {
+            col3_tile<T, A1, false, false, false, false, NT, SPLIT>(f.p1, (long long)slot, (long long)t, (long long)tile * 16, lds, hook);
+        });
 }
 
 }  // namespace mifft

@@ -460,7 +460,8 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     f.ring = (unsigned)ring_slots;
     f.tiles0 = (unsigned)(p0->M / 16);
     f.tiles1 = (unsigned)(p1->S / 16);
-    rc = hip_check(hipMemsetAsync(counters, 0, (size_t)(2 + 2 * p0->outer) * 4, (hipStream_t)stream), "hipMemsetAsync");
+    static_assert(mifft::kFusedCS == MIFFT_FUSED2_COUNTER_STRIDE, "counter stride");
+    rc = hip_check(hipMemsetAsync(counters, 0, MIFFT_FUSED2_COUNTER_BYTES(p0->outer), (hipStream_t)stream), "hipMemsetAsync");
     if (rc) return rc;
     rc = f64 ? mifft_fused3_f64_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)
              : mifft_fused2_f32_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream);

@@ -326,7 +326,7 @@ class FFTPlan(object):
             return
         if self._strategy[0] == "fused2":
             items = self._strategy[2]                     # ring slots
-            self._counters = ctx.allocate_raw((2 + 2 * batch) * 4)
+            self._counters = ctx.allocate_raw(N.fused2_counter_bytes(batch))
         elif self._strategy[0] == "pipelined":
             items = self._strategy[1] * self._strategy[2]  # chunk * streams
         else:
