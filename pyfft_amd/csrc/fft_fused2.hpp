@@ -224,6 +224,23 @@ __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
         });
 }
 
+// The 2-D form (BASELINE config 3: 1024 x 1024): a 2-D transform is two TRANSPOSING column passes without an inter-pass twiddle
+// -- pass 0 transforms the y axis of in[y][x] and writes ring[x][ky], pass 1 transforms the x axis of that and writes
+// out[ky][kx] -- i.e. the 1-D kernel above minus the twiddle, with contiguous 8 KiB runs on the output side.
+template <typename T, int A, bool SPLIT, bool NT>
+__global__ void __launch_bounds__(256, 2) fft_fused2d_kernel(const FusedArgs f) {
+    __shared__ __attribute__((aligned(16))) cplx<T> lds[Col2Lds<A, true>::ELEMS];
+    __shared__ unsigned s_item;
+    fused_loop<1, 1, !SPLIT>(
+        f, &s_item,
+        [&](unsigned t, unsigned slot, unsigned tile, auto hook) {
+            col2_tile<T, A, true, false, SPLIT, true, NT, false, false>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);
+        },
+        [&](unsigned slot, unsigned t, unsigned tile, auto hook) {
+            col2_tile<T, A, true, false, false, false, false, NT, SPLIT>(f.p1, (long long)slot, (long long)t, (long long)tile * 16, lds, hook);
+        });
+}
+
 // The same work list with the 512-thread tiles of fft_col3.hpp (L = 512 * A): fp32 N = 2^22 = 2048 x 2048 (BASELINE config 5;
 // one work-group per CU, the ring holds 7 transforms of 32 MiB), fp32 N = 2^21 = 2048 x 1024 and fp64 N = 2^20 = 1024 x 1024
 // (14 transforms of 16 MiB).

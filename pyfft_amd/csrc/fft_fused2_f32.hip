@@ -43,3 +43,11 @@ extern "C" int mifft_fused2_f32_launch(int L0, int L1, const mifft::FusedArgs* f
     }
     return -2;
 }
+
+// 2-D 1024 x 1024 (fft_fused2d_kernel)
+extern "C" int mifft_fused2d_f32_launch(int L, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s) {
+    if (L != 1024) return MIFFT_E_UNSUPPORTED;
+    if (split) hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 4, true, false>), dim3(grid), dim3(256), 0, s, *f);
+    else hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 4, false, true>), dim3(grid), dim3(256), 0, s, *f);
+    return (int)hipGetLastError();
+}

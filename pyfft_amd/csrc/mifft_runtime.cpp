@@ -434,36 +434,53 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     if (rc) return rc;
     if (p0->precision != p1->precision) return set_err(MIFFT_E_INVALID, "fused2: passes of two precisions");
     const bool f64 = p0->precision == MIFFT_F64;
+    // 2-D form: the ROW pass and the strided COL pass of a square 1024 x 1024 fp32 transform, run as two transposing column passes
+    const bool twod = p0->kind == MIFFT_PASS_ROW;
+    if (twod) {
+        if (f64 || p1->kind != MIFFT_PASS_COL || p0->L != 1024 || p1->L != 1024 || p1->S != 1024 || p1->M != 1 ||
+            p0->outer != p1->outer * 1024 || p0->layout != p1->layout || p0->inverse != p1->inverse)
+            return set_err(MIFFT_E_UNSUPPORTED, "fused2: the 2-D form is 1024 x 1024 fp32 only");
+    } else {
     if (p0->kind != MIFFT_PASS_COL || p1->kind != MIFFT_PASS_COL || p0->S != 1 || p0->M != p1->L || p1->M != 1 ||
         p1->S != p0->L || p0->outer != p1->outer || p0->layout != p1->layout || p0->inverse != p1->inverse)
         return set_err(MIFFT_E_INVALID, "fused2: passes are not the two passes of one long contiguous axis");
     auto ok_len = [](int L) { return L == 256 || L == 512 || L == 1024; };
     const bool big = p0->L == 2048 && (p1->L == 2048 || p1->L == 1024);   // 512-thread tiles (fft_col3.hpp)
     if (f64 ? (p0->L != 1024 || p1->L != 1024) : (!big && (!ok_len(p0->L) || !ok_len(p1->L)))) return set_err(MIFFT_E_UNSUPPORTED, "fused2: no kernel for %d x %d", p0->L, p1->L);
+    }
     const bool split = p0->layout == MIFFT_SPLIT;
     if (!in0 || !out0 || !ring0 || !counters || (split && (!in1 || !out1))) return set_err(MIFFT_E_INVALID, "fused2: null buffer");
     (void)ring1;  // the ring is always interleaved
     if (ring_slots < 2 || lag < 1 || lag >= ring_slots || grid < 1) return set_err(MIFFT_E_INVALID, "fused2: need 1 <= lag < ring_slots, grid >= 1");
     if (((uintptr_t)in0 | (uintptr_t)out0 | (uintptr_t)ring0 | (uintptr_t)in1 | (uintptr_t)out1) & 15)
         return set_err(MIFFT_E_INVALID, "data buffers must be 16-byte aligned");
-    if (p0->outer == 0) return 0;
-    if (p0->outer > 0x3fffffff) return set_err(MIFFT_E_INVALID, "fused2: batch too large");
+    if (p1->outer == 0) return 0;
+    if (p1->outer > 0x3fffffff) return set_err(MIFFT_E_INVALID, "fused2: batch too large");
     const int64_t n = (int64_t)p0->L * p1->L;
     mifft::FusedArgs f;
     fill_args(p0, in0, in1, ring0, nullptr, &f.p0);
     fill_args(p1, ring0, nullptr, out0, out1, &f.p1);
     f.p0.ostride_out = n;  // ring slot pitch
     f.p1.ostride_in = n;
+    if (twod) {
+        // pass 0 = the y axis as a transposing column pass over in[y][x] (L = 1024 rows of M = 1024 columns, S = 1), pass 1 = the
+        // x axis as the same pass over ring[x][ky]; both take w(1024) from the COL pass's table
+        f.p0.tw_L = p1->tw_L;
+        f.p0.ostride_in = p1->outer_stride_in;
+        f.p0.logMS = 10; f.p0.logS = 0; f.p0.has_tw = 0; f.p0.total = p1->outer * 1024;
+        f.p1.logMS = 10; f.p1.logS = 0; f.p1.has_tw = 0; f.p1.total = p1->outer * 1024;
+    }
     f.counters = (unsigned*)counters;
-    f.batch = (unsigned)p0->outer;
+    f.batch = (unsigned)p1->outer;
     f.lag = (unsigned)lag;
     f.ring = (unsigned)ring_slots;
-    f.tiles0 = (unsigned)(p0->M / 16);
+    f.tiles0 = twod ? 64u : (unsigned)(p0->M / 16);
     f.tiles1 = (unsigned)(p1->S / 16);
     static_assert(mifft::kFusedCS == MIFFT_FUSED2_COUNTER_STRIDE, "counter stride");
-    rc = hip_check(hipMemsetAsync(counters, 0, MIFFT_FUSED2_COUNTER_BYTES(p0->outer), (hipStream_t)stream), "hipMemsetAsync");
+    rc = hip_check(hipMemsetAsync(counters, 0, MIFFT_FUSED2_COUNTER_BYTES(p1->outer), (hipStream_t)stream), "hipMemsetAsync");
     if (rc) return rc;
-    rc = f64 ? mifft_fused3_f64_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)
+    rc = twod ? mifft_fused2d_f32_launch(p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)
+       : f64 ? mifft_fused3_f64_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)
              : mifft_fused2_f32_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream);
     if (rc == MIFFT_E_UNSUPPORTED) return set_err(rc, "fused2: no kernel for %d x %d", p0->L, p1->L);
     if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");

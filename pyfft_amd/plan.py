@@ -247,9 +247,21 @@ class FFTPlan(object):
     PIPELINE_STREAMS = 2
     XCD2_MIN_BATCH = 64                # 8 transforms per XCD: below that the pipelined chunks win
 
+    def _fused2d_eligible(self):
+        """2-D 1024 x 1024 fp32 (BASELINE config 3): ROW + strided COL, run by the fused kernel as two transposing passes."""
+        p = self._params
+        k = self._kernels
+        # (split planes: 29 % against 35 % for the pipelined chunks -- only on request)
+        return (p.precision == N.F32 and int(p.x) == 1024 and int(p.y) == 1024 and int(p.z) == 1 and len(k) == 2
+                and (not p.split or D.forced_strategy() == "fused")
+                and k[0].kind == N.PASS_ROW and k[0].L == 1024 and k[1].kind == N.PASS_COL and k[1].L == 1024
+                and k[1].M == 1 and k[1].S == 1024)
+
     def _fused2_eligible(self):
         p = self._params
         k = self._kernels
+        if self._fused2d_eligible():
+            return True
         if not (len(k) == 2 and int(p.y) == 1 and int(p.z) == 1 and k[0].kind == N.PASS_COL and k[1].kind == N.PASS_COL
                 and k[0].S == 1 and k[0].M == k[1].L and k[1].M == 1):
             return False
@@ -259,8 +271,8 @@ class FFTPlan(object):
 
     def _xcd2_eligible(self):
         k = self._kernels
-        return (self._fused2_eligible() and self._params.precision == N.F32 and k[0].L == 1024 and k[1].L == 1024
-                and self._context.compute_units == 256
+        return (self._fused2_eligible() and not self._fused2d_eligible() and self._params.precision == N.F32
+                and k[0].L == 1024 and k[1].L == 1024 and self._context.compute_units == 256
                 and not self._xcd2_disabled)
 
     def _select_strategy(self, batch):
@@ -273,10 +285,10 @@ class FFTPlan(object):
         strat = ("chain",)
         if forced == "xcd" and self._xcd2_eligible() and batch >= self.XCD2_MIN_BATCH:   # not the default yet: DESIGN.md section 4
             return ("xcd2", D.xcd2_flags(N.XCD2_PREFETCH))
-        if self._temp_buffer_needed and forced in ("auto", "fused") and self._fused2_eligible():
-            huge = self._kernels[0].L == 2048 or p.precision == N.F64   # 512-thread tiles: one work-group per CU
+        if (self._temp_buffer_needed or self._fused2d_eligible()) and forced in ("auto", "fused") and self._fused2_eligible():
+            huge = (self._kernels[0].L == 2048 or p.precision == N.F64) and not self._fused2d_eligible()   # 512-thread tiles: one work-group per CU
             grid = (1 if huge else 2) * self._context.compute_units
-            gsize = 2 * max(self._kernels[0].M // 16, self._kernels[1].S // 16)
+            gsize = 2 * max(max(self._kernels[0].M, self._kernels[0].L if self._fused2d_eligible() else 1) // 16, self._kernels[1].S // 16)
             # producers run `lag` transforms ahead of the consumers; ring = 2 * lag slots (1024 x 1024: lag 14, 224 MiB --
             # the largest ring that still fits the 256 MiB Infinity Cache measured best: fused_probe.py wide)
             # measured on MI355X: the persistent kernel beats stream-pipelined chunks only for 1024 x 1024
@@ -322,7 +334,7 @@ class FFTPlan(object):
                 self._xcd2_scratch = ctx.allocate_raw(N.XCD2_SCRATCH_BYTES)
             self._counters = ctx.allocate_raw(N.XCD2_CONTROL_BYTES + N.XCD2_TRACE_BYTES)
             return
-        if not self._temp_buffer_needed:
+        if not self._temp_buffer_needed and self._strategy[0] != "fused2":
             return
         if self._strategy[0] == "fused2":
             items = self._strategy[2]                     # ring slots

@@ -243,6 +243,48 @@ def test_fused_two_pass_kernel(ctx, monkeypatch, n, batch):
     assert oracle.difference(data, back, batch) < 1.1e-6
 
 
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.float32], ids=str)
+def test_fused_2d_1024(ctx, monkeypatch, dtype):
+    """BASELINE config 3 shape through the fused kernel's 2-D form (two transposing passes): same thresholds as the chain, in
+    place == out of place, inverse round trip, interleaved and split planes."""
+    shape, batch = (1024, 1024), 57
+    n = shape[0] * shape[1]
+    split = numpy.dtype(dtype).kind == "f"
+    data = oracle.get_test_data(shape, dtype, batch, 1003)
+    bufs_in = data if split else (data,)
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "fused" if split else "auto")   # (split planes default to the pipelined chunks)
+    plan = ctx.getPlan(shape, dtype=dtype)
+    assert plan.strategy(batch)[0] == "fused2"
+    gin = [ctx.toGpu(x) for x in bufs_in]
+    gout = [ctx.allocate(x.shape, x.dtype) for x in bufs_in]
+    plan.execute(*gin, *gout, batch=batch)
+    for g, x in zip(gin, bufs_in):
+        assert numpy.array_equal(g.get(), x)
+    out = [g.get() for g in gout]
+    plan.execute(*gin, batch=batch)                    # in place
+    for g, o in zip(gin, out):
+        assert numpy.array_equal(g.get(), o)
+    for item in (0, batch // 2, batch - 1):
+        sl = slice(item * shape[0], (item + 1) * shape[0])
+        x = (bufs_in[0][sl].astype(numpy.float64) + 1j * bufs_in[1][sl]) if split else bufs_in[0][sl].astype(numpy.complex128)
+        ref = numpy.fft.fft2(x)
+        got = (out[0][sl].astype(numpy.float64) + 1j * out[1][sl]) if split else out[0][sl]
+        assert numpy.abs(ref - got).sum() / numpy.abs(ref).sum() < 1.1e-6
+        assert numpy.abs(ref - got).max() <= 1e-5 * numpy.abs(ref).max()
+    plan.execute(*gin, batch=batch, inverse=True)      # back, in place
+    for g, x in zip(gin, bufs_in):
+        back = g.get()
+        assert numpy.abs(back - x).sum() / numpy.abs(x).sum() < 1.1e-6
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
+    plan_c = ctx.getPlan(shape, dtype=dtype)
+    assert plan_c.strategy(batch)[0] == "chain"
+    gin = [ctx.toGpu(x) for x in bufs_in]
+    plan_c.execute(*gin, batch=batch)
+    for g, o in zip(gin, out):
+        c = g.get()
+        assert numpy.abs(c - o).sum() / numpy.abs(c).sum() < 5e-7
+
+
 def test_fused_two_pass_kernel_fp64(ctx, monkeypatch):
     """fp64 N = 2^20 (1024 x 1024 on the 512-thread tiles): the fused kernel gives the bits of the two-launch chain."""
     n, batch = 1 << 20, 31

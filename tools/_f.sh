@@ -1,6 +1,5 @@
-timeout 900 python -m pytest tests/test_errors_gpu.py tests/test_round2_gpu.py -x -q -k "fused or split_plane or mailbox or async" 2>&1 | tail -2
-timeout 300 python bench.py --plain --steps 5 --warmup 2 | tail -1 | cut -c1-200
-timeout 300 python bench.py --plain --config c5 --steps 5 --warmup 2 | tail -1 | cut -c1-200
-timeout 300 python tools/quick_bench.py one 2097152 complex64 512 | tail -1 | cut -c100-220
-timeout 300 python tools/quick_bench.py one 1048576 complex128 512 | tail -1 | cut -c100-220
-timeout 300 python tools/quick_bench.py one 1048576 float32 4096 | tail -1 | cut -c100-220
+timeout 900 python -m pytest tests/test_errors_gpu.py -x -q -k "fused" 2>&1 | tail -8
+timeout 300 python bench.py --plain --config c3 --steps 5 --warmup 2 | tail -1 | cut -c1-260
+timeout 300 python tools/quick_bench.py one 1024x1024 complex64 512 inplace | tail -1 | cut -c60-220
+timeout 300 python tools/quick_bench.py one 1024x1024 float32 512 | tail -1 | cut -c60-220
+PYFFT_AMD_STRATEGY=pipelined timeout 300 python tools/quick_bench.py one 1024x1024 float32 512 | tail -1 | cut -c60-220
