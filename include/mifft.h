@@ -244,7 +244,7 @@ int mifft_launch_fused2(const mifft_pass *p0, const mifft_pass *p1, const void *
  * Requires a device with 8 XCDs x 32 CUs (MI355X); MIFFT_E_UNSUPPORTED otherwise or for other lengths.
  */
 #define MIFFT_XCD2_SCRATCH_BYTES (8u * 64u * 16u * 256u * 8u)
-#define MIFFT_XCD2_CONTROL_BYTES ((64u + 2u * 512u) * 4u)
+#define MIFFT_XCD2_CONTROL_BYTES ((64u + 2u * 512u * 32u) * 4u) /* one 128-byte line per flag */
 #define MIFFT_XCD2_PREFETCH 1
 #define MIFFT_XCD2_TRACE 2
 #define MIFFT_XCD2_TRACE_BYTES (512u * 32u * 8u)

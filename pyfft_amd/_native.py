@@ -25,7 +25,7 @@ PASS_COL, PASS_ROW, PASS_ND = 0, 1, 2
 FLAG_SRC_INTERLEAVED, FLAG_DST_INTERLEAVED = 1, 2
 FLAG_STREAM_SRC, FLAG_STREAM_DST = 4, 8
 XCD2_SCRATCH_BYTES = 8 * 64 * 16 * 256 * 8
-XCD2_CONTROL_BYTES = (64 + 2 * 512) * 4
+XCD2_CONTROL_BYTES = (64 + 2 * 512 * 32) * 4
 FUSED2_COUNTER_STRIDE = 64          # MIFFT_FUSED2_COUNTER_STRIDE (uint32 words between two counters)
 
 

@@ -33,14 +33,16 @@ struct Xcd2Args {
     TileArgs p0;     // pass 0: in0/in1 = user input, tw_L = w(1024), tw_lo/tw_hi/tw_shift = w(2^20) two-level table
     TileArgs p1;     // pass 1: out0/out1 = user output, tw_L = w(1024), scale
     unsigned* ctl;   // control block, zeroed per launch: [0] arrivals [1] error [8..16) work-groups per XCD
-                     //   [64 + 64x ..) ready[x][64]   [576 + 64x ..) rdone[x][64]
+                     //   ready[x][64] then rdone[x][64], one flag per 128-byte line (kXcd2FS words apart)
     void* scratch;   // [8 XCDs][64 consumers][16 slots][256 threads] complex<float>: 2 MiB per XCD
     unsigned batch;
     unsigned long long* trace;   // development: 32 time stamps (100 MHz) per work-group for transform index trace_iter, or null
     unsigned trace_iter;
     unsigned pace;               // development: throttle the HBM burst of the last stage
 };
-constexpr int kXcd2CtlWords = 64 + 2 * 512;
+constexpr unsigned kXcd2FS = 32u;   // words between two flags: one 128-byte line per flag (packed, the 64 flags of an XCD shared two lines
+                                    // that all its work-groups poll)
+constexpr int kXcd2CtlWords = 64 + 2 * 512 * (int)kXcd2FS;
 constexpr unsigned kXcd2ErrTimeout = 1u, kXcd2ErrCensus = 2u;
 
 __device__ __forceinline__ unsigned xcd2_xcc_id() {
@@ -148,8 +150,8 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
     const unsigned lane16 = (unsigned)tid0 & 15u;
 
     unsigned* const err = f.ctl + 1;
-    unsigned* const ready = f.ctl + 64 + 64 * x;
-    unsigned* const rdone = f.ctl + 64 + 512 + 64 * x;
+    unsigned* const ready = f.ctl + 64 + 64 * x * kXcd2FS;
+    unsigned* const rdone = f.ctl + 64 + (512 + 64 * x) * kXcd2FS;
     char* const sbase = reinterpret_cast<char*>(f.scratch) + (size_t)x * (64u * 16u * 256u * 8u);
     const unsigned slot = r >> 2;              // b1 of my columns in every consumer's first-stage butterfly
     const long long rem0 = (long long)r * 16;  // my 16 columns, both passes
@@ -270,9 +272,9 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
         auto rendezvous = [&](unsigned* mine, unsigned value, const unsigned* theirs, unsigned sel) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A: stores(k) acknowledged; B: loads(k) landed
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(mine + r, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (tid == 0) __hip_atomic_store(mine + r * kXcd2FS, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (wave0) {
-                const bool ok = xcd2_wait16(theirs, lane16 * 4u + sel, value, err);
+                const bool ok = xcd2_wait16(theirs, (lane16 * 4u + sel) * kXcd2FS, value, err);
                 if (tid == 0) *s_ok = ok ? 1u : 0u;
             }
             __syncthreads();
