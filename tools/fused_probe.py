@@ -33,7 +33,7 @@ def probe(n, B, combos, iters=3, check=True):
     print("N=%d B=%d two launches %s: %.3f ms  %.1f%% of 8 TB/s" % (n, B, plan.pass_list(), best, alg / best / 1e6 / 80), flush=True)
     descs = plan._descriptors(B, False, False)
     refh = ref.get() if check else None
-    counters = DeviceAllocation((2 + 2 * B) * 4)
+    counters = DeviceAllocation(N.fused2_counter_bytes(B))
     for lag, ring, grid in combos:
         scratch = DeviceAllocation(ring * n * isz)
         def once():
@@ -56,6 +56,10 @@ def probe(n, B, combos, iters=3, check=True):
 
 if __name__ == "__main__":
     combos = [(7, 14, 512), (8, 16, 512), (9, 18, 512), (10, 20, 512), (8, 12, 512), (8, 24, 512), (8, 16, 384), (8, 16, 448), (6, 16, 384)]
+    if len(sys.argv) > 1 and sys.argv[1] == "r2":     # end of round 2 (counters on their own lines): around the plan's lag 14 / ring 28
+        combos = [(14, 28, 512), (10, 28, 512), (18, 28, 512), (7, 28, 512), (12, 24, 512), (10, 20, 512), (7, 14, 512), (4, 8, 512), (16, 32, 512), (14, 28, 768)]
+        probe(1 << 20, 2048, combos, check=False)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "wide":
         combos = [(l, r, 512) for l in (6, 8, 10, 12, 14, 18, 24) for r in (2 * l, 3 * l // 2)] + [(18, 36, 768), (12, 24, 768), (18, 36, 384)]
     probe(1 << 20, 1024, combos)
