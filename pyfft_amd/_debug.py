@@ -31,6 +31,15 @@ def no_stream_hints():
     return bool(os.environ.get("PYFFT_AMD_NO_STREAM_HINTS"))
 
 
+def fused_grid_per_cu(default):
+    """PYFFT_AMD_FUSED_WGS = persistent work-groups per CU of the fused kernel (development sweep)"""
+    return int(os.environ.get("PYFFT_AMD_FUSED_WGS", "0")) or default
+
+
+def fused_lag_factor(default):
+    return int(os.environ.get("PYFFT_AMD_FUSED_LAGF", "0")) or default
+
+
 def fused3_lag_ring(lag, ring):
     """PYFFT_AMD_FUSED3 = lag,ring (development sweep of the 2048 x 2048 fused kernel)"""
     v = os.environ.get("PYFFT_AMD_FUSED3")

@@ -287,13 +287,14 @@ class FFTPlan(object):
             return ("xcd2", D.xcd2_flags(N.XCD2_PREFETCH))
         if (self._temp_buffer_needed or self._fused2d_eligible()) and forced in ("auto", "fused") and self._fused2_eligible():
             huge = (self._kernels[0].L == 2048 or p.precision == N.F64) and not self._fused2d_eligible()   # 512-thread tiles: one work-group per CU
-            grid = (1 if huge else 2) * self._context.compute_units
+            grid = D.fused_grid_per_cu(1 if huge else 2) * self._context.compute_units   # (four per CU for L <= 512: no gain)
             gsize = 2 * max(max(self._kernels[0].M, self._kernels[0].L if self._fused2d_eligible() else 1) // 16, self._kernels[1].S // 16)
             # producers run `lag` transforms ahead of the consumers; ring = 2 * lag slots (1024 x 1024: lag 14, 224 MiB --
             # the largest ring that still fits the 256 MiB Infinity Cache measured best: fused_probe.py wide)
-            # measured on MI355X: the persistent kernel beats stream-pipelined chunks only for 1024 x 1024
-            big = min(self._kernels[0].L, self._kernels[1].L) >= 1024
-            lag = max(2, -(-(14 if big else 9) * grid // (4 * gsize)))
+            # measured on MI355X (end of round 2, counters on their own lines): the persistent kernel beats the stream-pipelined
+            # chunks from N = 2^18 up (2^18: 42.0 vs 39.5 %, 2^19: 37.2 vs 36.2 %; 2^17: 39.1 vs 39.5, 2^16: 33 vs 40)
+            big = self._kernels[0].L * self._kernels[1].L >= (1 << 18)
+            lag = max(2, -(-D.fused_lag_factor(14) * grid // (4 * gsize)))
             ring = 2 * lag
             if huge:
                 # fp32 2048 x 2048: 32 MiB per transform, fp64 1024 x 1024: 16 MiB; the ring that fits the Infinity Cache is
@@ -301,6 +302,9 @@ class FFTPlan(object):
                 slots = (224 << 20) // item_bytes
                 lag, ring = D.fused3_lag_ring(4 * slots // 7, slots)
                 big = True
+            if forced == "fused" and batch < 2 * ring and batch >= 8:   # on request: a shorter pipeline for a small batch
+                lag = batch // 4
+                ring = 2 * lag
             if batch >= 2 * ring and (big or forced == "fused"):
                 return ("fused2", lag, ring, grid)
         # any multi-pass plan gains from cache-sized chunks (the second pass re-reads what the first just wrote),
