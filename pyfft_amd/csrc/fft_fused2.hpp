@@ -261,4 +261,19 @@ __global__ void __launch_bounds__(512, 2) fft_fused3_kernel(const FusedArgs f) {
         });
 }
 
+// 2-D 1024 x 1024 in fp64 on the 512-thread tiles (the published (1024, 1024) double-precision shape): fft_fused2d_kernel's data flow
+template <typename T, int A, bool SPLIT, bool NT>
+__global__ void __launch_bounds__(512, 2) fft_fused3d_kernel(const FusedArgs f) {
+    __shared__ __attribute__((aligned(16))) T lds[Col3Lds<T, true>::SCALARS];
+    __shared__ unsigned s_item;
+    fused_loop<1, 1, false>(
+        f, &s_item,
+        [&](unsigned t, unsigned slot, unsigned tile, auto hook) {
+            col3_tile<T, A, true, false, SPLIT, NT, false, false, true>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);
+        },
+        [&](unsigned slot, unsigned t, unsigned tile, auto hook) {
+            col3_tile<T, A, true, false, false, false, NT, SPLIT>(f.p1, (long long)slot, (long long)t, (long long)tile * 16, lds, hook);
+        });
+}
+
 }  // namespace mifft

@@ -23,6 +23,7 @@ int mifft_nd2_f64_supported(int x, int y, int z);
 int mifft_nd2_f64_launch(int x, int y, int z, const mifft::TileArgs* a, hipStream_t s);
 int mifft_fused2_f32_launch(int L0, int L1, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
 int mifft_fused2d_f32_launch(int L, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
+int mifft_fused3d_f64_launch(int L, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
 int mifft_fused3_f64_launch(int L0, int L1, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
 int mifft_aux_copy_launch(const struct mifft_copy* c, const void* s0, const void* s1, void* d0, void* d1, hipStream_t s);
 int mifft_aux_mul_rows_launch(int f64, void* a, const void* b, long long rows, long long n, hipStream_t s);

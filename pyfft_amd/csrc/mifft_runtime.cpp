@@ -437,9 +437,9 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     // 2-D form: the ROW pass and the strided COL pass of a square 1024 x 1024 fp32 transform, run as two transposing column passes
     const bool twod = p0->kind == MIFFT_PASS_ROW;
     if (twod) {
-        if (f64 || p1->kind != MIFFT_PASS_COL || p0->L != 1024 || p1->L != 1024 || p1->S != 1024 || p1->M != 1 ||
+        if (p1->kind != MIFFT_PASS_COL || p0->L != 1024 || p1->L != 1024 || p1->S != 1024 || p1->M != 1 ||
             p0->outer != p1->outer * 1024 || p0->layout != p1->layout || p0->inverse != p1->inverse)
-            return set_err(MIFFT_E_UNSUPPORTED, "fused2: the 2-D form is 1024 x 1024 fp32 only");
+            return set_err(MIFFT_E_UNSUPPORTED, "fused2: the 2-D form is 1024 x 1024 only");
     } else {
     if (p0->kind != MIFFT_PASS_COL || p1->kind != MIFFT_PASS_COL || p0->S != 1 || p0->M != p1->L || p1->M != 1 ||
         p1->S != p0->L || p0->outer != p1->outer || p0->layout != p1->layout || p0->inverse != p1->inverse)
@@ -479,7 +479,8 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     static_assert(mifft::kFusedCS == MIFFT_FUSED2_COUNTER_STRIDE, "counter stride");
     rc = hip_check(hipMemsetAsync(counters, 0, MIFFT_FUSED2_COUNTER_BYTES(p1->outer), (hipStream_t)stream), "hipMemsetAsync");
     if (rc) return rc;
-    rc = twod ? mifft_fused2d_f32_launch(p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)
+    rc = twod ? (f64 ? mifft_fused3d_f64_launch(p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)
+                     : mifft_fused2d_f32_launch(p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream))
        : f64 ? mifft_fused3_f64_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)
              : mifft_fused2_f32_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream);
     if (rc == MIFFT_E_UNSUPPORTED) return set_err(rc, "fused2: no kernel for %d x %d", p0->L, p1->L);
