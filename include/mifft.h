@@ -214,6 +214,7 @@ int mifft_launch_chain_pipelined(const mifft_pass *passes, int32_t npasses, void
                                  const mifft_stream_t *side, int32_t nside, const mifft_event_t *events);
 
 /*
+ * (Also the 2-D squares: p0 = the ROW pass, p1 = the strided COL pass of a (512|1024|2048)^2 fp32 or 1024^2 fp64 plan.)
  * Fused form of a two-pass long contiguous axis (N = p0->L * p1->L, both in {256, 512, 1024}, or 2048 x 2048 / 2048 x 1024, in fp32; 1024 x 1024 in fp64): both
  * Stockham passes of all `p0->outer` transforms in ONE persistent launch, pass 1 of transform t trailing pass 0
  * by `lag` transforms, with the intermediate in a scratch ring of `ring_slots` transforms (ring_slots > lag) that

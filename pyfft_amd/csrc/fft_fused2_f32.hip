@@ -44,8 +44,18 @@ extern "C" int mifft_fused2_f32_launch(int L0, int L1, const mifft::FusedArgs* f
     return -2;
 }
 
-// 2-D 1024 x 1024 (fft_fused2d_kernel)
+// 2-D squares: 512 and 1024 on the 256-thread tiles (fft_fused2d_kernel), 2048 on the 512-thread ones (fft_fused3d_kernel)
 extern "C" int mifft_fused2d_f32_launch(int L, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s) {
+    if (L == 512) {
+        if (split) hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 2, true, false>), dim3(grid), dim3(256), 0, s, *f);
+        else hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 2, false, true>), dim3(grid), dim3(256), 0, s, *f);
+        return (int)hipGetLastError();
+    }
+    if (L == 2048) {   // 512-thread tiles
+        if (split) hipLaunchKernelGGL((mifft::fft_fused3d_kernel<float, 4, true, false>), dim3(grid), dim3(512), 0, s, *f);
+        else hipLaunchKernelGGL((mifft::fft_fused3d_kernel<float, 4, false, true>), dim3(grid), dim3(512), 0, s, *f);
+        return (int)hipGetLastError();
+    }
     if (L != 1024) return MIFFT_E_UNSUPPORTED;
     if (split) hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 4, true, false>), dim3(grid), dim3(256), 0, s, *f);
     else hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 4, false, true>), dim3(grid), dim3(256), 0, s, *f);

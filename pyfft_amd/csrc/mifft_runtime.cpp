@@ -437,9 +437,10 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     // 2-D form: the ROW pass and the strided COL pass of a square 1024 x 1024 fp32 transform, run as two transposing column passes
     const bool twod = p0->kind == MIFFT_PASS_ROW;
     if (twod) {
-        if (p1->kind != MIFFT_PASS_COL || p0->L != 1024 || p1->L != 1024 || p1->S != 1024 || p1->M != 1 ||
-            p0->outer != p1->outer * 1024 || p0->layout != p1->layout || p0->inverse != p1->inverse)
-            return set_err(MIFFT_E_UNSUPPORTED, "fused2: the 2-D form is 1024 x 1024 only");
+        const bool okL = f64 ? p1->L == 1024 : (p1->L == 512 || p1->L == 1024 || p1->L == 2048);
+        if (p1->kind != MIFFT_PASS_COL || !okL || p0->L != p1->L || p1->S != p1->L || p1->M != 1 ||
+            p0->outer != p1->outer * p1->L || p0->layout != p1->layout || p0->inverse != p1->inverse)
+            return set_err(MIFFT_E_UNSUPPORTED, "fused2: the 2-D form is a square of 512, 1024 or 2048 (fp32) / 1024 (fp64)");
     } else {
     if (p0->kind != MIFFT_PASS_COL || p1->kind != MIFFT_PASS_COL || p0->S != 1 || p0->M != p1->L || p1->M != 1 ||
         p1->S != p0->L || p0->outer != p1->outer || p0->layout != p1->layout || p0->inverse != p1->inverse)
@@ -463,18 +464,18 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     f.p0.ostride_out = n;  // ring slot pitch
     f.p1.ostride_in = n;
     if (twod) {
-        // pass 0 = the y axis as a transposing column pass over in[y][x] (L = 1024 rows of M = 1024 columns, S = 1), pass 1 = the
-        // x axis as the same pass over ring[x][ky]; both take w(1024) from the COL pass's table
+        // pass 0 = the y axis as a transposing column pass over in[y][x] (L rows of M = L columns, S = 1), pass 1 = the x axis as
+        // the same pass over ring[x][ky]; both take w(L) from the COL pass's table
         f.p0.tw_L = p1->tw_L;
         f.p0.ostride_in = p1->outer_stride_in;
-        f.p0.logMS = 10; f.p0.logS = 0; f.p0.has_tw = 0; f.p0.total = p1->outer * 1024;
-        f.p1.logMS = 10; f.p1.logS = 0; f.p1.has_tw = 0; f.p1.total = p1->outer * 1024;
+        f.p0.logMS = ilog2(p1->L); f.p0.logS = 0; f.p0.has_tw = 0; f.p0.total = p1->outer * p1->L;
+        f.p1.logMS = ilog2(p1->L); f.p1.logS = 0; f.p1.has_tw = 0; f.p1.total = p1->outer * p1->L;
     }
     f.counters = (unsigned*)counters;
     f.batch = (unsigned)p1->outer;
     f.lag = (unsigned)lag;
     f.ring = (unsigned)ring_slots;
-    f.tiles0 = twod ? 64u : (unsigned)(p0->M / 16);
+    f.tiles0 = twod ? (unsigned)(p1->L / 16) : (unsigned)(p0->M / 16);
     f.tiles1 = (unsigned)(p1->S / 16);
     static_assert(mifft::kFusedCS == MIFFT_FUSED2_COUNTER_STRIDE, "counter stride");
     rc = hip_check(hipMemsetAsync(counters, 0, MIFFT_FUSED2_COUNTER_BYTES(p1->outer), (hipStream_t)stream), "hipMemsetAsync");

@@ -253,10 +253,13 @@ class FFTPlan(object):
         p = self._params
         k = self._kernels
         # (split planes: 29 % against 35 % for the pipelined chunks -- only on request)
-        return (int(p.x) == 1024 and int(p.y) == 1024 and int(p.z) == 1 and len(k) == 2
+        side = int(p.x)
+        if side not in ((1024,) if p.precision == N.F64 else (512, 1024, 2048)):
+            return False
+        return (int(p.y) == side and int(p.z) == 1 and len(k) == 2
                 and (not p.split or D.forced_strategy() == "fused")
-                and k[0].kind == N.PASS_ROW and k[0].L == 1024 and k[1].kind == N.PASS_COL and k[1].L == 1024
-                and k[1].M == 1 and k[1].S == 1024)
+                and k[0].kind == N.PASS_ROW and k[0].L == side and k[1].kind == N.PASS_COL and k[1].L == side
+                and k[1].M == 1 and k[1].S == side)
 
     def _fused2_eligible(self):
         p = self._params
@@ -287,7 +290,7 @@ class FFTPlan(object):
         if forced == "xcd" and self._xcd2_eligible() and batch >= self.XCD2_MIN_BATCH:   # not the default yet: DESIGN.md section 4
             return ("xcd2", D.xcd2_flags(N.XCD2_PREFETCH))
         if (self._temp_buffer_needed or self._fused2d_eligible()) and forced in ("auto", "fused") and self._fused2_eligible():
-            huge = self._kernels[0].L == 2048 or p.precision == N.F64   # 512-thread tiles: one work-group per CU
+            huge = self._kernels[1].L == 2048 or p.precision == N.F64   # 512-thread tiles: one work-group per CU
             grid = D.fused_grid_per_cu(1 if huge else 2) * self._context.compute_units   # (four per CU for L <= 512: no gain)
             gsize = 2 * max(max(self._kernels[0].M, self._kernels[0].L if self._fused2d_eligible() else 1) // 16, self._kernels[1].S // 16)
             # producers run `lag` transforms ahead of the consumers; ring = 2 * lag slots (1024 x 1024: lag 14, 224 MiB --

@@ -286,6 +286,30 @@ def test_fused_2d_1024(ctx, monkeypatch, dtype):
         assert numpy.abs(c - o).sum() / numpy.abs(c).sum() < tol_chain
 
 
+@pytest.mark.parametrize("side,batch", [(512, 120), (2048, 15)], ids=str)
+def test_fused_2d_other_squares(ctx, monkeypatch, side, batch):
+    """The 2-D form of the fused kernel for the 512 (256-thread tiles) and 2048 (512-thread tiles) squares, fp32 interleaved."""
+    shape = (side, side)
+    data = oracle.get_test_data(shape, numpy.complex64, batch, 1006)
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    plan = ctx.getPlan(shape, dtype=numpy.complex64)
+    assert plan.strategy(batch)[0] == "fused2"
+    a = ctx.toGpu(data)
+    b = ctx.allocate(data.shape, data.dtype)
+    plan.execute(a, b, batch=batch)
+    assert numpy.array_equal(a.get(), data)
+    out = b.get()
+    plan.execute(a, batch=batch)
+    assert numpy.array_equal(a.get(), out)
+    for item in (0, batch // 2, batch - 1):
+        sl = slice(item * side, (item + 1) * side)
+        ref = numpy.fft.fft2(data[sl].astype(numpy.complex128))
+        assert numpy.abs(ref - out[sl]).sum() / numpy.abs(ref).sum() < 1.1e-6
+        assert numpy.abs(ref - out[sl]).max() <= 1e-5 * numpy.abs(ref).max()
+    plan.execute(a, batch=batch, inverse=True)
+    assert oracle.difference(data, a.get(), batch) < 1.1e-6
+
+
 def test_fused_two_pass_kernel_fp64(ctx, monkeypatch):
     """fp64 N = 2^20 (1024 x 1024 on the 512-thread tiles): the fused kernel gives the bits of the two-launch chain."""
     n, batch = 1 << 20, 31
