@@ -68,19 +68,42 @@ def _free_port():
     return p
 
 
+def visible_gpus():
+    """Number of GPUs this process may use, found WITHOUT the HIP runtime: the *_VISIBLE_DEVICES lists if set, else the KFD
+    topology nodes that have SIMDs.  None if neither source exists."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir(base):
+        return None
+    n = 0
+    for node in os.listdir(base):
+        try:
+            with open(os.path.join(base, node, "properties")) as f:
+                for line in f:
+                    k, _, v = line.partition(" ")
+                    if k == "simd_count" and int(v) > 0:
+                        n += 1
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def self_launch(args, argv):
     """`--gpus N` without a launcher: start the N ranks as child processes (torch.distributed.run, rendezvous on
     127.0.0.1) and relay their output.  Called before this process imports torch or touches HIP: a process that has
     initialised the GPU must never be replaced or forked into another program."""
     n = args.gpus
     note = None
-    if not args.selftest_dist:
-        # counting devices does not initialise the GPU on this image; the children do the real work
-        import torch
-        visible = torch.cuda.device_count()
-        if visible < 1:
+    if not args.selftest_dist and not args.share_gpu:
+        # The parent only SPAWNS children: it counts the GPUs without touching torch or HIP (sysfs), so that nothing here can
+        # initialise the runtime; the children do the real work.  Unknown count (no sysfs): the children fail loudly.
+        visible = visible_gpus()
+        if visible is not None and visible < 1:
             raise SystemExit("bench.py: no GPU visible")
-        if visible < n:
+        if visible is not None and visible < n:
             note = "requested %d GPUs, %d visible: ran %d ranks" % (n, visible, visible)
             n = visible
     child = [a for a in argv]
@@ -252,20 +275,33 @@ def cpu_baseline(shape, dtype, host_items, flop_per_xform, budget_s=24.0):
     return out
 
 
-def make_host_block(shape, dtname, batch, seed, rank):
+def make_host_block(shape, dtname, batch, seed, gstart=0):
+    """The GLOBAL synthetic dataset is periodic in the transform index: transform g of the job holds block item g % blk of ONE
+    seeded block (the same on every rank).  A rank whose slice starts at global index `gstart` gets the block rotated so that
+    its local transform s holds global transform gstart + s -- `host_c[s % blk]` is then the data of local transform s, and a
+    rank's output can be checked against numpy on the global dataset's slice [gstart, gstart + count)."""
     import numpy
     dtype = numpy.dtype(dtname)
     cdtype = numpy.dtype(numpy.complex64 if dtype in (numpy.complex64, numpy.float32) else numpy.complex128)
     size = int(numpy.prod(shape))
     blk = min(batch, max(1, (512 << 20) // (size * cdtype.itemsize)), 64)
-    rng = numpy.random.default_rng(seed + rank)
+    rng = numpy.random.default_rng(seed)
     fdt = numpy.float32 if cdtype == numpy.complex64 else numpy.float64
     host_re = rng.standard_normal((blk,) + tuple(shape)).astype(fdt)
     host_im = rng.standard_normal((blk,) + tuple(shape)).astype(fdt)
+    if gstart % blk:
+        host_re = numpy.roll(host_re, -(gstart % blk), axis=0)
+        host_im = numpy.roll(host_im, -(gstart % blk), axis=0)
     host_c = numpy.empty((blk,) + tuple(shape), cdtype)
     host_c.real = host_re
     host_c.imag = host_im
     return blk, host_re, host_im, host_c
+
+
+def global_item(shape, dtname, batch, seed, g):
+    """Transform g of the global dataset, regenerated independently of any rank (test helper)."""
+    blk, _, _, host_c = make_host_block(shape, dtname, batch, seed, 0)
+    return host_c[g % blk]
 
 
 def stats(xs):
@@ -288,6 +324,14 @@ def main():
     ap.add_argument("--plain", action="store_true", help="only parity + warm-up + the K timed steps (no protocol repeats, per-pass timing or CPU baseline): profiler runs")
     ap.add_argument("--selftest-dist", action="store_true", help="CPU/gloo self-test of the multi-process harness")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even at world size 1 (test)")
+    ap.add_argument("--control", default="nccl", choices=["nccl", "gloo"],
+                    help="backend of the CONTROL plane (barrier, max over ranks); the data path has no collective.  gloo lets "
+                         "several ranks share one GPU")
+    ap.add_argument("--dump-dir", default=None,
+                    help="every rank writes the output of the first and the last transform of its slice there as "
+                         "xform_<global index>.npy (test: checked against numpy on the global dataset)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rank r uses device r %% (visible devices): runs the real sharded path with more ranks than GPUs (test)")
     args = ap.parse_args()
 
     if args.plain:
@@ -316,7 +360,7 @@ def main():
     gstart, _ = shard_batch(batch * world, rank, world)          # this rank's slice of the global batch
 
     # ---- synthetic data: one host block of <= 64 transforms (tiled across the batch on the device further down)
-    blk, host_re, host_im, host_c = make_host_block(shape, dtname, batch, seed, rank)
+    blk, host_re, host_im, host_c = make_host_block(shape, dtname, batch, seed, gstart)
 
     # ---- CPU baseline first: rank 0 at N = 1 only, before this process initialises the GPU (the pool forks)
     cpu = None
@@ -330,19 +374,23 @@ def main():
         if world > 1:
             raise
     dist = None
+    device = local_rank
+    if args.share_gpu:
+        from pyfft_amd.hip import device_count
+        device = local_rank % max(1, device_count())
     if torch is not None and torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(device)
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:            # --force-dist at world 1 without a launcher
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ["MASTER_PORT"] = str(_free_port())
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.control, rank=rank, world_size=world)
 
     from pyfft_amd import _native as N
     from pyfft_amd.hip import Plan, DeviceArray, Event, device_props
-    N.check(N.lib.mifft_set_device(local_rank), "set_device")
-    props = device_props(local_rank)
+    N.check(N.lib.mifft_set_device(device), "set_device")
+    props = device_props(device)
 
     nel = size * batch
     if split:
@@ -406,6 +454,8 @@ def main():
             ref = numpy.fft.fftn(host_c[s % blk].astype(numpy.complex128)).reshape(-1)
             worst_diff = max(worst_diff, float(numpy.abs(ref - got).sum() / numpy.abs(ref).sum()))
             worst_max = max(worst_max, float(numpy.abs(ref - got).max() / numpy.abs(ref).max()))
+            if args.dump_dir and s in (0, batch - 1):
+                numpy.save(os.path.join(args.dump_dir, "xform_%d.npy" % (gstart + s)), got)
         eps = 1.1e-6 if cdtype == numpy.complex64 else 1e-11
         mx = 1e-5 if cdtype == numpy.complex64 else 1e-10
         parity = {"samples": len(samples), "difference": worst_diff, "max_rel": worst_max,
@@ -432,10 +482,19 @@ def main():
     dev_ms = ev1.time_since(ev0)          # HIP events on the stream the kernels are launched on
     plan.finish()                          # raises if a persistent kernel reported a dependency time-out (results invalid)
 
+    rank_report = None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        ctl_dev = "cuda" if args.control == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's slice of the global batch and its own parity verdict (checked against the GLOBAL dataset)
+        mine = torch.tensor([float(gstart), float(batch), 1.0 if (parity is None or parity["ok"]) else 0.0,
+                             parity["difference"] if parity else 0.0, float(device)], dtype=torch.float64, device=ctl_dev)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        rank_report = [{"rank": r, "first_transform": int(g[0].item()), "count": int(g[1].item()), "parity_ok": bool(g[2].item() > 0.5),
+                        "difference": float(g[3].item()), "device": int(g[4].item())} for r, g in enumerate(gathered)]
 
     # ---- the reference's timing protocol (untimed for `value`): out of place AND in place, median of >= 5 repeats of a
     # block of back-to-back executes between two HIP events (test/test_performance.py:22-30 times 10 executes once;
@@ -536,7 +595,8 @@ def main():
             args.config, "x".join(map(str, shape)), dtname, batch,
             "split re/im planes" if split else "interleaved", "in place" if args.inplace else "out of place"),
             "global_batch": batch * world, "first_transform_of_rank0": gstart,
-            "parallelism": "batch-sharded x%d, no collective" % world,
+            "parallelism": "batch-sharded x%d, no collective%s" % (world, " (control plane: %s)" % args.control if dist is not None else ""),
+            "ranks": rank_report,
             "passes": [repr(p) for p in plan.pass_list()], "strategy": strategy[0]},
         "transforms_per_s": total_xforms / elapsed,
         "algorithmic_GBps": alg_gbs,

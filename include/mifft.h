@@ -24,7 +24,8 @@
  *   - every function returns 0 on success, a positive hipError_t, or a negative MIFFT_E_* code, and
  *     records a thread-local message readable with mifft_last_error();
  *   - all device buffers (user data, temp, twiddle tables) are owned by the caller and only borrowed for
- *     the duration of the enqueued work; the library keeps no mutable global state;
+ *     the duration of the enqueued work; the library keeps no per-plan or per-call state (process-wide are only the
+ *     development switches of mifft_debug_set and a cached compute-unit count);
  *   - launches are asynchronous on the caller's stream; nothing here synchronises except the *_sync calls.
  */
 #ifndef MIFFT_H
@@ -37,7 +38,9 @@
 extern "C" {
 #endif
 
-#define MIFFT_ABI_VERSION 1
+/* 2: mifft_launch_fused2's counter buffer is MIFFT_FUSED2_COUNTER_BYTES (one 256-byte line per counter) and is zeroed by the
+ * call; streams are blocking streams; mifft_stream_wait_event */
+#define MIFFT_ABI_VERSION 2
 
 /* negative library error codes (positive values are hipError_t) */
 #define MIFFT_E_INVALID      (-1)  /* malformed descriptor / argument              */
@@ -168,6 +171,9 @@ int mifft_event_destroy(mifft_event_t event);
 int mifft_event_record(mifft_event_t event, mifft_stream_t stream);
 int mifft_event_sync(mifft_event_t event);
 int mifft_event_query(mifft_event_t event); /* 0 = completed, 1 = not yet, else an error code */
+/* work enqueued on `stream` after this call starts only when `event` has completed (hipStreamWaitEvent): how a plan whose
+ * caller switches streams between asynchronous executes orders the second stream behind the first on its scratch */
+int mifft_stream_wait_event(mifft_stream_t stream, mifft_event_t event);
 int mifft_event_elapsed_ms(float *ms, mifft_event_t start, mifft_event_t stop);
 
 /* ---- pass launchers (replace cuda.py Function.__call__, cuda.py:35-46) ----------------------------- */
@@ -214,15 +220,17 @@ int mifft_launch_chain_pipelined(const mifft_pass *passes, int32_t npasses, void
                                  const mifft_stream_t *side, int32_t nside, const mifft_event_t *events);
 
 /*
- * (Also the 2-D squares: p0 = the ROW pass, p1 = the strided COL pass of a (512|1024|2048)^2 fp32 or 1024^2 fp64 plan.)
- * Fused form of a two-pass long contiguous axis (N = p0->L * p1->L, both in {256, 512, 1024}, or 2048 x 2048 / 2048 x 1024, in fp32; 1024 x 1024 in fp64): both
- * Stockham passes of all `p0->outer` transforms in ONE persistent launch, pass 1 of transform t trailing pass 0
- * by `lag` transforms, with the intermediate in a scratch ring of `ring_slots` transforms (ring_slots > lag) that
- * stays in the Infinity Cache.  p0 must be the transposing first pass (COL, S == 1, M == p1->L), p1 the plain
- * strided last pass (COL, M == 1, S == p0->L).  `counters` = caller-owned device buffer of at least
- * MIFFT_FUSED2_COUNTER_BYTES(outer) bytes (zeroed by this call on `stream`; one 256-byte line per counter, see fft_fused2.hpp); after completion counters[1] != 0 reports a
- * dependency time-out (results invalid).  Returns MIFFT_E_UNSUPPORTED when the shape has no fused kernel.
- * The ring is always interleaved (ring0; ring1 is ignored), also for split-plane in/out buffers.
+ * Fused form of a two-pass long contiguous axis N = p0->L * p1->L: both Stockham passes of all `p0->outer` transforms in
+ * ONE persistent launch, pass 1 of transform t trailing pass 0 by `lag` transforms, with the intermediate in a scratch
+ * ring of `ring_slots` transforms (ring_slots > lag) that stays in the Infinity Cache.
+ *   shapes    fp32: p0->L, p1->L in {256, 512, 1024}, or 2048 x 2048 / 2048 x 1024; fp64: 1024 x 1024.
+ *             1-D form: p0 = the transposing first pass (COL, S == 1, M == p1->L), p1 = the plain strided last pass
+ *             (COL, M == 1, S == p0->L).  2-D form (the squares 512 / 1024 / 2048 in fp32, 1024 in fp64): p0 = the ROW
+ *             pass, p1 = the strided COL pass of the plan.  Anything else: MIFFT_E_UNSUPPORTED.
+ *   counters  caller-owned device buffer of at least MIFFT_FUSED2_COUNTER_BYTES(outer) bytes, zeroed by this call on
+ *             `stream` (one 256-byte line per counter, csrc/fft_fused2.hpp).  After completion
+ *             ((uint32_t*)counters)[1] != 0 reports a dependency time-out (results invalid).
+ *   ring      always interleaved (ring0; ring1 is ignored), also for split-plane in/out buffers.
  */
 #define MIFFT_FUSED2_COUNTER_STRIDE 64u /* uint32 words between two counters */
 #define MIFFT_FUSED2_COUNTER_BYTES(outer) ((size_t)MIFFT_FUSED2_COUNTER_STRIDE * 4u * (1u + 2u * (size_t)(outer)))

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmifft.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 E_INVALID = -1
 E_UNSUPPORTED = -2
@@ -134,6 +134,7 @@ PROTOTYPES = {
     "mifft_event_record": (ctypes.c_int, [_vp, _vp]),
     "mifft_event_sync": (ctypes.c_int, [_vp]),
     "mifft_event_query": (ctypes.c_int, [_vp]),
+    "mifft_stream_wait_event": (ctypes.c_int, [_vp, _vp]),
     "mifft_event_elapsed_ms": (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), _vp, _vp]),
     "mifft_nd_max_points_for": (ctypes.c_int, [_i32]),
     "mifft_nd_shape_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32]),

@@ -13,7 +13,9 @@
 namespace {
 
 thread_local char g_err[512] = "";
-int g_debug[MIFFT_DEBUG_KEYS] = {0};   // development switches (mifft_debug_set); all zero in production
+// the library's only process-wide state: the development switches (mifft_debug_set; all zero in production) and the
+// compute-unit count cached by wave_max_blocks()
+int g_debug[MIFFT_DEBUG_KEYS] = {0};
 
 int set_err(int code, const char* fmt, ...) {
     va_list ap;
@@ -334,6 +336,9 @@ int mifft_event_query(mifft_event_t event) {
         return 1;
     }
     return hip_check(e, "hipEventQuery");
+}
+int mifft_stream_wait_event(mifft_stream_t stream, mifft_event_t event) {
+    return hip_check(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0), "hipStreamWaitEvent");
 }
 int mifft_stream_destroy(mifft_stream_t stream) { return hip_check(hipStreamDestroy((hipStream_t)stream), "hipStreamDestroy"); }
 int mifft_stream_sync(mifft_stream_t stream) { return hip_check(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize"); }

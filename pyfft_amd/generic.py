@@ -27,7 +27,7 @@ import ctypes
 import numpy
 
 from . import _native as N
-from .plan import FFTPlan, normalize_shape
+from .plan import FFTPlan, normalize_shape, on_plan_device
 
 
 def _is_pow2(n):
@@ -50,6 +50,8 @@ class _SubContext(object):
     """What the inner power-of-two plans see: the outer plan's context with the stream choice frozen (the outer execute()
     has already picked the stream of this call; an inner plan must not pick another one)."""
 
+    _guard = False      # the outer plan has made its device current before an inner plan runs
+
     def __init__(self, ctx):
         self._ctx = ctx
         self.compute_units = ctx.compute_units
@@ -60,6 +62,9 @@ class _SubContext(object):
 
     def createQueue(self, buffers=()):
         pass
+
+    def order_scratch(self):
+        pass            # (the outer execute() has ordered the stream of this call behind the previous one)
 
     def stream_handle(self):
         return self._ctx.stream_handle()
@@ -201,14 +206,17 @@ class GenericFFTPlan(object):
         worst = max((self._size // ax.n) * ax.m for ax in self._axes)
         self._rows = self._context.allocate(nt * worst * isz)
 
+    @on_plan_device
     def _execute(self, wait_for_finish, inverse, batch, ins, outs):
         ctx = self._context
         batch = int(batch)
         if batch < 1:
             raise ValueError("batch must be positive")
+        self.check()
         self._prepare(batch)
         ptr = ctx.pointer_of
         ctx.createQueue(ins + outs)
+        ctx.order_scratch()
         nt = batch * self._ntiles
         work, rows = ptr(self._work), ptr(self._rows)
         in0, in1 = ptr(ins[0]), (ptr(ins[1]) if self._split else None)
@@ -255,16 +263,29 @@ class GenericFFTPlan(object):
         if wait_for_finish is not None:
             wait = wait_for_finish
         if wait:
-            ctx.wait()
+            self.finish()
         else:
             ctx.flush()
             return ctx.getQueue()
 
-    def finish(self):
-        self._context.wait()
+    def _inner_plans(self):
+        plans = [self._ndplan] if self._ndplan is not None else []
+        plans += [ax.plan for ax in self._axes if getattr(ax, "plan", None) is not None]
+        return plans
 
+    @on_plan_device
+    def finish(self):
+        """Wait for the stream, then drain every inner plan's error mailbox (an inner power-of-two plan that runs a persistent
+        kernel posts its dependency time-outs to ITS mailbox; they are this plan's errors)."""
+        self._context.wait()
+        for p in self._inner_plans():
+            p.finish()
+
+    @on_plan_device
     def check(self):
-        pass
+        """Non-blocking: raise if a completed asynchronous execute() of an inner plan reported invalid results."""
+        for p in self._inner_plans():
+            p.check()
 
     def _executeInterleaved(self, data_in, data_out=None, inverse=False, batch=1, wait_for_finish=None):
         if data_out is None:

@@ -192,22 +192,31 @@ class ErrorMailbox(object):
         self._words = (ctypes.c_uint32 * self.SLOTS).from_address(p.value)
         self._events = [None] * self.SLOTS
         self._pending = []          # (slot, tag) in launch order
+        self._stashed = []          # (tag, word) of launches retired by post() when the ring was full
         self._next = 0
 
     def post(self, dev_ptr, stream, tag):
-        if len(self._pending) >= self.SLOTS:          # the ring is full: the oldest launch must have finished by now
-            self._events[self._pending[0][0]].synchronize()
+        if len(self._pending) >= self.SLOTS:
+            # the ring is full: retire the oldest launch (wait for it, read its word, keep a non-zero one for the next
+            # collect()) BEFORE its slot is reused -- its slot is exactly the one `_next` points at
+            slot0, tag0 = self._pending.pop(0)
+            self._events[slot0].synchronize()
+            word = int(self._words[slot0])
+            if word:
+                self._stashed.append((tag0, word))
         slot = self._next
         self._next = (slot + 1) % self.SLOTS
         if self._events[slot] is None:
             self._events[slot] = Event()
+        self._words[slot] = 0
         N.check(N.lib.mifft_memcpy_d2h_async(self._host + 4 * slot, dev_ptr, 4, _stream_handle(stream)), "mifft_memcpy_d2h_async")
         self._events[slot].record(stream)
         self._pending.append((slot, tag))
 
     def collect(self, wait):
         """[(tag, word)] of the finished launches whose word is non-zero; wait=True waits for every pending launch."""
-        errors, keep = [], []
+        errors, keep = self._stashed, []
+        self._stashed = []
         for slot, tag in self._pending:
             ev = self._events[slot]
             if wait:
@@ -262,19 +271,26 @@ class Context(object):
     """Plan execution context (cuda.py:64-113): stream lifecycle, allocator, device limits."""
 
     def __init__(self, device, stream, mempool):
-        if device is not None:
-            # HIP has one primary context per device: a plan runs on the device that is current when it is used
-            # (cuda.py:121-128 takes the current context's device); a different index is refused rather than ignored
+        # HIP has one primary context per device.  `device` None: the plan lives on the device that is current when it is
+        # built.  A device index (Plan(context=i), cuda.py:121-128: the plan is built on whatever context it is given): the
+        # plan's allocations, uploads and launches run with that device made current around them (activate / restore),
+        # so one process can drive one plan per GPU without switching devices itself.
+        if device is None:
             cur = ctypes.c_int()
             N.check(N.lib.mifft_get_device(ctypes.byref(cur)), "mifft_get_device")
-            if int(device) != cur.value:
-                raise ValueError("pyfft_amd: context=%d but device %d is current; call mifft_set_device / "
-                                 "torch.cuda.set_device first" % (int(device), cur.value))
-        self._device = device
+            self._device = cur.value
+            self._guard = False
+        else:
+            self._device = int(device)
+            if not 0 <= self._device < device_count():
+                raise ValueError("pyfft_amd: context=%d but %d device(s) are visible" % (self._device, device_count()))
+            self._guard = True
         self._stream = stream
         self._call_stream = stream
+        self._last_stream_handle = None     # stream of the previous enqueue (cross-stream ordering of plan scratch)
+        self._order_event = None
         self._recreate_stream = stream is None
-        props = device_props(device)
+        props = device_props(self._device)
         self.device_name = props.name.decode()
         self.gcn_arch = props.gcn_arch.decode()
         self.compute_units = props.compute_units
@@ -312,6 +328,40 @@ class Context(object):
     def stream_handle(self):
         return _stream_handle(self._call_stream)
 
+    @property
+    def device(self):
+        return self._device
+
+    def activate(self):
+        """Make the plan's device current; returns what restore() needs (None when nothing was switched)."""
+        if not self._guard:
+            return None
+        cur = ctypes.c_int()
+        N.check(N.lib.mifft_get_device(ctypes.byref(cur)), "mifft_get_device")
+        if cur.value == self._device:
+            return None
+        N.check(N.lib.mifft_set_device(self._device), "mifft_set_device")
+        return cur.value
+
+    def restore(self, prev):
+        if prev is not None:
+            N.check(N.lib.mifft_set_device(prev), "mifft_set_device")
+
+    def order_scratch(self):
+        """Called before an execute() touches plan-owned scratch (temp buffer, ring, counters): when this call runs on a
+        different stream than the previous one (a plan built without stream= follows torch's current stream per call), the
+        new stream first waits for the work the old one still has in flight.  The reference plan ran on ONE stream
+        (cuda.py:94-107,129), where that order is implicit."""
+        h = self.stream_handle()
+        last = self._last_stream_handle
+        if last is not None and last[0] != h:
+            if self._order_event is None:
+                self._order_event = Event()
+            self._order_event.record(last[1])
+            N.check(N.lib.mifft_stream_wait_event(h, self._order_event.handle), "mifft_stream_wait_event")
+        if last is None or last[0] != h:
+            self._last_stream_handle = (h, self._call_stream)     # (keeps the stream object alive)
+
     def wait(self):
         N.check(N.lib.mifft_stream_sync(self.stream_handle()), "mifft_stream_sync")
 
@@ -334,8 +384,10 @@ def Plan(*args, **kwds):
          wait_for_finish=None, fast_math=True, scale=1.0)
 
     `stream`: a pyfft_amd.hip.Stream, a torch.cuda.Stream, or a raw hipStream_t value; when given,
-    execute() is asynchronous by default and returns the stream.  `context`: accepted for
-    signature parity (a device index or None: HIP has one primary context per device).
+    execute() is asynchronous by default and returns the stream.  `context`: a device index (or
+    an object with a `.device` index) or None = the current device.  HIP has one primary context per device; a plan
+    built for a device that is not the caller's current one makes it current around its own calls and restores the
+    caller's afterwards, so one process can hold a plan per GPU (buffers must live on the plan's device).
     `mempool`: any object with an allocate(nbytes) method returning a buffer-like object.
     `parent_shape=`, `any_size=True`: opt-in extensions (tiles of a bigger array; sizes that are not powers of two), see
     pyfft_amd/generic.py.  Without them a size that is not a power of two is a ValueError, as in the reference.
@@ -373,11 +425,12 @@ def Plan(*args, **kwds):
     if 'wait_for_finish' not in kwds or kwds['wait_for_finish'] is None:
         kwds['wait_for_finish'] = wait_for_finish
 
-    if generic:
-        from .generic import GenericFFTPlan
-        if device_count() < 1:
-            raise RuntimeError("pyfft_amd: no HIP device visible (there is no CPU fallback)")
-        context = Context(device, stream_obj, mempool)
-        return GenericFFTPlan(context, *args, parent_shape=parent_shape, any_size=any_size, **kwds)
     context = Context(device, stream_obj, mempool)
-    return FFTPlan(context, *args, **kwds)
+    prev = context.activate()       # context=i: tables and scratch are allocated on device i
+    try:
+        if generic:
+            from .generic import GenericFFTPlan
+            return GenericFFTPlan(context, *args, parent_shape=parent_shape, any_size=any_size, **kwds)
+        return FFTPlan(context, *args, **kwds)
+    finally:
+        context.restore(prev)

@@ -18,6 +18,23 @@ from . import passes as P
 _FFT_1D, _FFT_2D, _FFT_3D = 1, 2, 3
 
 
+def on_plan_device(method):
+    """Run a plan method with the plan's device current (Plan(context=i) for a device that is not the caller's current
+    one, cuda.py:121-128); a no-op wrapper for plans built on the current device."""
+    def wrapped(self, *args, **kwds):
+        ctx = self._context
+        if not ctx._guard:
+            return method(self, *args, **kwds)
+        prev = ctx.activate()
+        try:
+            return method(self, *args, **kwds)
+        finally:
+            ctx.restore(prev)
+    wrapped.__name__ = method.__name__
+    wrapped.__doc__ = method.__doc__
+    return wrapped
+
+
 class _FFTParams(object):
     """Plan parameters derived from shape and dtype (plan.py:10-63)."""
 
@@ -117,7 +134,7 @@ class FFTPlan(object):
         else:
             self.execute = self._executeInterleaved
 
-        self._generateKernelCode()
+        on_plan_device(FFTPlan._generateKernelCode)(self)
 
     # ------------------------------------------------------------------------------------
     def _generateKernelCode(self):
@@ -408,11 +425,13 @@ class FFTPlan(object):
             self._mailbox = ErrorMailbox()
         self._mailbox.post(self._context.pointer_of(self._counters) + 4, stream, self._strategy[0])
 
+    @on_plan_device
     def check(self):
         """Raise if a completed asynchronous execute() reported invalid results (non-blocking)."""
         if self._mailbox is not None:
             self._handle_errors(self._mailbox.collect(False))
 
+    @on_plan_device
     def finish(self):
         """Wait for the plan's stream, then raise if any execute() since the last check reported invalid results."""
         self._context.wait()
@@ -450,6 +469,7 @@ class FFTPlan(object):
             bufs1 = None
         return is_inplace, bufs0, bufs1
 
+    @on_plan_device
     def _execute(self, wait_for_finish, is_inplace, inverse, batch, *args):
         """Execute plan for given data type (plan.py:173-259)."""
         ctx = self._context
@@ -470,6 +490,7 @@ class FFTPlan(object):
         is_inplace, bufs0, bufs1 = self._last_call
 
         ctx.createQueue(args)
+        ctx.order_scratch()
         self._enqueue(batch, is_inplace, inverse, bufs0, bufs1)
 
         # global wait setting has lower priority than the local one (plan.py:250-253)
@@ -526,10 +547,12 @@ class FFTPlan(object):
     def pass_list(self):
         return list(self._kernels)
 
+    @on_plan_device
     def strategy(self, batch):
         self._prepare(int(batch))
         return self._strategy
 
+    @on_plan_device
     def timed_execute(self, repeats, is_inplace, inverse, batch, bufs_in, bufs_out):
         """Device time (ms) of `repeats` back-to-back executions, measured with HIP events recorded on the
         plan's stream (hipEvents see the stream the kernels are launched on)."""

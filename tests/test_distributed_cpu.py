@@ -70,3 +70,39 @@ def test_world_size_mismatch_is_an_error():
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode != 0
     assert "WORLD_SIZE=2 but --gpus 4" in (out.stderr + out.stdout)
+
+
+def test_global_dataset_is_indexed_by_transform_not_by_rank():
+    """bench.make_host_block: local transform s of a rank whose slice starts at gstart holds global transform gstart + s,
+    for every rank (no per-rank seed), so a slice can be checked against the global dataset."""
+    sys.path.insert(0, ROOT)
+    import numpy
+    import bench
+    shape, dtname, batch, seed = (64,), "complex64", 200, 11
+    blk, _, _, whole = bench.make_host_block(shape, dtname, batch, seed, 0)
+    assert blk == 64
+    for world in (2, 3):
+        for rank in range(world):
+            gstart, count = bench.shard_batch(batch * world, rank, world)
+            b2, re, im, local = bench.make_host_block(shape, dtname, batch, seed, gstart)
+            assert b2 == blk
+            for s in (0, 1, blk - 1, blk, count - 1):
+                g = gstart + s
+                assert numpy.array_equal(local[s % blk], whole[g % blk])
+                assert numpy.array_equal(local[s % blk], bench.global_item(shape, dtname, batch, seed, g))
+                assert numpy.array_equal(re[s % blk] + 1j * im[s % blk], local[s % blk])
+
+
+def test_visible_gpus_does_not_need_the_runtime(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,3")
+    assert bench.visible_gpus() == 2
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpus() == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    n = bench.visible_gpus()
+    assert n is None or n >= 0
+    assert "torch" not in bench.self_launch.__code__.co_names      # the parent only spawns children

@@ -285,3 +285,45 @@ def test_generic_plan_index_spaces():
     w[woff] = par.ravel()[uoff]
     tiles = w.reshape(3 * 2, 3, 2, 2, 2, 4)                      # [item*cz][cy][cx][z][y][x]
     assert numpy.array_equal(tiles[1 * 2 + 1, 2, 1], par[1, 2:4, 4:6, 4:8])
+
+
+def test_plan_device_guard_switches_and_restores():
+    """plan.on_plan_device (Plan(context=i), cuda.py:121-128): a guarded context is activated around the call and the caller's
+    device restored afterwards, also when the call raises; an unguarded one is left alone."""
+    from pyfft_amd.plan import on_plan_device
+
+    class Ctx(object):
+        def __init__(self, guard):
+            self._guard = guard
+            self.log = []
+
+        def activate(self):
+            self.log.append("activate")
+            return 3
+
+        def restore(self, prev):
+            self.log.append(("restore", prev))
+
+    class P(object):
+        def __init__(self, guard):
+            self._context = Ctx(guard)
+
+        @on_plan_device
+        def work(self, x, fail=False):
+            """doc"""
+            self._context.log.append("work")
+            if fail:
+                raise RuntimeError("boom")
+            return x + 1
+
+    p = P(True)
+    assert p.work(1) == 2 and p._context.log == ["activate", "work", ("restore", 3)]
+    p = P(True)
+    try:
+        p.work(1, fail=True)
+    except RuntimeError:
+        pass
+    assert p._context.log == ["activate", "work", ("restore", 3)]
+    p = P(False)
+    assert p.work(5) == 6 and p._context.log == ["work"]
+    assert P.work.__name__ == "work" and P.work.__doc__ == "doc"

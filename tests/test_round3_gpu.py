@@ -1,0 +1,224 @@
+"""Round-3 GPU tests: the reference's error grid verbatim (test/test_errors.py:125-145), the real batch-sharded path with two
+ranks on one GPU (gloo control plane), and the robustness fixes of the round (error mailbox ring, generic plans draining
+their inner plans, a stream-following plan switching streams without a host sync, Plan(context=i))."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy
+import pytest
+
+import pyfft_oracle as oracle
+from helpers import getDimensions
+from test_errors_gpu import run_protocol
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- the reference's error grid, verbatim (test/test_errors.py:125-145) ------------------------------------------------
+def _reference_grid():
+    shapes = []
+    for x in [3, 8, 9, 10, 11, 13, 20]:                       # 1D
+        shapes.append((2 ** x,))
+    for x in [4, 7, 8, 10]:                                   # 2D
+        for y in [4, 7, 8, 10]:
+            shapes.append((2 ** x, 2 ** y))
+    for x in [4, 7, 10]:                                      # 3D
+        for y in [4, 7, 10]:
+            for z in [4, 7, 10]:
+                shapes.append((2 ** x, 2 ** y, 2 ** z))
+    batch_sizes = [1, 16, 128, 1024, 4096]
+    buffer_size = 32                                          # MiB (test/test_errors.py default)
+    cases = []
+    for double in (False, True):
+        dtypes = [numpy.float64, numpy.complex128] if double else [numpy.float32, numpy.complex64]
+        for dtype in dtypes:
+            for shape in shapes:
+                for batch in batch_sizes:
+                    x, y, z = getDimensions(shape)
+                    if x * y * z * batch * dtype().nbytes > buffer_size * 1024 * 1024:
+                        continue                              # (test_errors.py:143-145: skipped, not failed)
+                    cases.append((shape, dtype, batch))
+    return cases
+
+
+@pytest.mark.parametrize("shape,dtype,batch", _reference_grid(),
+                         ids=lambda v: numpy.dtype(v).name if isinstance(v, type) else str(v).replace(" ", ""))
+def test_reference_error_grid(ctx, shape, dtype, batch):
+    """7 + 16 + 27 shapes x batch {1, 16, 128, 1024, 4096} x both layouts per precision under the 32 MiB cap, the six
+    assertions of testErrors (test/test_errors.py:18-114) with its thresholds, plus the north star's max-norm bound."""
+    x, y, z = getDimensions(shape)
+    run_protocol(ctx, shape, dtype, batch, seed=4321, check_oracle=(x * y * z * batch <= (1 << 16)))
+
+
+# ---- the sharded path with more than one rank --------------------------------------------------------------------------
+def test_two_ranks_share_one_gpu_sharded_path(tmp_path):
+    """`bench.py --gpus 2` for real: two processes (one plan, stream and scratch each) on ONE device, gloo as the control
+    plane, data taken from the GLOBAL dataset by transform index.  Each rank parity-checks its slice [start, start + count)
+    in-process; here the first and last transform of every slice are checked again, against numpy on the global dataset
+    regenerated independently of any rank."""
+    sys.path.insert(0, ROOT)
+    import bench
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    batch = 96                                                # per rank: 2 x 96 transforms of 8 MiB
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--control", "gloo", "--share-gpu",
+                          "--config", "c2", "--batch", str(batch), "--steps", "2", "--warmup", "1", "--plain",
+                          "--dump-dir", str(tmp_path)],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 2 * batch and res["scaling"] == "weak"
+    ranks = res["config"]["ranks"]
+    assert [r["first_transform"] for r in ranks] == [0, batch] and [r["count"] for r in ranks] == [batch, batch]
+    assert all(r["parity_ok"] for r in ranks) and all(r["device"] == 0 for r in ranks)
+    assert res["config"]["strategy"] == "fused2"              # the persistent kernel of the headline path, in both processes
+    shape, dtname, _, seed = bench.CONFIGS["c2"]
+    for g in (0, batch - 1, batch, 2 * batch - 1):
+        got = numpy.load(os.path.join(str(tmp_path), "xform_%d.npy" % g))
+        ref = numpy.fft.fft(bench.global_item(shape, dtname, batch, seed, g).astype(numpy.complex128))
+        assert numpy.abs(got - ref).sum() / numpy.abs(ref).sum() < 1.1e-6, g
+        assert numpy.abs(got - ref).max() <= 1e-5 * numpy.abs(ref).max(), g
+    # weak scaling arithmetic of the line: value = all ranks' transforms over the max-over-ranks time
+    assert abs(res["transforms_per_s"] - 2 * batch * res["steps"] / (res["ms_per_step"] * 1e-3 * res["steps"])) < 1e-6 * res["transforms_per_s"]
+
+
+# ---- f2: the vendor comparator as a value cross-check, and the published-table benchmark ------------------------------
+def _run_tool(args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    return subprocess.run([sys.executable] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_hipfft_and_libmifft_agree_on_the_comparator_shapes():
+    """tools/hipfft_check.py (cuda/test.cu:13-95 counterpart): hipFFT and libmifft transform the same seeded device buffer;
+    values agree within the reference's thresholds on the eight comparator shapes, and both agree with numpy."""
+    out = _run_tool([os.path.join(ROOT, "tools", "hipfft_check.py")])
+    if out.returncode == 2:
+        pytest.skip("no hipFFT library on this box")
+    assert out.returncode == 0, (out.stdout[-3000:], out.stderr[-2000:])
+    lines = [l for l in out.stdout.splitlines() if "L1-rel" in l]
+    assert len(lines) == 8 and all(l.rstrip().endswith("ok") for l in lines), out.stdout
+
+
+def test_perf_table_quick_uses_the_reference_formula():
+    """tools/perf_table.py --quick (test/test_performance.py:11,22-30): batch fills the 32 MiB buffer, GFLOPS =
+    5e-9 * sum(log2 dims) * points * batch / t, and the numbers are in a sane range for this part."""
+    out = _run_tool([os.path.join(ROOT, "tools", "perf_table.py"), "--quick"])
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert [tuple(r["shape"]) for r in rows] == [(1024,), (128, 128)]
+    for r in rows:
+        size = int(numpy.prod(r["shape"]))
+        assert r["batch"] == (32 << 20) // (size * 8)
+        want = 5.0e-9 * sum(numpy.log2(s) for s in r["shape"]) * size * r["batch"] / r["seconds_per_execute"]
+        assert abs(r["gflops"] - want) < 1e-6 * want
+        # one HBM round trip of a 32 MiB buffer: between 2 % and 100 % of the 8 TB/s roofline
+        frac = 2.0 * size * 8 * r["batch"] / r["seconds_per_execute"] / 8e12
+        assert 0.02 < frac < 1.0, frac
+
+
+# ---- robustness --------------------------------------------------------------------------------------------------------
+def test_error_mailbox_keeps_the_oldest_word_when_the_ring_is_full(ctx):
+    """ErrorMailbox.post with SLOTS launches pending: the oldest entry is retired (its word read and kept) before its slot is
+    reused; nothing is reported twice."""
+    hip = ctx.hip
+    box = hip.ErrorMailbox()
+    bad = ctx.toGpu(numpy.array([7], dtype=numpy.uint32))
+    good = ctx.toGpu(numpy.array([0], dtype=numpy.uint32))
+    stream = hip.Stream()
+    box.post(bad.ptr, stream, "first")
+    for i in range(box.SLOTS + 5):
+        box.post(good.ptr, stream, "later%d" % i)
+    assert len(box._pending) <= box.SLOTS
+    errors = box.collect(True)
+    assert errors == [("first", 7)]
+    assert box.collect(True) == [] and box._pending == []
+    box.post(bad.ptr, stream, "again")
+    assert box.collect(True) == [("again", 7)]
+
+
+def test_generic_plan_reports_inner_plan_errors(ctx):
+    """GenericFFTPlan.finish()/check() drain the mailboxes of the inner power-of-two plans (a persistent kernel inside a tiled
+    or Bluestein plan posts its dependency time-outs there)."""
+    hip = ctx.hip
+    plan = ctx.getPlan((16, 16), parent_shape=(64, 64), dtype=numpy.complex64, wait_for_finish=True)
+    data = oracle.get_test_data((64, 64), numpy.complex64, 2, 5)
+    a = ctx.toGpu(data)
+    plan.execute(a, batch=2)                                  # fine
+    inner = plan._inner_plans()
+    assert inner
+    inner[0]._mailbox = hip.ErrorMailbox()
+    inner[0]._mailbox._stashed.append(("fused2", 1))          # what a timed-out persistent launch leaves behind
+    with pytest.raises(RuntimeError, match="time-out"):
+        plan.finish()
+    plan.finish()                                             # reported once
+    inner[0]._mailbox._stashed.append(("fused2", 1))
+    with pytest.raises(RuntimeError, match="time-out"):
+        plan.execute(a, batch=2)                              # a waiting execute() cannot return success either
+
+
+def test_plan_following_two_torch_streams_without_host_sync(ctx):
+    """A plan built without stream= runs each execute() on torch's CURRENT stream.  Alternating two torch streams with no
+    host synchronisation in between must not let the second launch's counter reset / ring writes race with the first
+    persistent kernel: the plan orders the new stream behind the old one on its scratch (Context.order_scratch)."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    n, batch = 1 << 18, 128                                   # fused2 (persistent, ring + counters owned by the plan)
+    plan = ctx.getPlan((n,), dtype=numpy.complex64, wait_for_finish=False)
+    assert plan.strategy(batch)[0] == "fused2"
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    host = torch.randn(2, n, dtype=torch.complex64, generator=g)
+    xs = [host[i].repeat(batch, 1).cuda() for i in range(2)]
+    ys = [torch.empty_like(x) for x in xs]
+    torch.cuda.synchronize()
+    for rep in range(6):
+        for i, s in enumerate((s1, s2)):
+            with torch.cuda.stream(s):
+                ret = plan.execute(xs[i], ys[i], batch=batch)
+                assert int(ret.cuda_stream) == int(s.cuda_stream)
+    torch.cuda.synchronize()
+    plan.finish()
+    for i in range(2):
+        ref = numpy.fft.fft(host[i].numpy().astype(numpy.complex128))
+        got = ys[i].cpu().numpy()
+        for b in (0, 1, batch // 2, batch - 1):
+            assert numpy.abs(got[b] - ref).sum() / numpy.abs(ref).sum() < 1.1e-6, (i, b)
+
+
+def test_plan_for_a_device_given_by_index(ctx):
+    """Plan(context=i) (cuda.py:121-128: the plan is built on whatever context it is given): the plan makes device i current
+    around its own calls and restores the caller's.  With one visible device this exercises the guard with i == current; with
+    more, a plan per device is driven from one process without the caller switching devices."""
+    hip = ctx.hip
+    N = hip.N
+    import ctypes
+    ndev = hip.device_count()
+    with pytest.raises(ValueError):
+        ctx.getPlan((1024,), dtype=numpy.complex64, context=ndev)      # not a visible device
+    data = oracle.get_test_data((4096,), numpy.complex64, 4, 9)
+    ref = oracle.numpy_fft(numpy.fft.fftn, data, 4)
+    cur = ctypes.c_int()
+    N.check(N.lib.mifft_get_device(ctypes.byref(cur)), "get")
+    home = cur.value
+    for dev in range(ndev):
+        plan = ctx.getPlan((4096,), dtype=numpy.complex64, context=dev)
+        assert plan._context.device == dev and plan._context._guard
+        N.check(N.lib.mifft_get_device(ctypes.byref(cur)), "get")
+        assert cur.value == home                               # construction restored the caller's device
+        N.check(N.lib.mifft_set_device(dev), "set")            # buffers live on the plan's device
+        a = ctx.toGpu(data)
+        N.check(N.lib.mifft_set_device(home), "set")
+        plan.execute(a, batch=4)                               # called with `home` current
+        N.check(N.lib.mifft_get_device(ctypes.byref(cur)), "get")
+        assert cur.value == home
+        N.check(N.lib.mifft_set_device(dev), "set")
+        got = a.get()
+        N.check(N.lib.mifft_set_device(home), "set")
+        assert oracle.difference(ref, got, 4) < 1.1e-6

@@ -39,6 +39,13 @@ def run(shape, double, buffer_mib):
     return batch, t, gflop / t
 
 if __name__ == "__main__":
+    if "--quick" in sys.argv:
+        # two shapes at the reference's 32 MiB buffer, machine-readable (tests/test_round3_gpu.py checks the GFLOPS formula)
+        import json
+        for shape in ((1024,), (128, 128)):
+            batch, t, gf = run(shape, False, 32)
+            print(json.dumps({"shape": list(shape), "batch": batch, "seconds_per_execute": t, "gflops": gf}), flush=True)
+        sys.exit(0)
     for buffer_mib in (32, 1024):
         print("buffer %d MiB (the reference uses 32 MiB, test/helpers.py:7)" % buffer_mib)
         print("%-16s %8s %12s %12s   %s" % ("shape", "batch", "sp GFLOPS", "dp GFLOPS", "published C2050 pyfft/cufft sp, pyfft/cufft dp"))
