@@ -67,6 +67,10 @@ extern "C" {
    which leaves the Infinity Cache to the intermediate of the pipelined strategy.  Results are unaffected. */
 #define MIFFT_FLAG_STREAM_SRC 4
 #define MIFFT_FLAG_STREAM_DST 8
+/* this pass and the NEXT one of the chain are run by one launch (a "pass pair", csrc/fft_pair.hpp): the launch reads the
+   buffer `src` of this pass and writes the buffer `dst` of the next one; the chain launchers skip the second descriptor.
+   Only set where mifft_pass_pair_supported() says so. */
+#define MIFFT_FLAG_PAIR_WITH_NEXT 16
 
 /* pass kinds */
 #define MIFFT_PASS_COL 0  /* strided pass: [outer][L][M*S] -> [outer][M][L][S]  (kernel.mako:805-1047) */
@@ -141,6 +145,7 @@ const char *mifft_last_error(void);
 #define MIFFT_DEBUG_FORCE_WAVE 3   /* wave-autonomous kernels wherever one exists, whatever the buffer size */
 #define MIFFT_DEBUG_PERSIST 4      /* persistent (prefetching) form of the long fp32 rows (measured: no gain) */
 #define MIFFT_DEBUG_ALT_ROWS 5     /* alternative stage lists of the longest fp32 rows (A/B measurements) */
+#define MIFFT_DEBUG_PAIR 6         /* pass pairs: 0 = default split, 1 = off, 2 = the alternative y split (A/B measurements) */
 #define MIFFT_DEBUG_KEYS 8
 int mifft_debug_set(int32_t key, int32_t value);
 int mifft_debug_get(int32_t key);
@@ -197,6 +202,21 @@ int mifft_pass_supported(int32_t kind, int32_t precision, int32_t L, int32_t var
  * MIFFT_PASS_COL with M == 1 (pyfft/kernel.py:144,238-241). */
 int mifft_launch_pass(const mifft_pass *pass, const void *in0, const void *in1, void *out0, void *out1,
                       mifft_stream_t stream);
+
+/*
+ * Pass pairs: two CONSECUTIVE passes of a chain run by one launch on tiles that hold the points of both, so that a 3-D
+ * transform whose (y, x) plane fits no work-group still crosses HBM twice instead of three times.  With the y axis
+ * factored R0 * R1 as the chain factors a long axis (pyfft/kernel.py:259-283), the four passes
+ *     ROW x | COL y (L = R0, M = R1, S = nx) | COL y (L = R1, M = 1, S = nx * R0) | COL z (L = nz, M = 1, S = nx * ny)
+ * are the pairs (ROW x, COL y R0) -- out of place only -- and (COL y R1, COL z) -- in place capable.  Interleaved data,
+ * dense batches (outer stride = the transform size) only.
+ *   mifft_pair_split          R0 (> 0) if the library has both pair kernels for a (z, y, x) transform, else 0
+ *   mifft_pass_pair_supported 0 if (p0, p1) is such a pair with a compiled kernel, else MIFFT_E_UNSUPPORTED
+ *   mifft_launch_pass_pair    enqueue it: reads `in`, writes `out` (p0's input side, p1's output side; scale = p0 * p1)
+ */
+int mifft_pair_split(int32_t precision, int32_t x, int32_t y, int32_t z);
+int mifft_pass_pair_supported(const mifft_pass *p0, const mifft_pass *p1);
+int mifft_launch_pass_pair(const mifft_pass *p0, const mifft_pass *p1, const void *in, void *out, mifft_stream_t stream);
 
 /* Enqueue a whole plan: passes[i] reads bufs0/bufs1[passes[i].src] and writes [passes[i].dst]
  * (0 = data_in, 1 = data_out, 2 = temp -- the ping-pong loop of pyfft/plan.py:217-248 with the

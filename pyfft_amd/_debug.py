@@ -60,3 +60,5 @@ def apply_native_switches(native):
                      ("MIFFT_PERSIST", native.DEBUG_PERSIST)):
         if os.environ.get(env):
             native.lib.mifft_debug_set(key, 1)
+    if os.environ.get("MIFFT_PAIR"):        # pass pairs: 1 = off, 2 = the alternative y split
+        native.lib.mifft_debug_set(native.DEBUG_PAIR, int(os.environ["MIFFT_PAIR"]))

@@ -24,6 +24,7 @@ VARIANT_INTERLEAVED_ONLY = 2
 PASS_COL, PASS_ROW, PASS_ND = 0, 1, 2
 FLAG_SRC_INTERLEAVED, FLAG_DST_INTERLEAVED = 1, 2
 FLAG_STREAM_SRC, FLAG_STREAM_DST = 4, 8
+FLAG_PAIR_WITH_NEXT = 16
 XCD2_SCRATCH_BYTES = 8 * 64 * 16 * 256 * 8
 XCD2_CONTROL_BYTES = (64 + 2 * 512 * 32) * 4
 FUSED2_COUNTER_STRIDE = 64          # MIFFT_FUSED2_COUNTER_STRIDE (uint32 words between two counters)
@@ -35,7 +36,7 @@ def fused2_counter_bytes(outer):
 
 
 XCD2_PREFETCH = 1
-DEBUG_NO_ND2, DEBUG_FUSED_NO_NT, DEBUG_NO_WAVE, DEBUG_FORCE_WAVE, DEBUG_PERSIST, DEBUG_ALT_ROWS = 0, 1, 2, 3, 4, 5
+DEBUG_NO_ND2, DEBUG_FUSED_NO_NT, DEBUG_NO_WAVE, DEBUG_FORCE_WAVE, DEBUG_PERSIST, DEBUG_ALT_ROWS, DEBUG_PAIR = 0, 1, 2, 3, 4, 5, 6
 XCD2_TRACE = 2
 XCD2_TRACE_BYTES = 512 * 32 * 8
 
@@ -140,6 +141,9 @@ PROTOTYPES = {
     "mifft_nd_shape_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32]),
     "mifft_pass_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
     "mifft_launch_pass": (ctypes.c_int, [_pass_p, _vp, _vp, _vp, _vp, _vp]),
+    "mifft_pair_split": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
+    "mifft_pass_pair_supported": (ctypes.c_int, [_pass_p, _pass_p]),
+    "mifft_launch_pass_pair": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp]),
     "mifft_launch_chain": (ctypes.c_int, [_pass_p, _i32, _vpp, _vpp, _vp]),
     "mifft_launch_chain_pipelined": (ctypes.c_int, [_pass_p, _i32, _vpp, _vpp, ctypes.c_int64, ctypes.c_int64,
                                                       ctypes.c_int64, _vp, _vpp, _i32, _vpp]),

@@ -7,6 +7,7 @@
 #include "fft_xcd2.hpp"
 #include "fft_nd.hpp"
 #include "fft_wave.hpp"
+#include "fft_pair.hpp"
 
 // Each returns 0 on success, MIFFT_E_UNSUPPORTED (-2) when no kernel is compiled for (L, tr, variant),
 // or a hipError_t.  With query_only != 0 nothing is launched.
@@ -30,6 +31,7 @@ int mifft_aux_mul_rows_launch(int f64, void* a, const void* b, long long rows, l
 int mifft_wave_supported(int f64, int N);
 int mifft_wave_launch(int f64, int N, const mifft::WaveArgs* a, int max_blocks, hipStream_t s);
 int mifft_wave_16x16_launch(const mifft::WaveArgs* a, int max_blocks, hipStream_t s);
+int mifft_pair_f64(int kind, int k0, int k1, int k2, const mifft::PairArgs* a, hipStream_t s, int query);
 int mifft_xcd2_f32_launch(const mifft::Xcd2Args* f, int split, int prefetch, unsigned grid, hipStream_t s);
 }
 

@@ -244,6 +244,42 @@ int dispatch(const mifft_pass* p, const mifft::TileArgs* a, hipStream_t s, int q
     return 0;
 }
 
+// ---- pass pairs (fft_pair.hpp) -------------------------------------------------------------------------------------
+// kind 0 = XY (ROW x + COL y R0), kind 1 = YZ (COL y R1 + COL z); keys as in mifft_pair_f64.  Returns 0 and fills kind / keys,
+// or MIFFT_E_UNSUPPORTED when (p0, p1) is not a pair shape.
+int classify_pair(const mifft_pass* p0, const mifft_pass* p1, int* kind, int key[3]) {
+    if (!p0 || !p1) return MIFFT_E_INVALID;
+    if (p0->precision != p1->precision || p0->inverse != p1->inverse || p0->layout != p1->layout) return MIFFT_E_UNSUPPORTED;
+    const bool inter_in = p0->layout != MIFFT_SPLIT || (p0->flags & MIFFT_FLAG_SRC_INTERLEAVED);
+    const bool inter_out = p1->layout != MIFFT_SPLIT || (p1->flags & MIFFT_FLAG_DST_INTERLEAVED);
+    if (!inter_in || !inter_out) return MIFFT_E_UNSUPPORTED;
+    if (p0->kind == MIFFT_PASS_ROW && p1->kind == MIFFT_PASS_COL && p1->M > 1 && p1->S == p0->L) {
+        const long long plane = (long long)p0->L * p1->L * p1->M;            // nx * ny
+        if (p1->outer_stride_in != plane || p1->outer_stride_out != plane || p0->outer != p1->outer * p1->L * p1->M ||
+            p0->outer_stride_in != p0->L || p0->outer_stride_out != p0->L || p1->M > (1 << 20))
+            return MIFFT_E_UNSUPPORTED;
+        *kind = 0;
+        key[0] = p0->L; key[1] = p1->L; key[2] = (int)p1->M;
+        return 0;
+    }
+    if (p0->kind == MIFFT_PASS_COL && p1->kind == MIFFT_PASS_COL && p0->M == 1 && p1->M == 1 && p1->S == p0->S * p0->L) {
+        const long long xform = p1->S * p1->L;                                // nx * ny * nz
+        if (p1->outer_stride_in != xform || p1->outer_stride_out != xform || p0->outer != p1->outer * p1->L ||
+            p0->outer_stride_in != p1->S || p0->outer_stride_out != p1->S || p0->S > (1 << 30))
+            return MIFFT_E_UNSUPPORTED;
+        *kind = 1;
+        key[0] = (int)p0->S; key[1] = p0->L; key[2] = p1->L;
+        return 0;
+    }
+    return MIFFT_E_UNSUPPORTED;
+}
+
+int pair_call(int precision, int kind, const int key[3], const mifft::PairArgs* a, hipStream_t s, int query) {
+    if (g_debug[MIFFT_DEBUG_PAIR] == 1) return MIFFT_E_UNSUPPORTED;
+    if (precision == MIFFT_F64) return mifft_pair_f64(kind, key[0], key[1], key[2], a, s, query);
+    return MIFFT_E_UNSUPPORTED;
+}
+
 }  // namespace
 
 extern "C" {
@@ -417,15 +453,92 @@ int mifft_launch_pass(const mifft_pass* p, const void* in0, const void* in1, voi
     return dispatch(p, &a, (hipStream_t)stream, 0);
 }
 
+
+int mifft_pair_split(int32_t precision, int32_t x, int32_t y, int32_t z) {
+    if (x < 2 || y < 2 || z < 2 || !is_pow2(x) || !is_pow2(y) || !is_pow2(z)) return 0;
+    // candidates in order of preference (measured: profiles/r03_c4_pair_split.log); MIFFT_DEBUG_PAIR = 2 swaps them
+    int cand[2] = {32, 64};
+    if (g_debug[MIFFT_DEBUG_PAIR] == 2) { cand[0] = 64; cand[1] = 32; }
+    for (int r0 : cand) {
+        if (y % r0 || y / r0 < 2) continue;
+        const int kxy[3] = {x, r0, y / r0}, kyz[3] = {x * r0, y / r0, z};
+        if (pair_call(precision, 0, kxy, nullptr, nullptr, 1) == 0 && pair_call(precision, 1, kyz, nullptr, nullptr, 1) == 0) return r0;
+    }
+    return 0;
+}
+
+int mifft_pass_pair_supported(const mifft_pass* p0, const mifft_pass* p1) {
+    int kind, key[3];
+    int rc = classify_pair(p0, p1, &kind, key);
+    if (rc) return MIFFT_E_UNSUPPORTED;
+    return pair_call(p0->precision, kind, key, nullptr, nullptr, 1) == 0 ? 0 : MIFFT_E_UNSUPPORTED;
+}
+
+int mifft_launch_pass_pair(const mifft_pass* p0, const mifft_pass* p1, const void* in, void* out, mifft_stream_t stream) {
+    int rc = validate(p0);
+    if (rc) return rc;
+    rc = validate(p1);
+    if (rc) return rc;
+    int kind, key[3];
+    if (classify_pair(p0, p1, &kind, key) != 0) return set_err(MIFFT_E_UNSUPPORTED, "pass pair: not a (ROW x, COL y) / (COL y, COL z) pair of a dense interleaved batch");
+    if (!in || !out) return set_err(MIFFT_E_INVALID, "null data buffer");
+    if (((uintptr_t)in | (uintptr_t)out) & 15) return set_err(MIFFT_E_INVALID, "data buffers must be 16-byte aligned");
+    if (kind == 0 && in == out) return set_err(MIFFT_E_INVALID, "the (ROW x, COL y) pair cannot run in place");
+    if (p1->outer == 0) return 0;
+    mifft::PairArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in0 = in;
+    a.out0 = out;
+    if (kind == 0) {
+        a.tw[0] = p0->tw_L;   // w(nx)
+        a.tw[1] = p1->tw_L;   // w(R0)
+        a.tw_lo = p1->tw_lo;  // w(ny), two-level
+        a.tw_hi = p1->tw_hi;
+        a.tw_shift = p1->tw_shift;
+        a.tiles = p1->outer * p1->M;                 // planes * R1
+    } else {
+        a.tw[1] = p0->tw_L;   // w(R1)
+        a.tw[2] = p1->tw_L;   // w(nz)
+        a.tiles = p1->outer * (p0->S / 8);           // transforms * groups of 8 adjacent columns
+    }
+    a.inverse = p0->inverse ? 1 : 0;
+    a.nt = ((p0->flags & MIFFT_FLAG_STREAM_SRC) ? 1 : 0) | ((p1->flags & MIFFT_FLAG_STREAM_DST) ? 2 : 0);
+    a.scale = p0->scale * p1->scale;
+    rc = pair_call(p0->precision, kind, key, &a, (hipStream_t)stream, 0);
+    if (rc == MIFFT_E_UNSUPPORTED) return set_err(rc, "pass pair: no kernel for kind %d keys (%d, %d, %d)", kind, key[0], key[1], key[2]);
+    if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
+    if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
+    return 0;
+}
+
+// one unit of a chain: a single pass, or a pass pair (MIFFT_FLAG_PAIR_WITH_NEXT on the first); *consumed = descriptors used
+static int launch_unit(const mifft_pass* passes, int32_t i, int32_t npasses, const void* in0, const void* in1, void* out0, void* out1,
+                       mifft_stream_t stream, int* consumed) {
+    const mifft_pass* p = &passes[i];
+    if (p->flags & MIFFT_FLAG_PAIR_WITH_NEXT) {
+        if (i + 1 >= npasses) return set_err(MIFFT_E_INVALID, "pass %d: MIFFT_FLAG_PAIR_WITH_NEXT on the last pass", i);
+        *consumed = 2;
+        return mifft_launch_pass_pair(p, &passes[i + 1], in0, out0, stream);
+    }
+    *consumed = 1;
+    return mifft_launch_pass(p, in0, in1, out0, out1, stream);
+}
+
 int mifft_launch_chain(const mifft_pass* passes, int32_t npasses, void* const bufs0[3], void* const bufs1[3], mifft_stream_t stream) {
     if (npasses < 0 || (npasses > 0 && !passes) || !bufs0) return set_err(MIFFT_E_INVALID, "bad chain arguments");
     for (int i = 0; i < npasses; ++i) {
         const mifft_pass* p = &passes[i];
         if (p->src < 0 || p->src > 2 || p->dst < 0 || p->dst > 2) return set_err(MIFFT_E_INVALID, "pass %d: bad buffer index", i);
+    }
+    for (int i = 0; i < npasses;) {
+        const mifft_pass* p = &passes[i];
+        const mifft_pass* pl = (p->flags & MIFFT_FLAG_PAIR_WITH_NEXT) && i + 1 < npasses ? &passes[i + 1] : p;   // the unit writes pl->dst
         const void* i1 = bufs1 ? bufs1[p->src] : nullptr;
-        void* o1 = bufs1 ? bufs1[p->dst] : nullptr;
-        int rc = mifft_launch_pass(p, bufs0[p->src], i1, bufs0[p->dst], o1, stream);
+        void* o1 = bufs1 ? bufs1[pl->dst] : nullptr;
+        int used = 1;
+        int rc = launch_unit(passes, i, npasses, bufs0[p->src], i1, bufs0[pl->dst], o1, stream, &used);
         if (rc) return rc;
+        i += used;
     }
     return 0;
 }
@@ -573,16 +686,21 @@ int mifft_launch_chain_pipelined(const mifft_pass* passes, int32_t npasses, void
         const int slot = (int)(c % nside);
         const int64_t off_io = c * chunk * item_elems * ebytes;
         const int64_t off_tmp = (int64_t)slot * chunk * item_elems * tbytes;
-        for (int i = 0; i < npasses; ++i) {
-            mifft_pass p = passes[i];
-            p.outer = p.outer / batch * nb;
+        for (int i = 0; i < npasses;) {
+            mifft_pass p[2] = {passes[i], passes[i + 1 < npasses ? i + 1 : i]};
+            p[0].outer = p[0].outer / batch * nb;
+            p[1].outer = p[1].outer / batch * nb;
+            const bool pair = (p[0].flags & MIFFT_FLAG_PAIR_WITH_NEXT) && i + 1 < npasses;
+            const int dst = pair ? p[1].dst : p[0].dst;
             auto at = [&](void* const* bufs, int idx) -> void* {
                 if (!bufs || !bufs[idx]) return nullptr;
                 return (char*)bufs[idx] + (idx == 2 ? off_tmp : off_io);
             };
-            rc = mifft_launch_pass(&p, at(bufs0, p.src), split ? at(bufs1, p.src) : nullptr, at(bufs0, p.dst),
-                                   split ? at(bufs1, p.dst) : nullptr, side[slot]);
+            int used = 1;
+            rc = launch_unit(p, 0, pair ? 2 : 1, at(bufs0, p[0].src), split ? at(bufs1, p[0].src) : nullptr, at(bufs0, dst),
+                             split ? at(bufs1, dst) : nullptr, side[slot], &used);
             if (rc) return rc;
+            i += used;
         }
     }
     for (int s = 0; s < used; ++s) {

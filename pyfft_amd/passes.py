@@ -76,9 +76,10 @@ class PassSpec(object):
     Counterpart of a compiled LocalFFTKernel / GlobalFFTKernel object (kernel.py:124-283)."""
 
     __slots__ = ("kind", "axis", "n", "L", "M", "S", "outer_per_batch", "outer_stride",
-                 "in_place_possible", "curr_n")
+                 "in_place_possible", "curr_n", "pair_with_next")
 
     def __init__(self, kind, axis, n, L, M, S, outer_per_batch, outer_stride, in_place_possible):
+        self.pair_with_next = False      # this pass and the next one are run by ONE launch (csrc/fft_pair.hpp)
         self.kind = kind
         self.axis = axis
         self.n = n
@@ -94,7 +95,8 @@ class PassSpec(object):
         if self.kind == N.PASS_ND:
             return "nd(x=%d,y=%d,z=%d)*" % (self.L, self.M, self.S)
         name = "row" if self.kind == N.PASS_ROW else "col"
-        return "%s(L=%d,M=%d,S=%d)%s" % (name, self.L, self.M, self.S, "*" if self.in_place_possible else "")
+        return "%s(L=%d,M=%d,S=%d)%s%s" % (name, self.L, self.M, self.S, "*" if self.in_place_possible else "",
+                                            " +" if self.pair_with_next else "")
 
 
 def col_chain(axis, n, radix_init, outer_per_batch, precision):
@@ -110,6 +112,19 @@ def col_chain(axis, n, radix_init, outer_per_batch, precision):
         chain.append(PassSpec(N.PASS_COL, axis, n, R, M, S, outer_per_batch, n * radix_init, M == 1))
         S *= R
         curr_n //= R
+    return chain
+
+
+def pair_chain(x, y, z, r0):
+    """The four passes of a (z, y, x) transform with the y axis factored r0 * r1 (the chain's own factorisation of a long axis,
+    kernel.py:259-283), marked as the two pass pairs csrc/fft_pair.hpp runs: (ROW x, COL y r0) and (COL y r1, COL z)."""
+    r1 = y // r0
+    chain = [PassSpec(N.PASS_ROW, X_DIRECTION, x, x, 1, 1, y * z, x, True),
+             PassSpec(N.PASS_COL, Y_DIRECTION, y, r0, r1, x, z, y * x, False),
+             PassSpec(N.PASS_COL, Y_DIRECTION, y, r1, 1, x * r0, z, y * x, True),
+             PassSpec(N.PASS_COL, Z_DIRECTION, z, z, 1, x * y, 1, x * y * z, True)]
+    chain[0].pair_with_next = True
+    chain[2].pair_with_next = True
     return chain
 
 
@@ -133,6 +148,12 @@ def build_chain(x, y, z, precision, interleaved=False):
     if ndims == 3 and nd_ok(x, y, 1):
         return [PassSpec(N.PASS_ND, X_DIRECTION, x * y, x, y, 1, z, x * y, True)] + \
             col_chain(Z_DIRECTION, z, x * y, 1, precision)
+    # 3-D shapes whose plane fits no tile: two launches of two passes each -- (ROW x, COL y R0) on R0 rows of a plane and
+    # (COL y R1, COL z) on 128-byte column segments -- instead of one HBM round trip per axis (csrc/fft_pair.hpp)
+    if ndims == 3 and interleaved:
+        r0 = N.lib.mifft_pair_split(precision, x, y, z)
+        if r0 > 0:
+            return pair_chain(x, y, z, r0)
     if x > 1:
         if x <= row_max(precision, interleaved):
             chain.append(PassSpec(N.PASS_ROW, X_DIRECTION, x, x, 1, 1, y * z, x, True))
@@ -159,6 +180,28 @@ def build_chain(x, y, z, precision, interleaved=False):
     return chain
 
 
+class _Unit(object):
+    """One launch of a chain as the buffer schedule sees it."""
+    __slots__ = ("in_place_possible", "pair_with_next")
+
+    def __init__(self, in_place_possible):
+        self.in_place_possible = in_place_possible
+        self.pair_with_next = False
+
+
+def launch_units(chain):
+    """[(unit, number of descriptors)]: a pass, or a pass pair (in-place capable only when both passes are)."""
+    units, i = [], 0
+    while i < len(chain):
+        if chain[i].pair_with_next:
+            units.append((_Unit(chain[i].in_place_possible and chain[i + 1].in_place_possible), 2))
+            i += 2
+        else:
+            units.append((_Unit(chain[i].in_place_possible), 1))
+            i += 1
+    return units
+
+
 def buffer_schedule(chain, is_inplace, via_temp=False):
     """Which buffer every pass reads and writes: returns (temp_needed, [(src, dst), ...]) with 0 = data_in,
     1 = data_out, 2 = the plan's temp buffer.  Contract of FFTPlan._execute (plan.py:194-248): an out-of-place call never
@@ -168,6 +211,14 @@ def buffer_schedule(chain, is_inplace, via_temp=False):
     The chain alternates between data_out and temp, and the LAST pass must land on data_out: so pass i (of n) writes data_out
     exactly when an even number of buffer switches follows it.  An in-place call starts ON data_out; with an odd number of
     passes one pass has to stay where it is, and that is the first one that can run in place (plan.py:214-221)."""
+    if any(getattr(p, "pair_with_next", False) for p in chain):
+        # a pass pair is ONE launch: schedule the units, then give both descriptors of a pair the unit's (src, dst)
+        units = launch_units(chain)
+        temp_needed, usched = buffer_schedule([u for u, _ in units], is_inplace, via_temp)
+        sched = []
+        for (u, count), sd in zip(units, usched):
+            sched.extend([sd] * count)
+        return temp_needed, sched
     n = len(chain)
     temp_needed = any(not p.in_place_possible for p in chain)
     start = 1 if is_inplace else 0

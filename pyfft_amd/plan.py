@@ -142,7 +142,8 @@ class FFTPlan(object):
         compiled here -- the kernels are ahead-of-time HIP)."""
         p = self._params
         self._kernels = P.build_chain(int(p.x), int(p.y), int(p.z), p.precision, interleaved=not p.split)
-        self._temp_buffer_needed = any(not k.in_place_possible for k in self._kernels)
+        self._paired = any(k.pair_with_next for k in self._kernels)
+        self._temp_buffer_needed = any(not u.in_place_possible for u, _ in P.launch_units(self._kernels))
         # fp32 split planes: 16 columns of a plane are 64-byte segments, so multi-pass plans detour through an
         # interleaved temp even when every pass could run in place (passes.buffer_schedule)
         self._via_temp = (p.split and p.precision == N.F32 and len(self._kernels) >= 2 and not self._temp_buffer_needed)
@@ -152,7 +153,7 @@ class FFTPlan(object):
         # slab by slab (a few z planes) through the pipelined launcher before the z passes run over whole transforms --
         # the x -> y intermediate then stays on die.  (_slab_passes leading passes, every pass in place capable.)
         self._slab_passes = 0
-        if int(p.z) > 1 and not self._temp_buffer_needed and p.size * p.complex_nbytes > self.PIPELINE_TARGET_BYTES:
+        if int(p.z) > 1 and not self._temp_buffer_needed and not self._paired and p.size * p.complex_nbytes > self.PIPELINE_TARGET_BYTES:
             k = 0
             while k < len(self._kernels) and self._kernels[k].kind != N.PASS_ND and \
                     self._kernels[k].axis in (P.X_DIRECTION, P.Y_DIRECTION):
@@ -231,7 +232,7 @@ class FFTPlan(object):
             d.src = src
             d.dst = dst
             # the plan-owned temp buffer is always interleaved, also for split-plane plans (include/mifft.h)
-            d.flags = 0
+            d.flags = N.FLAG_PAIR_WITH_NEXT if k.pair_with_next else 0
             if p.split:
                 if src == 2:
                     d.flags |= N.FLAG_SRC_INTERLEAVED
@@ -240,7 +241,7 @@ class FFTPlan(object):
             # multi-pass plans: the first pass reads the input once, nobody re-reads what the last pass writes.  Only
             # while a transform's intermediate can stay in the 256 MiB Infinity Cache (256^3 fp64: 256 MiB per transform,
             # measured 1 % slower with the hints)
-            if last >= 1 and (p.size * p.complex_nbytes <= (64 << 20) or self._slab_passes) and not D.no_stream_hints():
+            if last >= 1 and (p.size * p.complex_nbytes <= (64 << 20) or self._slab_passes or self._paired) and not D.no_stream_hints():
                 if i == 0:
                     d.flags |= N.FLAG_STREAM_SRC
                 if i == last:

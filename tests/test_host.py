@@ -327,3 +327,36 @@ def test_plan_device_guard_switches_and_restores():
     p = P(False)
     assert p.work(5) == 6 and p._context.log == ["work"]
     assert P.work.__name__ == "work" and P.work.__doc__ == "doc"
+
+
+def test_pass_pair_chain_algebra_and_schedule():
+    """passes.pair_chain (the two pass pairs of csrc/fft_pair.hpp): the four passes pushed through the oracle's pass algebra
+    reproduce numpy.fft.fftn on small shapes; the buffer schedule treats a pair as one launch (both descriptors carry the
+    unit's src / dst, the (ROW x, COL y) pair never runs in place); the library reports the split it has kernels for."""
+    from pyfft_amd import _native as N
+    from pyfft_amd import passes as P
+    rng = numpy.random.default_rng(8)
+    for (x, y, z, r0) in ((8, 16, 4, 4), (4, 8, 8, 2), (16, 4, 2, 2)):
+        chain = P.pair_chain(x, y, z, r0)
+        assert [k.pair_with_next for k in chain] == [True, False, True, False]
+        batch = 2
+        data = rng.standard_normal((batch, z, y, x)) + 1j * rng.standard_normal((batch, z, y, x))
+        cur = data.reshape(-1).copy()
+        for k in chain:
+            assert cur.size == k.outer_per_batch * batch * k.outer_stride
+            cur = oracle.global_pass(cur, k.L, k.M, k.S, -1).reshape(-1)
+        ref = numpy.fft.fftn(data, axes=(1, 2, 3)).reshape(-1)
+        assert numpy.abs(cur - ref).max() < 1e-10 * numpy.abs(ref).max()
+        units = P.launch_units(chain)
+        assert [c for _, c in units] == [2, 2] and [u.in_place_possible for u, _ in units] == [False, True]
+        for inplace in (False, True):
+            temp, sched = P.buffer_schedule(chain, inplace)
+            assert temp and sched[0] == sched[1] and sched[2] == sched[3]
+            assert sched[0][0] == (1 if inplace else 0) and sched[0][1] != sched[0][0] and sched[3][1] == 1
+            assert sched[2][0] == sched[0][1]
+    r0 = N.lib.mifft_pair_split(N.F64, 256, 256, 256)
+    assert r0 in (32, 64)
+    chain = P.build_chain(256, 256, 256, N.F64, interleaved=True)
+    assert len(chain) == 4 and chain[1].L == r0 and chain[1].M == 256 // r0 and chain[2].S == 256 * r0
+    assert len(P.build_chain(256, 256, 256, N.F64, interleaved=False)) == 3      # split planes: one pass per axis
+    assert N.lib.mifft_pair_split(N.F64, 256, 256, 1) == 0 and N.lib.mifft_pair_split(N.F64, 100, 256, 256) == 0

@@ -44,6 +44,12 @@ template <int P> __device__ __forceinline__ void st(u4* p, u4 v) {
     else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
 }
 
+// The loads above are asynchronous and invisible to the compiler: the wait names every destination register as read-write,
+// so no use (and no re-allocation of those registers) can be scheduled in front of it.
+__device__ __forceinline__ void wait8(u4 (&a)[8]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])::"memory");
+}
+
 struct Args {
     const u4* A;
     u4* B;
@@ -66,7 +72,7 @@ __global__ void __launch_bounds__(256, 2) k_mix(const Args p) {
         u4 v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = ld<LD>(p.A + g + k * 256 + tid);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait8(v);
         if (p.exchange) {
             u4* const s0 = xb + (size_t)((r + it) % p.slots) * 2048u;
 #pragma unroll
@@ -75,12 +81,13 @@ __global__ void __launch_bounds__(256, 2) k_mix(const Args p) {
             u4 w[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) w[k] = ld<2>(s1 + k * 256 + tid);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait8(w);
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] += w[k];
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) st<ST>(p.B + g + k * 256 + tid, v[k]);
+        asm volatile("s_nop 1" ::: "memory");   // store-data hazard: the next iteration's loads overwrite v[]
     }
 }
 
