@@ -146,6 +146,7 @@ const char *mifft_last_error(void);
 #define MIFFT_DEBUG_PERSIST 4      /* persistent (prefetching) form of the long fp32 rows (measured: no gain) */
 #define MIFFT_DEBUG_ALT_ROWS 5     /* alternative stage lists of the longest fp32 rows (A/B measurements) */
 #define MIFFT_DEBUG_PAIR 6         /* pass pairs: 0 = default split, 1 = off, 2 = the alternative y split (A/B measurements) */
+#define MIFFT_DEBUG_STORE 7        /* streamed output stores (A/B): 0 = default, 1 = non-temporal, 2 = write-through (sc1), 3 = plain */
 #define MIFFT_DEBUG_KEYS 8
 int mifft_debug_set(int32_t key, int32_t value);
 int mifft_debug_get(int32_t key);
@@ -208,15 +209,18 @@ int mifft_launch_pass(const mifft_pass *pass, const void *in0, const void *in1, 
  * transform whose (y, x) plane fits no work-group still crosses HBM twice instead of three times.  With the y axis
  * factored R0 * R1 as the chain factors a long axis (pyfft/kernel.py:259-283), the four passes
  *     ROW x | COL y (L = R0, M = R1, S = nx) | COL y (L = R1, M = 1, S = nx * R0) | COL z (L = nz, M = 1, S = nx * ny)
- * are the pairs (ROW x, COL y R0) -- out of place only -- and (COL y R1, COL z) -- in place capable.  Interleaved data,
- * dense batches (outer stride = the transform size) only.
- *   mifft_pair_split          R0 (> 0) if the library has both pair kernels for a (z, y, x) transform, else 0
+ * are the pairs (ROW x, COL y R0) -- out of place only -- and (COL y R1, COL z) -- in place capable.  Dense batches (outer
+ * stride = the transform size) only.  The buffer BETWEEN the two launches is interleaved; with layout MIFFT_SPLIT the first
+ * launch reads and the second writes two scalar planes (flags MIFFT_FLAG_DST_INTERLEAVED / _SRC_INTERLEAVED on the inner side).
+ *   mifft_pair_split          R0 (> 0) if the library has both pair kernels for a (z, y, x) transform of that layout, else 0
  *   mifft_pass_pair_supported 0 if (p0, p1) is such a pair with a compiled kernel, else MIFFT_E_UNSUPPORTED
- *   mifft_launch_pass_pair    enqueue it: reads `in`, writes `out` (p0's input side, p1's output side; scale = p0 * p1)
+ *   mifft_launch_pass_pair    enqueue it: reads in0 / in1 (p0's input side), writes out0 / out1 (p1's output side); in1 / out1
+ *                             are the imaginary planes of a split side, else ignored; scale = p0->scale * p1->scale
  */
-int mifft_pair_split(int32_t precision, int32_t x, int32_t y, int32_t z);
+int mifft_pair_split(int32_t precision, int32_t layout, int32_t x, int32_t y, int32_t z);
 int mifft_pass_pair_supported(const mifft_pass *p0, const mifft_pass *p1);
-int mifft_launch_pass_pair(const mifft_pass *p0, const mifft_pass *p1, const void *in, void *out, mifft_stream_t stream);
+int mifft_launch_pass_pair(const mifft_pass *p0, const mifft_pass *p1, const void *in0, const void *in1, void *out0, void *out1,
+                           mifft_stream_t stream);
 
 /* Enqueue a whole plan: passes[i] reads bufs0/bufs1[passes[i].src] and writes [passes[i].dst]
  * (0 = data_in, 1 = data_out, 2 = temp -- the ping-pong loop of pyfft/plan.py:217-248 with the
@@ -270,6 +274,8 @@ int mifft_launch_fused2(const mifft_pass *p0, const mifft_pass *p1, const void *
  *   flags    bit 0: issue the next transform's loads while the current one is being stored (default form)
  *            bit 1 (development): `control` is MIFFT_XCD2_CONTROL_BYTES + MIFFT_XCD2_TRACE_BYTES long and receives, behind
  *            the control words, 32 time stamps (100 MHz) per work-group for the per-XCD transform index (flags >> 8)
+ *            bits 4..6 (development): elimination variant 1..5 of csrc/fft_xcd2.hpp -- same launch with a part of the work
+ *            removed; the results are WRONG by construction (profiles/r03_xcd2_elimination.log)
  * Requires a device with 8 XCDs x 32 CUs (MI355X); MIFFT_E_UNSUPPORTED otherwise or for other lengths.
  */
 #define MIFFT_XCD2_SCRATCH_BYTES (8u * 64u * 16u * 256u * 8u)

@@ -48,6 +48,12 @@ def fused3_lag_ring(lag, ring):
     return lag, ring
 
 
+def small_fused(default):
+    """PYFFT_AMD_SMALL_FUSED = lag divisor of the small-batch fused form (0 = off)"""
+    v = os.environ.get("PYFFT_AMD_SMALL_FUSED")
+    return default if v is None else int(v)
+
+
 def xcd2_flags(default):
     v = os.environ.get("PYFFT_AMD_XCD2_FLAGS")
     return default if v is None else int(v)
@@ -60,5 +66,7 @@ def apply_native_switches(native):
                      ("MIFFT_PERSIST", native.DEBUG_PERSIST)):
         if os.environ.get(env):
             native.lib.mifft_debug_set(key, 1)
+    if os.environ.get("MIFFT_STORE"):       # streamed output stores: 1 = non-temporal, 2 = write-through, 3 = plain
+        native.lib.mifft_debug_set(native.DEBUG_STORE, int(os.environ["MIFFT_STORE"]))
     if os.environ.get("MIFFT_PAIR"):        # pass pairs: 1 = off, 2 = the alternative y split
         native.lib.mifft_debug_set(native.DEBUG_PAIR, int(os.environ["MIFFT_PAIR"]))

@@ -36,7 +36,7 @@ def fused2_counter_bytes(outer):
 
 
 XCD2_PREFETCH = 1
-DEBUG_NO_ND2, DEBUG_FUSED_NO_NT, DEBUG_NO_WAVE, DEBUG_FORCE_WAVE, DEBUG_PERSIST, DEBUG_ALT_ROWS, DEBUG_PAIR = 0, 1, 2, 3, 4, 5, 6
+DEBUG_NO_ND2, DEBUG_FUSED_NO_NT, DEBUG_NO_WAVE, DEBUG_FORCE_WAVE, DEBUG_PERSIST, DEBUG_ALT_ROWS, DEBUG_PAIR, DEBUG_STORE = 0, 1, 2, 3, 4, 5, 6, 7
 XCD2_TRACE = 2
 XCD2_TRACE_BYTES = 512 * 32 * 8
 
@@ -141,9 +141,9 @@ PROTOTYPES = {
     "mifft_nd_shape_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32]),
     "mifft_pass_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
     "mifft_launch_pass": (ctypes.c_int, [_pass_p, _vp, _vp, _vp, _vp, _vp]),
-    "mifft_pair_split": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
+    "mifft_pair_split": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32]),
     "mifft_pass_pair_supported": (ctypes.c_int, [_pass_p, _pass_p]),
-    "mifft_launch_pass_pair": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp]),
+    "mifft_launch_pass_pair": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp, _vp, _vp]),
     "mifft_launch_chain": (ctypes.c_int, [_pass_p, _i32, _vpp, _vpp, _vp]),
     "mifft_launch_chain_pipelined": (ctypes.c_int, [_pass_p, _i32, _vpp, _vpp, ctypes.c_int64, ctypes.c_int64,
                                                       ctypes.c_int64, _vp, _vpp, _i32, _vpp]),

@@ -1,4 +1,6 @@
-// Fused two-pass kernel for a long contiguous axis N = L0 * L1 (L0, L1 in {256, 512, 1024}): both Stockham
+// Fused two-pass kernels for a long contiguous axis N = L0 * L1 -- fp32: L0, L1 in {256, 512, 1024} on the 256-thread tiles
+// of fft_col2.hpp, 2048 x 2048 / 2048 x 1024 on the 512-thread tiles of fft_col3.hpp; fp64: 1024 x 1024 -- and for the 2-D
+// squares 512 / 1024 / 2048 (fp32) and 1024 (fp64): both Stockham
 // passes of every transform run inside ONE persistent launch, in dependency order, so the inter-pass
 // intermediate of a transform is consumed a few transforms later while it is still in the 256 MiB Infinity
 // Cache, and there are no launch boundaries (with 128 KiB tiles a cache-sized chunk is only ~2 machine-waves
@@ -207,7 +209,9 @@ __device__ __forceinline__ void fused_loop(const FusedArgs& f, unsigned* s_item,
     fused_flush(pend);
 }
 
-template <typename T, int A0, int A1, bool SPLIT, bool NT>
+// NT: 0 = plain accesses on the streamed side, 1 = non-temporal loads of the input and stores of the output, 2 = non-temporal
+// loads and write-through (sc1) stores of the output
+template <typename T, int A0, int A1, bool SPLIT, int NT>
 __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
     constexpr int E0 = Col2Lds<A0, true>::ELEMS, E1 = Col2Lds<A1, false>::ELEMS;
     __shared__ __attribute__((aligned(16))) cplx<T> lds[E0 > E1 ? E0 : E1];
@@ -217,10 +221,10 @@ __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
     fused_loop<per0, per1, !SPLIT>(   // early poll: C2 19.49 -> 19.32 ms; split planes 26.7 -> 25.6 ms WITHOUT it
         f, &s_item,
         [&](unsigned t, unsigned slot, unsigned tile, auto hook) {
-            col2_tile<T, A0, true, true, SPLIT, true, NT, false, false>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);
+            col2_tile<T, A0, true, true, SPLIT, true, NT != 0, false, false>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);
         },
         [&](unsigned slot, unsigned t, unsigned tile, auto hook) {
-            col2_tile<T, A1, false, false, false, false, false, NT, SPLIT>(f.p1, (long long)slot, (long long)t, (long long)tile * 16, lds, hook);
+            col2_tile<T, A1, false, false, false, NT == 2, false, NT == 1, SPLIT>(f.p1, (long long)slot, (long long)t, (long long)tile * 16, lds, hook);
         });
 }
 

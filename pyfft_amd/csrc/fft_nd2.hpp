@@ -103,7 +103,8 @@ template <typename T, int P, int NT, bool HALF, typename D> struct Nd2Stage {
             });
         });
     }
-    template <bool NTS = false>
+    // NTS: 0 plain, 1 non-temporal, 2 write-through (sc1) stores
+    template <int NTS = 0>
     static __device__ __forceinline__ void store(char* outb, const cplx<T>* v, int tid, T sx, T sy, long long left) {
         static_for<NB>([&](auto bb) {
             constexpr int b = bb;
@@ -116,8 +117,10 @@ template <typename T, int P, int NT, bool HALF, typename D> struct Nd2Stage {
                     cplx<T> p = v[b * R + k];
                     p.x *= sx;
                     p.y *= sy;
-                    cplx<T>* q = reinterpret_cast<cplx<T>*>(outb + (size_t)(k * Ns * SA) * sizeof(cplx<T>) + voff);
-                    if constexpr (NTS) __builtin_nontemporal_store(p, q);
+                    char* kb = outb + (size_t)(k * Ns * SA) * sizeof(cplx<T>);
+                    cplx<T>* q = reinterpret_cast<cplx<T>*>(kb + voff);
+                    if constexpr (NTS == 2) store_wt<T>(kb, voff, p);
+                    else if constexpr (NTS == 1) __builtin_nontemporal_store(p, q);
                     else *q = p;
                 });
             }
@@ -147,11 +150,12 @@ struct Nd2Chain<T, P, NT, HALF, FIRST, Nd2StageList<D, Rest...>> {
 
     // v holds the operands of this stage; tw[ax] = twiddle table of axis ax
     static __device__ __forceinline__ void run(LdsT* lds, cplx<T>* v, const cplx<T>* const* tw, int tid, char* outb, T sx,
-                                               T sy, long long left, bool nt_out) {
+                                               T sy, long long left, int nt_out) {
         St::compute(v, tw[D::AX], tid);
         if constexpr (LAST) {
-            if (nt_out) St::template store<true>(outb, v, tid, sx, sy, left);  // MIFFT_FLAG_STREAM_DST
-            else St::template store<false>(outb, v, tid, sx, sy, left);
+            if (nt_out == 2) St::template store<2>(outb, v, tid, sx, sy, left);
+            else if (nt_out == 1) St::template store<1>(outb, v, tid, sx, sy, left);  // MIFFT_FLAG_STREAM_DST
+            else St::template store<0>(outb, v, tid, sx, sy, left);
         } else {
             using NextChain = Nd2Chain<T, P, NT, HALF, false, Nd2StageList<Rest...>>;
             using Next = typename NextChain::St;
@@ -230,7 +234,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) 
         __syncthreads();
     }
     if (a.inverse) static_for<PPT>([&](auto i) { v[i].y = -v[i].y; });
-    Nd2Chain<T, P, NT, HALF, true, SL>::run(lds, v, tw, tid, outb, sx, sy, left, (a.nt & 2) != 0);
+    Nd2Chain<T, P, NT, HALF, true, SL>::run(lds, v, tw, tid, outb, sx, sy, left, (a.nt & 4) ? 2 : ((a.nt & 2) ? 1 : 0));
 }
 
 template <typename T, int LX, int LY, int LZ, int P, int NT, bool HALF, int OCC, bool EDGE_IN, typename RLX, typename RLY,

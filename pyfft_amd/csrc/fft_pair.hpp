@@ -8,7 +8,7 @@
 // are run as two launches:
 //   XY  = ROW x + COL y (R0):  tile (z, l): the R0 rows y = r * R1 + l of one plane, whole x (R0 * nx points: strided rows in,
 //         a contiguous block of R0 rows out -- Stockham autosort puts row l * R0 + q there), inter-pass twiddle w(ny)^(l * q)
-//   YZ  = COL y (R1) + COL z:  tile (q, x-chunk): W adjacent x (128-byte segments) of the rows y = r * R0 + q, all z
+//   YZ  = COL y (R1) + COL z:  tile (q, x-chunk): W adjacent x (128-byte segments; 16 x 8 bytes per plane for split fp64 output) of the rows y = r * R0 + q, all z
 //         (W * R1 * nz points, every point of a segment gathered / scattered in place)
 // Both are the register-edged, LDS-exchanged stage chain of fft_nd2.hpp (same Nd2Stage arithmetic, same exchanges) on a
 // tile-LOCAL dense index space (d0, d1, d2); what is new is the map from that space to global memory: every tile dimension
@@ -20,15 +20,17 @@
 namespace mifft {
 
 struct PairArgs {
-    const void* in0;
-    void* out0;
+    const void* in0;     // interleaved data, or the real plane (XY of a split-plane plan)
+    const void* in1;     // imaginary plane or null
+    void* out0;          // interleaved data, or the real plane (YZ of a split-plane plan)
+    void* out1;
     const void* tw[3];   // w(len)^k table of the transformed length of tile dimension 0 / 1 / 2 (null when not transformed)
     const void* tw_lo;   // XY: the inter-pass twiddle of the y axis as the chain's two-level table: w(ny)^e =
     const void* tw_hi;   //     tw_lo[e & (2^tw_shift - 1)] * tw_hi[e >> tw_shift]
     int tw_shift;
     long long tiles;     // number of tiles = grid
     int inverse;
-    int nt;              // bit 0: non-temporal loads, bit 1: non-temporal stores
+    int nt;              // bit 0: non-temporal loads, bit 1: non-temporal stores, bit 2: write-through (sc1) stores
     double scale;
 };
 
@@ -49,36 +51,51 @@ struct PairMap {
     }
 };
 
-// first-stage operands straight from HBM through the map
-template <typename T, typename St, typename MAP, bool NTL>
-__device__ __forceinline__ void pair_load(const char* inb, cplx<T>* v, int tid) {
+// first-stage operands straight from HBM through the map.  SPLIT: two scalar planes (inb / inb1 = the tile's first real / imaginary
+// scalar), else interleaved complex numbers at inb.
+template <typename T, typename St, typename MAP, bool NTL, bool SPLIT>
+__device__ __forceinline__ void pair_load(const char* inb, const char* inb1, cplx<T>* v, int tid) {
     constexpr long long G = MAP::GI[St::AX];
+    constexpr unsigned ESZ = SPLIT ? sizeof(T) : sizeof(cplx<T>);
     static_for<St::NB>([&](auto bb) {
         constexpr int b = bb;
         int base, jb;
         St::geom(b, tid, base, jb);
-        const unsigned voff = MAP::in_off(base + jb * St::SA) * (unsigned)sizeof(cplx<T>);
+        const unsigned voff = MAP::in_off(base + jb * St::SA) * ESZ;
         static_for<St::R>([&](auto kk) {
             constexpr int k = kk;
-            const cplx<T>* q = reinterpret_cast<const cplx<T>*>(inb + (size_t)((long long)(k * St::LR) * G) * sizeof(cplx<T>) + voff);
-            if constexpr (NTL) v[b * St::R + k] = __builtin_nontemporal_load(q);
-            else v[b * St::R + k] = *q;
+            const size_t koff = (size_t)((long long)(k * St::LR) * G) * ESZ;
+            if constexpr (SPLIT) {
+                const T* qr = reinterpret_cast<const T*>(inb + koff + voff);
+                const T* qi = reinterpret_cast<const T*>(inb1 + koff + voff);
+                if constexpr (NTL) {
+                    v[b * St::R + k].x = __builtin_nontemporal_load(qr);
+                    v[b * St::R + k].y = __builtin_nontemporal_load(qi);
+                } else {
+                    v[b * St::R + k].x = *qr;
+                    v[b * St::R + k].y = *qi;
+                }
+            } else {
+                const cplx<T>* q = reinterpret_cast<const cplx<T>*>(inb + koff + voff);
+                if constexpr (NTL) v[b * St::R + k] = __builtin_nontemporal_load(q);
+                else v[b * St::R + k] = *q;
+            }
         });
     });
 }
 
-// last-stage results straight to HBM through the map.  TWOUT: times w(n)^(l * q), q = the tile-dimension-1 coordinate of the
-// result (the last stage runs along dimension 1), l = `lrow` (uniform).
-template <typename T, typename St, typename MAP, bool NTS, bool TWOUT>
-__device__ __forceinline__ void pair_store(char* outb, const cplx<T>* v, int tid, T sx, T sy, const PairArgs& a, int lrow) {
+// NTS: 0 plain, 1 non-temporal, 2 write-through stores
+template <typename T, typename St, typename MAP, int NTS, bool TWOUT, bool SPLIT>
+__device__ __forceinline__ void pair_store(char* outb, char* outb1, const cplx<T>* v, int tid, T sx, T sy, const PairArgs& a, int lrow) {
     constexpr long long G = MAP::GO[St::AX];
+    constexpr unsigned ESZ = SPLIT ? sizeof(T) : sizeof(cplx<T>);
     static_assert(!TWOUT || St::AX == 1, "the twiddled store belongs to the last stage of tile dimension 1");
     static_for<St::NB>([&](auto bb) {
         constexpr int b = bb;
         int base, jb;
         St::geom(b, tid, base, jb);
         const int e0 = base + St::idxd(jb) * St::SA;
-        const unsigned voff = MAP::out_off(e0) * (unsigned)sizeof(cplx<T>);
+        const unsigned voff = MAP::out_off(e0) * ESZ;
         const int q0 = (e0 / MAP::E0) % MAP::E1;
         static_for<St::R>([&](auto kk) {
             constexpr int k = kk;
@@ -91,29 +108,45 @@ __device__ __forceinline__ void pair_store(char* outb, const cplx<T>* v, int tid
             }
             p.x *= sx;
             p.y *= sy;
-            cplx<T>* q = reinterpret_cast<cplx<T>*>(outb + (size_t)((long long)(k * St::Ns) * G) * sizeof(cplx<T>) + voff);
-            if constexpr (NTS) __builtin_nontemporal_store(p, q);
-            else *q = p;
+            const size_t koff = (size_t)((long long)(k * St::Ns) * G) * ESZ;
+            if constexpr (SPLIT) {
+                T* qr = reinterpret_cast<T*>(outb + koff + voff);
+                T* qi = reinterpret_cast<T*>(outb1 + koff + voff);
+                if constexpr (NTS != 0) {
+                    __builtin_nontemporal_store(p.x, qr);
+                    __builtin_nontemporal_store(p.y, qi);
+                } else {
+                    *qr = p.x;
+                    *qi = p.y;
+                }
+            } else {
+                char* kb = outb + koff;
+                cplx<T>* q = reinterpret_cast<cplx<T>*>(kb + voff);
+                if constexpr (NTS == 2) store_wt<T>(kb, voff, p);
+                else if constexpr (NTS == 1) __builtin_nontemporal_store(p, q);
+                else *q = p;
+            }
         });
     });
 }
 
-template <typename T, int P, int NT, bool HALF, bool FIRST, typename MAP, bool TWOUT, typename SL> struct PairChain;
+template <typename T, int P, int NT, bool HALF, bool FIRST, typename MAP, bool TWOUT, bool SPLIT_OUT, typename SL> struct PairChain;
 
-template <typename T, int P, int NT, bool HALF, bool FIRST, typename MAP, bool TWOUT, typename D, typename... Rest>
-struct PairChain<T, P, NT, HALF, FIRST, MAP, TWOUT, Nd2StageList<D, Rest...>> {
+template <typename T, int P, int NT, bool HALF, bool FIRST, typename MAP, bool TWOUT, bool SPLIT_OUT, typename D, typename... Rest>
+struct PairChain<T, P, NT, HALF, FIRST, MAP, TWOUT, SPLIT_OUT, Nd2StageList<D, Rest...>> {
     using St = Nd2Stage<T, P, NT, HALF, D>;
     using LdsT = typename St::LdsT;
     static constexpr bool LAST = sizeof...(Rest) == 0;
 
-    static __device__ __forceinline__ void run(LdsT* lds, cplx<T>* v, const cplx<T>* const* tw, int tid, char* outb, T sx, T sy,
-                                               bool nt_out, const PairArgs& a, int lrow) {
+    static __device__ __forceinline__ void run(LdsT* lds, cplx<T>* v, const cplx<T>* const* tw, int tid, char* outb, char* outb1,
+                                               T sx, T sy, int nt_out, const PairArgs& a, int lrow) {
         St::compute(v, tw[D::AX], tid);
         if constexpr (LAST) {
-            if (nt_out) pair_store<T, St, MAP, true, TWOUT>(outb, v, tid, sx, sy, a, lrow);
-            else pair_store<T, St, MAP, false, TWOUT>(outb, v, tid, sx, sy, a, lrow);
+            if (nt_out == 2) pair_store<T, St, MAP, 2, TWOUT, SPLIT_OUT>(outb, outb1, v, tid, sx, sy, a, lrow);
+            else if (nt_out == 1) pair_store<T, St, MAP, 1, TWOUT, SPLIT_OUT>(outb, outb1, v, tid, sx, sy, a, lrow);
+            else pair_store<T, St, MAP, 0, TWOUT, SPLIT_OUT>(outb, outb1, v, tid, sx, sy, a, lrow);
         } else {
-            using NextChain = PairChain<T, P, NT, HALF, false, MAP, TWOUT, Nd2StageList<Rest...>>;
+            using NextChain = PairChain<T, P, NT, HALF, false, MAP, TWOUT, SPLIT_OUT, Nd2StageList<Rest...>>;
             using Next = typename NextChain::St;
             if constexpr (!FIRST) __syncthreads();  // everybody has fetched its operands of this stage
             if constexpr (!HALF) {
@@ -129,12 +162,12 @@ struct PairChain<T, P, NT, HALF, FIRST, MAP, TWOUT, Nd2StageList<D, Rest...>> {
                 __syncthreads();
                 Next::template fetch<2>(lds, v, tid);
             }
-            NextChain::run(lds, v, tw, tid, outb, sx, sy, nt_out, a, lrow);
+            NextChain::run(lds, v, tw, tid, outb, outb1, sx, sy, nt_out, a, lrow);
         }
     }
 };
 
-// CFG: P, NT, HALF, OCC, MAP, SL (stage list over the tile-local space), TWOUT
+// CFG: P, NT, HALF, OCC, MAP, SL (stage list over the tile-local space), TWOUT, SPLIT_IN, SPLIT_OUT
 template <typename T, typename CFG>
 __global__ void __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::OCC))) fft_pair_kernel(const PairArgs a) {
     using MAP = typename CFG::MAP;
@@ -151,26 +184,32 @@ __global__ void __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CF
     const long long o = tile / (unsigned)(MAP::C0 * MAP::C1);
     const long long bin = o * MAP::BOUTER + (long long)c0 * MAP::BI0 + (long long)c1 * MAP::BI1;
     const long long bout = o * MAP::BOUTER + (long long)c0 * MAP::BO0 + (long long)c1 * MAP::BO1;
-    const char* inb = reinterpret_cast<const char*>(reinterpret_cast<const cplx<T>*>(a.in0) + bin);
-    char* outb = reinterpret_cast<char*>(reinterpret_cast<cplx<T>*>(a.out0) + bout);
+    constexpr bool SI = CFG::SPLIT_IN, SO = CFG::SPLIT_OUT;
+    const char* inb = SI ? reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.in0) + bin)
+                         : reinterpret_cast<const char*>(reinterpret_cast<const cplx<T>*>(a.in0) + bin);
+    const char* inb1 = SI ? reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.in1) + bin) : nullptr;
+    char* outb = SO ? reinterpret_cast<char*>(reinterpret_cast<T*>(a.out0) + bout)
+                    : reinterpret_cast<char*>(reinterpret_cast<cplx<T>*>(a.out0) + bout);
+    char* outb1 = SO ? reinterpret_cast<char*>(reinterpret_cast<T*>(a.out1) + bout) : nullptr;
     const cplx<T>* tw[3] = {reinterpret_cast<const cplx<T>*>(a.tw[0]), reinterpret_cast<const cplx<T>*>(a.tw[1]),
                             reinterpret_cast<const cplx<T>*>(a.tw[2])};
     const T sx = (T)a.scale;
     const T sy = a.inverse ? -sx : sx;
     cplx<T> v[PPT];
-    if (a.nt & 1) pair_load<T, First, MAP, true>(inb, v, tid);
-    else pair_load<T, First, MAP, false>(inb, v, tid);
+    if (a.nt & 1) pair_load<T, First, MAP, true, SI>(inb, inb1, v, tid);
+    else pair_load<T, First, MAP, false, SI>(inb, inb1, v, tid);
     if (a.inverse) static_for<PPT>([&](auto i) { v[i].y = -v[i].y; });
-    PairChain<T, P, NT, HALF, true, MAP, CFG::TWOUT, SL>::run(lds, v, tw, tid, outb, sx, sy, (a.nt & 2) != 0, a, (int)c0);
+    PairChain<T, P, NT, HALF, true, MAP, CFG::TWOUT, SO, SL>::run(lds, v, tw, tid, outb, outb1, sx, sy,
+                                                                 (a.nt & 4) ? 2 : ((a.nt & 2) ? 1 : 0), a, (int)c0);
 }
 
 // ---- the two tile kinds for a (NZ, NY, NX) transform with NY = R0 * R1 ------------------------------------------------
 // XY: tile dims (x: NX, r: R0); tile coordinates c0 = l < R1, o = plane (z and batch)
-template <typename T, int NX, int R0, int R1, int NT_, bool HALF_, int OCC_, typename RLX, typename RLY>
+template <typename T, int NX, int R0, int R1, int NT_, bool HALF_, int OCC_, typename RLX, typename RLY, bool SPLIT_IN_ = false>
 struct PairXY {
     static constexpr int NY = R0 * R1;
     static constexpr int P = NX * R0, NT = NT_, OCC = OCC_;
-    static constexpr bool HALF = HALF_, TWOUT = true;
+    static constexpr bool HALF = HALF_, TWOUT = true, SPLIT_IN = SPLIT_IN_, SPLIT_OUT = false;
     using MAP = PairMap<NX, R0, 1, /*GI*/ 1, (long long)R1 * NX, 0, /*GO*/ 1, NX, 0, /*C*/ R1, 1,
                         /*BI*/ NX, 0, /*BO*/ (long long)R0 * NX, 0, /*outer: one plane*/ (long long)NX * NY>;
     using SX = typename Nd2AxisStages<0, NX, 1, 1, RLX, Nd2StageList<>>::type;
@@ -180,10 +219,10 @@ struct PairXY {
 
 // YZ: tile dims (x: W untransformed, r: R1, z: NZ) of the [NZ][R1][S0] view of one transform, S0 = nx * R0 (everything faster
 // than the digit r); tile coordinate c0 = group of W adjacent elements of S0 (W * sizeof = one 128-byte segment), o = batch item
-template <typename T, int S0, int R1, int NZ, int W, int NT_, bool HALF_, int OCC_, typename RLY, typename RLZ>
+template <typename T, int S0, int R1, int NZ, int W, int NT_, bool HALF_, int OCC_, typename RLY, typename RLZ, bool SPLIT_OUT_ = false>
 struct PairYZ {
-    static constexpr int P = W * R1 * NZ, NT = NT_, OCC = OCC_;
-    static constexpr bool HALF = HALF_, TWOUT = false;
+    static constexpr int P = W * R1 * NZ, NT = NT_, OCC = OCC_, WIDTH = W;
+    static constexpr bool HALF = HALF_, TWOUT = false, SPLIT_IN = false, SPLIT_OUT = SPLIT_OUT_;
     using MAP = PairMap<W, R1, NZ, /*GI*/ 1, S0, (long long)S0 * R1, /*GO*/ 1, S0, (long long)S0 * R1,
                         /*C*/ S0 / W, 1, /*BI*/ W, 0, /*BO*/ W, 0, /*outer: one transform*/ (long long)S0 * R1 * NZ>;
     using SY = typename Nd2AxisStages<1, R1, W, 1, RLY, Nd2StageList<>>::type;

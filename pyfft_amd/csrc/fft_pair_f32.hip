@@ -1,0 +1,24 @@
+// fp32 instances of the pass-pair kernels (fft_pair.hpp): 256^3 interleaved with the y axis split 64 x 4 -- both tiles are
+// 16384 points = 128 KiB (two work-groups per CU in half-exchange form), YZ tiles 16 columns wide (128-byte segments).
+#include "mifft_internal.h"
+#include "fft_pair.hpp"
+
+using namespace mifft;
+
+extern "C" int mifft_pair_f32(int kind, int k0, int k1, int k2, int split, const PairArgs* a, hipStream_t s, int query, int* width) {
+#define XY(NX, R0, R1, NT, HALF, OCC, RLX, RLY, SPLIT)                                       \
+    if (kind == 0 && k0 == NX && k1 == R0 && k2 == R1 && split == (SPLIT ? 1 : 0))          \
+        return query ? 0 : launch_pair<float, PairXY<float, NX, R0, R1, NT, HALF, OCC, RLX, RLY, SPLIT>>(a, s);
+#define YZ(S0, R1, NZ, W, NT, HALF, OCC, RLY, RLZ, SPLIT)                                    \
+    if (kind == 1 && k0 == S0 && k1 == R1 && k2 == NZ && split == (SPLIT ? 1 : 0)) {        \
+        if (width) *width = W;                                                               \
+        return query ? 0 : launch_pair<float, PairYZ<float, S0, R1, NZ, W, NT, HALF, OCC, RLY, RLZ, SPLIT>>(a, s); \
+    }
+#define RL(...) RadixList<__VA_ARGS__>
+    XY(256, 64, 4, 512, true, 4, RL(16, 16), RL(16, 4), false)
+    YZ(256 * 64, 4, 256, 16, 512, true, 4, RL(4), RL(16, 16), false)
+#undef XY
+#undef YZ
+#undef RL
+    return -2;
+}

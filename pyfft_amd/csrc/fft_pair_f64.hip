@@ -1,23 +1,30 @@
-// fp64 instances of the pass-pair kernels (fft_pair.hpp): 256 x 256 planes with 256 z (BASELINE config 4), the y axis split
-// 32 x 8 (XY tile 128 KiB at two work-groups per CU, YZ tile 256 KiB at one) or 64 x 4 (the other way round).
+// fp64 instances of the pass-pair kernels (fft_pair.hpp): 256 x 256 planes with 256 z (BASELINE config 4, both layouts).
+// Interleaved: the y axis split 32 x 8 (XY tile 128 KiB at two work-groups per CU, YZ tile 256 KiB at one) or 64 x 4 (the other
+// way round; measured 28.7 against 30.7 %, profiles/r03_b_c4_pair_split.log).  Split planes: 64 x 4 with 16-column YZ tiles
+// (16 x 8 bytes = one 128-byte segment per plane); the intermediate between the two launches is interleaved either way.
 #include "mifft_internal.h"
 #include "fft_pair.hpp"
 
 using namespace mifft;
 
-// kind 0 = XY keyed by (nx, R0, R1); kind 1 = YZ keyed by (S0, R1, nz).  0 = launched (query: exists), -2 = no such kernel.
-extern "C" int mifft_pair_f64(int kind, int k0, int k1, int k2, const PairArgs* a, hipStream_t s, int query) {
-#define XY(NX, R0, R1, NT, HALF, OCC, RLX, RLY)                                              \
-    if (kind == 0 && k0 == NX && k1 == R0 && k2 == R1)                                       \
-        return query ? 0 : launch_pair<double, PairXY<double, NX, R0, R1, NT, HALF, OCC, RLX, RLY>>(a, s);
-#define YZ(S0, R1, NZ, NT, HALF, OCC, RLY, RLZ)                                              \
-    if (kind == 1 && k0 == S0 && k1 == R1 && k2 == NZ)                                       \
-        return query ? 0 : launch_pair<double, PairYZ<double, S0, R1, NZ, 8, NT, HALF, OCC, RLY, RLZ>>(a, s);
+// kind 0 = XY keyed by (nx, R0, R1); kind 1 = YZ keyed by (S0, R1, nz); `split`: XY reads / YZ writes two scalar planes.
+// 0 = launched (query: exists), -2 = no such kernel.  *width = adjacent columns per YZ tile (tiles = batch * S0 / width).
+extern "C" int mifft_pair_f64(int kind, int k0, int k1, int k2, int split, const PairArgs* a, hipStream_t s, int query, int* width) {
+#define XY(NX, R0, R1, NT, HALF, OCC, RLX, RLY, SPLIT)                                       \
+    if (kind == 0 && k0 == NX && k1 == R0 && k2 == R1 && split == (SPLIT ? 1 : 0))          \
+        return query ? 0 : launch_pair<double, PairXY<double, NX, R0, R1, NT, HALF, OCC, RLX, RLY, SPLIT>>(a, s);
+#define YZ(S0, R1, NZ, W, NT, HALF, OCC, RLY, RLZ, SPLIT)                                    \
+    if (kind == 1 && k0 == S0 && k1 == R1 && k2 == NZ && split == (SPLIT ? 1 : 0)) {        \
+        if (width) *width = W;                                                               \
+        return query ? 0 : launch_pair<double, PairYZ<double, S0, R1, NZ, W, NT, HALF, OCC, RLY, RLZ, SPLIT>>(a, s); \
+    }
 #define RL(...) RadixList<__VA_ARGS__>
-    XY(256, 32, 8, 512, true, 4, RL(16, 16), RL(8, 4))
-    YZ(256 * 32, 8, 256, 1024, true, 4, RL(8), RL(16, 16))
-    XY(256, 64, 4, 1024, true, 4, RL(16, 16), RL(16, 4))
-    YZ(256 * 64, 4, 256, 512, true, 4, RL(4), RL(16, 16))
+    XY(256, 32, 8, 512, true, 4, RL(16, 16), RL(8, 4), false)
+    YZ(256 * 32, 8, 256, 8, 1024, true, 4, RL(8), RL(16, 16), false)
+    XY(256, 64, 4, 1024, true, 4, RL(16, 16), RL(16, 4), false)
+    YZ(256 * 64, 4, 256, 8, 512, true, 4, RL(4), RL(16, 16), false)
+    XY(256, 64, 4, 1024, true, 4, RL(16, 16), RL(16, 4), true)
+    YZ(256 * 64, 4, 256, 16, 1024, true, 4, RL(4), RL(16, 16), true)
 #undef XY
 #undef YZ
 #undef RL

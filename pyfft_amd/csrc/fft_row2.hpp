@@ -168,7 +168,7 @@ struct Row2Stages<T, L, TPR, Ns, FIRST, HALF, RadixList<R, Rest...>> {
             const T sy = a.inverse ? -sx : sx;
             if (valid) {
                 auto stores = [&](auto ntc) __attribute__((always_inline)) {
-                    constexpr bool NTS = ntc;
+                    constexpr int NTS = ntc;   // 0 plain, 1 non-temporal, 2 write-through
                     static_for<NB>([&](auto bb) {
                         constexpr int b = bb;  // Ns == LR: idxD = j = b * NT + tid
                         static_for<R>([&](auto kk) {
@@ -176,13 +176,15 @@ struct Row2Stages<T, L, TPR, Ns, FIRST, HALF, RadixList<R, Rest...>> {
                             cplx<T> p = v[b * R + k];
                             p.x *= sx;
                             p.y *= sy;
-                            cplx<T>* q = reinterpret_cast<cplx<T>*>(outb + (size_t)(b * NT + k * Ns) * sizeof(cplx<T>) + voff);
-                            if constexpr (NTS) __builtin_nontemporal_store(p, q);
+                            char* kb = outb + (size_t)(b * NT + k * Ns) * sizeof(cplx<T>);
+                            cplx<T>* q = reinterpret_cast<cplx<T>*>(kb + voff);
+                            if constexpr (NTS == 2) store_wt_ptr<T>(kb + voff, p);   // (the row base may differ across the wave)
+                            else if constexpr (NTS == 1) __builtin_nontemporal_store(p, q);
                             else *q = p;
                         });
                     });
                 };
-                if (a.nt & 2) stores(IC<1>{}); else stores(IC<0>{});
+                if (a.nt & 4) stores(IC<2>{}); else if (a.nt & 2) stores(IC<1>{}); else stores(IC<0>{});
             }
         } else {
             using Next = Row2Stages<T, L, TPR, Ns * R, false, HALF, RadixList<Rest...>>;

@@ -140,9 +140,20 @@ __device__ __forceinline__ void xcd2_load_slab(const TileArgs& a, long long t, l
     }
 }
 
-template <typename T, int ROT, bool SPLIT, bool NT, bool PREFETCH>
+// MODE (development, elimination measurements of profiles/r03_xcd2_elimination.log; every mode but 0 gives WRONG results):
+//   0 the kernel   1 no exchange waits (flags still written)   2 no exchange at all (no scratch traffic, no flags)
+//   3 HBM only (loads and stores, no butterflies, no LDS, no exchange)   5 butterflies and LDS only
+//   (4 = no HBM but exchange with waits: compiles to 750-1950 spilled registers without the loads' live ranges -- not instantiated)
+template <typename T, int ROT, bool SPLIT, bool NT, bool PREFETCH, int MODE = 0>
 __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, const unsigned r, cplx<T>* lds, unsigned* s_ok) {
     static_assert(sizeof(cplx<T>) == 8, "fp32 only: the hand-off moves one 8-byte word per point");
+    constexpr bool kNoWait = MODE == 1, kNoXchg = MODE == 2 || MODE == 3 || MODE == 5, kNoFlop = MODE == 3,
+                   kNoHbm = MODE == 4 || MODE == 5;
+    auto load_all = [&](long long t, unsigned voff, int sh, cplx<T>* v) __attribute__((always_inline)) {
+        if constexpr (kNoHbm) static_for<64>([&](auto kk) { v[kk] = cplx<T>{(T)(voff & 1023u), (T)(int)(kk & 3)}; });
+        else static_for<4>([&](auto aa) { xcd2_load_slab<T, SPLIT, NT, aa>(f.p0, t, (long long)r * 16, voff, sh, v); });
+    };
+    cplx<T> sink = {(T)0, (T)0};
     constexpr int PITCH0 = 17;                 // pass 0 (transposing) exchange: [b0][c][qb1 + pad]
     constexpr int BUF1 = 16 * 16 * 16;         // pass 1 exchange: [b0][qb1][c], double-buffered
     const int tid0 = threadIdx.x;
@@ -170,9 +181,7 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
 
     const unsigned nx = (f.batch + 7u - x) >> 3;   // this XCD's transforms: t = x + 8 i
     cplx<T> v[64];
-    if (nx > 0) {
-        static_for<4>([&](auto aa) { xcd2_load_slab<T, SPLIT, NT, aa>(f.p0, (long long)x, rem0, voff_in0, 10, v); });
-    }
+    if (nx > 0) load_all((long long)x, voff_in0, 10, v);
     bool alive = true;
     for (unsigned i = 0; i < nx && alive; ++i) {
         const bool tracing = f.trace != nullptr && i == f.trace_iter;
@@ -194,16 +203,18 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
         const int lo4 = tid & 15, hi4 = tid >> 4;  // pass 0 phase 1: (c, b0); pass 0 phase 2: (u, c2); pass 1: (c, b0) and (c2, u)
         const unsigned voff_in = ((unsigned)hi4 << sh10) + (unsigned)lo4;
         // ================= pass 0: stages 1 and 2 on the loaded columns (thread = (c = lo4, b0 = hi4))
-        static_for<64>([&](auto kk) {
-            constexpr int k = kk;
-            v[k].y *= csign;
-        });
-        {
-            ColStageTw<T> tw;
-            tw.init(twL0, hi4);
-            static_for<4>([&](auto aa) { xcd2_stage1<T, aa>(v, tw); });
+        if constexpr (!kNoFlop) {
+            static_for<64>([&](auto kk) {
+                constexpr int k = kk;
+                v[k].y *= csign;
+            });
+            {
+                ColStageTw<T> tw;
+                tw.init(twL0, hi4);
+                static_for<4>([&](auto aa) { xcd2_stage1<T, aa>(v, tw); });
+            }
+            xcd2_stage2<T>(v, twL0, hi4);
         }
-        xcd2_stage2<T>(v, twL0, hi4);
         stamp(1);
         // ================= four rounds: slab qa of pass 0 out, first-stage butterfly ia of pass 1 in.  The butterflies of
         // the next slab run under the store acknowledgements, stage 1 of the previous arrival under the load latency:
@@ -247,6 +258,7 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
             constexpr int k = kk;
             constexpr int qa = (ROT - k) & 3;
             constexpr unsigned par = 0u;
+            if constexpr (kNoXchg) return;
             static_for<16>([&](auto qq) {
                 constexpr int qb0 = qq;
                 char* p = sbase + ((size_t)((par * 64u + (unsigned)(qb0 * 4 + qa)) * 16u + slot_l) << (sh10 + 1));
@@ -258,6 +270,10 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
             constexpr int k = kk;
             constexpr int ia = (ROT + k) & 3;    // butterfly I receive in round k; my producers are r = j*4 + ia
             constexpr unsigned par = 0u;
+            if constexpr (kNoXchg) {
+                static_for<16>([&](auto jj) { y[ia * 16 + jj] = xs[jj]; });
+                return;
+            }
             static_for<16>([&](auto jj) {
                 constexpr int j = jj;
                 const char* p = sbase + ((size_t)((par * 64u + r_l) * 16u + (unsigned)j) << (sh10 + 1));
@@ -270,11 +286,12 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
         // round has TWO rendezvous: A = my 16 producers have published round k (then loads(k)); B = my 16 consumers of
         // round k+1 have read round k (then stores(k+1) may overwrite their blocks).
         auto rendezvous = [&](unsigned* mine, unsigned value, const unsigned* theirs, unsigned sel) {
+            if constexpr (kNoXchg) return;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A: stores(k) acknowledged; B: loads(k) landed
             __syncthreads();
             if (tid == 0) __hip_atomic_store(mine + r * kXcd2FS, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (wave0) {
-                const bool ok = xcd2_wait16(theirs, (lane16 * 4u + sel) * kXcd2FS, value, err);
+                const bool ok = kNoWait ? true : xcd2_wait16(theirs, (lane16 * 4u + sel) * kXcd2FS, value, err);
                 if (tid == 0) *s_ok = ok ? 1u : 0u;
             }
             __syncthreads();
@@ -289,6 +306,9 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
             xcd2_stage1<T, ia>(y, tw1);
         };
         stamp(2);
+        if constexpr (kNoFlop) {
+            static_for<64>([&](auto kk) { y[kk] = v[kk]; });
+        } else {
         compute(IC<0>{});
         stores(IC<0>{});       // (my consumers of round 0 have read the previous transform: rendezvous B of its round 3)
         static_for<4>([&](auto kk) {
@@ -305,6 +325,7 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
         stage1_y(IC<3>{});
         if (!alive) break;
         xcd2_stage2<T>(y, twL1, hi4);
+        }
         stamp(11);
 
         // ================= pass 1 phase 2 (thread = (c2 = lo4, u = hi4)): exchange, radix-16, store; prefetch the next transform
@@ -316,6 +337,9 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
             constexpr int qa = rr;
             cplx<T>* buf = lds + (qa & 1) * BUF1;
             cplx<T> xv[16];
+            if constexpr (kNoFlop) {
+                static_for<16>([&](auto ss) { xv[ss] = y[qa * 16 + ss]; });
+            } else {
             static_for<16>([&](auto ss) {
                 constexpr int qb1 = ss;
                 buf[(hi4 * 16 + qb1) * 16 + lo4] = y[qa * 16 + qb1];
@@ -326,13 +350,16 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
                 xv[bi] = buf[(bi * 16 + hi4) * 16 + lo4];
             });
             Dft<16, T>::run(xv);
+            }
             static_for<16>([&](auto qq) {
                 constexpr int qb0 = qq;
                 const long long gu = oubase + ((long long)(qb0 * 64 + 16 * qa) << sh10);
                 cplx<T> o;
                 o.x = xv[qb0].x * sx;
                 o.y = xv[qb0].y * sy;
-                if constexpr (!SPLIT) {
+                if constexpr (kNoHbm) {
+                    sink += o;
+                } else if constexpr (!SPLIT) {
                     char* p = reinterpret_cast<char*>(reinterpret_cast<cplx<T>*>(f.p1.out0) + gu);
                     if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<cplx<T>*>(p + ovoff * (unsigned)sizeof(cplx<T>)));
                     else *reinterpret_cast<cplx<T>*>(p + ovoff * (unsigned)sizeof(cplx<T>)) = o;
@@ -347,8 +374,12 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
             if constexpr (PREFETCH) {
                 // (the else branch ends the live range of the consumed slab: without it the stale registers stay live
                 // around the whole loop through the PHI of the conditional load and the kernel spills)
+                if constexpr (kNoHbm) {
+                    static_for<16>([&](auto bb) { v[qa * 16 + bb] = sink; });   // (the next transform's "data": nothing to hold)
+                } else {
                 if (more) xcd2_load_slab<T, SPLIT, NT, qa>(f.p0, t + 8, rem0, voff_in, sh10, v);
                 else static_for<16>([&](auto bb) { v[qa * 16 + bb] = cplx<T>{(T)0, (T)0}; });
+                }
             }
         });
         if constexpr (!PREFETCH) {
@@ -358,9 +389,12 @@ __device__ __forceinline__ void xcd2_body(const Xcd2Args& f, const unsigned x, c
         stamp(12);
         __syncthreads();   // LDS is free for the next transform's pass 0
     }
+    if constexpr (kNoHbm) {   // (keeps the arithmetic alive)
+        if (sink.x == (T)123456.789) *reinterpret_cast<cplx<T>*>(f.p1.out0) = sink;
+    }
 }
 
-template <typename T, bool SPLIT, bool NT, bool PREFETCH>
+template <typename T, bool SPLIT, bool NT, bool PREFETCH, int MODE = 0>
 __global__ void __launch_bounds__(256, 2) fft_xcd2_kernel(const Xcd2Args f) {
     __shared__ __attribute__((aligned(16))) cplx<T> lds[2 * 16 * 16 * 16];   // 64 KiB: pass 0 uses 34 KiB of it
     __shared__ unsigned s_w[4];
@@ -387,10 +421,10 @@ __global__ void __launch_bounds__(256, 2) fft_xcd2_kernel(const Xcd2Args f) {
     const unsigned r = __builtin_amdgcn_readfirstlane(s_w[0]);   // (an LDS read is not provably uniform: without this every address is a VGPR pair)
     if (s_w[1] == 0u || r >= 64u) return;
     switch (r & 3u) {
-        case 0: xcd2_body<T, 0, SPLIT, NT, PREFETCH>(f, x, r, lds, s_w + 2); break;
-        case 1: xcd2_body<T, 1, SPLIT, NT, PREFETCH>(f, x, r, lds, s_w + 2); break;
-        case 2: xcd2_body<T, 2, SPLIT, NT, PREFETCH>(f, x, r, lds, s_w + 2); break;
-        default: xcd2_body<T, 3, SPLIT, NT, PREFETCH>(f, x, r, lds, s_w + 2); break;
+        case 0: xcd2_body<T, 0, SPLIT, NT, PREFETCH, MODE>(f, x, r, lds, s_w + 2); break;
+        case 1: xcd2_body<T, 1, SPLIT, NT, PREFETCH, MODE>(f, x, r, lds, s_w + 2); break;
+        case 2: xcd2_body<T, 2, SPLIT, NT, PREFETCH, MODE>(f, x, r, lds, s_w + 2); break;
+        default: xcd2_body<T, 3, SPLIT, NT, PREFETCH, MODE>(f, x, r, lds, s_w + 2); break;
     }
 }
 

@@ -31,8 +31,9 @@ int mifft_aux_mul_rows_launch(int f64, void* a, const void* b, long long rows, l
 int mifft_wave_supported(int f64, int N);
 int mifft_wave_launch(int f64, int N, const mifft::WaveArgs* a, int max_blocks, hipStream_t s);
 int mifft_wave_16x16_launch(const mifft::WaveArgs* a, int max_blocks, hipStream_t s);
-int mifft_pair_f64(int kind, int k0, int k1, int k2, const mifft::PairArgs* a, hipStream_t s, int query);
-int mifft_xcd2_f32_launch(const mifft::Xcd2Args* f, int split, int prefetch, unsigned grid, hipStream_t s);
+int mifft_pair_f64(int kind, int k0, int k1, int k2, int split, const mifft::PairArgs* a, hipStream_t s, int query, int* width);
+int mifft_pair_f32(int kind, int k0, int k1, int k2, int split, const mifft::PairArgs* a, hipStream_t s, int query, int* width);
+int mifft_xcd2_f32_launch(const mifft::Xcd2Args* f, int split, int prefetch, int mode, unsigned grid, hipStream_t s);
 }
 
 namespace mifft {

@@ -71,6 +71,16 @@ int validate(const mifft_pass* p) {
     return 0;
 }
 
+// TileArgs.nt from the MIFFT_FLAG_STREAM_* hints: bit 0 non-temporal loads, bit 1 non-temporal stores, bit 2 write-through stores
+// (development switch MIFFT_DEBUG_STORE overrides the store side for A/B measurements)
+int stream_policy(int flags) {
+    int nt = ((flags & MIFFT_FLAG_STREAM_SRC) ? 1 : 0) | ((flags & MIFFT_FLAG_STREAM_DST) ? 2 : 0);
+    if (g_debug[MIFFT_DEBUG_STORE] == 1) nt = (nt & 1) | 2;
+    else if (g_debug[MIFFT_DEBUG_STORE] == 2) nt = (nt & 1) | 4;
+    else if (g_debug[MIFFT_DEBUG_STORE] == 3) nt = nt & 1;
+    return nt;
+}
+
 void fill_args(const mifft_pass* p, const void* in0, const void* in1, void* out0, void* out1, mifft::TileArgs* pa) {
     mifft::TileArgs& a = *pa;
     const bool split = p->layout == MIFFT_SPLIT && !(p->flags & MIFFT_FLAG_SRC_INTERLEAVED);
@@ -98,7 +108,7 @@ void fill_args(const mifft_pass* p, const void* in0, const void* in1, void* out0
     a.split_out = split_out ? 1 : 0;
     a.inverse = p->inverse ? 1 : 0;
     a.has_tw = (p->kind == MIFFT_PASS_COL && p->M > 1) ? 1 : 0;
-    a.nt = ((p->flags & MIFFT_FLAG_STREAM_SRC) ? 1 : 0) | ((p->flags & MIFFT_FLAG_STREAM_DST) ? 2 : 0);
+    a.nt = stream_policy(p->flags);
     a.scale = p->scale;
 }
 
@@ -162,7 +172,7 @@ int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0,
         t.total = p->outer * p->L * p->M * p->S;
         t.inverse = p->inverse ? 1 : 0;
         t.scale = p->scale;
-        t.nt = ((p->flags & MIFFT_FLAG_STREAM_SRC) ? 1 : 0) | ((p->flags & MIFFT_FLAG_STREAM_DST) ? 2 : 0);
+        t.nt = stream_policy(p->flags);
         const int rc = f64nd ? mifft_nd2_f64_launch((int)p->L, (int)p->M, (int)p->S, &t, s)
                              : mifft_nd2_f32_launch((int)p->L, (int)p->M, (int)p->S, &t, s);
         if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
@@ -245,38 +255,41 @@ int dispatch(const mifft_pass* p, const mifft::TileArgs* a, hipStream_t s, int q
 }
 
 // ---- pass pairs (fft_pair.hpp) -------------------------------------------------------------------------------------
-// kind 0 = XY (ROW x + COL y R0), kind 1 = YZ (COL y R1 + COL z); keys as in mifft_pair_f64.  Returns 0 and fills kind / keys,
-// or MIFFT_E_UNSUPPORTED when (p0, p1) is not a pair shape.
-int classify_pair(const mifft_pass* p0, const mifft_pass* p1, int* kind, int key[3]) {
+// kind 0 = XY (ROW x + COL y R0), kind 1 = YZ (COL y R1 + COL z); keys as in mifft_pair_f64; *split = the user-facing side of
+// the launch is two scalar planes (XY: its input, YZ: its output; the side between the two launches is always interleaved).
+// Returns 0 and fills kind / keys / split, or MIFFT_E_UNSUPPORTED when (p0, p1) is not a pair shape.
+int classify_pair(const mifft_pass* p0, const mifft_pass* p1, int* kind, int key[3], int* split) {
     if (!p0 || !p1) return MIFFT_E_INVALID;
     if (p0->precision != p1->precision || p0->inverse != p1->inverse || p0->layout != p1->layout) return MIFFT_E_UNSUPPORTED;
     const bool inter_in = p0->layout != MIFFT_SPLIT || (p0->flags & MIFFT_FLAG_SRC_INTERLEAVED);
     const bool inter_out = p1->layout != MIFFT_SPLIT || (p1->flags & MIFFT_FLAG_DST_INTERLEAVED);
-    if (!inter_in || !inter_out) return MIFFT_E_UNSUPPORTED;
     if (p0->kind == MIFFT_PASS_ROW && p1->kind == MIFFT_PASS_COL && p1->M > 1 && p1->S == p0->L) {
         const long long plane = (long long)p0->L * p1->L * p1->M;            // nx * ny
-        if (p1->outer_stride_in != plane || p1->outer_stride_out != plane || p0->outer != p1->outer * p1->L * p1->M ||
+        if (!inter_out || p1->outer_stride_in != plane || p1->outer_stride_out != plane || p0->outer != p1->outer * p1->L * p1->M ||
             p0->outer_stride_in != p0->L || p0->outer_stride_out != p0->L || p1->M > (1 << 20))
             return MIFFT_E_UNSUPPORTED;
         *kind = 0;
+        *split = inter_in ? 0 : 1;
         key[0] = p0->L; key[1] = p1->L; key[2] = (int)p1->M;
         return 0;
     }
     if (p0->kind == MIFFT_PASS_COL && p1->kind == MIFFT_PASS_COL && p0->M == 1 && p1->M == 1 && p1->S == p0->S * p0->L) {
         const long long xform = p1->S * p1->L;                                // nx * ny * nz
-        if (p1->outer_stride_in != xform || p1->outer_stride_out != xform || p0->outer != p1->outer * p1->L ||
+        if (!inter_in || p1->outer_stride_in != xform || p1->outer_stride_out != xform || p0->outer != p1->outer * p1->L ||
             p0->outer_stride_in != p1->S || p0->outer_stride_out != p1->S || p0->S > (1 << 30))
             return MIFFT_E_UNSUPPORTED;
         *kind = 1;
+        *split = inter_out ? 0 : 1;
         key[0] = (int)p0->S; key[1] = p0->L; key[2] = p1->L;
         return 0;
     }
     return MIFFT_E_UNSUPPORTED;
 }
 
-int pair_call(int precision, int kind, const int key[3], const mifft::PairArgs* a, hipStream_t s, int query) {
+int pair_call(int precision, int kind, const int key[3], int split, const mifft::PairArgs* a, hipStream_t s, int query, int* width) {
     if (g_debug[MIFFT_DEBUG_PAIR] == 1) return MIFFT_E_UNSUPPORTED;
-    if (precision == MIFFT_F64) return mifft_pair_f64(kind, key[0], key[1], key[2], a, s, query);
+    if (precision == MIFFT_F64) return mifft_pair_f64(kind, key[0], key[1], key[2], split, a, s, query, width);
+    if (precision == MIFFT_F32) return mifft_pair_f32(kind, key[0], key[1], key[2], split, a, s, query, width);
     return MIFFT_E_UNSUPPORTED;
 }
 
@@ -454,41 +467,52 @@ int mifft_launch_pass(const mifft_pass* p, const void* in0, const void* in1, voi
 }
 
 
-int mifft_pair_split(int32_t precision, int32_t x, int32_t y, int32_t z) {
+int mifft_pair_split(int32_t precision, int32_t layout, int32_t x, int32_t y, int32_t z) {
     if (x < 2 || y < 2 || z < 2 || !is_pow2(x) || !is_pow2(y) || !is_pow2(z)) return 0;
-    // candidates in order of preference (measured: profiles/r03_c4_pair_split.log); MIFFT_DEBUG_PAIR = 2 swaps them
+    const int split = layout == MIFFT_SPLIT ? 1 : 0;
+    // candidates in order of preference (measured: profiles/r03_b_c4_pair_split.log); MIFFT_DEBUG_PAIR = 2 swaps them
     int cand[2] = {32, 64};
     if (g_debug[MIFFT_DEBUG_PAIR] == 2) { cand[0] = 64; cand[1] = 32; }
     for (int r0 : cand) {
         if (y % r0 || y / r0 < 2) continue;
         const int kxy[3] = {x, r0, y / r0}, kyz[3] = {x * r0, y / r0, z};
-        if (pair_call(precision, 0, kxy, nullptr, nullptr, 1) == 0 && pair_call(precision, 1, kyz, nullptr, nullptr, 1) == 0) return r0;
+        if (pair_call(precision, 0, kxy, split, nullptr, nullptr, 1, nullptr) == 0 &&
+            pair_call(precision, 1, kyz, split, nullptr, nullptr, 1, nullptr) == 0)
+            return r0;
     }
     return 0;
 }
 
 int mifft_pass_pair_supported(const mifft_pass* p0, const mifft_pass* p1) {
-    int kind, key[3];
-    int rc = classify_pair(p0, p1, &kind, key);
+    int kind, key[3], split;
+    int rc = classify_pair(p0, p1, &kind, key, &split);
     if (rc) return MIFFT_E_UNSUPPORTED;
-    return pair_call(p0->precision, kind, key, nullptr, nullptr, 1) == 0 ? 0 : MIFFT_E_UNSUPPORTED;
+    return pair_call(p0->precision, kind, key, split, nullptr, nullptr, 1, nullptr) == 0 ? 0 : MIFFT_E_UNSUPPORTED;
 }
 
-int mifft_launch_pass_pair(const mifft_pass* p0, const mifft_pass* p1, const void* in, void* out, mifft_stream_t stream) {
+int mifft_launch_pass_pair(const mifft_pass* p0, const mifft_pass* p1, const void* in0, const void* in1, void* out0, void* out1,
+                           mifft_stream_t stream) {
     int rc = validate(p0);
     if (rc) return rc;
     rc = validate(p1);
     if (rc) return rc;
-    int kind, key[3];
-    if (classify_pair(p0, p1, &kind, key) != 0) return set_err(MIFFT_E_UNSUPPORTED, "pass pair: not a (ROW x, COL y) / (COL y, COL z) pair of a dense interleaved batch");
-    if (!in || !out) return set_err(MIFFT_E_INVALID, "null data buffer");
-    if (((uintptr_t)in | (uintptr_t)out) & 15) return set_err(MIFFT_E_INVALID, "data buffers must be 16-byte aligned");
-    if (kind == 0 && in == out) return set_err(MIFFT_E_INVALID, "the (ROW x, COL y) pair cannot run in place");
+    int kind, key[3], split;
+    if (classify_pair(p0, p1, &kind, key, &split) != 0)
+        return set_err(MIFFT_E_UNSUPPORTED, "pass pair: not a (ROW x, COL y) / (COL y, COL z) pair of a dense batch with an interleaved intermediate");
+    if (!in0 || !out0) return set_err(MIFFT_E_INVALID, "null data buffer");
+    if (split && ((kind == 0 && !in1) || (kind == 1 && !out1))) return set_err(MIFFT_E_INVALID, "split layout needs imaginary planes");
+    if (((uintptr_t)in0 | (uintptr_t)out0 | (uintptr_t)in1 | (uintptr_t)out1) & 15) return set_err(MIFFT_E_INVALID, "data buffers must be 16-byte aligned");
+    if (kind == 0 && in0 == out0) return set_err(MIFFT_E_INVALID, "the (ROW x, COL y) pair cannot run in place");
     if (p1->outer == 0) return 0;
+    int width = 0;
+    if (pair_call(p0->precision, kind, key, split, nullptr, nullptr, 1, &width) != 0)
+        return set_err(MIFFT_E_UNSUPPORTED, "pass pair: no kernel for kind %d keys (%d, %d, %d) split %d", kind, key[0], key[1], key[2], split);
     mifft::PairArgs a;
     memset(&a, 0, sizeof(a));
-    a.in0 = in;
-    a.out0 = out;
+    a.in0 = in0;
+    a.in1 = (kind == 0 && split) ? in1 : nullptr;
+    a.out0 = out0;
+    a.out1 = (kind == 1 && split) ? out1 : nullptr;
     if (kind == 0) {
         a.tw[0] = p0->tw_L;   // w(nx)
         a.tw[1] = p1->tw_L;   // w(R0)
@@ -499,13 +523,18 @@ int mifft_launch_pass_pair(const mifft_pass* p0, const mifft_pass* p1, const voi
     } else {
         a.tw[1] = p0->tw_L;   // w(R1)
         a.tw[2] = p1->tw_L;   // w(nz)
-        a.tiles = p1->outer * (p0->S / 8);           // transforms * groups of 8 adjacent columns
+        a.tiles = p1->outer * (p0->S / width);       // transforms * groups of `width` adjacent columns
     }
     a.inverse = p0->inverse ? 1 : 0;
-    a.nt = ((p0->flags & MIFFT_FLAG_STREAM_SRC) ? 1 : 0) | ((p1->flags & MIFFT_FLAG_STREAM_DST) ? 2 : 0);
+    // streamed sides: non-temporal loads of the plan's input, PLAIN stores on both launches (BASELINE config 4 at batch 64, one
+    // box: plain 13.31 ms, write-through 14.44 ms; non-temporal stores measured below plain ones at batch 16 --
+    // profiles/r03_c_store_policy.log)
+    a.nt = (p0->flags & MIFFT_FLAG_STREAM_SRC) ? 1 : 0;
+    if (g_debug[MIFFT_DEBUG_STORE] == 1) a.nt = (a.nt & 1) | 2;
+    else if (g_debug[MIFFT_DEBUG_STORE] == 2) a.nt = (a.nt & 1) | 4;
+    else if (g_debug[MIFFT_DEBUG_STORE] == 3) a.nt = a.nt & 1;
     a.scale = p0->scale * p1->scale;
-    rc = pair_call(p0->precision, kind, key, &a, (hipStream_t)stream, 0);
-    if (rc == MIFFT_E_UNSUPPORTED) return set_err(rc, "pass pair: no kernel for kind %d keys (%d, %d, %d)", kind, key[0], key[1], key[2]);
+    rc = pair_call(p0->precision, kind, key, split, &a, (hipStream_t)stream, 0, nullptr);
     if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
     if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
     return 0;
@@ -518,7 +547,7 @@ static int launch_unit(const mifft_pass* passes, int32_t i, int32_t npasses, con
     if (p->flags & MIFFT_FLAG_PAIR_WITH_NEXT) {
         if (i + 1 >= npasses) return set_err(MIFFT_E_INVALID, "pass %d: MIFFT_FLAG_PAIR_WITH_NEXT on the last pass", i);
         *consumed = 2;
-        return mifft_launch_pass_pair(p, &passes[i + 1], in0, out0, stream);
+        return mifft_launch_pass_pair(p, &passes[i + 1], in0, in1, out0, out1, stream);
     }
     *consumed = 1;
     return mifft_launch_pass(p, in0, in1, out0, out1, stream);
@@ -643,11 +672,12 @@ int mifft_launch_xcd2(const mifft_pass* p0, const mifft_pass* p1, const void* in
     f.batch = (unsigned)p0->outer;
     // development trace (MIFFT_XCD2_TRACE): 32 time stamps per work-group behind the control words
     f.trace = (flags & MIFFT_XCD2_TRACE) ? (unsigned long long*)((char*)control + MIFFT_XCD2_CONTROL_BYTES) : nullptr;
-    f.trace_iter = (unsigned)((flags >> 8) & 0xffff);
+    f.trace_iter = (unsigned)((flags >> 8) & 0xffff);   // (flags bits 4..6: elimination mode, development)
     f.pace = (flags & 4) ? 1u : 0u;
     rc = hip_check(hipMemsetAsync(control, 0, MIFFT_XCD2_CONTROL_BYTES, (hipStream_t)stream), "hipMemsetAsync");
     if (rc) return rc;
-    rc = mifft_xcd2_f32_launch(&f, split ? 1 : 0, (flags & MIFFT_XCD2_PREFETCH) ? 1 : 0, 2u * (unsigned)cus, (hipStream_t)stream);
+    rc = mifft_xcd2_f32_launch(&f, split ? 1 : 0, (flags & MIFFT_XCD2_PREFETCH) ? 1 : 0, (flags >> 4) & 7, 2u * (unsigned)cus, (hipStream_t)stream);
+    if (rc == MIFFT_E_UNSUPPORTED) return set_err(rc, "xcd2: elimination modes exist for the interleaved prefetching form only");
     if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
     return 0;
 }

@@ -150,8 +150,8 @@ def build_chain(x, y, z, precision, interleaved=False):
             col_chain(Z_DIRECTION, z, x * y, 1, precision)
     # 3-D shapes whose plane fits no tile: two launches of two passes each -- (ROW x, COL y R0) on R0 rows of a plane and
     # (COL y R1, COL z) on 128-byte column segments -- instead of one HBM round trip per axis (csrc/fft_pair.hpp)
-    if ndims == 3 and interleaved:
-        r0 = N.lib.mifft_pair_split(precision, x, y, z)
+    if ndims == 3:
+        r0 = N.lib.mifft_pair_split(precision, N.INTERLEAVED if interleaved else N.SPLIT, x, y, z)
         if r0 > 0:
             return pair_chain(x, y, z, r0)
     if x > 1:

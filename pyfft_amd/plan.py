@@ -264,6 +264,7 @@ class FFTPlan(object):
     SLAB_TARGET_BYTES = 128 << 20      # slabs of the leading passes of a big 3-D transform (C4: 24.7 % at 64 MiB, 25.5 % at 128)
     PIPELINE_STREAMS = 2
     XCD2_MIN_BATCH = 64                # 8 transforms per XCD: below that the pipelined chunks win
+    SMALL_FUSED_LAG_DIV = 0            # small-batch fused form: off (see _select_strategy)
 
     def _fused2d_eligible(self):
         """2-D 1024 x 1024 (BASELINE config 3, and the published double-precision shape): ROW + strided COL, run by the fused
@@ -324,11 +325,17 @@ class FFTPlan(object):
                 slots = (224 << 20) // item_bytes
                 lag, ring = D.fused3_lag_ring(4 * slots // 7, slots)
                 big = True
-            if forced == "fused" and batch < 2 * ring and batch >= 8:   # on request: a shorter pipeline for a small batch
-                lag = batch // 4
-                ring = 2 * lag
             if batch >= 2 * ring and (big or forced == "fused"):
                 return ("fused2", lag, ring, grid)
+            # small batches (the reference's own 32 MiB protocol: (1024, 1024) x 4) through the same persistent launch with one ring
+            # slot per transform and the consumers `lag` transforms behind: MEASURED SLOWER than one launch per pass at every
+            # batch below the normal form's threshold ((1024, 1024) x 4: 64.9 against 28.4 us, x 16: 133 against 85 us; the
+            # launch's counter reset + error-word copy cost ~30 us and a short pipeline never fills: profiles/
+            # r03_small_batch_fused.log) -- development switch only (PYFFT_AMD_SMALL_FUSED = lag divisor), off by default
+            small = D.small_fused(self.SMALL_FUSED_LAG_DIV)
+            if small and 2 <= batch < 2 * ring and (big or forced == "fused") and forced != "pipelined" and \
+                    (batch < 4 * chunk or forced == "fused"):
+                return ("fused2", max(1, batch // small), batch, grid)
         # any multi-pass plan gains from cache-sized chunks (the second pass re-reads what the first just wrote),
         # whether or not it needs a temp buffer
         if len(self._kernels) >= 2 and forced in ("auto", "pipelined") and batch >= 4 * chunk:

@@ -354,9 +354,11 @@ def test_pass_pair_chain_algebra_and_schedule():
             assert temp and sched[0] == sched[1] and sched[2] == sched[3]
             assert sched[0][0] == (1 if inplace else 0) and sched[0][1] != sched[0][0] and sched[3][1] == 1
             assert sched[2][0] == sched[0][1]
-    r0 = N.lib.mifft_pair_split(N.F64, 256, 256, 256)
+    r0 = N.lib.mifft_pair_split(N.F64, N.INTERLEAVED, 256, 256, 256)
     assert r0 in (32, 64)
     chain = P.build_chain(256, 256, 256, N.F64, interleaved=True)
     assert len(chain) == 4 and chain[1].L == r0 and chain[1].M == 256 // r0 and chain[2].S == 256 * r0
-    assert len(P.build_chain(256, 256, 256, N.F64, interleaved=False)) == 3      # split planes: one pass per axis
-    assert N.lib.mifft_pair_split(N.F64, 256, 256, 1) == 0 and N.lib.mifft_pair_split(N.F64, 100, 256, 256) == 0
+    split = P.build_chain(256, 256, 256, N.F64, interleaved=False)               # split planes: the 64 x 4 split, 16-column tiles
+    assert len(split) == 4 and split[1].L == 64 and N.lib.mifft_pair_split(N.F64, N.SPLIT, 256, 256, 256) == 64
+    assert N.lib.mifft_pair_split(N.F32, N.INTERLEAVED, 256, 256, 256) == 64 and N.lib.mifft_pair_split(N.F32, N.SPLIT, 256, 256, 256) == 0
+    assert N.lib.mifft_pair_split(N.F64, N.INTERLEAVED, 256, 256, 1) == 0 and N.lib.mifft_pair_split(N.F64, N.INTERLEAVED, 100, 256, 256) == 0

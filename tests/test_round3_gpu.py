@@ -54,6 +54,45 @@ def test_reference_error_grid(ctx, shape, dtype, batch):
     run_protocol(ctx, shape, dtype, batch, seed=4321, check_oracle=(x * y * z * batch <= (1 << 16)))
 
 
+# ---- pass pairs (csrc/fft_pair.hpp): 256^3 as two launches of two passes each -----------------------------------------
+@pytest.mark.parametrize("dtype", [numpy.complex128, numpy.float64, numpy.complex64], ids=lambda d: numpy.dtype(d).name)
+def test_pass_pairs_256_cubed(ctx, dtype):
+    """BASELINE config 4's shape through the pair kernels (interleaved and split fp64, interleaved fp32): the reference's
+    six-assertion protocol at batch 1 and 3, and the same data through the one-pass-per-axis chain (pairs switched off) within
+    the same thresholds -- two factorisations of one transform (pyfft/kernel.py:259-283 splits a long axis the same way)."""
+    from pyfft_amd import _native as N
+    from pyfft_amd import passes as P
+    shape = (256, 256, 256)
+    plan = ctx.getPlan(shape, dtype=dtype, context=ctx.context)
+    assert [k.pair_with_next for k in plan.pass_list()] == [True, False, True, False]
+    for batch in (1, 3):
+        run_protocol(ctx, shape, dtype, batch, seed=600 + batch, check_oracle=False)
+    # pairs against the three-launch chain on the same buffer
+    dt = numpy.dtype(dtype)
+    split = dt.kind == "f"
+    cdt = numpy.complex128 if dt in (numpy.complex128, numpy.float64) else numpy.complex64
+    eps = 1e-11 if cdt == numpy.complex128 else 1.1e-6
+    rng = numpy.random.default_rng(12)
+    data = (rng.standard_normal((2,) + shape) + 1j * rng.standard_normal((2,) + shape)).astype(cdt)
+    results = []
+    for off in (0, 1):
+        N.check(N.lib.mifft_debug_set(N.DEBUG_PAIR, off), "debug_set")
+        try:
+            pl = ctx.getPlan(shape, dtype=dtype, context=ctx.context)
+            assert len(pl.pass_list()) == (3 if off else 4)
+            if split:
+                re, im = ctx.toGpu(numpy.ascontiguousarray(data.real)), ctx.toGpu(numpy.ascontiguousarray(data.imag))
+                pl.execute(re, im, batch=2)
+                results.append(re.get().astype(numpy.complex128) + 1j * im.get())
+            else:
+                g = ctx.toGpu(data)
+                pl.execute(g, batch=2)
+                results.append(g.get().astype(numpy.complex128))
+        finally:
+            N.check(N.lib.mifft_debug_set(N.DEBUG_PAIR, 0), "debug_set")
+    assert oracle.difference(results[1], results[0], 2) < eps
+
+
 # ---- the sharded path with more than one rank --------------------------------------------------------------------------
 def test_two_ranks_share_one_gpu_sharded_path(tmp_path):
     """`bench.py --gpus 2` for real: two processes (one plan, stream and scratch each) on ONE device, gloo as the control

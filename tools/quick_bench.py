@@ -76,6 +76,11 @@ if __name__ == "__main__":
         cases = [((32, 32, 32), c64, 8192), ((256, 128), c64, 8192), ((128, 256), c64, 8192), ((32, 1024), c64, 8192), ((1024, 32), c64, 8192),
                  ((128, 128), c128, 8192), ((64, 256), c128, 8192), ((32, 32, 16), c128, 8192), ((128, 128, 128), c128, 64),
                  ((32, 32, 32), f32, 8192), ((128, 128), f64, 8192)]
+    elif len(sys.argv) > 1 and sys.argv[1] == "ab":      # store-policy A/B set (MIFFT_STORE): single-pass rows / N-D, fused, pairs
+        cases = [((1024,), c64, 1 << 17), ((4096,), c64, 1 << 15), ((16384,), c64, 1 << 13), ((32768,), c64, 1 << 12),
+                 ((4096,), c128, 1 << 14), ((16,), c64, 1 << 23), ((16, 16, 16), c64, 1 << 15), ((128, 128), c64, 1 << 13),
+                 ((128, 128), c128, 1 << 12), ((1 << 20,), c64, 512), ((1024, 1024), c64, 256), ((256, 256, 256), c128, 16),
+                 ((1 << 22,), c64, 128), ((1 << 16,), c64, 8192)]
     elif len(sys.argv) > 1 and sys.argv[1] == "1d":
         cases = [((1 << k,), c64, max(64, (1 << 31) >> (k + 3))) for k in (13, 14, 15, 16, 17, 18, 19, 20, 21, 22)]
     else:
