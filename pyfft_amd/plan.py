@@ -325,6 +325,9 @@ class FFTPlan(object):
                 slots = (224 << 20) // item_bytes
                 lag, ring = D.fused3_lag_ring(4 * slots // 7, slots)
                 big = True
+            if forced == "fused" and batch < 2 * ring and batch >= 8:   # on request: a shorter pipeline for a small batch
+                lag = batch // 4
+                ring = 2 * lag
             if batch >= 2 * ring and (big or forced == "fused"):
                 return ("fused2", lag, ring, grid)
             # small batches (the reference's own 32 MiB protocol: (1024, 1024) x 4) through the same persistent launch with one ring
