@@ -178,6 +178,49 @@ struct Nd2Chain<T, P, NT, HALF, FIRST, Nd2StageList<D, Rest...>> {
     }
 };
 
+// The same chain with the last stage's results handed to `sink(St{}, v)` instead of the dense store (fft_colx.hpp: strided
+// and transposing stores with an inter-pass twiddle).
+template <typename T, int P, int NT, bool HALF, bool FIRST, typename SL> struct Nd2ChainSink;
+template <typename T, int P, int NT, bool HALF, bool FIRST, typename D, typename... Rest>
+struct Nd2ChainSink<T, P, NT, HALF, FIRST, Nd2StageList<D, Rest...>> {
+    using St = Nd2Stage<T, P, NT, HALF, D>;
+    using LdsT = typename St::LdsT;
+    template <typename Sink>
+    static __device__ __forceinline__ void run(LdsT* lds, cplx<T>* v, const cplx<T>* const* tw, int tid, Sink& sink) {
+        St::compute(v, tw[D::AX], tid);
+        if constexpr (sizeof...(Rest) == 0) {
+            sink(St{}, v);
+        } else {
+            using NextChain = Nd2ChainSink<T, P, NT, HALF, false, Nd2StageList<Rest...>>;
+            using Next = typename NextChain::St;
+            if constexpr (!FIRST) __syncthreads();
+            if constexpr (!HALF) {
+                St::template spill<0>(lds, v, tid);
+                __syncthreads();
+                Next::template fetch<0>(lds, v, tid);
+            } else {
+                St::template spill<1>(lds, v, tid);
+                __syncthreads();
+                Next::template fetch<1>(lds, v, tid);
+                __syncthreads();
+                St::template spill<2>(lds, v, tid);
+                __syncthreads();
+                Next::template fetch<2>(lds, v, tid);
+            }
+            // the next stage gets an opaque copy of the thread index: what it derives from it (LDS / global addresses, twiddle
+            // look-ups) is then computed when that stage runs instead of being hoisted above the first stage's loads, where it
+            // pushed 36-80 registers of freshly loaded operands into scratch
+            int tnext = tid;
+            asm volatile("" : "+v"(tnext));
+            NextChain::run(lds, v, tw, tnext, sink);
+        }
+    }
+};
+template <typename T, int P, int NT, bool HALF, bool FIRST, typename SL, typename LdsT, typename Sink>
+__device__ __forceinline__ void nd2_chain_sink(LdsT* lds, cplx<T>* v, const cplx<T>* const* tw, int tid, Sink& sink) {
+    Nd2ChainSink<T, P, NT, HALF, FIRST, SL>::run(lds, v, tw, tid, sink);
+}
+
 template <typename A, typename B> struct Nd2Concat;
 template <typename... A, typename... B> struct Nd2Concat<Nd2StageList<A...>, Nd2StageList<B...>> {
     using type = Nd2StageList<A..., B...>;

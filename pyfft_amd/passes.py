@@ -99,11 +99,16 @@ class PassSpec(object):
                                             " +" if self.pair_with_next else "")
 
 
-def col_chain(axis, n, radix_init, outer_per_batch, precision):
+def col_chain(axis, n, radix_init, outer_per_batch, precision, interleaved=True):
     """Chain of COL passes for an axis of length n whose faster axes multiply to radix_init
     (GlobalFFTKernel.createChain, kernel.py:259-283; strides kernel.py:196-204).  Only the last
     pass (M == 1) can run in place (cf. kernel.py:238-241)."""
-    radices = split_radices(n, col_max(precision))
+    cmax = col_max(precision)
+    # fp64 L = 2048 exists as a fast kernel for interleaved data with 8 whole columns per tile (csrc/fft_colx.hpp: S == 1 or
+    # S >= 8); anything else would take its 4-column fallback (64-byte segments), where the 1024-point factorisation is faster
+    if precision == N.F64 and cmax > 1024 and (not interleaved or 1 < radix_init < 8):
+        cmax = 1024
+    radices = split_radices(n, cmax)
     chain = []
     S = radix_init
     curr_n = n
@@ -147,7 +152,7 @@ def build_chain(x, y, z, precision, interleaved=False):
     # are just more batch items), then only z as a strided chain -- two HBM round trips instead of three
     if ndims == 3 and nd_ok(x, y, 1):
         return [PassSpec(N.PASS_ND, X_DIRECTION, x * y, x, y, 1, z, x * y, True)] + \
-            col_chain(Z_DIRECTION, z, x * y, 1, precision)
+            col_chain(Z_DIRECTION, z, x * y, 1, precision, interleaved)
     # 3-D shapes whose plane fits no tile: two launches of two passes each -- (ROW x, COL y R0) on R0 rows of a plane and
     # (COL y R1, COL z) on 128-byte column segments -- instead of one HBM round trip per axis (csrc/fft_pair.hpp)
     if ndims == 3:
@@ -158,7 +163,7 @@ def build_chain(x, y, z, precision, interleaved=False):
         if x <= row_max(precision, interleaved):
             chain.append(PassSpec(N.PASS_ROW, X_DIRECTION, x, x, 1, 1, y * z, x, True))
         else:
-            chain.extend(col_chain(X_DIRECTION, x, 1, y * z, precision))
+            chain.extend(col_chain(X_DIRECTION, x, 1, y * z, precision, interleaved))
     if y > 1:
         if x == 1:
             # degenerate: the y axis is the contiguous one
@@ -168,7 +173,7 @@ def build_chain(x, y, z, precision, interleaved=False):
                 p.outer_per_batch *= z
             chain.extend(sub)
         else:
-            chain.extend(col_chain(Y_DIRECTION, y, x, z, precision))
+            chain.extend(col_chain(Y_DIRECTION, y, x, z, precision, interleaved))
     if z > 1:
         if x * y == 1:
             sub = build_chain(z, 1, 1, precision, interleaved)
@@ -176,7 +181,7 @@ def build_chain(x, y, z, precision, interleaved=False):
                 p.axis = Z_DIRECTION
             chain.extend(sub)
         else:
-            chain.extend(col_chain(Z_DIRECTION, z, x * y, 1, precision))
+            chain.extend(col_chain(Z_DIRECTION, z, x * y, 1, precision, interleaved))
     return chain
 
 

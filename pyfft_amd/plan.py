@@ -246,6 +246,11 @@ class FFTPlan(object):
                     d.flags |= N.FLAG_STREAM_SRC
                 if i == last:
                     d.flags |= N.FLAG_STREAM_DST
+            # one-launch N-D plans on buffers beyond the Infinity Cache: non-temporal stores of the result (nobody finds it in a
+            # cache anyway): (16, 16, 16) 70.4 -> 72.6 %, (128, 128) 64.8 -> 68.1 %, fp64 (128, 128) 58.6 -> 59.9 % at 1 GiB
+            # (profiles/r03_c_store_policy.log; the long ROW kernels measured better with plain stores and keep them)
+            if last == 0 and k.kind == N.PASS_ND and batch * p.size * p.complex_nbytes > self.CHAIN_MAX_BYTES and not D.no_stream_hints():
+                d.flags |= N.FLAG_STREAM_DST
         if len(self._desc_cache) > 64:
             self._desc_cache.clear()
         self._desc_cache[key] = arr
@@ -263,6 +268,7 @@ class FFTPlan(object):
     PIPELINE_TARGET_BYTES = 64 << 20
     SLAB_TARGET_BYTES = 128 << 20      # slabs of the leading passes of a big 3-D transform (C4: 24.7 % at 64 MiB, 25.5 % at 128)
     PIPELINE_STREAMS = 2
+    CHAIN_MAX_BYTES = 256 << 20        # per side (batch x transform): below this the plain launch chain wins
     XCD2_MIN_BATCH = 64                # 8 transforms per XCD: below that the pipelined chunks win
     SMALL_FUSED_LAG_DIV = 0            # small-batch fused form: off (see _select_strategy)
 
@@ -306,6 +312,12 @@ class FFTPlan(object):
         nstreams = D.pipeline_streams(self.PIPELINE_STREAMS)
         chunk = max(1, target // item_bytes)
         strat = ("chain",)
+        # up to 256 MiB per side one launch per pass over the whole batch is the fastest form: the side-stream fork / join of the
+        # pipelined chunks and the fill / drain of the persistent kernels only pay beyond it (profiles/r03_d_pipeline_threshold.log:
+        # (1024, 1024) x 32 chain 0.348 / pipelined 0.317, 2^18 x 128 chain 0.374 / fused 0.329, 2^16 x 512 0.387 / 0.343,
+        # 128^3 x 16 0.346 / 0.299; at twice the size the order flips)
+        if forced == "auto" and batch * item_bytes <= self.CHAIN_MAX_BYTES:
+            return strat
         if forced == "xcd" and self._xcd2_eligible() and batch >= self.XCD2_MIN_BATCH:   # not the default yet: DESIGN.md section 4
             return ("xcd2", D.xcd2_flags(N.XCD2_PREFETCH))
         if (self._temp_buffer_needed or self._fused2d_eligible()) and forced in ("auto", "fused") and self._fused2_eligible():

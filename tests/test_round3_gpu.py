@@ -93,6 +93,45 @@ def test_pass_pairs_256_cubed(ctx, dtype):
     assert oracle.difference(results[1], results[0], 2) < eps
 
 
+# ---- fp64 strided passes of 2048 points (csrc/fft_colx.hpp): fp64 2^21 / 2^22 in two passes ---------------------------
+@pytest.mark.parametrize("shape,batch", [((1 << 21,), 3), ((1 << 22,), 2), ((2048, 16), 5), ((2048, 2048), 1), ((2048, 4, 8), 3),
+                                         ((2048, 2), 9)])
+def test_l2048_fp64_strided_pass(ctx, shape, batch):
+    """The stage-chain strided kernel for L = 2048 in fp64 (8-column tiles): the transposing first pass with the inter-pass
+    twiddle (S == 1), the plain last pass (S >= 8), strided axes of 2-D / 3-D shapes, and the 4-column fallback for tiny S --
+    the reference's accuracy protocol against numpy (pyfft/kernel.mako:805-1047 semantics)."""
+    from pyfft_amd import _native as N
+    plan = ctx.getPlan(shape, dtype=numpy.complex128, context=ctx.context)
+    if shape != (2048, 2):
+        assert any(p.kind == N.PASS_COL and p.L == 2048 for p in plan.pass_list()), plan.pass_list()
+    if len(shape) == 1:
+        assert len(plan.pass_list()) == 2
+    run_protocol(ctx, shape, numpy.complex128, batch, seed=900 + len(shape) + batch, check_oracle=False)
+
+
+def test_l2048_fp64_fallback_kernel(ctx):
+    """The 4-column generic tile kernel behind the fast L = 2048 fp64 kernel (variant 1 = always the generic kernel), driven
+    through the C ABI directly on a [2048][M * S] matrix with S = 2: compared with numpy along axis 0."""
+    import ctypes
+    from pyfft_amd import _native as N
+    from pyfft_amd.plan import _twiddle_table
+    L, S, outer = 2048, 2, 3
+    rng = numpy.random.default_rng(4)
+    data = (rng.standard_normal((outer, L, S)) + 1j * rng.standard_normal((outer, L, S))).astype(numpy.complex128)
+    a = ctx.toGpu(data)
+    b = ctx.allocate(data.shape, data.dtype)
+    tw = ctx.toGpu(_twiddle_table(L, L, 1, numpy.dtype(numpy.complex128)))
+    d = N.MifftPass()
+    d.kind, d.precision, d.layout, d.inverse, d.L, d.variant = N.PASS_COL, N.F64, N.INTERLEAVED, 0, L, 1
+    d.M, d.S, d.outer, d.outer_stride_in, d.outer_stride_out, d.scale = 1, S, outer, L * S, L * S, 1.0
+    d.tw_L = tw.ptr
+    N.check(N.lib.mifft_launch_pass(ctypes.byref(d), a.ptr, None, b.ptr, None, None), "launch_pass")
+    N.check(N.lib.mifft_device_sync(), "sync")
+    ref = numpy.fft.fft(data, axis=1)
+    got = b.get()
+    assert numpy.abs(got - ref).sum() / numpy.abs(ref).sum() < 1e-11
+
+
 # ---- the sharded path with more than one rank --------------------------------------------------------------------------
 def test_two_ranks_share_one_gpu_sharded_path(tmp_path):
     """`bench.py --gpus 2` for real: two processes (one plan, stream and scratch each) on ONE device, gloo as the control
