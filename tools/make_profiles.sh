@@ -1,11 +1,11 @@
 #!/bin/bash
 # Regenerates the round's evidence under profiles/ ON THE GPU BOX (run through gpurun from the repo root):
-#     gpurun --timeout 3000 -- 'bash tools/make_profiles.sh r02'
+#     gpurun --timeout 3000 -- 'bash tools/make_profiles.sh r03'
 # Everything is written to gpurun_out/<tag>/ (scratch, merged back by gpurun); the summaries that are judged are gathered in
 # gpurun_out/<tag>/to_profiles/ under their final names -- back in the build container:
-#     cp gpurun_out/r02/to_profiles/* profiles/  rocprofv3 gets the program directly after `--` (no env/bash hop), counters in their own runs.
+#     cp gpurun_out/r03/to_profiles/* profiles/  rocprofv3 gets the program directly after `--` (no env/bash hop), counters in their own runs.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT/to_profiles profiles
 P=$OUT/to_profiles
@@ -24,21 +24,24 @@ for c in c1 c3 c4 c4s c5; do
 done
 for c in c1 c2 c3 c4 c4s c5; do cp $OUT/bench_$c.json $P/${TAG}_bench_$c.json; done
 
-# 3. the reference's published shapes (test/test_performance.py method) and the vendor yardstick (cuda/test.cu counterpart)
+# 3. the reference's published shapes (test/test_performance.py method), the vendor yardstick (cuda/test.cu counterpart) and its
+#    value cross-check
 timeout 900 python3 tools/perf_table.py > $OUT/perf_table.log 2>&1 && cp $OUT/perf_table.log $P/${TAG}_perf_table_reference_shapes.log
 [ -x tools/rocfft_compare ] && timeout 600 ./tools/rocfft_compare > $OUT/rocfft.log 2>&1 && cp $OUT/rocfft.log $P/${TAG}_rocfft_comparator.log
+timeout 600 python3 tools/hipfft_check.py > $OUT/hipfft_check.log 2>&1; cp $OUT/hipfft_check.log $P/${TAG}_hipfft_value_check.log
 
-# 4. memory-system ceilings and the XCD probes behind DESIGN.md section 4
+# 4. memory-system ceilings
 [ -x tools/membench ] && timeout 300 ./tools/membench > $OUT/membench.log 2>&1 && cp $OUT/membench.log $P/${TAG}_fabric_ceiling_membench.log
-[ -x tools/xcd_probe ] && timeout 300 ./tools/xcd_probe > $OUT/xcd_probe.log 2>&1 && cp $OUT/xcd_probe.log $P/${TAG}_xcd_probe.log
-timeout 600 python3 tools/xcd2_probe.py 512 5 > $OUT/xcd2_probe.log 2>&1 && cp $OUT/xcd2_probe.log $P/${TAG}_xcd2_strategy_trace.log
 
-# 5. the long 1-D sizes in both precisions (two-pass kernels; fused persistent forms at 2^20 / 2^21 / 2^22)
+# 5. the long 1-D sizes in both precisions, the small-batch rows of the reference's 32 MiB protocol
 timeout 900 python3 tools/quick_bench.py 1d > $OUT/long_1d.log 2>&1
 timeout 900 python3 tools/quick_bench.py f64 >> $OUT/long_1d.log 2>&1
 cp $OUT/long_1d.log $P/${TAG}_long_1d_sizes.log
+timeout 300 python3 tools/small_batch_probe.py sp > $OUT/small_batch.log 2>&1
+timeout 300 python3 tools/small_batch_probe.py dp >> $OUT/small_batch.log 2>&1
+cp $OUT/small_batch.log $P/${TAG}_small_batch_32MiB.log
 
-# 6. SQ counters of the long fp32 rows (occupancy / LDS pressure; VERDICT round 1 item 8)
+# 6. SQ counters of the long fp32 rows (occupancy / LDS pressure)
 timeout 900 python3 tools/row_counters.py 32768 complex64 8192 16384 complex64 16384 8192 complex64 32768 > $OUT/row_counters.log 2>&1
 cp $OUT/row_counters.log $P/${TAG}_i_row_sq_counters.log
 echo done

@@ -23,14 +23,17 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEPS, WARMUP = 3, 1
-EXECUTES = 1 + WARMUP + STEPS            # parity gate + warm-up + timed
+EXECUTES = 1 + WARMUP + STEPS            # parity gate + warm-up + timed (the counter runs)
+STATS_STEPS = 12                         # the kernel-stats run: enough warm calls that the two cold ones (parity gate, warm-up)
+                                         # move the average by < 2 %; the csv's MinNs column is the warm figure
 
 
 def run(kind, cfg, outdir):
     shutil.rmtree(outdir, ignore_errors=True)
     opts = ["--kernel-trace", "--stats"] if kind == "stats" else ["--pmc", kind, "--kernel-trace"]
+    steps = STATS_STEPS if kind == "stats" else STEPS
     cmd = ["rocprofv3"] + opts + ["--output-format", "csv", "-d", outdir, "--", "python3", os.path.join(ROOT, "bench.py"),
-           "--config", cfg, "--plain", "--steps", str(STEPS), "--warmup", str(WARMUP)]
+           "--config", cfg, "--plain", "--steps", str(steps), "--warmup", str(WARMUP)]
     p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     line = [l for l in p.stdout.splitlines() if l.startswith("{")]
     if p.returncode != 0 or not line:
@@ -50,7 +53,7 @@ def counter_sum(outdir, name):
 
 def main():
     args = sys.argv[1:]
-    tag = "r02"
+    tag = "r03"
     if args and args[0] == "--tag":
         tag, args = args[1], args[2:]
     scratch = os.path.join(ROOT, "gpurun_out", "pmc_traffic")
