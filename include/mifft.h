@@ -297,6 +297,22 @@ int mifft_launch_xcd2(const mifft_pass *p0, const mifft_pass *p1, const void *in
  *                       scale, conjugation of the output.  Strides are in elements.
  *   mifft_aux_mul_rows  a[r][j] *= b[j] for `rows` dense rows of n complex numbers (interleaved).
  */
+/*
+ * Tiled batches in ONE launch (csrc/fft_nd2t.hpp): a MIFFT_PASS_ND pass (L, M, S = the TILE's x, y, z; interleaved) whose
+ * `outer` transforms are the non-overlapping tiles of `outer / (cx*cy*cz)` parent arrays, taken from and written to their places
+ * in the parent -- tile g = item*(cx*cy*cz) + (iz*cy + iy)*cx + ix starts at item*parent_elems + iz*z*pitch_z + iy*y*pitch_y + ix*x.
+ * In place or out of place (same geometry on both sides).  Exists for a list of tile shapes only:
+ *   mifft_nd_tiled_supported  0 if the tile shape has such a kernel, else MIFFT_E_UNSUPPORTED
+ */
+typedef struct mifft_tiling {
+    int64_t pitch_y;       /* elements between consecutive y of the parent array (its x extent) */
+    int64_t pitch_z;       /* elements between consecutive z of the parent array (x extent * y extent) */
+    int64_t parent_elems;  /* elements per parent array */
+    int32_t cx, cy, cz;    /* tiles per parent axis */
+} mifft_tiling;
+int mifft_nd_tiled_supported(int32_t precision, int32_t x, int32_t y, int32_t z);
+int mifft_launch_nd_tiled(const mifft_pass *pass, const mifft_tiling *tiling, const void *in, void *out, mifft_stream_t stream);
+
 typedef struct mifft_copy {
     int32_t precision;          /* MIFFT_F32 | MIFFT_F64 */
     int32_t ndim;               /* 1 .. 6 */

@@ -84,6 +84,18 @@ class MifftCopy(ctypes.Structure):
     ]
 
 
+class MifftTiling(ctypes.Structure):
+    """struct mifft_tiling (include/mifft.h)."""
+    _fields_ = [
+        ("pitch_y", ctypes.c_int64),
+        ("pitch_z", ctypes.c_int64),
+        ("parent_elems", ctypes.c_int64),
+        ("cx", ctypes.c_int32),
+        ("cy", ctypes.c_int32),
+        ("cz", ctypes.c_int32),
+    ]
+
+
 class MifftDeviceProps(ctypes.Structure):
     """struct mifft_device_props (include/mifft.h)."""
     _fields_ = [
@@ -149,6 +161,8 @@ PROTOTYPES = {
                                                       ctypes.c_int64, _vp, _vpp, _i32, _vpp]),
     "mifft_launch_fused2": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "mifft_launch_xcd2": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "mifft_nd_tiled_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
+    "mifft_launch_nd_tiled": (ctypes.c_int, [_pass_p, ctypes.POINTER(MifftTiling), _vp, _vp, _vp]),
     "mifft_aux_copy": (ctypes.c_int, [ctypes.POINTER(MifftCopy), _vp, _vp, _vp, _vp, _vp]),
     "mifft_aux_mul_rows": (ctypes.c_int, [_i32, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp]),
     "mifft_time_chain": (ctypes.c_int, [_pass_p, _i32, _vpp, _vpp, _vp, _i32, ctypes.POINTER(ctypes.c_float)]),

@@ -39,6 +39,18 @@ struct FusedArgs {
     unsigned tiles1;     // 16-column tiles per transform in pass 1 (= L0 / 16)
 };
 
+// XCD-local form (development strategy `fusedx`, round 3): one work list PER XCD (chiplet).  A work-group reads its XCD from
+// HW_REG_XCC_ID and draws tickets from that XCD's counter; XCD x owns the transforms t = x + 8 i, its ring slots are
+// [x * ring, (x + 1) * ring), so a transform's intermediate is written and read by work-groups of ONE XCD and -- written with
+// plain stores -- can stay in that XCD's 4 MiB L2 (tools/l2_resident_probe.hip: ~1 MiB stays next to non-temporal streams, 2 MiB
+// leaks 44 % of its writes).  Same dependency order per list, so the same no-deadlock argument; an XCD that receives no
+// work-group at all would leave its transforms undone, which the launch detects (a census word per XCD, error bit 2).
+__device__ __forceinline__ unsigned fused_xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 7u;
+}
+
 // Deferred publish of a pass-0 tile: its write-through stores drain under the first poll of the NEXT item's dependency, and
 // the counter is bumped BEFORE this work-group starts to wait.  (Publishing only after the wait has ended deadlocks: work-group
 // X owes a tile of transform T and waits for U while Y owes a tile of U and waits for T -- measured as dependency time-outs.)
@@ -104,29 +116,36 @@ struct FusedQueue {
 struct FusedItem {
     unsigned pass;     // 0, 1, or 2 = nothing to do (fill / drain of the pipeline)
     unsigned t;        // transform
+    unsigned slot;     // its ring slot
     unsigned tile;
     unsigned* dep;     // counter this item waits for (nullptr: none)
     unsigned target;
 };
 
+// xs = 8 and x = the XCD for the XCD-local lists (group g of the list = transform x + 8 g, `nb` = transforms of this list);
+// xs = 1, x = 0, nb = batch for the one global list.  it.t is the GLOBAL transform, it.slot its ring slot.
 template <unsigned PER0, unsigned PER1>
-__device__ __forceinline__ FusedItem fused_decode(const FusedArgs& f, unsigned item, unsigned gsize, unsigned* wdone, unsigned* rdone) {
+__device__ __forceinline__ FusedItem fused_decode(const FusedArgs& f, unsigned item, unsigned gsize, unsigned* wdone, unsigned* rdone,
+                                                  unsigned x = 0u, unsigned xs = 1u, unsigned nb = 0xffffffffu) {
     constexpr unsigned period = PER0 + PER1;
     const unsigned g = item / gsize, k = item % gsize, j = k / period, m = k % period;
+    if (xs == 1u) nb = f.batch;
     FusedItem it;
     it.dep = nullptr;
     it.target = 0;
     if (m < PER0) {
-        it.pass = g < f.batch ? 0u : 2u;
-        it.t = g;
+        it.pass = g < nb ? 0u : 2u;
+        it.t = x + xs * g;
+        it.slot = x * f.ring * (xs >> 3) + g % f.ring;
         it.tile = j * PER0 + m;
         if (it.pass == 0u && g >= f.ring) {
-            it.dep = rdone + kFusedCS * (g - f.ring);   // the ring slot it overwrites has been read
+            it.dep = rdone + kFusedCS * (x + xs * (g - f.ring));   // the ring slot it overwrites has been read
             it.target = f.tiles1;
         }
     } else {
         it.pass = g >= f.lag ? 1u : 2u;
-        it.t = g - f.lag;
+        it.t = x + xs * (g - f.lag);
+        it.slot = x * f.ring * (xs >> 3) + (g - f.lag) % f.ring;
         it.tile = j * PER1 + (m - PER0);
         if (it.pass == 1u) {
             it.dep = wdone + kFusedCS * it.t;           // every pass-0 tile of the transform has published
@@ -152,19 +171,27 @@ template <unsigned PER0, unsigned PER1> struct FusedHook {
     FusedQueue& q;
     unsigned total, gsize;
     unsigned *wdone, *rdone;
+    unsigned x, xs, nb;
     __device__ __forceinline__ void operator()() const {
         if (threadIdx.x == 0 && q.t1 < total) {
-            const FusedItem nx = fused_decode<PER0, PER1>(f, q.t1, gsize, wdone, rdone);
+            const FusedItem nx = fused_decode<PER0, PER1>(f, q.t1, gsize, wdone, rdone, x, xs, nb);
             if (nx.dep != nullptr) q.seen1 = __hip_atomic_load(nx.dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 };
 
 // one persistent work-group: TILE0(t, slot, tile, hook) / TILE1(slot, t, tile, hook) run one tile of pass 0 / pass 1
-template <unsigned PER0, unsigned PER1, bool EARLY, typename TILE0, typename TILE1>
+template <unsigned PER0, unsigned PER1, bool EARLY, typename TILE0, typename TILE1, bool XCD = false>
 __device__ __forceinline__ void fused_loop(const FusedArgs& f, unsigned* s_item, TILE0&& tile0, TILE1&& tile1) {
-    unsigned* const next = f.counters;
+    // XCD-local lists: ticket counter of XCD x on its own line behind the dependency counters, census word beside it
+    const unsigned x = XCD ? fused_xcc_id() : 0u;
+    constexpr unsigned xs = XCD ? 8u : 1u;
+    const unsigned nb = XCD ? (f.batch + 7u - x) >> 3 : f.batch;
+    unsigned* const next = XCD ? f.counters + kFusedCS * (1u + 2u * f.batch + x) : f.counters;
     unsigned* const err = f.counters + 1;
+    if constexpr (XCD) {
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(next + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // census
+    }
     // One counter per 256-byte line: the counters of the few transforms in flight are polled and bumped by all 512 work-groups,
     // and packed 32 to a line they shared one memory channel's atomic unit (C2 with no polls at all -- wrong results, same
     // traffic -- ran 15 % faster; hiding the poll LATENCY changed nothing: it is the rate of same-line agent-scope accesses).
@@ -173,12 +200,12 @@ __device__ __forceinline__ void fused_loop(const FusedArgs& f, unsigned* s_item,
     // a group = the tiles0 pass-0 tiles of transform g and the tiles1 pass-1 tiles of transform g - lag, interleaved in their
     // ratio (tiles0 : tiles1 = PER0 : PER1), so that no ticket is an empty item
     const unsigned gsize = f.tiles0 + f.tiles1;
-    const unsigned total = (f.batch + f.lag) * gsize;
+    const unsigned total = (nb + f.lag) * gsize;
 
     FusedPending pend = {nullptr};
     FusedQueue q = {0u, 0u};
     if (threadIdx.x == 0) q.t1 = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const FusedHook<PER0, PER1> hook = {f, q, total, gsize, wdone, rdone};
+    const FusedHook<PER0, PER1> hook = {f, q, total, gsize, wdone, rdone, x, xs, nb};
     for (;;) {
         __syncthreads();  // the previous item's LDS traffic and its s_item read are over
         unsigned seen = 0;
@@ -186,7 +213,7 @@ __device__ __forceinline__ void fused_loop(const FusedArgs& f, unsigned* s_item,
         __syncthreads();
         const unsigned item = *s_item;
         if (item >= total) break;
-        const FusedItem it = fused_decode<PER0, PER1>(f, item, gsize, wdone, rdone);
+        const FusedItem it = fused_decode<PER0, PER1>(f, item, gsize, wdone, rdone, x, xs, nb);
         if (it.pass == 2u) {             // fill / drain of the pipeline: nothing to do, but never sit on a publish
             fused_flush(pend);
             continue;
@@ -194,15 +221,15 @@ __device__ __forceinline__ void fused_loop(const FusedArgs& f, unsigned* s_item,
         if (it.pass == 0u) {
             if (it.dep != nullptr) fused_wait_ge<false>(it.dep, it.target, seen, err, pend);
             else fused_flush(pend);
-            if constexpr (EARLY) tile0(it.t, it.t % f.ring, it.tile, hook);
-            else tile0(it.t, it.t % f.ring, it.tile, TileNoHook());
+            if constexpr (EARLY) tile0(it.t, it.slot, it.tile, hook);
+            else tile0(it.t, it.slot, it.tile, TileNoHook());
             pend.ctr = wdone + kFusedCS * it.t;     // published behind the next item's dependency wait (or at the end)
         } else {
             // (reading the ring with sc1 loads instead of the acquire fence measured the same, and 8-byte sc1 loads at two
             // work-groups per CU are outside the hand-off forms MI355X_MICROARCH.md lists as validated: the fence stays)
             fused_wait_ge<true>(it.dep, it.target, seen, err, pend);
-            if constexpr (EARLY) tile1(it.t % f.ring, it.t, it.tile, hook);
-            else tile1(it.t % f.ring, it.t, it.tile, TileNoHook());
+            if constexpr (EARLY) tile1(it.slot, it.t, it.tile, hook);
+            else tile1(it.slot, it.t, it.tile, TileNoHook());
             fused_signal_read(rdone + kFusedCS * it.t);
         }
     }
@@ -226,6 +253,24 @@ __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
         [&](unsigned slot, unsigned t, unsigned tile, auto hook) {
             col2_tile<T, A1, false, false, false, NT == 2, false, NT == 1, SPLIT>(f.p1, (long long)slot, (long long)t, (long long)tile * 16, lds, hook);
         });
+}
+
+// XCD-local lists (see FusedArgs above).  WT0: write the intermediate with write-through stores (as the global form must) or
+// with plain ones (it then lives in the XCD's L2 and is written back only when evicted).
+template <typename T, int A0, int A1, bool WT0>
+__global__ void __launch_bounds__(256, 2) fft_fused2x_kernel(const FusedArgs f) {
+    constexpr int E0 = Col2Lds<A0, true>::ELEMS, E1 = Col2Lds<A1, false>::ELEMS;
+    __shared__ __attribute__((aligned(16))) cplx<T> lds[E0 > E1 ? E0 : E1];
+    __shared__ unsigned s_item;
+    constexpr unsigned per0 = A0 > A1 ? 1u : (unsigned)(A1 / A0);
+    constexpr unsigned per1 = A1 > A0 ? 1u : (unsigned)(A0 / A1);
+    auto t0 = [&](unsigned t, unsigned slot, unsigned tile, auto hook) {
+        col2_tile<T, A0, true, true, false, WT0, true, false, false>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);
+    };
+    auto t1 = [&](unsigned slot, unsigned t, unsigned tile, auto hook) {
+        col2_tile<T, A1, false, false, false, false, false, true, false>(f.p1, (long long)slot, (long long)t, (long long)tile * 16, lds, hook);
+    };
+    fused_loop<per0, per1, true, decltype(t0)&, decltype(t1)&, true>(f, &s_item, t0, t1);
 }
 
 // The 2-D form (BASELINE config 3: 1024 x 1024): a 2-D transform is two TRANSPOSING column passes without an inter-pass twiddle

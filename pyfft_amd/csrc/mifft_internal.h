@@ -8,6 +8,7 @@
 #include "fft_nd.hpp"
 #include "fft_wave.hpp"
 #include "fft_pair.hpp"
+#include "fft_nd2t.hpp"
 
 // Each returns 0 on success, MIFFT_E_UNSUPPORTED (-2) when no kernel is compiled for (L, tr, variant),
 // or a hipError_t.  With query_only != 0 nothing is launched.
@@ -33,6 +34,7 @@ int mifft_wave_launch(int f64, int N, const mifft::WaveArgs* a, int max_blocks, 
 int mifft_wave_16x16_launch(const mifft::WaveArgs* a, int max_blocks, hipStream_t s);
 int mifft_pair_f64(int kind, int k0, int k1, int k2, int split, const mifft::PairArgs* a, hipStream_t s, int query, int* width);
 int mifft_pair_f32(int kind, int k0, int k1, int k2, int split, const mifft::PairArgs* a, hipStream_t s, int query, int* width);
+int mifft_nd2t(int f64, int x, int y, int z, const mifft::TileArgs* a, const mifft::TiledGeom* g, hipStream_t s, int query);
 int mifft_xcd2_f32_launch(const mifft::Xcd2Args* f, int split, int prefetch, int mode, unsigned grid, hipStream_t s);
 }
 

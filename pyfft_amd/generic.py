@@ -132,6 +132,14 @@ class GenericFFTPlan(object):
         self._ndplan = None
         if all(_is_pow2(v) for v in self._xyz):
             self._ndplan = FFTPlan(self._sub, shape, dtype=self._cdtype, normalize=True, wait_for_finish=False)
+        # ... and, for the tile shapes that have such a kernel, ONE launch straight on the parent array (csrc/fft_nd2t.hpp): no
+        # gather, no scatter, no work array
+        self._tiled = False
+        if self._ndplan is not None and not self._split and parent_shape is not None:
+            k = self._ndplan.pass_list()
+            tx, ty, tz = self._xyz
+            if len(k) == 1 and k[0].kind == N.PASS_ND and N.lib.mifft_nd_tiled_supported(self._precision, tx, ty, tz) == 0:
+                self._tiled = True
         self._tables = []
         self._axes = []
         for n in self._xyz:
@@ -200,6 +208,8 @@ class GenericFFTPlan(object):
         if batch == self._last_batch:
             return
         self._last_batch = batch
+        if self._tiled:
+            return                      # no work arrays
         isz = self._cdtype.itemsize
         nt = batch * self._ntiles
         self._work = self._context.allocate(nt * self._size * isz)
@@ -217,6 +227,8 @@ class GenericFFTPlan(object):
         ptr = ctx.pointer_of
         ctx.createQueue(ins + outs)
         ctx.order_scratch()
+        if self._tiled:
+            return self._execute_tiled(wait_for_finish, bool(inverse), batch, ptr(ins[0]), ptr(outs[0]))
         nt = batch * self._ntiles
         work, rows = ptr(self._work), ptr(self._rows)
         in0, in1 = ptr(ins[0]), (ptr(ins[1]) if self._split else None)
@@ -262,6 +274,31 @@ class GenericFFTPlan(object):
         wait = self._wait_for_finish
         if wait_for_finish is not None:
             wait = wait_for_finish
+        if wait:
+            self.finish()
+        else:
+            ctx.flush()
+            return ctx.getQueue()
+
+    def _execute_tiled(self, wait_for_finish, inverse, batch, src, dst):
+        """Every tile transformed where it lies: one MIFFT_PASS_ND launch over batch * tiles transforms with the parent's pitches."""
+        ctx = self._context
+        tx, ty, tz = self._xyz
+        px, py, pz = self._parent
+        cx, cy, cz = self._counts
+        d = N.MifftPass()
+        d.kind, d.precision, d.layout, d.inverse = N.PASS_ND, self._precision, N.INTERLEAVED, 1 if inverse else 0
+        d.L, d.M, d.S = tx, ty, tz
+        d.outer = batch * self._ntiles
+        d.outer_stride_in = d.outer_stride_out = self._size
+        d.scale = self._scale if not inverse else 1.0 / ((self._size if self._normalize else 1.0) * self._scale)
+        twx, twy, twz, _ = self._ndplan._table_ptrs[0]
+        d.tw_L, d.tw_lo, d.tw_hi = twx, twy, twz
+        t = N.MifftTiling()
+        t.pitch_y, t.pitch_z, t.parent_elems = px, px * py, px * py * pz
+        t.cx, t.cy, t.cz = cx, cy, cz
+        N.check(N.lib.mifft_launch_nd_tiled(ctypes.byref(d), ctypes.byref(t), src, dst, ctx.stream_handle()), "mifft_launch_nd_tiled")
+        wait = self._wait_for_finish if wait_for_finish is None else wait_for_finish
         if wait:
             self.finish()
         else:

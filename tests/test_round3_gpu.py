@@ -132,6 +132,50 @@ def test_l2048_fp64_fallback_kernel(ctx):
     assert numpy.abs(got - ref).sum() / numpy.abs(ref).sum() < 1e-11
 
 
+# ---- tiled batches in one launch (csrc/fft_nd2t.hpp; the reference's TODO.txt:6-7) -------------------------------------
+TILED = [((8, 8), (24, 40)), ((16, 16), (48, 80)), ((32, 32), (96, 64)), ((64, 64), (192, 128)), ((128, 128), (256, 384)),
+         ((16, 32), (32, 96)), ((32, 64), (96, 64)), ((64, 128), (128, 384)), ((8, 8, 8), (16, 24, 8)), ((16, 16, 16), (32, 16, 48)),
+         ((8, 16, 16), (8, 48, 32)), ((8, 32, 32), (24, 32, 64))]
+
+
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
+@pytest.mark.parametrize("shape,parent", TILED + [((32, 32, 32), (64, 32, 96))], ids=str)
+def test_tiled_batch_single_launch(ctx, shape, parent, dtype):
+    """Every tile shape of the tiled N-D kernel: the tiles of 3 parent arrays transformed where they lie (one launch, no work
+    array), tile counts that leave the last work-group ragged -- against numpy tile by tile (reference thresholds), against the
+    gather / dense plan / scatter form of the same plan, out of place with the input untouched, in place, and the inverse."""
+    from test_round2_gpu import _numpy_tiles
+    if shape == (32, 32, 32) and numpy.dtype(dtype) == numpy.complex128:
+        shape, parent = (16, 32, 32), (32, 32, 96)            # fp64: the largest cube-like tile is (z, y, x) = (16, 32, 32)
+    batch = 3
+    cd = numpy.dtype(dtype)
+    eps, mx = (1e-11, 1e-10) if cd == numpy.complex128 else (1.1e-6, 1e-5)
+    full = (batch * parent[0],) + tuple(parent[1:])
+    rng = numpy.random.default_rng(77 + sum(parent))
+    x = (rng.standard_normal(full) + 1j * rng.standard_normal(full)).astype(cd)
+    ref = _numpy_tiles(x, batch, shape, parent)
+    plan = ctx.getPlan(shape, dtype=dtype, parent_shape=parent)
+    assert plan._tiled and plan._work is None
+    a, b = ctx.toGpu(x), ctx.allocate(full, cd)
+    plan.execute(a, b, batch=batch)
+    got = b.get()
+    assert numpy.array_equal(a.get(), x), "out-of-place execute modified its input"
+    assert numpy.abs(got - ref).sum() / numpy.abs(ref).sum() < eps
+    assert numpy.abs(got - ref).max() <= mx * numpy.abs(ref).max()
+    c = ctx.toGpu(x)
+    plan.execute(c, batch=batch)                              # in place
+    assert numpy.array_equal(c.get(), got)
+    plan.execute(c, inverse=True, batch=batch)
+    assert numpy.abs(c.get() - x).sum() / numpy.abs(x).sum() < 2 * eps
+    assert plan._work is None                                 # never needed a work array
+    # the three-round-trip form of the same plan
+    plan._tiled = False
+    plan._last_batch = 0
+    d = ctx.allocate(full, cd)
+    plan.execute(a, d, batch=batch)
+    assert numpy.abs(d.get() - got).sum() / numpy.abs(got).sum() < eps
+
+
 # ---- the sharded path with more than one rank --------------------------------------------------------------------------
 def test_two_ranks_share_one_gpu_sharded_path(tmp_path):
     """`bench.py --gpus 2` for real: two processes (one plan, stream and scratch each) on ONE device, gloo as the control

@@ -31,3 +31,5 @@ if __name__ == "__main__":
     run((100, 100), c64, 8192); run((60, 60, 60), c64, 512)
     run((128, 128), c64, 16, parent=(4096, 4096)); run((128, 128), c64, 16 * 1024)
     run((16, 16, 16), c64, 8, parent=(256, 256, 256))
+    run((16, 16), c64, 16, parent=(4096, 4096)); run((64, 64), c64, 16, parent=(4096, 4096)); run((128, 128), c128, 8, parent=(4096, 4096))
+    run((32, 32, 32), c64, 8, parent=(256, 256, 256)); run((8, 8, 8), c64, 8, parent=(256, 256, 256))
