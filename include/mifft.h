@@ -257,10 +257,19 @@ int mifft_launch_chain_pipelined(const mifft_pass *passes, int32_t npasses, void
  *   ring      always interleaved (ring0; ring1 is ignored), also for split-plane in/out buffers.
  */
 #define MIFFT_FUSED2_COUNTER_STRIDE 64u /* uint32 words between two counters */
-#define MIFFT_FUSED2_COUNTER_BYTES(outer) ((size_t)MIFFT_FUSED2_COUNTER_STRIDE * 4u * (1u + 2u * (size_t)(outer)))
+#define MIFFT_FUSED2_COUNTER_BYTES(outer) ((size_t)MIFFT_FUSED2_COUNTER_STRIDE * 4u * (9u + 2u * (size_t)(outer)))
 int mifft_launch_fused2(const mifft_pass *p0, const mifft_pass *p1, const void *in0, const void *in1, void *out0,
                         void *out1, void *ring0, void *ring1, int32_t ring_slots, int32_t lag, void *counters,
                         int32_t grid, mifft_stream_t stream);
+
+/*
+ * Development (strategy `fusedx`, csrc/fft_fused2.hpp): the same launch with one work list PER XCD -- XCD x owns the transforms
+ * x, x + 8, ... and the ring slots [x * ring_slots, (x + 1) * ring_slots), so the ring holds 8 * ring_slots transforms; with
+ * write_through == 0 the intermediate is written with plain stores and can stay in the XCD's L2.  Interleaved fp32 1-D pairs
+ * only.  After completion counters[1] bit 0 = dependency time-out, bit 2 = an XCD received no work-group (results invalid).
+ */
+int mifft_launch_fused2x(const mifft_pass *p0, const mifft_pass *p1, const void *in0, void *out0, void *ring0, int32_t ring_slots,
+                         int32_t lag, void *counters, int32_t grid, int32_t write_through, mifft_stream_t stream);
 
 /*
  * XCD-cooperative form of the same two-pass axis for N = 1024 * 1024, fp32 (csrc/fft_xcd2.hpp): ONE persistent launch of

@@ -48,6 +48,12 @@ def fused3_lag_ring(lag, ring):
     return lag, ring
 
 
+def fusedx():
+    """PYFFT_AMD_FUSEDX = lag,ring,write_through of the XCD-local fused form (development strategy `fusedx`)"""
+    v = os.environ.get("PYFFT_AMD_FUSEDX", "1,2,0")
+    return tuple(int(t) for t in v.split(","))
+
+
 def small_fused(default):
     """PYFFT_AMD_SMALL_FUSED = lag divisor of the small-batch fused form (0 = off)"""
     v = os.environ.get("PYFFT_AMD_SMALL_FUSED")

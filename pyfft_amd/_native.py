@@ -32,7 +32,7 @@ FUSED2_COUNTER_STRIDE = 64          # MIFFT_FUSED2_COUNTER_STRIDE (uint32 words 
 
 def fused2_counter_bytes(outer):
     """MIFFT_FUSED2_COUNTER_BYTES(outer)"""
-    return FUSED2_COUNTER_STRIDE * 4 * (1 + 2 * int(outer))
+    return FUSED2_COUNTER_STRIDE * 4 * (9 + 2 * int(outer))
 
 
 XCD2_PREFETCH = 1
@@ -160,6 +160,7 @@ PROTOTYPES = {
     "mifft_launch_chain_pipelined": (ctypes.c_int, [_pass_p, _i32, _vpp, _vpp, ctypes.c_int64, ctypes.c_int64,
                                                       ctypes.c_int64, _vp, _vpp, _i32, _vpp]),
     "mifft_launch_fused2": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
+    "mifft_launch_fused2x": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp]),
     "mifft_launch_xcd2": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "mifft_nd_tiled_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
     "mifft_launch_nd_tiled": (ctypes.c_int, [_pass_p, ctypes.POINTER(MifftTiling), _vp, _vp, _vp]),

@@ -636,6 +636,42 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     return 0;
 }
 
+int mifft_launch_fused2x(const mifft_pass* p0, const mifft_pass* p1, const void* in0, void* out0, void* ring0, int32_t ring_slots,
+                         int32_t lag, void* counters, int32_t grid, int32_t write_through, mifft_stream_t stream) {
+    int rc = validate(p0);
+    if (rc) return rc;
+    rc = validate(p1);
+    if (rc) return rc;
+    if (p0->precision != MIFFT_F32 || p1->precision != MIFFT_F32 || p0->layout != MIFFT_INTERLEAVED || p1->layout != MIFFT_INTERLEAVED)
+        return set_err(MIFFT_E_UNSUPPORTED, "fused2x: interleaved fp32 only");
+    if (p0->kind != MIFFT_PASS_COL || p1->kind != MIFFT_PASS_COL || p0->S != 1 || p0->M != p1->L || p1->M != 1 ||
+        p1->S != p0->L || p0->outer != p1->outer || p0->inverse != p1->inverse)
+        return set_err(MIFFT_E_INVALID, "fused2x: passes are not the two passes of one long contiguous axis");
+    if (!in0 || !out0 || !ring0 || !counters) return set_err(MIFFT_E_INVALID, "fused2x: null buffer");
+    if (ring_slots < 2 || lag < 1 || lag >= ring_slots || grid < 8) return set_err(MIFFT_E_INVALID, "fused2x: need 1 <= lag < ring_slots, grid >= 8");
+    if (((uintptr_t)in0 | (uintptr_t)out0 | (uintptr_t)ring0) & 15) return set_err(MIFFT_E_INVALID, "data buffers must be 16-byte aligned");
+    if (p1->outer == 0) return 0;
+    if (p1->outer > 0x3fffffff) return set_err(MIFFT_E_INVALID, "fused2x: batch too large");
+    const int64_t n = (int64_t)p0->L * p1->L;
+    mifft::FusedArgs f;
+    fill_args(p0, in0, nullptr, ring0, nullptr, &f.p0);
+    fill_args(p1, ring0, nullptr, out0, nullptr, &f.p1);
+    f.p0.ostride_out = n;
+    f.p1.ostride_in = n;
+    f.counters = (unsigned*)counters;
+    f.batch = (unsigned)p1->outer;
+    f.lag = (unsigned)lag;
+    f.ring = (unsigned)ring_slots;
+    f.tiles0 = (unsigned)(p0->M / 16);
+    f.tiles1 = (unsigned)(p1->S / 16);
+    rc = hip_check(hipMemsetAsync(counters, 0, MIFFT_FUSED2_COUNTER_BYTES(p1->outer), (hipStream_t)stream), "hipMemsetAsync");
+    if (rc) return rc;
+    rc = mifft_fused2x_f32_launch(p0->L, p1->L, &f, write_through ? 1 : 0, (unsigned)grid, (hipStream_t)stream);
+    if (rc == MIFFT_E_UNSUPPORTED) return set_err(rc, "fused2x: no kernel for %d x %d", p0->L, p1->L);
+    if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
+    return 0;
+}
+
 int mifft_launch_xcd2(const mifft_pass* p0, const mifft_pass* p1, const void* in0, const void* in1, void* out0, void* out1,
                       void* scratch, void* control, int32_t flags, mifft_stream_t stream) {
     int rc = validate(p0);

@@ -318,6 +318,10 @@ class FFTPlan(object):
         # 128^3 x 16 0.346 / 0.299; at twice the size the order flips)
         if forced == "auto" and batch * item_bytes <= self.CHAIN_MAX_BYTES:
             return strat
+        if forced == "fusedx" and self._fused2_eligible() and not self._fused2d_eligible() and not p.split and p.precision == N.F32 \
+                and self._kernels[0].L <= 1024 and batch >= 64:
+            lag, ring, wt = D.fusedx()            # development: one work list per XCD, ring slots per XCD
+            return ("fused2x", lag, ring, 2 * self._context.compute_units, wt)
         if forced == "xcd" and self._xcd2_eligible() and batch >= self.XCD2_MIN_BATCH:   # not the default yet: DESIGN.md section 4
             return ("xcd2", D.xcd2_flags(N.XCD2_PREFETCH))
         if (self._temp_buffer_needed or self._fused2d_eligible()) and forced in ("auto", "fused") and self._fused2_eligible():
@@ -382,9 +386,12 @@ class FFTPlan(object):
                 self._xcd2_scratch = ctx.allocate_raw(N.XCD2_SCRATCH_BYTES)
             self._counters = ctx.allocate_raw(N.XCD2_CONTROL_BYTES + N.XCD2_TRACE_BYTES)
             return
-        if not self._temp_buffer_needed and self._strategy[0] != "fused2":
+        if not self._temp_buffer_needed and self._strategy[0] not in ("fused2", "fused2x"):
             return
-        if self._strategy[0] == "fused2":
+        if self._strategy[0] == "fused2x":
+            items = 8 * self._strategy[2]                 # ring slots per XCD
+            self._counters = ctx.allocate_raw(N.fused2_counter_bytes(batch))
+        elif self._strategy[0] == "fused2":
             items = self._strategy[2]                     # ring slots
             self._counters = ctx.allocate_raw(N.fused2_counter_bytes(batch))
         elif self._strategy[0] == "pipelined":
@@ -407,6 +414,12 @@ class FFTPlan(object):
             N.check(N.lib.mifft_launch_xcd2(ctypes.byref(d0), ctypes.byref(d1), bufs0[d0.src], in1, bufs0[d1.dst], out1,
                                             ctx.pointer_of(self._xcd2_scratch), ctx.pointer_of(self._counters),
                                             strat[1], stream), "mifft_launch_xcd2")
+            self._post_error_word(stream)
+        elif strat[0] == "fused2x":
+            _, lag, ring, grid, wt = strat
+            d0, d1 = descs[0], descs[1]
+            N.check(N.lib.mifft_launch_fused2x(ctypes.byref(d0), ctypes.byref(d1), bufs0[d0.src], bufs0[d1.dst], bufs0[2], ring, lag,
+                                               ctx.pointer_of(self._counters), grid, wt, stream), "mifft_launch_fused2x")
             self._post_error_word(stream)
         elif strat[0] == "fused2":
             _, lag, ring, grid = strat
@@ -470,6 +483,8 @@ class FFTPlan(object):
                 self._last_batch_size = 0
                 raise RuntimeError("pyfft_amd: XCD-cooperative launch found no full XCD residency; results of that execute() "
                                    "are invalid -- the plan has switched strategy, run it again")
+            if strategy == "fused2x" and (word & 4):
+                raise RuntimeError("pyfft_amd: the XCD-local launch left an XCD without work-groups (results invalid)")
             raise RuntimeError("pyfft_amd: %s kernel dependency time-out (results invalid)" % strategy)
 
     def _buffers(self, is_inplace, args):
