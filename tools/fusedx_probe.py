@@ -38,7 +38,9 @@ def run(log2n, env):
     print(" ".join("%s=%s" % kv for kv in env.items()).ljust(60), r.stdout.strip() or r.stderr.strip()[-400:], flush=True)
 
 
-if len(sys.argv) > 1 and sys.argv[1] == "one":
+if __name__ != "__main__":
+    pass
+elif len(sys.argv) > 1 and sys.argv[1] == "one":
     run(int(sys.argv[2]), {"PYFFT_AMD_STRATEGY": "fusedx", "PYFFT_AMD_FUSEDX": "%s,%s,%s" % tuple(sys.argv[3:6])})
 else:
     for log2n in (16, 17, 18, 19, 20):
