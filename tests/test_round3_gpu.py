@@ -291,7 +291,7 @@ def test_plan_following_two_torch_streams_without_host_sync(ctx):
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.skip("torch sees no GPU")
-    n, batch = 1 << 18, 128                                   # fused2 (persistent, ring + counters owned by the plan)
+    n, batch = 1 << 18, 160                                   # fused2 (persistent, ring + counters owned by the plan; > 256 MiB per side)
     plan = ctx.getPlan((n,), dtype=numpy.complex64, wait_for_finish=False)
     assert plan.strategy(batch)[0] == "fused2"
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
