@@ -23,6 +23,9 @@ extern "C" int mifft_pair_f64(int kind, int k0, int k1, int k2, int split, const
     YZ(256 * 32, 8, 256, 8, 1024, true, 4, RL(8), RL(16, 16), false)
     XY(256, 64, 4, 1024, true, 4, RL(16, 16), RL(16, 4), false)
     YZ(256 * 64, 4, 256, 8, 512, true, 4, RL(4), RL(16, 16), false)
+    // 128^3: y = 32 x 4; XY tile 4096 points (64 KiB), YZ tile 8 x 4 x 128 = 4096 points (64 KiB)
+    XY(128, 32, 4, 256, false, 1, RL(8, 16), RL(8, 4), false)
+    YZ(128 * 32, 4, 128, 8, 256, false, 1, RL(4), RL(8, 16), false)
     XY(256, 64, 4, 1024, true, 4, RL(16, 16), RL(16, 4), true)
     YZ(256 * 64, 4, 256, 16, 1024, true, 4, RL(4), RL(16, 16), true)
 #undef XY

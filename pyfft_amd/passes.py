@@ -148,17 +148,18 @@ def build_chain(x, y, z, precision, interleaved=False):
     ndims = (x > 1) + (y > 1) + (z > 1)
     if ndims >= 2 and x * y * z >= 4 and nd_ok(x, y, z):
         return [PassSpec(N.PASS_ND, X_DIRECTION, x * y * z, x, y, z, 1, x * y * z, True)]
+    # 3-D shapes the library has pass-pair kernels for: two launches of two passes each -- (ROW x, COL y R0) on R0 rows of a plane
+    # and (COL y R1, COL z) on 128-byte column segments (csrc/fft_pair.hpp).  256^3: the plane fits no tile, so this replaces one
+    # HBM round trip per axis; 128^3: two launches on 32-64 KiB tiles instead of a 128 KiB plane tile + a generic column pass
+    if ndims == 3:
+        r0 = N.lib.mifft_pair_split(precision, N.INTERLEAVED if interleaved else N.SPLIT, x, y, z)
+        if r0 > 0:
+            return pair_chain(x, y, z, r0)
     # 3-D shapes too big for one tile but with a small (y, x) plane: x and y together in LDS per plane (the planes
     # are just more batch items), then only z as a strided chain -- two HBM round trips instead of three
     if ndims == 3 and nd_ok(x, y, 1):
         return [PassSpec(N.PASS_ND, X_DIRECTION, x * y, x, y, 1, z, x * y, True)] + \
             col_chain(Z_DIRECTION, z, x * y, 1, precision, interleaved)
-    # 3-D shapes whose plane fits no tile: two launches of two passes each -- (ROW x, COL y R0) on R0 rows of a plane and
-    # (COL y R1, COL z) on 128-byte column segments -- instead of one HBM round trip per axis (csrc/fft_pair.hpp)
-    if ndims == 3:
-        r0 = N.lib.mifft_pair_split(precision, N.INTERLEAVED if interleaved else N.SPLIT, x, y, z)
-        if r0 > 0:
-            return pair_chain(x, y, z, r0)
     if x > 1:
         if x <= row_max(precision, interleaved):
             chain.append(PassSpec(N.PASS_ROW, X_DIRECTION, x, x, 1, 1, y * z, x, True))
