@@ -8,10 +8,15 @@ extern "C" int mifft_col2_f32_launch(int L, int tr, const mifft::TileArgs* a, hi
 extern "C" int mifft_col3_f32_eligible(int L, int tr, const mifft::TileArgs* a);
 extern "C" int mifft_col3_f32_launch(int tr, const mifft::TileArgs* a, hipStream_t s);
 
+// register-only kernels for L <= 32 in the plain form (fft_colr.hip)
+extern "C" int mifft_colr_eligible(int f64, int L, int tr, const mifft::TileArgs* a);
+extern "C" int mifft_colr_launch(int f64, int L, const mifft::TileArgs* a, hipStream_t s);
+
 // variant 0: library default (two-phase kernel for L = 256/512/1024 when the tile is 16 whole columns of one
 //            matrix, i.e. M*S >= 16; generic tile kernel otherwise);  variant 1: always the generic tile kernel.
 extern "C" int mifft_dispatch_col_f32(int L, int tr, int variant, const mifft::TileArgs* a, hipStream_t s, int query_only) {
     if (variant != 0 && variant != 1) return -2;
+    if (variant == 0 && !query_only && mifft_colr_eligible(0, L, tr, a)) return mifft_colr_launch(0, L, a, s);
     if (variant == 0 && !query_only && mifft_col2_f32_eligible(L, tr, a)) return mifft_col2_f32_launch(L, tr, a, s);
     if (variant == 0 && !query_only && mifft_col3_f32_eligible(L, tr, a)) return mifft_col3_f32_launch(tr, a, s);
     switch (L) {

@@ -10,9 +10,14 @@ extern "C" int mifft_col3_f64_launch(int tr, const mifft::TileArgs* a, hipStream
 extern "C" int mifft_colx_f64_eligible(int L, int tr, const mifft::TileArgs* a);
 extern "C" int mifft_colx_f64_launch(int tr, const mifft::TileArgs* a, hipStream_t s);
 
+// register-only kernels for L <= 32 in the plain form (fft_colr.hip)
+extern "C" int mifft_colr_eligible(int f64, int L, int tr, const mifft::TileArgs* a);
+extern "C" int mifft_colr_launch(int f64, int L, const mifft::TileArgs* a, hipStream_t s);
+
 // variant 0: library default (two-phase kernel for L = 256 when eligible); variant 1: always the generic tile kernel
 extern "C" int mifft_dispatch_col_f64(int L, int tr, int variant, const mifft::TileArgs* a, hipStream_t s, int query_only) {
     if (variant != 0 && variant != 1) return -2;
+    if (variant == 0 && !query_only && mifft_colr_eligible(1, L, tr, a)) return mifft_colr_launch(1, L, a, s);
     if (variant == 0 && !query_only && mifft_col2_f64_eligible(L, tr, a)) return mifft_col2_f64_launch(L, tr, a, s);
     if (variant == 0 && !query_only && mifft_col3_f64_eligible(L, tr, a)) return mifft_col3_f64_launch(tr, a, s);
     if (variant == 0 && !query_only && mifft_colx_f64_eligible(L, tr, a)) return mifft_colx_f64_launch(tr, a, s);

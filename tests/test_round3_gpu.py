@@ -176,6 +176,56 @@ def test_tiled_batch_single_launch(ctx, shape, parent, dtype):
     assert numpy.abs(d.get() - got).sum() / numpy.abs(got).sum() < eps
 
 
+# ---- short strided passes in registers (csrc/fft_colr.hpp) -------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
+@pytest.mark.parametrize("L,M,S,outer", [(4, 1, 64, 3), (8, 1, 2, 5), (16, 1, 256, 2), (32, 1, 4096, 1), (16, 4, 8, 3), (8, 16, 2, 2),
+                                         (32, 2, 64, 2), (4, 8, 1024, 1)], ids=str)
+def test_register_only_short_strided_pass(ctx, L, M, S, outer, dtype):
+    """One COL pass with L <= 32 through the C ABI: the register-only kernel (library default) against the generic LDS-staged tile
+    kernel (variant 1) and against the pass algebra evaluated with numpy -- out[l][q][j] = w(L*M)^(l*q) * sum_r in[r][l][j] *
+    w(L)^(r*q) (pyfft/kernel.mako:805-1047) -- forward and inverse, with and without the inter-pass twiddle."""
+    import ctypes
+    from pyfft_amd import _native as N
+    from pyfft_amd.plan import _twiddle_table
+    from pyfft_amd import passes as P
+    cd = numpy.dtype(dtype)
+    prec = N.F64 if cd == numpy.complex128 else N.F32
+    eps = 1e-12 if prec == N.F64 else 2e-6
+    rng = numpy.random.default_rng(L * 131 + M * 17 + S)
+    data = (rng.standard_normal((outer, L, M, S)) + 1j * rng.standard_normal((outer, L, M, S))).astype(cd)
+    a = ctx.toGpu(data)
+    tw = ctx.toGpu(_twiddle_table(L, L, 1, cd))
+    n = L * M
+    shift = (P.log2(n) + 1) // 2
+    lo = ctx.toGpu(_twiddle_table(n, 1 << shift, 1, cd))
+    hi = ctx.toGpu(_twiddle_table(n, n >> shift, 1 << shift, cd))
+    for inverse in (0, 1):
+        x = data.astype(numpy.complex128)
+        if inverse:
+            x = numpy.conj(x)
+        y = numpy.fft.fft(x, axis=1)                                       # [outer][q][l][j]
+        ll, qq = numpy.arange(M)[None, :, None], numpy.arange(L)[:, None, None]
+        y = y * numpy.exp(-2j * numpy.pi * (ll * qq) / n)[None]
+        ref = numpy.transpose(y, (0, 2, 1, 3)) * 0.5                        # out[o][l][q][j], scale 0.5
+        if inverse:
+            ref = numpy.conj(ref)
+        outs = []
+        for variant in (0, 1):
+            b = ctx.allocate(data.shape, cd)
+            d = N.MifftPass()
+            d.kind, d.precision, d.layout, d.inverse, d.L, d.variant = N.PASS_COL, prec, N.INTERLEAVED, inverse, L, variant
+            d.M, d.S, d.outer, d.outer_stride_in, d.outer_stride_out, d.scale = M, S, outer, L * M * S, L * M * S, 0.5
+            d.tw_L = tw.ptr
+            if M > 1:
+                d.tw_lo, d.tw_hi, d.tw_shift = lo.ptr, hi.ptr, shift
+            N.check(N.lib.mifft_launch_pass(ctypes.byref(d), a.ptr, None, b.ptr, None, None), "launch_pass")
+            N.check(N.lib.mifft_device_sync(), "sync")
+            outs.append(b.get().reshape(outer, M, L, S).astype(numpy.complex128))
+        for got in outs:
+            assert numpy.abs(got - ref).sum() / numpy.abs(ref).sum() < eps
+        assert numpy.abs(outs[0] - outs[1]).sum() / numpy.abs(ref).sum() < eps
+
+
 # ---- the sharded path with more than one rank --------------------------------------------------------------------------
 def test_two_ranks_share_one_gpu_sharded_path(tmp_path):
     """`bench.py --gpus 2` for real: two processes (one plan, stream and scratch each) on ONE device, gloo as the control
