@@ -1,6 +1,7 @@
 // fp64 instances of the pass-pair kernels (fft_pair.hpp): 256 x 256 planes with 256 z (BASELINE config 4, both layouts).
 // Interleaved: the y axis split 32 x 8 (XY tile 128 KiB at two work-groups per CU, YZ tile 256 KiB at one) or 64 x 4 (the other
-// way round; measured 28.7 against 30.7 %, profiles/r03_b_c4_pair_split.log).  Split planes: 64 x 4 with 16-column YZ tiles
+// way round; measured 28.7 against 30.7 %, profiles/r03_b_c4_pair_split.log; the 256 KiB YZ tile on 512 threads x 32 points
+// instead of 1024 x 16, and non-temporal loads of the intermediate, both measured within 1 % of this form on bench.py --config c4).  Split planes: 64 x 4 with 16-column YZ tiles
 // (16 x 8 bytes = one 128-byte segment per plane); the intermediate between the two launches is interleaved either way.
 #include "mifft_internal.h"
 #include "fft_pair.hpp"
