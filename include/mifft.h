@@ -339,6 +339,16 @@ typedef struct mifft_copy {
 int mifft_aux_copy(const mifft_copy *copy, const void *src0, const void *src1, void *dst0, void *dst1, mifft_stream_t stream);
 int mifft_aux_mul_rows(int32_t precision, void *a, const void *b, int64_t rows, int64_t n, mifft_stream_t stream);
 
+/*
+ * Mixed-radix rows (csrc/fft_mixed.hip; the reference's TODO.txt:8): `rows` contiguous transforms of SMOOTH length
+ * n = 2^a 3^b 5^c 7^d, 2 <= n <= 4096 (fp32) / 2048 (fp64), interleaved, row r at element r * stride on either side, in place or
+ * out of place; tw = device table of n entries w(n)^m.  out = scale * DFT(in) (inverse: conjugated in and out).
+ *   mifft_mixed_supported  0 if rows of n points have such a kernel, else MIFFT_E_UNSUPPORTED
+ */
+int mifft_mixed_supported(int32_t precision, int32_t n);
+int mifft_launch_mixed_rows(int32_t precision, int32_t n, int64_t rows, int64_t stride_in, int64_t stride_out, const void *in,
+                            void *out, const void *tw, int32_t inverse, double scale, mifft_stream_t stream);
+
 /* Same as mifft_launch_chain but brackets the chain with two events on `stream` and, after
  * synchronising, reports the elapsed device time of `repeats` back-to-back chains. (bench/test helper) */
 int mifft_time_chain(const mifft_pass *passes, int32_t npasses, void *const bufs0[3], void *const bufs1[3],

@@ -831,6 +831,23 @@ int mifft_aux_mul_rows(int32_t precision, void* a, const void* b, int64_t rows, 
     return 0;
 }
 
+int mifft_mixed_supported(int32_t precision, int32_t n) {
+    if (precision != MIFFT_F32 && precision != MIFFT_F64) return MIFFT_E_UNSUPPORTED;
+    return mifft_mixed_supported_impl(precision == MIFFT_F64, n) == 0 ? 0 : MIFFT_E_UNSUPPORTED;
+}
+
+int mifft_launch_mixed_rows(int32_t precision, int32_t n, int64_t rows, int64_t stride_in, int64_t stride_out, const void* in, void* out,
+                            const void* tw, int32_t inverse, double scale, mifft_stream_t stream) {
+    if (mifft_mixed_supported(precision, n) != 0) return set_err(MIFFT_E_UNSUPPORTED, "mixed rows: no kernel for n = %d", n);
+    if (!in || !out || !tw) return set_err(MIFFT_E_INVALID, "mixed rows: null buffer");
+    if (rows < 0 || stride_in < n || stride_out < n) return set_err(MIFFT_E_INVALID, "mixed rows: bad row count / stride");
+    if (rows == 0) return 0;
+    const int rc = mifft_mixed_launch(precision == MIFFT_F64, n, rows, stride_in, stride_out, in, out, tw, inverse ? 1 : 0, scale, (hipStream_t)stream);
+    if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
+    if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
+    return 0;
+}
+
 int mifft_time_chain(const mifft_pass* passes, int32_t npasses, void* const bufs0[3], void* const bufs1[3], mifft_stream_t stream,
                      int32_t repeats, float* ms_total) {
     if (!ms_total || repeats < 1) return set_err(MIFFT_E_INVALID, "bad timing arguments");

@@ -12,6 +12,8 @@ streaming helper kernels of the C ABI (`mifft_aux_copy`, `mifft_aux_mul_rows`):
     gather   user buffers (interleaved or split planes, dense or tiles of a parent array) -> dense interleaved work array
     per axis  * power of two: the lines of the axis gathered into dense rows, one batched ROW plan, scattered back
                 (the contiguous axis runs in place on the work array)
+              * a SMOOTH length n = 2^a 3^b 5^c 7^d up to 4096 (fp32) / 2048 (fp64): the lines gathered into dense rows, ONE
+                mixed-radix launch (csrc/fft_mixed.hip: radix-3 / 5 / 7 butterflies next to the power-of-two ones), scattered back
               * any other length n: Bluestein -- rows a[j] = x[j] * c[j] zero-padded to m = 2^k >= 2n - 1 with the chirp
                 c[j] = exp(-i pi j^2 / n), A = FFT_m(a), A *= FFT_m(b) (b = conj chirp, wrapped; computed once on the
                 host in float64), y = IFFT_m(A), X[k] = y[k] * c[k]
@@ -43,7 +45,7 @@ def _chirp(n, complex_dtype):
 
 
 class _Axis(object):
-    __slots__ = ("n", "m", "plan", "chirp", "bhat", "pow2")
+    __slots__ = ("n", "m", "plan", "chirp", "bhat", "pow2", "mixed_tw")
 
 
 class _SubContext(object):
@@ -146,6 +148,15 @@ class GenericFFTPlan(object):
             ax = _Axis()
             ax.n = n
             ax.pow2 = _is_pow2(n)
+            ax.mixed_tw = None
+            if not ax.pow2 and N.lib.mifft_mixed_supported(self._precision, n) == 0:
+                # smooth length (2^a 3^b 5^c 7^d): ONE mixed-radix launch on the dense rows instead of Bluestein's three transforms
+                k = numpy.arange(n, dtype=numpy.float64)
+                ang = -2.0 * numpy.pi * k / float(n)
+                ax.mixed_tw = self._upload((numpy.cos(ang) + 1j * numpy.sin(ang)).astype(self._cdtype))
+                ax.m, ax.plan, ax.chirp, ax.bhat = n, None, None, None
+                self._axes.append(ax)
+                continue
             ax.m = n if ax.pow2 else 1 << int(numpy.ceil(numpy.log2(2 * n - 1)))
             ax.plan = self._rowplan(ax.m) if ax.m > 1 else None
             ax.chirp = ax.bhat = None
@@ -157,6 +168,10 @@ class GenericFFTPlan(object):
                 ax.chirp = self._upload(c.astype(self._cdtype))
                 ax.bhat = self._upload(numpy.fft.fft(b).astype(self._cdtype))
             self._axes.append(ax)
+        # 1-D smooth length, interleaved, dense: the mixed-radix launch reads the user's input and writes the user's output itself
+        # (conjugation of the inverse direction and the scale included): one HBM round trip, no work array
+        self._direct_mixed = (self._xyz[1] == 1 and self._xyz[2] == 1 and self._axes[0].mixed_tw is not None
+                              and not self._split and self._ntiles == 1)
         self._work = None
         self._rows = None
         self._last_batch = 0
@@ -208,7 +223,7 @@ class GenericFFTPlan(object):
         if batch == self._last_batch:
             return
         self._last_batch = batch
-        if self._tiled:
+        if self._tiled or self._direct_mixed:
             return                      # no work arrays
         isz = self._cdtype.itemsize
         nt = batch * self._ntiles
@@ -229,6 +244,18 @@ class GenericFFTPlan(object):
         ctx.order_scratch()
         if self._tiled:
             return self._execute_tiled(wait_for_finish, bool(inverse), batch, ptr(ins[0]), ptr(outs[0]))
+        if self._direct_mixed:
+            n = self._xyz[0]
+            inv = bool(inverse)
+            factor = self._scale if not inv else 1.0 / ((n if self._normalize else 1.0) * self._scale)
+            N.check(N.lib.mifft_launch_mixed_rows(self._precision, n, batch, n, n, ptr(ins[0]), ptr(outs[0]), self._axes[0].mixed_tw,
+                                                  1 if inv else 0, factor, ctx.stream_handle()), "mifft_launch_mixed_rows")
+            wait = self._wait_for_finish if wait_for_finish is None else wait_for_finish
+            if wait:
+                self.finish()
+                return None
+            ctx.flush()
+            return ctx.getQueue()
         nt = batch * self._ntiles
         work, rows = ptr(self._work), ptr(self._rows)
         in0, in1 = ptr(ins[0]), (ptr(ins[1]) if self._split else None)
@@ -249,7 +276,17 @@ class GenericFFTPlan(object):
                 lines = (n, inner, outer)              # index space of the axis' lines in the work array
                 wstride = (inner, 1, n * inner)
                 rstride = (1, m, m * inner)            # dense rows [outer][inner][m]
-                if ax.pow2 and inner == 1:
+                if ax.mixed_tw is not None:
+                    # (the conjugation of the inverse direction and the scale live in the gather / scatter: always forward, scale 1)
+                    if inner == 1:
+                        N.check(N.lib.mifft_launch_mixed_rows(self._precision, n, outer, n, n, work, work, ax.mixed_tw, 0, 1.0,
+                                                              ctx.stream_handle()), "mifft_launch_mixed_rows")
+                    else:
+                        self._copy(lines, wstride, rstride, work, None, rows, None)
+                        N.check(N.lib.mifft_launch_mixed_rows(self._precision, n, outer * inner, n, n, rows, rows, ax.mixed_tw, 0, 1.0,
+                                                              ctx.stream_handle()), "mifft_launch_mixed_rows")
+                        self._copy(lines, rstride, wstride, rows, None, work, None)
+                elif ax.pow2 and inner == 1:
                     ax.plan.execute(work, batch=outer, wait_for_finish=False)
                 elif ax.pow2:
                     self._copy(lines, wstride, rstride, work, None, rows, None)

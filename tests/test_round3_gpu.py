@@ -226,6 +226,49 @@ def test_register_only_short_strided_pass(ctx, L, M, S, outer, dtype):
         assert numpy.abs(outs[0] - outs[1]).sum() / numpy.abs(ref).sum() < eps
 
 
+# ---- mixed-radix rows for smooth lengths (csrc/fft_mixed.hip; the reference's TODO.txt:8) -------------------------------
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
+@pytest.mark.parametrize("n", [2, 3, 5, 6, 7, 9, 10, 12, 15, 21, 25, 27, 35, 49, 60, 64, 100, 105, 125, 210, 243, 343, 360, 625, 1000,
+                               1029, 1200, 2000, 2048, 2187, 2401, 3125, 3600, 4000, 4096])
+def test_mixed_radix_rows(ctx, n, dtype):
+    """Rows of smooth length through the C ABI: forward out of place with padded rows, inverse in place, against numpy with the
+    reference's thresholds; lengths the kernel does not take are refused."""
+    import ctypes
+    from pyfft_amd import _native as N
+    cd = numpy.dtype(dtype)
+    prec = N.F64 if cd == numpy.complex128 else N.F32
+    if N.lib.mifft_mixed_supported(prec, n) != 0:
+        assert prec == N.F64 and n > 2048
+        return
+    eps, mx = (1e-11, 1e-10) if prec == N.F64 else (1.1e-6, 1e-5)
+    rows, pad = 37, 4
+    rng = numpy.random.default_rng(n)
+    x = (rng.standard_normal((rows, n + pad)) + 1j * rng.standard_normal((rows, n + pad))).astype(cd)
+    k = numpy.arange(n, dtype=numpy.float64)
+    tw = ctx.toGpu(numpy.exp(-2j * numpy.pi * k / n).astype(cd))
+    a = ctx.toGpu(x)
+    b = ctx.allocate((rows, n), cd)
+    N.check(N.lib.mifft_launch_mixed_rows(prec, n, rows, n + pad, n, a.ptr, b.ptr, tw.ptr, 0, 2.0, None), "mixed")
+    N.check(N.lib.mifft_device_sync(), "sync")
+    ref = 2.0 * numpy.fft.fft(x[:, :n].astype(numpy.complex128), axis=1)
+    got = b.get()
+    assert numpy.abs(got - ref).sum() / numpy.abs(ref).sum() < eps
+    assert numpy.abs(got - ref).max() <= mx * numpy.abs(ref).max()
+    assert numpy.array_equal(a.get(), x)
+    N.check(N.lib.mifft_launch_mixed_rows(prec, n, rows, n, n, b.ptr, b.ptr, tw.ptr, 1, 0.5 / n, None), "mixed")
+    N.check(N.lib.mifft_device_sync(), "sync")
+    back = b.get()
+    assert numpy.abs(back - x[:, :n]).sum() / numpy.abs(x[:, :n]).sum() < 2 * eps
+
+
+def test_mixed_radix_is_what_smooth_any_size_plans_run(ctx):
+    """Plan(shape, any_size=True): smooth axes take the mixed-radix rows, other lengths Bluestein, powers of two the batched plans."""
+    plan = ctx.getPlan((1000, 17, 64), dtype=numpy.complex64, any_size=True)
+    kinds = [("mixed" if ax.mixed_tw is not None else "pow2" if ax.pow2 else "bluestein") for ax in plan._axes]   # x, y, z
+    assert kinds == ["pow2", "bluestein", "mixed"]
+    assert ctx.hip.N.lib.mifft_mixed_supported(0, 1023) != 0 and ctx.hip.N.lib.mifft_mixed_supported(0, 8192) != 0
+
+
 # ---- the sharded path with more than one rank --------------------------------------------------------------------------
 def test_two_ranks_share_one_gpu_sharded_path(tmp_path):
     """`bench.py --gpus 2` for real: two processes (one plan, stream and scratch each) on ONE device, gloo as the control
