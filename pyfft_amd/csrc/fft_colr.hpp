@@ -1,4 +1,4 @@
-// Short strided-axis (COL) passes entirely in registers: L = 4 ... 32 (fp32) / 4 ... 16 (fp64).  A thread owns V adjacent columns
+// Short strided-axis (COL) passes entirely in registers: L = 4 ... 32.  A thread owns V adjacent columns
 // (16 bytes) of the [L][M*S] matrix: L coalesced loads one row pitch apart (a wave covers 1 KiB of every row), ONE radix-L
 // butterfly, the inter-pass twiddle if M > 1, L coalesced stores.  No LDS, no barrier -- the generic tile kernel stages the same
 // single-radix pass through LDS twice (global -> LDS -> registers -> LDS -> global).  These are the z (or y) passes of 3-D shapes
