@@ -348,6 +348,12 @@ int mifft_aux_mul_rows(int32_t precision, void *a, const void *b, int64_t rows, 
 int mifft_mixed_supported(int32_t precision, int32_t n);
 int mifft_launch_mixed_rows(int32_t precision, int32_t n, int64_t rows, int64_t stride_in, int64_t stride_out, const void *in,
                             void *out, const void *tw, int32_t inverse, double scale, mifft_stream_t stream);
+/* The same transform along ANY axis of a dense array viewed as [outer][n][inner] (inner = product of the faster axes; inner == 1
+ * is the row form): line (o, j) starts at o*n*inner + j, its points are `inner` apart; a work-group takes adjacent lines, so the
+ * accesses coalesce across lines.  conj_in / conj_out conjugate on load / store separately (an N-D inverse conjugates once at
+ * either end of its chain of launches).  In place or out of place. */
+int mifft_launch_mixed_lines(int32_t precision, int32_t n, int64_t outer, int64_t inner, const void *in, void *out, const void *tw,
+                             int32_t conj_in, int32_t conj_out, double scale, mifft_stream_t stream);
 
 /* Same as mifft_launch_chain but brackets the chain with two events on `stream` and, after
  * synchronising, reports the elapsed device time of `repeats` back-to-back chains. (bench/test helper) */

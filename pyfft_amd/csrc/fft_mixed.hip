@@ -25,7 +25,10 @@ struct MixedArgs {
     void* out;
     const void* tw;        // n entries w(n)^m
     long long rows, stride_in, stride_out;
+    long long inner;       // 1: contiguous rows `stride` apart.  > 1: LINES of a strided axis -- line L = o * inner + j starts at element
+                           // o * n * inner + j and its points are `inner` elements apart (stride_in / stride_out unused)
     int n, W, nstages, inverse;
+    int conj_in, conj_out; // conjugate on load / on store (inverse = both; an N-D plan conjugates once at either end)
     int radix[kMaxStages];
     float inv_n;           // 1 / n, 1 / (n / R) and 1 / Ns per stage: index divisions as one float multiply (indices < 2^22, exact
     float inv_per_row[kMaxStages], inv_ns[kMaxStages];   // with the + 0.5 below)
@@ -108,13 +111,32 @@ template <typename T, int NT> __global__ void __launch_bounds__(NT) fft_mixed_ke
     const int half = W * n;
     const long long row0 = (long long)blockIdx.x * W;
     const int nrows = (int)((a.rows - row0) < W ? (a.rows - row0) : W);
-    const T csign = a.inverse ? (T)-1 : (T)1;
-    // rows -> LDS (consecutive threads, consecutive points)
-    for (int e = tid; e < nrows * n; e += NT) {
-        const int r = fast_div(e, a.inv_n), i = e - r * n;
-        cplx<T> p = reinterpret_cast<const cplx<T>*>(a.in)[(row0 + r) * a.stride_in + i];
-        p.y *= csign;
-        lds[e] = p;
+    const T csign = a.conj_in ? (T)-1 : (T)1;
+    const long long inner = a.inner;
+    long long line_base = 0;      // strided axis: the tile's first line (its W lines are adjacent in memory: coalesced across lines)
+    float inv_rows = 1.0f;
+    if (inner > 1) {
+        // (the launcher makes W divide `inner`, so a tile never straddles two values of o)
+        const long long o = row0 / inner, j0 = row0 - o * inner;
+        line_base = o * (long long)n * inner + j0;
+        inv_rows = 1.0f / (float)nrows;
+    }
+    if (inner == 1) {
+        // rows -> LDS (consecutive threads, consecutive points)
+        for (int e = tid; e < nrows * n; e += NT) {
+            const int r = fast_div(e, a.inv_n), i = e - r * n;
+            cplx<T> p = reinterpret_cast<const cplx<T>*>(a.in)[(row0 + r) * a.stride_in + i];
+            p.y *= csign;
+            lds[e] = p;
+        }
+    } else {
+        // lines -> LDS (consecutive threads, consecutive LINES of the same point index)
+        for (int e = tid; e < nrows * n; e += NT) {
+            const int i = fast_div(e, inv_rows), c = e - i * nrows;
+            cplx<T> p = reinterpret_cast<const cplx<T>*>(a.in)[line_base + (long long)i * inner + c];
+            p.y *= csign;
+            lds[c * n + i] = p;
+        }
     }
     __syncthreads();
     int Ns = 1, cur = 0;
@@ -142,14 +164,24 @@ template <typename T, int NT> __global__ void __launch_bounds__(NT) fft_mixed_ke
         Ns *= R;
         cur ^= 1;
     }
-    const T sx = (T)a.scale, sy = a.inverse ? -sx : sx;
+    const T sx = (T)a.scale, sy = a.conj_out ? -sx : sx;
     const cplx<T>* res = lds + cur * half;
-    for (int e = tid; e < nrows * n; e += NT) {
-        const int r = fast_div(e, a.inv_n), i = e - r * n;
-        cplx<T> p = res[e];
-        p.x *= sx;
-        p.y *= sy;
-        reinterpret_cast<cplx<T>*>(a.out)[(row0 + r) * a.stride_out + i] = p;
+    if (inner == 1) {
+        for (int e = tid; e < nrows * n; e += NT) {
+            const int r = fast_div(e, a.inv_n), i = e - r * n;
+            cplx<T> p = res[e];
+            p.x *= sx;
+            p.y *= sy;
+            reinterpret_cast<cplx<T>*>(a.out)[(row0 + r) * a.stride_out + i] = p;
+        }
+    } else {
+        for (int e = tid; e < nrows * n; e += NT) {
+            const int i = fast_div(e, inv_rows), c = e - i * nrows;
+            cplx<T> p = res[c * n + i];
+            p.x *= sx;
+            p.y *= sy;
+            reinterpret_cast<cplx<T>*>(a.out)[line_base + (long long)i * inner + c] = p;
+        }
     }
 }
 
@@ -188,14 +220,17 @@ extern "C" int mifft_mixed_supported_impl(int f64, int n) {
     return factor(n, radix) ? 0 : -2;
 }
 
-extern "C" int mifft_mixed_launch(int f64, int n, long long rows, long long stride_in, long long stride_out, const void* in, void* out,
-                                  const void* tw, int inverse, double scale, hipStream_t s) {
+// flags: bit 0 conjugate on load, bit 1 conjugate on store (inverse transform = 3).  inner > 1: lines of a strided axis.
+extern "C" int mifft_mixed_launch(int f64, int n, long long rows, long long stride_in, long long stride_out, long long inner,
+                                  const void* in, void* out, const void* tw, int flags, double scale, hipStream_t s) {
     MixedArgs a;
     a.nstages = factor(n, a.radix);
     if (!a.nstages) return -2;
     a.in = in; a.out = out; a.tw = tw;
     a.rows = rows; a.stride_in = stride_in; a.stride_out = stride_out;
-    a.n = n; a.inverse = inverse; a.scale = scale;
+    a.n = n; a.inverse = (flags & 3) == 3; a.scale = scale;
+    a.conj_in = flags & 1; a.conj_out = (flags >> 1) & 1;
+    a.inner = inner < 1 ? 1 : inner;
     a.inv_n = 1.0f / (float)n;
     for (int i = 0, nsx = 1; i < a.nstages; ++i) {
         a.inv_per_row[i] = 1.0f / (float)(n / a.radix[i]);
@@ -209,6 +244,10 @@ extern "C" int mifft_mixed_launch(int f64, int n, long long rows, long long stri
     int W = cap / n;
     if (W < 1) W = 1;
     if (W > rows) W = (int)rows;
+    if (a.inner > 1) {
+        // a tile's W lines are adjacent and share one o: the largest W <= cap / n that divides `inner`
+        while (W > 1 && a.inner % W) --W;
+    }
     a.W = W;
     const long long blocks = (rows + W - 1) / W;
     if (blocks <= 0) return 0;

@@ -37,8 +37,8 @@ int mifft_pair_f64(int kind, int k0, int k1, int k2, int split, const mifft::Pai
 int mifft_pair_f32(int kind, int k0, int k1, int k2, int split, const mifft::PairArgs* a, hipStream_t s, int query, int* width);
 int mifft_nd2t(int f64, int x, int y, int z, const mifft::TileArgs* a, const mifft::TiledGeom* g, hipStream_t s, int query);
 int mifft_mixed_supported_impl(int f64, int n);
-int mifft_mixed_launch(int f64, int n, long long rows, long long stride_in, long long stride_out, const void* in, void* out,
-                       const void* tw, int inverse, double scale, hipStream_t s);
+int mifft_mixed_launch(int f64, int n, long long rows, long long stride_in, long long stride_out, long long inner, const void* in,
+                       void* out, const void* tw, int flags, double scale, hipStream_t s);
 int mifft_xcd2_f32_launch(const mifft::Xcd2Args* f, int split, int prefetch, int mode, unsigned grid, hipStream_t s);
 }
 

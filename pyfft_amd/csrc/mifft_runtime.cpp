@@ -842,7 +842,20 @@ int mifft_launch_mixed_rows(int32_t precision, int32_t n, int64_t rows, int64_t 
     if (!in || !out || !tw) return set_err(MIFFT_E_INVALID, "mixed rows: null buffer");
     if (rows < 0 || stride_in < n || stride_out < n) return set_err(MIFFT_E_INVALID, "mixed rows: bad row count / stride");
     if (rows == 0) return 0;
-    const int rc = mifft_mixed_launch(precision == MIFFT_F64, n, rows, stride_in, stride_out, in, out, tw, inverse ? 1 : 0, scale, (hipStream_t)stream);
+    const int rc = mifft_mixed_launch(precision == MIFFT_F64, n, rows, stride_in, stride_out, 1, in, out, tw, inverse ? 3 : 0, scale, (hipStream_t)stream);
+    if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
+    if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
+    return 0;
+}
+
+int mifft_launch_mixed_lines(int32_t precision, int32_t n, int64_t outer, int64_t inner, const void* in, void* out, const void* tw,
+                             int32_t conj_in, int32_t conj_out, double scale, mifft_stream_t stream) {
+    if (mifft_mixed_supported(precision, n) != 0) return set_err(MIFFT_E_UNSUPPORTED, "mixed lines: no kernel for n = %d", n);
+    if (!in || !out || !tw) return set_err(MIFFT_E_INVALID, "mixed lines: null buffer");
+    if (outer < 0 || inner < 1) return set_err(MIFFT_E_INVALID, "mixed lines: bad index space");
+    if (outer == 0) return 0;
+    const int flags = (conj_in ? 1 : 0) | (conj_out ? 2 : 0);
+    const int rc = mifft_mixed_launch(precision == MIFFT_F64, n, outer * inner, n, n, inner, in, out, tw, flags, scale, (hipStream_t)stream);
     if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
     if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
     return 0;

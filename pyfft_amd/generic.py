@@ -172,6 +172,23 @@ class GenericFFTPlan(object):
         # (conjugation of the inverse direction and the scale included): one HBM round trip, no work array
         self._direct_mixed = (self._xyz[1] == 1 and self._xyz[2] == 1 and self._axes[0].mixed_tw is not None
                               and not self._split and self._ntiles == 1)
+        # N-D, every axis a smooth length the mixed-radix kernel takes (powers of two included), at least one of them not a power of
+        # two, interleaved, dense: ONE launch per axis straight on the user's buffers -- the x axis as rows from input to output,
+        # the slower axes as lines of the output array in place (mifft_launch_mixed_lines); no gather, no scatter, no work array
+        self._direct_nd = None
+        if not self._direct_mixed and not self._split and self._ntiles == 1 and any(ax.mixed_tw is not None for ax in self._axes) and \
+                all(ax.n == 1 or N.lib.mifft_mixed_supported(self._precision, ax.n) == 0 for ax in self._axes):
+            tabs = []
+            for ax in self._axes:
+                if ax.n == 1:
+                    tabs.append(None)
+                elif ax.mixed_tw is not None:
+                    tabs.append(ax.mixed_tw)
+                else:
+                    k = numpy.arange(ax.n, dtype=numpy.float64)
+                    ang = -2.0 * numpy.pi * k / float(ax.n)
+                    tabs.append(self._upload((numpy.cos(ang) + 1j * numpy.sin(ang)).astype(self._cdtype)))
+            self._direct_nd = tabs
         self._work = None
         self._rows = None
         self._last_batch = 0
@@ -223,7 +240,7 @@ class GenericFFTPlan(object):
         if batch == self._last_batch:
             return
         self._last_batch = batch
-        if self._tiled or self._direct_mixed:
+        if self._tiled or self._direct_mixed or self._direct_nd is not None:
             return                      # no work arrays
         isz = self._cdtype.itemsize
         nt = batch * self._ntiles
@@ -244,6 +261,26 @@ class GenericFFTPlan(object):
         ctx.order_scratch()
         if self._tiled:
             return self._execute_tiled(wait_for_finish, bool(inverse), batch, ptr(ins[0]), ptr(outs[0]))
+        if self._direct_nd is not None:
+            inv = bool(inverse)
+            factor = self._scale if not inv else 1.0 / ((self._size if self._normalize else 1.0) * self._scale)
+            todo = [a for a, ax in enumerate(self._axes) if ax.n > 1]
+            src, inner = ptr(ins[0]), 1
+            for a, ax in enumerate(self._axes):            # x, y, z
+                if ax.n > 1:
+                    first, last = a == todo[0], a == todo[-1]
+                    outer = batch * self._size // (ax.n * inner)
+                    N.check(N.lib.mifft_launch_mixed_lines(self._precision, ax.n, outer, inner, src, ptr(outs[0]), self._direct_nd[a],
+                                                           1 if (inv and first) else 0, 1 if (inv and last) else 0,
+                                                           factor if last else 1.0, ctx.stream_handle()), "mifft_launch_mixed_lines")
+                    src = ptr(outs[0])
+                inner *= ax.n
+            wait = self._wait_for_finish if wait_for_finish is None else wait_for_finish
+            if wait:
+                self.finish()
+                return None
+            ctx.flush()
+            return ctx.getQueue()
         if self._direct_mixed:
             n = self._xyz[0]
             inv = bool(inverse)

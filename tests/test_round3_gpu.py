@@ -267,6 +267,22 @@ def test_mixed_radix_is_what_smooth_any_size_plans_run(ctx):
     kinds = [("mixed" if ax.mixed_tw is not None else "pow2" if ax.pow2 else "bluestein") for ax in plan._axes]   # x, y, z
     assert kinds == ["pow2", "bluestein", "mixed"]
     assert ctx.hip.N.lib.mifft_mixed_supported(0, 1023) != 0 and ctx.hip.N.lib.mifft_mixed_supported(0, 8192) != 0
+    assert plan._direct_nd is None and not plan._direct_mixed          # (an axis needs Bluestein: gathers stay)
+    # every axis smooth: one launch per axis on the user's buffers, no work array -- against numpy, out of place and in place
+    for shape in ((100, 64), (6, 10, 14), (49, 125)):
+        p2 = ctx.getPlan(shape, dtype=numpy.complex128, any_size=True)
+        assert p2._direct_nd is not None
+        x = oracle.get_test_data(shape, numpy.complex128, 3, 21)
+        a, b = ctx.toGpu(x), ctx.allocate(x.shape, x.dtype)
+        p2.execute(a, b, batch=3)
+        ref = oracle.numpy_fft(numpy.fft.fftn, x, 3)
+        assert oracle.difference(ref, b.get(), 3) < 1e-11 and numpy.array_equal(a.get(), x)
+        p2.execute(a, batch=3)
+        assert numpy.array_equal(a.get(), b.get())
+        p2.execute(a, batch=3, inverse=True)
+        assert oracle.difference(x, a.get(), 3) < 1e-11
+        assert p2._work is None
+    assert ctx.getPlan((1000,), dtype=numpy.complex64, any_size=True)._direct_mixed
 
 
 # ---- the sharded path with more than one rank --------------------------------------------------------------------------
