@@ -1,5 +1,5 @@
 #!/bin/bash
-# gpurun -- 'bash tools/run_l2_probe.sh'   -> gpurun_out/r03a/{plain.log,pmc.log}
+# gpurun -- 'bash tools/r03_runs/run_l2_probe.sh'   -> gpurun_out/r03a/{plain.log,pmc.log}
 set -u
 OUT=gpurun_out/r03a
 mkdir -p $OUT

@@ -1,5 +1,5 @@
 #!/bin/bash
-# gpurun -- 'bash tools/run_r03b.sh'
+# gpurun -- 'bash tools/r03_runs/run_r03b.sh'
 set -u
 OUT=gpurun_out/r03b
 mkdir -p $OUT

@@ -1,5 +1,5 @@
 #!/bin/bash
-# gpurun -- 'bash tools/run_r03c.sh'
+# gpurun -- 'bash tools/r03_runs/run_r03c.sh'
 set -u
 OUT=gpurun_out/r03c
 mkdir -p $OUT

@@ -1,5 +1,5 @@
 #!/bin/bash
-# gpurun -- 'bash tools/run_r03d.sh'
+# gpurun -- 'bash tools/r03_runs/run_r03d.sh'
 set -u
 OUT=gpurun_out/r03d
 mkdir -p $OUT
