@@ -156,11 +156,14 @@ __device__ __forceinline__ FusedItem fused_decode(const FusedArgs& f, unsigned i
 }
 
 // lane 0 only: hand out this item's ticket and its early poll, draw the next ticket
-__device__ __forceinline__ unsigned fused_advance(FusedQueue& q, unsigned& seen, unsigned total, unsigned* next) {
+// (tmul, tadd): a drawn ticket k is item k * tmul + tadd -- (1, 0) for one ticket counter; (8, x) when the counter is sharded per
+// XCD and XCD x owns the items x, x + 8, ... of the SAME global list (development switch, see fused_loop)
+__device__ __forceinline__ unsigned fused_advance(FusedQueue& q, unsigned& seen, unsigned total, unsigned* next, unsigned tmul = 1u,
+                                                  unsigned tadd = 0u) {
     const unsigned item = q.t1;
     seen = q.seen1;
     q.seen1 = 0u;     // "not polled yet" (the hook of this item's tile sets it)
-    if (item < total) q.t1 = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (item < total) q.t1 = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * tmul + tadd;
     return item;
 }
 
@@ -181,13 +184,18 @@ template <unsigned PER0, unsigned PER1> struct FusedHook {
 };
 
 // one persistent work-group: TILE0(t, slot, tile, hook) / TILE1(slot, t, tile, hook) run one tile of pass 0 / pass 1
-template <unsigned PER0, unsigned PER1, bool EARLY, typename TILE0, typename TILE1, bool XCD = false>
+// XCD = 1: one work list per XCD.  XCD = 2 (development): the ONE global list with its ticket counter sharded per XCD -- XCD x draws
+// the items x, x + 8, ...; every dependency still points to a lower item of the same list, and the lowest unfinished item is
+// either running or the next ticket of its XCD, so the order argument holds as long as every XCD has a resident work-group.
+template <unsigned PER0, unsigned PER1, bool EARLY, typename TILE0, typename TILE1, int XCD = 0>
 __device__ __forceinline__ void fused_loop(const FusedArgs& f, unsigned* s_item, TILE0&& tile0, TILE1&& tile1) {
     // XCD-local lists: ticket counter of XCD x on its own line behind the dependency counters, census word beside it
-    const unsigned x = XCD ? fused_xcc_id() : 0u;
-    constexpr unsigned xs = XCD ? 8u : 1u;
-    const unsigned nb = XCD ? (f.batch + 7u - x) >> 3 : f.batch;
-    unsigned* const next = XCD ? f.counters + kFusedCS * (1u + 2u * f.batch + x) : f.counters;
+    const unsigned xq = XCD ? fused_xcc_id() : 0u;
+    const unsigned x = XCD == 1 ? xq : 0u;
+    constexpr unsigned xs = XCD == 1 ? 8u : 1u;
+    const unsigned tmul = XCD == 2 ? 8u : 1u, tadd = XCD == 2 ? xq : 0u;
+    const unsigned nb = XCD == 1 ? (f.batch + 7u - x) >> 3 : f.batch;
+    unsigned* const next = XCD ? f.counters + kFusedCS * (1u + 2u * f.batch + xq) : f.counters;
     unsigned* const err = f.counters + 1;
     if constexpr (XCD) {
         if (threadIdx.x == 0) __hip_atomic_fetch_add(next + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // census
@@ -204,12 +212,12 @@ __device__ __forceinline__ void fused_loop(const FusedArgs& f, unsigned* s_item,
 
     FusedPending pend = {nullptr};
     FusedQueue q = {0u, 0u};
-    if (threadIdx.x == 0) q.t1 = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) q.t1 = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * tmul + tadd;
     const FusedHook<PER0, PER1> hook = {f, q, total, gsize, wdone, rdone, x, xs, nb};
     for (;;) {
         __syncthreads();  // the previous item's LDS traffic and its s_item read are over
         unsigned seen = 0;
-        if (threadIdx.x == 0) *s_item = fused_advance(q, seen, total, next);
+        if (threadIdx.x == 0) *s_item = fused_advance(q, seen, total, next, tmul, tadd);
         __syncthreads();
         const unsigned item = *s_item;
         if (item >= total) break;
@@ -257,7 +265,7 @@ __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
 
 // XCD-local lists (see FusedArgs above).  WT0: write the intermediate with write-through stores (as the global form must) or
 // with plain ones (it then lives in the XCD's L2 and is written back only when evicted).
-template <typename T, int A0, int A1, bool WT0>
+template <typename T, int A0, int A1, bool WT0, int XCD = 1>
 __global__ void __launch_bounds__(256, 2) fft_fused2x_kernel(const FusedArgs f) {
     constexpr int E0 = Col2Lds<A0, true>::ELEMS, E1 = Col2Lds<A1, false>::ELEMS;
     __shared__ __attribute__((aligned(16))) cplx<T> lds[E0 > E1 ? E0 : E1];
@@ -270,7 +278,7 @@ __global__ void __launch_bounds__(256, 2) fft_fused2x_kernel(const FusedArgs f) 
     auto t1 = [&](unsigned slot, unsigned t, unsigned tile, auto hook) {
         col2_tile<T, A1, false, false, false, false, false, true, false>(f.p1, (long long)slot, (long long)t, (long long)tile * 16, lds, hook);
     };
-    fused_loop<per0, per1, true, decltype(t0)&, decltype(t1)&, true>(f, &s_item, t0, t1);
+    fused_loop<per0, per1, true, decltype(t0)&, decltype(t1)&, XCD>(f, &s_item, t0, t1);
 }
 
 // The 2-D form (BASELINE config 3: 1024 x 1024): a 2-D transform is two TRANSPOSING column passes without an inter-pass twiddle

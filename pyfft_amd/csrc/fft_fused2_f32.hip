@@ -50,7 +50,9 @@ extern "C" int mifft_fused2_f32_launch(int L0, int L1, const mifft::FusedArgs* f
 // XCD-local work lists (development strategy `fusedx`): interleaved fp32, L0, L1 in {256, 512, 1024}; wt = write-through intermediate
 namespace {
 template <int A0, int A1> int launchx(const mifft::FusedArgs* f, int wt, unsigned grid, hipStream_t s) {
-    if (wt) hipLaunchKernelGGL((mifft::fft_fused2x_kernel<float, A0, A1, true>), dim3(grid), dim3(256), 0, s, *f);
+    // wt == 2: the GLOBAL list with a per-XCD sharded ticket counter (write-through intermediate, as the global form needs)
+    if (wt == 2) hipLaunchKernelGGL((mifft::fft_fused2x_kernel<float, A0, A1, true, 2>), dim3(grid), dim3(256), 0, s, *f);
+    else if (wt) hipLaunchKernelGGL((mifft::fft_fused2x_kernel<float, A0, A1, true>), dim3(grid), dim3(256), 0, s, *f);
     else hipLaunchKernelGGL((mifft::fft_fused2x_kernel<float, A0, A1, false>), dim3(grid), dim3(256), 0, s, *f);
     return (int)hipGetLastError();
 }

@@ -666,7 +666,7 @@ int mifft_launch_fused2x(const mifft_pass* p0, const mifft_pass* p1, const void*
     f.tiles1 = (unsigned)(p1->S / 16);
     rc = hip_check(hipMemsetAsync(counters, 0, MIFFT_FUSED2_COUNTER_BYTES(p1->outer), (hipStream_t)stream), "hipMemsetAsync");
     if (rc) return rc;
-    rc = mifft_fused2x_f32_launch(p0->L, p1->L, &f, write_through ? 1 : 0, (unsigned)grid, (hipStream_t)stream);
+    rc = mifft_fused2x_f32_launch(p0->L, p1->L, &f, write_through, (unsigned)grid, (hipStream_t)stream);
     if (rc == MIFFT_E_UNSUPPORTED) return set_err(rc, "fused2x: no kernel for %d x %d", p0->L, p1->L);
     if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
     return 0;

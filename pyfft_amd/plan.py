@@ -389,7 +389,7 @@ class FFTPlan(object):
         if not self._temp_buffer_needed and self._strategy[0] not in ("fused2", "fused2x"):
             return
         if self._strategy[0] == "fused2x":
-            items = 8 * self._strategy[2]                 # ring slots per XCD
+            items = (1 if self._strategy[4] == 2 else 8) * self._strategy[2]     # ring slots per XCD (wt == 2: one global ring)
             self._counters = ctx.allocate_raw(N.fused2_counter_bytes(batch))
         elif self._strategy[0] == "fused2":
             items = self._strategy[2]                     # ring slots
