@@ -362,3 +362,60 @@ def test_pass_pair_chain_algebra_and_schedule():
     assert len(split) == 4 and split[1].L == 64 and N.lib.mifft_pair_split(N.F64, N.SPLIT, 256, 256, 256) == 64
     assert N.lib.mifft_pair_split(N.F32, N.INTERLEAVED, 256, 256, 256) == 64 and N.lib.mifft_pair_split(N.F32, N.SPLIT, 256, 256, 256) == 0
     assert N.lib.mifft_pair_split(N.F64, N.INTERLEAVED, 256, 256, 1) == 0 and N.lib.mifft_pair_split(N.F64, N.INTERLEAVED, 100, 256, 256) == 0
+
+
+def test_round3_entry_points_reject_bad_arguments_without_touching_the_gpu():
+    """The pass-pair, tiled N-D and mixed-radix launchers validate before any HIP call: wrong shapes are MIFFT_E_UNSUPPORTED,
+    malformed arguments MIFFT_E_INVALID (no GPU needed: this is the host side of the C ABI)."""
+    import ctypes
+    from pyfft_amd import _native as N
+
+    def row(L, outer):
+        p = N.MifftPass()
+        p.kind, p.precision, p.layout, p.L, p.M, p.S, p.outer = N.PASS_ROW, N.F64, N.INTERLEAVED, L, 1, 1, outer
+        p.outer_stride_in = p.outer_stride_out = L
+        p.scale, p.tw_L = 1.0, 16
+        return p
+
+    def col(L, M, S, outer, stride):
+        p = N.MifftPass()
+        p.kind, p.precision, p.layout, p.L, p.M, p.S, p.outer = N.PASS_COL, N.F64, N.INTERLEAVED, L, M, S, outer
+        p.outer_stride_in = p.outer_stride_out = stride
+        p.scale, p.tw_L, p.tw_lo, p.tw_hi, p.tw_shift = 1.0, 16, 16, 16, 4
+        return p
+
+    # the pair of BASELINE config 4 is recognised ...
+    x0, y0 = row(256, 256 * 256), col(32, 8, 256, 256, 65536)
+    assert N.lib.mifft_pass_pair_supported(ctypes.byref(x0), ctypes.byref(y0)) == 0
+    y1, z1 = col(8, 1, 8192, 256, 65536), col(256, 1, 65536, 1, 1 << 24)
+    assert N.lib.mifft_pass_pair_supported(ctypes.byref(y1), ctypes.byref(z1)) == 0
+    # ... two passes that are not consecutive passes of one plan are not, a shape without kernels is not
+    assert N.lib.mifft_pass_pair_supported(ctypes.byref(x0), ctypes.byref(z1)) == N.E_UNSUPPORTED
+    bad = col(16, 16, 256, 256, 65536)
+    assert N.lib.mifft_pass_pair_supported(ctypes.byref(x0), ctypes.byref(bad)) == N.E_UNSUPPORTED
+    assert N.lib.mifft_launch_pass_pair(ctypes.byref(x0), ctypes.byref(bad), 16, None, 32, None, None) == N.E_UNSUPPORTED
+    # the (ROW x, COL y) pair never runs in place; buffers must be aligned
+    assert N.lib.mifft_launch_pass_pair(ctypes.byref(x0), ctypes.byref(y0), 64, None, 64, None, None) == N.E_INVALID
+    assert "in place" in N.last_error()
+    assert N.lib.mifft_launch_pass_pair(ctypes.byref(x0), ctypes.byref(y0), 8, None, 64, None, None) == N.E_INVALID
+    # tiled N-D: a shape without a tiled kernel, an inconsistent tiling
+    nd = N.MifftPass()
+    nd.kind, nd.precision, nd.layout, nd.L, nd.M, nd.S, nd.outer = N.PASS_ND, N.F32, N.INTERLEAVED, 16, 16, 1, 32
+    nd.scale, nd.tw_L, nd.tw_lo = 1.0, 16, 16
+    t = N.MifftTiling()
+    t.pitch_y, t.pitch_z, t.parent_elems, t.cx, t.cy, t.cz = 64, 64 * 64, 64 * 64, 4, 4, 1
+    assert N.lib.mifft_nd_tiled_supported(N.F32, 16, 16, 1) == 0 and N.lib.mifft_nd_tiled_supported(N.F32, 16, 4, 1) == N.E_UNSUPPORTED
+    t.pitch_y = 32                                   # four tiles of 16 do not fit a row of 32
+    assert N.lib.mifft_launch_nd_tiled(ctypes.byref(nd), ctypes.byref(t), 16, 16, None) == N.E_INVALID
+    nd.M = 4
+    t.pitch_y = 64
+    assert N.lib.mifft_launch_nd_tiled(ctypes.byref(nd), ctypes.byref(t), 16, 16, None) == N.E_UNSUPPORTED
+    # mixed-radix rows: smooth lengths only, up to 4096 (fp32) / 2048 (fp64)
+    assert [N.lib.mifft_mixed_supported(N.F32, n) == 0 for n in (1000, 4096, 4097, 11, 1, 3 * 5 * 7 * 16)] == [True, True, False, False, False, True]
+    assert N.lib.mifft_mixed_supported(N.F64, 4096) == N.E_UNSUPPORTED and N.lib.mifft_mixed_supported(N.F64, 2000) == 0
+    assert N.lib.mifft_launch_mixed_rows(N.F32, 1023, 4, 1023, 1023, 16, 16, 16, 0, 1.0, None) == N.E_UNSUPPORTED
+    assert N.lib.mifft_launch_mixed_rows(N.F32, 1000, 4, 999, 1000, 16, 16, 16, 0, 1.0, None) == N.E_INVALID     # stride < n
+    assert N.lib.mifft_launch_mixed_lines(N.F32, 1000, 4, 0, 16, 16, 16, 0, 0, 1.0, None) == N.E_INVALID
+    # the fp64 strided passes of 2048 points exist, the pair split answers per layout
+    assert N.lib.mifft_pass_supported(N.PASS_COL, N.F64, 2048, 0) == 0
+    assert N.lib.mifft_pair_split(N.F64, N.SPLIT, 256, 256, 256) == 64 and N.lib.mifft_pair_split(N.F32, N.INTERLEAVED, 128, 128, 128) == 32
