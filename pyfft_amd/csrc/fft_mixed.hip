@@ -1,17 +1,20 @@
-// Mixed-radix rows: contiguous transforms of SMOOTH length n = 2^a 3^b 5^c 7^d (the reference's TODO.txt:8, "support for
-// non-power-of-2 sized arrays"), one LDS-resident Stockham transform per row with radix-3 / 5 / 7 butterflies next to the
-// power-of-two ones -- instead of Bluestein's three padded power-of-two transforms and four streaming copies
+// Mixed-radix rows and lines: transforms of SMOOTH length n = 2^a 3^b 5^c 7^d (the reference's TODO.txt:8, "support for
+// non-power-of-2 sized arrays"), one Stockham transform per row with radix-3 / 5 / 7 butterflies and their composites (6, 9, 10, 12,
+// 14, 15) next to the power-of-two ones -- instead of Bluestein's three padded power-of-two transforms and four streaming copies
 // (pyfft_amd/generic.py), which stays for lengths with a larger prime factor.
 //
-// A work-group owns W consecutive rows of n points in LDS (W * n <= 4096 fp32 / 2048 fp64 points, two buffers of that size: 64 KiB,
-// two work-groups per CU); every stage reads its butterflies' R operands from one buffer and writes the other at the autosort position:
+// A work-group owns W transforms of n points (W * n <= 2048 fp32 / 1024 fp64 points when a transform fits that, two LDS buffers of
+// that size: 32 KiB, four work-groups per CU).  The first stage takes its operands from HBM, the last one stores to HBM, the stages
+// in between read one LDS buffer and write the other at the autosort position:
 //     stage with radix R, Ns = product of the earlier radices:  butterfly jb < n / R
 //         reads   x[jb + k * n / R]                                   k < R
 //         twiddle w(n)^(k * (jb mod Ns) * n / (Ns * R))               (table of n entries, float64-evaluated on the host)
 //         writes  y[(jb div Ns) * Ns * R + (jb mod Ns) + k * Ns]
 // (the same algebra as fft_tile.hpp, without the power-of-two shortcuts: lengths are run-time values, the radix list comes with
-// the launch).  The inverse is conj -> forward -> conj.  Interleaved data, in place or out of place, rows `stride` apart.
+// the launch; the radix is a compile-time constant inside each stage loop).  The inverse is conj -> forward -> conj.  Interleaved
+// data, in place or out of place; rows `stride` apart, or the lines of a strided axis (`inner` elements between a line's points).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "../../include/mifft.h"
 #include "fft_butterfly.hpp"
 
@@ -30,8 +33,8 @@ struct MixedArgs {
     int n, W, nstages, inverse;
     int conj_in, conj_out; // conjugate on load / on store (inverse = both; an N-D plan conjugates once at either end)
     int radix[kMaxStages];
-    float inv_n;           // 1 / n, 1 / (n / R) and 1 / Ns per stage: index divisions as one float multiply (indices < 2^22, exact
-    float inv_per_row[kMaxStages], inv_ns[kMaxStages];   // with the + 0.5 below)
+    // 1 / (n / R) and 1 / Ns per stage: index divisions as one float multiply (indices < 2^22, exact with the + 0.5 below)
+    float inv_per_row[kMaxStages], inv_ns[kMaxStages];
     double scale;
 };
 
@@ -76,23 +79,89 @@ template <typename T> __device__ __forceinline__ void dft7(cplx<T>* v) {
     v[3] = cplx<T>{m3.x + n3.y, m3.y - n3.x};
     v[4] = cplx<T>{m3.x - n3.y, m3.y + n3.x};
 }
+// exp(-2 pi i m / n) at compile time (octant reduction in integers, Taylor series on [0, pi / 4]: 1 ulp of double)
+struct UnitRoot { double c, s; };
+constexpr double series_sin(double x) {
+    double t = x, r = x;
+    for (int k = 1; k < 14; ++k) { t *= -x * x / ((2.0 * k) * (2.0 * k + 1.0)); r += t; }
+    return r;
+}
+constexpr double series_cos(double x) {
+    double t = 1.0, r = 1.0;
+    for (int k = 1; k < 14; ++k) { t *= -x * x / ((2.0 * k - 1.0) * (2.0 * k)); r += t; }
+    return r;
+}
+constexpr UnitRoot unit_root(int m, int n) {
+    int p = (8 * (m % n)), q = n;                 // angle = 2 pi p / (8 q); 1/8 turn = q
+    bool neg_s = false, neg_c = false, swap = false;
+    if (p > 4 * q) { p = 8 * q - p; neg_s = true; }
+    if (p > 2 * q) { p = 4 * q - p; neg_c = true; }
+    if (p > q) { p = 2 * q - p; swap = true; }
+    const double x = 6.283185307179586476925286766559 * (double)p / (8.0 * (double)q);
+    double c = series_cos(x), s = series_sin(x);
+    if (swap) { const double t = c; c = s; s = t; }
+    if (neg_c) c = -c;
+    if (neg_s) s = -s;
+    return UnitRoot{c, -s};
+}
+
+template <int R, typename T> __device__ __forceinline__ void dft_any(cplx<T>* v);
+
+// composite radix A * B in registers (natural order in and out): i = i1 + A i2, k = B k1 + k2,
+//     X[B k1 + k2] = sum_i1 w(A)^(i1 k1) * [ w(AB)^(i1 k2) * sum_i2 w(B)^(i2 k2) x[i1 + A i2] ]
+template <int A, int B, typename T> __device__ __forceinline__ void dft_comp(cplx<T>* v) {
+    cplx<T> y[A * B];
+    static_for<A>([&](auto ii) {
+        constexpr int i1 = ii;
+        cplx<T> u[B];
+        static_for<B>([&](auto i2) { u[i2] = v[i1 + A * i2]; });
+        dft_any<B, T>(u);
+        static_for<B>([&](auto kk) {
+            constexpr int k2 = kk;
+            if constexpr (i1 == 0 || k2 == 0) y[i1 * B + k2] = u[k2];
+            else {
+                constexpr UnitRoot w = unit_root(i1 * k2, A * B);
+                y[i1 * B + k2] = cmul<T>(u[k2], cplx<T>{(T)w.c, (T)w.s});
+            }
+        });
+    });
+    static_for<B>([&](auto kk) {
+        constexpr int k2 = kk;
+        cplx<T> u[A];
+        static_for<A>([&](auto i1) { u[i1] = y[i1 * B + k2]; });
+        dft_any<A, T>(u);
+        static_for<A>([&](auto k1) { v[B * k1 + k2] = u[k1]; });
+    });
+}
+
 template <int R, typename T> __device__ __forceinline__ void dft_any(cplx<T>* v) {
     if constexpr (R == 3) dft3<T>(v);
     else if constexpr (R == 5) dft5<T>(v);
     else if constexpr (R == 7) dft7<T>(v);
+    else if constexpr (R == 6) dft_comp<2, 3, T>(v);
+    else if constexpr (R == 9) dft_comp<3, 3, T>(v);
+    else if constexpr (R == 10) dft_comp<2, 5, T>(v);
+    else if constexpr (R == 12) dft_comp<4, 3, T>(v);
+    else if constexpr (R == 14) dft_comp<2, 7, T>(v);
+    else if constexpr (R == 15) dft_comp<3, 5, T>(v);
     else Dft<R, T>::run(v);
 }
 
-// one butterfly of radix R, row-local index jb: operands from `src` (twiddled), DFT in registers, results to `dst` at the autosort
-// position.  GIN / GOUT: `src` / `dst` is the row in GLOBAL memory (first / last stage of the row form: consecutive butterflies read
-// consecutive points of every operand, and the last stage, Ns = n / R, writes consecutive points of every result), with the
+// one butterfly of radix R, transform-local index jb: operands from `src` (twiddled), DFT in registers, results to `dst` at the
+// autosort position.  A transform's point i sits at base + i * es: es = 1 for ROWS (the tile's rows one after the other), es = the
+// number of the tile's lines for LINES (the tile is [point][line] in LDS, and `inner` elements apart in HBM: adjacent lanes take
+// adjacent lines, so both sides are coalesced).  GIN / GOUT: `src` / `dst` is HBM (the first / last stage: consecutive butterflies
+// read consecutive points of every operand, and the last stage, Ns = n / R, writes consecutive points of every result), with the
 // conjugation of the inverse direction / the scale folded in.
-template <int R, typename T, bool GIN, bool GOUT>
-__device__ __forceinline__ void stage_butterfly(const cplx<T>* src, cplx<T>* dst, const cplx<T>* tw, int LR, int Ns, float inv_ns, int jb,
-                                                T csign, T sx, T sy) {
+template <int R, typename T, bool GIN, bool GOUT, bool LINES, typename SI, typename DI>
+__device__ __forceinline__ void stage_butterfly(const cplx<T>* src, SI es_s, cplx<T>* dst, DI es_d, const cplx<T>* tw, int LR, int Ns,
+                                                float inv_ns, int jb, T csign, T sx, T sy) {
     const int jm = jb - fast_div(jb, inv_ns) * Ns;
     cplx<T> v[R];
-    static_for<R>([&](auto kk) { v[kk] = src[jb + kk * LR]; });
+    static_for<R>([&](auto kk) {
+        if constexpr (LINES) v[kk] = src[(SI)(jb + kk * LR) * es_s];
+        else v[kk] = src[jb + kk * LR];
+    });
     if constexpr (GIN) static_for<R>([&](auto kk) { v[kk].y *= csign; });
     if (Ns > 1) {
         const int step = jm * (LR / Ns);                 // jm * n / (Ns * R)
@@ -102,137 +171,152 @@ __device__ __forceinline__ void stage_butterfly(const cplx<T>* src, cplx<T>* dst
         });
     }
     dft_any<R, T>(v);
-    cplx<T>* q = dst + (jb - jm) * R + jm;
+    const int q0 = (jb - jm) * R + jm;
     static_for<R>([&](auto kk) {
         cplx<T> p = v[kk];
         if constexpr (GOUT) {
             p.x *= sx;
             p.y *= sy;
         }
-        q[kk * Ns] = p;
+        if constexpr (LINES) dst[(DI)(q0 + kk * Ns) * es_d] = p;
+        else dst[q0 + kk * Ns] = p;
     });
 }
 
-template <typename T, bool GIN, bool GOUT>
-__device__ __forceinline__ void stage_switch(int R, const cplx<T>* sr, cplx<T>* dr, const cplx<T>* tw, int per_row, int Ns, float ins, int jb,
-                                             T csign, T sx, T sy) {
-    switch (R) {
-        case 2: stage_butterfly<2, T, GIN, GOUT>(sr, dr, tw, per_row, Ns, ins, jb, csign, sx, sy); break;
-        case 3: stage_butterfly<3, T, GIN, GOUT>(sr, dr, tw, per_row, Ns, ins, jb, csign, sx, sy); break;
-        case 4: stage_butterfly<4, T, GIN, GOUT>(sr, dr, tw, per_row, Ns, ins, jb, csign, sx, sy); break;
-        case 5: stage_butterfly<5, T, GIN, GOUT>(sr, dr, tw, per_row, Ns, ins, jb, csign, sx, sy); break;
-        case 7: stage_butterfly<7, T, GIN, GOUT>(sr, dr, tw, per_row, Ns, ins, jb, csign, sx, sy); break;
-        case 8: stage_butterfly<8, T, GIN, GOUT>(sr, dr, tw, per_row, Ns, ins, jb, csign, sx, sy); break;
-        default: stage_butterfly<16, T, GIN, GOUT>(sr, dr, tw, per_row, Ns, ins, jb, csign, sx, sy); break;
+struct StageCtx {
+    const void* gin;       // HBM: first transform of the tile (rows) / first line of the tile (lines)
+    void* gout;
+    long long stride_in, stride_out, inner;
+    int n, nrows;
+    float inv_rows;
+};
+
+// one whole stage of the tile: butterflies tid, tid + NT, ... (the radix is a compile-time constant INSIDE the loop, so the
+// compiler overlaps the operand loads of consecutive butterflies)
+template <int R, typename T, int NT, bool GIN, bool GOUT, bool LINES>
+__device__ __forceinline__ void run_stage(const StageCtx& c, const cplx<T>* src, cplx<T>* dst, const cplx<T>* tw, int Ns, float ipr, float ins,
+                                          T csign, T sx, T sy) {
+    const int n = c.n, per_row = n / R, total = c.nrows * per_row;
+    for (int j = threadIdx.x; j < total; j += NT) {
+        int r, jb;
+        if constexpr (LINES) { jb = fast_div(j, c.inv_rows); r = j - jb * c.nrows; }
+        else { r = fast_div(j, ipr); jb = j - r * per_row; }
+        const cplx<T>* sr;
+        cplx<T>* dr;
+        if constexpr (GIN) sr = reinterpret_cast<const cplx<T>*>(c.gin) + (LINES ? (long long)r : r * c.stride_in);
+        else sr = src + (LINES ? r : r * n);
+        if constexpr (GOUT) dr = reinterpret_cast<cplx<T>*>(c.gout) + (LINES ? (long long)r : r * c.stride_out);
+        else dr = dst + (LINES ? r : r * n);
+        using SI = typename std::conditional<GIN, long long, int>::type;
+        using DI = typename std::conditional<GOUT, long long, int>::type;
+        stage_butterfly<R, T, GIN, GOUT, LINES, SI, DI>(sr, GIN ? (SI)c.inner : (SI)c.nrows, dr, GOUT ? (DI)c.inner : (DI)c.nrows, tw, per_row, Ns,
+                                                        ins, jb, csign, sx, sy);
     }
 }
 
-// Two LDS buffers of W * n points: a stage reads one and writes the other (one barrier per stage).
-template <typename T, int NT> __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) fft_mixed_kernel(const MixedArgs a) {
+template <typename T, int NT, bool GIN, bool GOUT, bool LINES, typename... Args>
+__device__ __forceinline__ void stage_switch(int R, Args&&... args) {
+    switch (R) {
+        case 2: run_stage<2, T, NT, GIN, GOUT, LINES>(args...); break;
+        case 3: run_stage<3, T, NT, GIN, GOUT, LINES>(args...); break;
+        case 4: run_stage<4, T, NT, GIN, GOUT, LINES>(args...); break;
+        case 5: run_stage<5, T, NT, GIN, GOUT, LINES>(args...); break;
+        case 6: run_stage<6, T, NT, GIN, GOUT, LINES>(args...); break;
+        case 7: run_stage<7, T, NT, GIN, GOUT, LINES>(args...); break;
+        case 8: run_stage<8, T, NT, GIN, GOUT, LINES>(args...); break;
+        case 9: run_stage<9, T, NT, GIN, GOUT, LINES>(args...); break;
+        case 10: run_stage<10, T, NT, GIN, GOUT, LINES>(args...); break;
+        case 12: run_stage<12, T, NT, GIN, GOUT, LINES>(args...); break;
+        case 14: run_stage<14, T, NT, GIN, GOUT, LINES>(args...); break;
+        case 15: run_stage<15, T, NT, GIN, GOUT, LINES>(args...); break;
+        default: run_stage<16, T, NT, GIN, GOUT, LINES>(args...); break;
+    }
+}
+
+// Two LDS buffers of W * n points: a stage reads one and writes the other (one barrier per stage); the first stage reads HBM and the
+// last one writes it (N = 1000 fp32: 32.5 % of the roofline through staging copies, 49.4 % with these register edges).
+template <typename T, int NT, bool LINES>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) fft_mixed_kernel(const MixedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cplx<T>* lds = reinterpret_cast<cplx<T>*>(smem);
     const cplx<T>* tw = reinterpret_cast<const cplx<T>*>(a.tw);
-    const int n = a.n, W = a.W, tid = threadIdx.x;
+    const int n = a.n, W = a.W;
     const int half = W * n;
     const long long row0 = (long long)blockIdx.x * W;
-    const int nrows = (int)((a.rows - row0) < W ? (a.rows - row0) : W);
+    StageCtx c;
+    c.n = n;
+    c.nrows = (int)((a.rows - row0) < W ? (a.rows - row0) : W);
+    c.stride_in = a.stride_in; c.stride_out = a.stride_out; c.inner = a.inner;
+    c.inv_rows = 1.0f / (float)c.nrows;
+    if constexpr (LINES) {
+        // (the launcher makes W divide `inner`, so a tile never straddles two values of o; its W lines are adjacent in memory)
+        const long long o = row0 / a.inner, j0 = row0 - o * a.inner;
+        const long long line_base = o * (long long)n * a.inner + j0;
+        c.gin = reinterpret_cast<const cplx<T>*>(a.in) + line_base;
+        c.gout = reinterpret_cast<cplx<T>*>(a.out) + line_base;
+    } else {
+        c.gin = reinterpret_cast<const cplx<T>*>(a.in) + row0 * a.stride_in;
+        c.gout = reinterpret_cast<cplx<T>*>(a.out) + row0 * a.stride_out;
+    }
     const T csign = a.conj_in ? (T)-1 : (T)1;
-    const long long inner = a.inner;
-    long long line_base = 0;      // strided axis: the tile's first line (its W lines are adjacent in memory: coalesced across lines)
-    float inv_rows = 1.0f;
-    if (inner > 1) {
-        // (the launcher makes W divide `inner`, so a tile never straddles two values of o)
-        const long long o = row0 / inner, j0 = row0 - o * inner;
-        line_base = o * (long long)n * inner + j0;
-        inv_rows = 1.0f / (float)nrows;
-    }
     const T sx = (T)a.scale, sy = a.conj_out ? -sx : sx;
-    // register edges (the first stage reads HBM, the last one writes HBM) for fp64 rows: N = 1000 31.1 -> 34.4 %; fp32 rows measured
-    // better through the linear 8-byte staging copy (30.2 against 28.6 %) and keep it
-    const bool rowform = inner == 1 && sizeof(T) == 8;
-    if (inner == 1 && !rowform) {
-        // rows -> LDS (consecutive threads, consecutive points)
-        for (int e = tid; e < nrows * n; e += NT) {
-            const int r = fast_div(e, a.inv_n), i = e - r * n;
-            cplx<T> p = reinterpret_cast<const cplx<T>*>(a.in)[(row0 + r) * a.stride_in + i];
-            p.y *= csign;
-            lds[e] = p;
-        }
-        __syncthreads();
-    } else if (!rowform) {
-        // lines -> LDS (consecutive threads, consecutive LINES of the same point index)
-        for (int e = tid; e < nrows * n; e += NT) {
-            const int i = fast_div(e, inv_rows), c = e - i * nrows;
-            cplx<T> p = reinterpret_cast<const cplx<T>*>(a.in)[line_base + (long long)i * inner + c];
-            p.y *= csign;
-            lds[c * n + i] = p;
-        }
-        __syncthreads();
-    }
     int Ns = 1, cur = 0;
     for (int s = 0; s < a.nstages; ++s) {
         const int R = a.radix[s];
-        const int per_row = n / R, total = nrows * per_row;
         const float ipr = a.inv_per_row[s], ins = a.inv_ns[s];
         const cplx<T>* src = lds + cur * half;
         cplx<T>* dst = lds + (cur ^ 1) * half;
-        const bool gin = rowform && s == 0, gout = rowform && s == a.nstages - 1;
-        for (int j = tid; j < total; j += NT) {
-            const int r = fast_div(j, ipr), jb = j - r * per_row;
-            const cplx<T>* sr = gin ? reinterpret_cast<const cplx<T>*>(a.in) + (row0 + r) * a.stride_in : src + r * n;
-            cplx<T>* dr = gout ? reinterpret_cast<cplx<T>*>(a.out) + (row0 + r) * a.stride_out : dst + r * n;
-            if (gin && gout) stage_switch<T, true, true>(R, sr, dr, tw, per_row, Ns, ins, jb, csign, sx, sy);
-            else if (gin) stage_switch<T, true, false>(R, sr, dr, tw, per_row, Ns, ins, jb, csign, sx, sy);
-            else if (gout) stage_switch<T, false, true>(R, sr, dr, tw, per_row, Ns, ins, jb, csign, sx, sy);
-            else stage_switch<T, false, false>(R, sr, dr, tw, per_row, Ns, ins, jb, csign, sx, sy);
-        }
-        __syncthreads();
+        const bool gin = s == 0, gout = s == a.nstages - 1;
+        if (gin && gout) stage_switch<T, NT, true, true, LINES>(R, c, src, dst, tw, Ns, ipr, ins, csign, sx, sy);
+        else if (gin) stage_switch<T, NT, true, false, LINES>(R, c, src, dst, tw, Ns, ipr, ins, csign, sx, sy);
+        else if (gout) stage_switch<T, NT, false, true, LINES>(R, c, src, dst, tw, Ns, ipr, ins, csign, sx, sy);
+        else stage_switch<T, NT, false, false, LINES>(R, c, src, dst, tw, Ns, ipr, ins, csign, sx, sy);
+        if (!gout) __syncthreads();
         Ns *= R;
         cur ^= 1;
     }
-    if (rowform) return;
-    const cplx<T>* res = lds + cur * half;
-    if (inner == 1) {
-        for (int e = tid; e < nrows * n; e += NT) {
-            const int r = fast_div(e, a.inv_n), i = e - r * n;
-            cplx<T> p = res[e];
-            p.x *= sx;
-            p.y *= sy;
-            reinterpret_cast<cplx<T>*>(a.out)[(row0 + r) * a.stride_out + i] = p;
-        }
-    } else {
-        for (int e = tid; e < nrows * n; e += NT) {
-            const int i = fast_div(e, inv_rows), c = e - i * nrows;
-            cplx<T> p = res[c * n + i];
-            p.x *= sx;
-            p.y *= sy;
-            reinterpret_cast<cplx<T>*>(a.out)[line_base + (long long)i * inner + c] = p;
-        }
-    }
 }
 
-// radix list of n; 0 if n has a prime factor beyond 7.  Odd radices FIRST, the powers of two last (largest last): the first
-// stage writes with stride R -- 10 / 14 dwords for radix 5 / 7 spread over the LDS banks, 16 or 32 dwords for radix 8 / 16 would
-// put a wave on 4 or 2 of the 64 banks -- and the last stage (Ns = n / R) writes consecutive addresses whatever its radix.
+// radix list of n; 0 if n has a prime factor beyond 7.  The fewest stages (every stage is one trip through LDS and one barrier:
+// 1000 = 10 * 10 * 10, not 5 * 5 * 5 * 8), then the smallest sum of radices (the least butterfly arithmetic).  Order: by the
+// power of two in the radix, odd ones FIRST and 16 last -- the first stage writes with stride R (2 R dwords: 10 / 14 / 30 dwords
+// for radix 5 / 7 / 15 spread over the LDS banks, 32 dwords for radix 16 would put a wave on 2 of the 64 banks) and the last
+// stage (Ns = n / R) writes consecutive addresses whatever its radix.
+constexpr int kRadices[] = {16, 15, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+
+bool search(int n, int depth, int first, int* pick, int at, int sum, int* best, int* best_sum) {
+    if (depth == 0) {
+        if (n != 1 || sum >= *best_sum) return false;
+        *best_sum = sum;
+        for (int i = 0; i < at; ++i) best[i] = pick[i];
+        return true;
+    }
+    bool found = false;
+    for (int i = first; i < (int)(sizeof(kRadices) / sizeof(int)); ++i) {      // non-increasing radices: combinations, not orders
+        const int r = kRadices[i];
+        if (n % r) continue;
+        pick[at] = r;
+        found |= search(n / r, depth - 1, i, pick, at + 1, sum + r, best, best_sum);
+    }
+    return found;
+}
+
 int factor(int n, int* radix) {
-    int ns = 0;
-    for (int c : {7, 5, 3}) {
-        while (n % c == 0) {
-            if (ns >= kMaxStages) return 0;
-            radix[ns++] = c;
-            n /= c;
-        }
+    int m = n;
+    for (int c : {2, 3, 5, 7}) while (m % c == 0) m /= c;
+    if (n < 2 || m != 1) return 0;
+    int pick[kMaxStages], best[kMaxStages];
+    for (int depth = 1; depth <= kMaxStages; ++depth) {
+        int best_sum = 1 << 30;
+        if (!search(n, depth, 0, pick, 0, 0, best, &best_sum)) continue;
+        // stable sort by the power of two dividing the radix
+        int ns = 0;
+        for (int pw = 1; pw <= 16; pw *= 2)
+            for (int i = depth - 1; i >= 0; --i)
+                if ((best[i] & -best[i]) == pw) radix[ns++] = best[i];
+        return ns;
     }
-    if (n & (n - 1)) return 0;             // what is left must be a power of two
-    int tail[kMaxStages], nt = 0;
-    while (n > 1) {
-        const int r = n % 16 == 0 ? 16 : n % 8 == 0 ? 8 : n % 4 == 0 ? 4 : 2;
-        if (ns + nt >= kMaxStages) return 0;
-        tail[nt++] = r;
-        n /= r;
-    }
-    for (int i = nt - 1; i >= 0; --i) radix[ns++] = tail[i];   // smallest power of two first, the largest last
-    return ns;
+    return 0;
 }
 
 constexpr int kTilePoints32 = 4096, kTilePoints64 = 2048, kThreads = 256;
@@ -257,7 +341,6 @@ extern "C" int mifft_mixed_launch(int f64, int n, long long rows, long long stri
     a.n = n; a.inverse = (flags & 3) == 3; a.scale = scale;
     a.conj_in = flags & 1; a.conj_out = (flags >> 1) & 1;
     a.inner = inner < 1 ? 1 : inner;
-    a.inv_n = 1.0f / (float)n;
     for (int i = 0, nsx = 1; i < a.nstages; ++i) {
         a.inv_per_row[i] = 1.0f / (float)(n / a.radix[i]);
         a.inv_ns[i] = 1.0f / (float)nsx;
@@ -279,7 +362,10 @@ extern "C" int mifft_mixed_launch(int f64, int n, long long rows, long long stri
     if (blocks <= 0) return 0;
     if (blocks > 2147483647ll) return -1;
     const size_t lds_bytes = 2 * (size_t)W * n * (f64 ? 16 : 8);
-    if (f64) hipLaunchKernelGGL((fft_mixed_kernel<double, kThreads>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, a);
-    else hipLaunchKernelGGL((fft_mixed_kernel<float, kThreads>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, a);
+    const bool lines = a.inner > 1;
+    if (f64 && lines) hipLaunchKernelGGL((fft_mixed_kernel<double, kThreads, true>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, a);
+    else if (f64) hipLaunchKernelGGL((fft_mixed_kernel<double, kThreads, false>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, a);
+    else if (lines) hipLaunchKernelGGL((fft_mixed_kernel<float, kThreads, true>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, a);
+    else hipLaunchKernelGGL((fft_mixed_kernel<float, kThreads, false>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, a);
     return (int)hipGetLastError();
 }

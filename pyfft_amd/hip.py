@@ -402,6 +402,14 @@ def Plan(*args, **kwds):
     parent_shape = kwds.pop('parent_shape', None)
     any_size = bool(kwds.pop('any_size', False))
     generic = parent_shape is not None or any_size
+    if generic and parent_shape is None:
+        # any_size=True on a power-of-two shape: the dense plan itself (no work array, no gather / scatter)
+        shape = args[0] if args else kwds.get('shape')
+        try:
+            dims = tuple(int(v) for v in ((shape,) if isinstance(shape, (int, numpy.integer)) else shape))
+            generic = not (len(dims) in (1, 2, 3) and all(v >= 1 and (v & (v - 1)) == 0 for v in dims))
+        except TypeError:
+            pass
 
     # argument errors first (ValueError, as in the reference), then the device
     if not generic:
