@@ -235,8 +235,8 @@ __device__ __forceinline__ void stage_switch(int R, Args&&... args) {
 
 // Two LDS buffers of W * n points: a stage reads one and writes the other (one barrier per stage); the first stage reads HBM and the
 // last one writes it (N = 1000 fp32: 32.5 % of the roofline through staging copies, 49.4 % with these register edges).
-template <typename T, int NT, bool LINES>
-__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) fft_mixed_kernel(const MixedArgs a) {
+template <typename T, int NT, bool LINES, int OCC>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) fft_mixed_kernel(const MixedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cplx<T>* lds = reinterpret_cast<cplx<T>*>(smem);
     const cplx<T>* tw = reinterpret_cast<const cplx<T>*>(a.tw);
@@ -319,6 +319,12 @@ int factor(int n, int* radix) {
     return 0;
 }
 
+#ifndef OCC32
+#define OCC32 4
+#endif
+#ifndef OCC64
+#define OCC64 4
+#endif
 constexpr int kTilePoints32 = 4096, kTilePoints64 = 2048, kThreads = 256;
 
 }  // namespace
@@ -363,9 +369,9 @@ extern "C" int mifft_mixed_launch(int f64, int n, long long rows, long long stri
     if (blocks > 2147483647ll) return -1;
     const size_t lds_bytes = 2 * (size_t)W * n * (f64 ? 16 : 8);
     const bool lines = a.inner > 1;
-    if (f64 && lines) hipLaunchKernelGGL((fft_mixed_kernel<double, kThreads, true>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, a);
-    else if (f64) hipLaunchKernelGGL((fft_mixed_kernel<double, kThreads, false>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, a);
-    else if (lines) hipLaunchKernelGGL((fft_mixed_kernel<float, kThreads, true>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, a);
-    else hipLaunchKernelGGL((fft_mixed_kernel<float, kThreads, false>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, a);
+    if (f64 && lines) hipLaunchKernelGGL((fft_mixed_kernel<double, kThreads, true, OCC64>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, a);
+    else if (f64) hipLaunchKernelGGL((fft_mixed_kernel<double, kThreads, false, OCC64>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, a);
+    else if (lines) hipLaunchKernelGGL((fft_mixed_kernel<float, kThreads, true, OCC32>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, a);
+    else hipLaunchKernelGGL((fft_mixed_kernel<float, kThreads, false, OCC32>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, a);
     return (int)hipGetLastError();
 }

@@ -1,3 +1,5 @@
+"""Throughput of the mixed-radix kernel (csrc/fft_mixed.hip) through Plan(any_size=True): smooth lengths, both precisions, smooth
+N-D shapes (one launch per axis).  Development tool; columns as in generic_probe.py."""
 import sys; sys.path.insert(0,'.'); sys.path.insert(0,'tools')
 import numpy
 from generic_probe import run
