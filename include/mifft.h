@@ -354,6 +354,16 @@ int mifft_launch_mixed_rows(int32_t precision, int32_t n, int64_t rows, int64_t 
  * either end of its chain of launches).  In place or out of place. */
 int mifft_launch_mixed_lines(int32_t precision, int32_t n, int64_t outer, int64_t inner, const void *in, void *out, const void *tw,
                              int32_t conj_in, int32_t conj_out, double scale, mifft_stream_t stream);
+/* LONG smooth lengths, N = n1 * n2 beyond one tile, in two launches (four-step form without a separate transposition): lines of n1
+ * points n2 apart, stored as rows and multiplied by w(N)^(k1 * i2) into `mid`; then lines of n2 points n1 apart from `mid` to `out`
+ * in place order = natural order.  `mid` must not be `in`; it may be `out` (out-of-place transforms need no scratch).
+ *   mifft_mixed_long_split   0 and the factors (both with a mixed-radix kernel, as many adjacent lines per tile as possible) or
+ *                            MIFFT_E_UNSUPPORTED (N not smooth, N > 2^24, or no split with >= 8 (fp64: 4) lines per tile)
+ *   tables: tw1 / tw2 = w(n1)^m / w(n2)^m; w(N)^e = tw_lo[e & (2^tw_shift - 1)] * tw_hi[e >> tw_shift], e < N */
+int mifft_mixed_long_split(int32_t precision, int64_t n, int32_t *n1, int32_t *n2);
+int mifft_launch_mixed_long(int32_t precision, int32_t n1, int32_t n2, int64_t batch, const void *in, void *mid, void *out,
+                            const void *tw1, const void *tw2, const void *tw_lo, const void *tw_hi, int32_t tw_shift,
+                            int32_t inverse, double scale, mifft_stream_t stream);
 
 /* Same as mifft_launch_chain but brackets the chain with two events on `stream` and, after
  * synchronising, reports the elapsed device time of `repeats` back-to-back chains. (bench/test helper) */

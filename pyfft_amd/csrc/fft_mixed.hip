@@ -27,6 +27,9 @@ struct MixedArgs {
     const void* in;
     void* out;
     const void* tw;        // n entries w(n)^m
+    const void* tw_lo;     // long transforms (mode 2): w(N)^e = tw_lo[e & (2^tw_shift - 1)] * tw_hi[e >> tw_shift], N = n * inner
+    const void* tw_hi;
+    int tw_shift;
     long long rows, stride_in, stride_out;
     long long inner;       // 1: contiguous rows `stride` apart.  > 1: LINES of a strided axis -- line L = o * inner + j starts at element
                            // o * n * inner + j and its points are `inner` elements apart (stride_in / stride_out unused)
@@ -153,13 +156,14 @@ template <int R, typename T> __device__ __forceinline__ void dft_any(cplx<T>* v)
 // adjacent lines, so both sides are coalesced).  GIN / GOUT: `src` / `dst` is HBM (the first / last stage: consecutive butterflies
 // read consecutive points of every operand, and the last stage, Ns = n / R, writes consecutive points of every result), with the
 // conjugation of the inverse direction / the scale folded in.
-template <int R, typename T, bool GIN, bool GOUT, bool LINES, typename SI, typename DI>
+template <int R, typename T, bool GIN, bool GOUT, bool SL, bool DL, bool BIGTW, typename SI, typename DI>
 __device__ __forceinline__ void stage_butterfly(const cplx<T>* src, SI es_s, cplx<T>* dst, DI es_d, const cplx<T>* tw, int LR, int Ns,
-                                                float inv_ns, int jb, T csign, T sx, T sy) {
+                                                float inv_ns, int jb, T csign, T sx, T sy, const cplx<T>* twlo, const cplx<T>* twhi,
+                                                int tw_shift, unsigned line) {
     const int jm = jb - fast_div(jb, inv_ns) * Ns;
     cplx<T> v[R];
     static_for<R>([&](auto kk) {
-        if constexpr (LINES) v[kk] = src[(SI)(jb + kk * LR) * es_s];
+        if constexpr (SL) v[kk] = src[(SI)(jb + kk * LR) * es_s];
         else v[kk] = src[jb + kk * LR];
     });
     if constexpr (GIN) static_for<R>([&](auto kk) { v[kk].y *= csign; });
@@ -174,11 +178,15 @@ __device__ __forceinline__ void stage_butterfly(const cplx<T>* src, SI es_s, cpl
     const int q0 = (jb - jm) * R + jm;
     static_for<R>([&](auto kk) {
         cplx<T> p = v[kk];
+        if constexpr (BIGTW) {
+            const unsigned e = (unsigned)(q0 + kk * Ns) * line;           // < N <= 2^24
+            p = cmul<T>(p, cmul<T>(twlo[e & ((1u << tw_shift) - 1u)], twhi[e >> tw_shift]));
+        }
         if constexpr (GOUT) {
             p.x *= sx;
             p.y *= sy;
         }
-        if constexpr (LINES) dst[(DI)(q0 + kk * Ns) * es_d] = p;
+        if constexpr (DL) dst[(DI)(q0 + kk * Ns) * es_d] = p;
         else dst[q0 + kk * Ns] = p;
     });
 }
@@ -187,73 +195,91 @@ struct StageCtx {
     const void* gin;       // HBM: first transform of the tile (rows) / first line of the tile (lines)
     void* gout;
     long long stride_in, stride_out, inner;
-    int n, nrows;
+    const void* tw_lo;
+    const void* tw_hi;
+    int tw_shift, line0;   // mode 2: the tile's first line within its array
+    int n, nrows, es;      // es: LDS distance between a line's points (lines: the number of lines; mode 2: that made odd)
     float inv_rows;
 };
 
 // one whole stage of the tile: butterflies tid, tid + NT, ... (the radix is a compile-time constant INSIDE the loop, so the
-// compiler overlaps the operand loads of consecutive butterflies)
-template <int R, typename T, int NT, bool GIN, bool GOUT, bool LINES>
+// compiler overlaps the operand loads of consecutive butterflies).  MODE 0: rows.  1: lines.  2: lines in, ROWS out (the first
+// pass of a long transform N = n * inner: the W lines of a tile leave as W contiguous rows of n points, times w(N)^(q * line)):
+// every stage but the last is the lines form; the last one walks the tile row by row (consecutive lanes, consecutive q).
+template <int R, typename T, int NT, bool GIN, bool GOUT, int MODE>
 __device__ __forceinline__ void run_stage(const StageCtx& c, const cplx<T>* src, cplx<T>* dst, const cplx<T>* tw, int Ns, float ipr, float ins,
                                           T csign, T sx, T sy) {
+    constexpr bool LINES = MODE != 0;
+    constexpr bool XOUT = MODE == 2 && GOUT;             // rows out of a lines tile
     const int n = c.n, per_row = n / R, total = c.nrows * per_row;
     for (int j = threadIdx.x; j < total; j += NT) {
         int r, jb;
-        if constexpr (LINES) { jb = fast_div(j, c.inv_rows); r = j - jb * c.nrows; }
+        if constexpr (LINES && !XOUT) { jb = fast_div(j, c.inv_rows); r = j - jb * c.nrows; }
         else { r = fast_div(j, ipr); jb = j - r * per_row; }
         const cplx<T>* sr;
         cplx<T>* dr;
         if constexpr (GIN) sr = reinterpret_cast<const cplx<T>*>(c.gin) + (LINES ? (long long)r : r * c.stride_in);
         else sr = src + (LINES ? r : r * n);
-        if constexpr (GOUT) dr = reinterpret_cast<cplx<T>*>(c.gout) + (LINES ? (long long)r : r * c.stride_out);
+        if constexpr (XOUT) dr = reinterpret_cast<cplx<T>*>(c.gout) + (long long)r * n;
+        else if constexpr (GOUT) dr = reinterpret_cast<cplx<T>*>(c.gout) + (LINES ? (long long)r : r * c.stride_out);
         else dr = dst + (LINES ? r : r * n);
         using SI = typename std::conditional<GIN, long long, int>::type;
         using DI = typename std::conditional<GOUT, long long, int>::type;
-        stage_butterfly<R, T, GIN, GOUT, LINES, SI, DI>(sr, GIN ? (SI)c.inner : (SI)c.nrows, dr, GOUT ? (DI)c.inner : (DI)c.nrows, tw, per_row, Ns,
-                                                        ins, jb, csign, sx, sy);
+        stage_butterfly<R, T, GIN, GOUT, LINES, LINES && !XOUT, XOUT, SI, DI>(
+            sr, GIN ? (SI)c.inner : (SI)c.es, dr, GOUT ? (DI)c.inner : (DI)c.es, tw, per_row, Ns, ins, jb, csign, sx, sy,
+            reinterpret_cast<const cplx<T>*>(c.tw_lo), reinterpret_cast<const cplx<T>*>(c.tw_hi), c.tw_shift, (unsigned)(c.line0 + r));
     }
 }
 
-template <typename T, int NT, bool GIN, bool GOUT, bool LINES, typename... Args>
+template <typename T, int NT, bool GIN, bool GOUT, int MODE, typename... Args>
 __device__ __forceinline__ void stage_switch(int R, Args&&... args) {
     switch (R) {
-        case 2: run_stage<2, T, NT, GIN, GOUT, LINES>(args...); break;
-        case 3: run_stage<3, T, NT, GIN, GOUT, LINES>(args...); break;
-        case 4: run_stage<4, T, NT, GIN, GOUT, LINES>(args...); break;
-        case 5: run_stage<5, T, NT, GIN, GOUT, LINES>(args...); break;
-        case 6: run_stage<6, T, NT, GIN, GOUT, LINES>(args...); break;
-        case 7: run_stage<7, T, NT, GIN, GOUT, LINES>(args...); break;
-        case 8: run_stage<8, T, NT, GIN, GOUT, LINES>(args...); break;
-        case 9: run_stage<9, T, NT, GIN, GOUT, LINES>(args...); break;
-        case 10: run_stage<10, T, NT, GIN, GOUT, LINES>(args...); break;
-        case 12: run_stage<12, T, NT, GIN, GOUT, LINES>(args...); break;
-        case 14: run_stage<14, T, NT, GIN, GOUT, LINES>(args...); break;
-        case 15: run_stage<15, T, NT, GIN, GOUT, LINES>(args...); break;
-        default: run_stage<16, T, NT, GIN, GOUT, LINES>(args...); break;
+        case 2: run_stage<2, T, NT, GIN, GOUT, MODE>(args...); break;
+        case 3: run_stage<3, T, NT, GIN, GOUT, MODE>(args...); break;
+        case 4: run_stage<4, T, NT, GIN, GOUT, MODE>(args...); break;
+        case 5: run_stage<5, T, NT, GIN, GOUT, MODE>(args...); break;
+        case 6: run_stage<6, T, NT, GIN, GOUT, MODE>(args...); break;
+        case 7: run_stage<7, T, NT, GIN, GOUT, MODE>(args...); break;
+        case 8: run_stage<8, T, NT, GIN, GOUT, MODE>(args...); break;
+        case 9: run_stage<9, T, NT, GIN, GOUT, MODE>(args...); break;
+        case 10: run_stage<10, T, NT, GIN, GOUT, MODE>(args...); break;
+        case 12: run_stage<12, T, NT, GIN, GOUT, MODE>(args...); break;
+        case 14: run_stage<14, T, NT, GIN, GOUT, MODE>(args...); break;
+        case 15: run_stage<15, T, NT, GIN, GOUT, MODE>(args...); break;
+        default: run_stage<16, T, NT, GIN, GOUT, MODE>(args...); break;
     }
 }
 
 // Two LDS buffers of W * n points: a stage reads one and writes the other (one barrier per stage); the first stage reads HBM and the
 // last one writes it (N = 1000 fp32: 32.5 % of the roofline through staging copies, 49.4 % with these register edges).
-template <typename T, int NT, bool LINES, int OCC>
+template <typename T, int NT, int MODE, int OCC>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) fft_mixed_kernel(const MixedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cplx<T>* lds = reinterpret_cast<cplx<T>*>(smem);
     const cplx<T>* tw = reinterpret_cast<const cplx<T>*>(a.tw);
     const int n = a.n, W = a.W;
-    const int half = W * n;
     const long long row0 = (long long)blockIdx.x * W;
     StageCtx c;
     c.n = n;
     c.nrows = (int)((a.rows - row0) < W ? (a.rows - row0) : W);
     c.stride_in = a.stride_in; c.stride_out = a.stride_out; c.inner = a.inner;
     c.inv_rows = 1.0f / (float)c.nrows;
-    if constexpr (LINES) {
+    c.tw_lo = a.tw_lo; c.tw_hi = a.tw_hi; c.tw_shift = a.tw_shift; c.line0 = 0;
+    c.es = c.nrows;
+    int half = W * n;
+    if constexpr (MODE != 0) {
         // (the launcher makes W divide `inner`, so a tile never straddles two values of o; its W lines are adjacent in memory)
         const long long o = row0 / a.inner, j0 = row0 - o * a.inner;
         const long long line_base = o * (long long)n * a.inner + j0;
         c.gin = reinterpret_cast<const cplx<T>*>(a.in) + line_base;
-        c.gout = reinterpret_cast<cplx<T>*>(a.out) + line_base;
+        if constexpr (MODE == 2) {
+            c.gout = reinterpret_cast<cplx<T>*>(a.out) + (o * a.inner + j0) * (long long)n;     // line j0 + r -> row j0 + r of n points
+            c.line0 = (int)j0;
+            c.es = c.nrows | 1;        // the row-by-row walk of the last stage reads LDS `es` points apart: odd = conflict-free
+            half = (W | 1) * n;
+        } else {
+            c.gout = reinterpret_cast<cplx<T>*>(a.out) + line_base;
+        }
     } else {
         c.gin = reinterpret_cast<const cplx<T>*>(a.in) + row0 * a.stride_in;
         c.gout = reinterpret_cast<cplx<T>*>(a.out) + row0 * a.stride_out;
@@ -267,10 +293,10 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) 
         const cplx<T>* src = lds + cur * half;
         cplx<T>* dst = lds + (cur ^ 1) * half;
         const bool gin = s == 0, gout = s == a.nstages - 1;
-        if (gin && gout) stage_switch<T, NT, true, true, LINES>(R, c, src, dst, tw, Ns, ipr, ins, csign, sx, sy);
-        else if (gin) stage_switch<T, NT, true, false, LINES>(R, c, src, dst, tw, Ns, ipr, ins, csign, sx, sy);
-        else if (gout) stage_switch<T, NT, false, true, LINES>(R, c, src, dst, tw, Ns, ipr, ins, csign, sx, sy);
-        else stage_switch<T, NT, false, false, LINES>(R, c, src, dst, tw, Ns, ipr, ins, csign, sx, sy);
+        if (gin && gout) stage_switch<T, NT, true, true, MODE>(R, c, src, dst, tw, Ns, ipr, ins, csign, sx, sy);
+        else if (gin) stage_switch<T, NT, true, false, MODE>(R, c, src, dst, tw, Ns, ipr, ins, csign, sx, sy);
+        else if (gout) stage_switch<T, NT, false, true, MODE>(R, c, src, dst, tw, Ns, ipr, ins, csign, sx, sy);
+        else stage_switch<T, NT, false, false, MODE>(R, c, src, dst, tw, Ns, ipr, ins, csign, sx, sy);
         if (!gout) __syncthreads();
         Ns *= R;
         cur ^= 1;
@@ -336,13 +362,31 @@ extern "C" int mifft_mixed_supported_impl(int f64, int n) {
     return factor(n, radix) ? 0 : -2;
 }
 
-// flags: bit 0 conjugate on load, bit 1 conjugate on store (inverse transform = 3).  inner > 1: lines of a strided axis.
-extern "C" int mifft_mixed_launch(int f64, int n, long long rows, long long stride_in, long long stride_out, long long inner,
-                                  const void* in, void* out, const void* tw, int flags, double scale, hipStream_t s) {
+namespace {
+
+// lines per tile: the largest W <= cap / n that divides `inner` (a tile's W lines are adjacent and share one o); the full tile when
+// the half one holds fewer than 16 lines (a line's points are W * sizeof(complex) bytes of one memory segment)
+int lines_per_tile(int f64, int n, long long inner, bool odd_pad) {
+    const int full = f64 ? kTilePoints64 : kTilePoints32;
+    auto fit = [&](int cap) {
+        int W = cap / n;
+        if (odd_pad) while (W > 1 && (W | 1) * n > cap) --W;
+        if (W < 1) W = 1;
+        while (W > 1 && inner % W) --W;
+        return W;
+    };
+    const int wh = n <= full / 2 ? fit(full / 2) : 0;
+    return wh >= 16 ? wh : fit(full);
+}
+
+// mode 0: rows (inner == 1).  1: lines.  2: lines in, rows out, times w(n * inner)^(q * line) (tw_lo / tw_hi / tw_shift)
+int mixed_launch_impl(int f64, int n, long long rows, long long stride_in, long long stride_out, long long inner, const void* in, void* out,
+                      const void* tw, int flags, double scale, int mode, const void* tw_lo, const void* tw_hi, int tw_shift, hipStream_t s) {
     MixedArgs a;
     a.nstages = factor(n, a.radix);
     if (!a.nstages) return -2;
     a.in = in; a.out = out; a.tw = tw;
+    a.tw_lo = tw_lo; a.tw_hi = tw_hi; a.tw_shift = tw_shift;
     a.rows = rows; a.stride_in = stride_in; a.stride_out = stride_out;
     a.n = n; a.inverse = (flags & 3) == 3; a.scale = scale;
     a.conj_in = flags & 1; a.conj_out = (flags >> 1) & 1;
@@ -352,26 +396,75 @@ extern "C" int mifft_mixed_launch(int f64, int n, long long rows, long long stri
         a.inv_ns[i] = 1.0f / (float)nsx;
         nsx *= a.radix[i];
     }
-    // tiles of half the capacity (32 KiB of LDS, four work-groups per CU) whenever a row fits one: the kernel is latency-bound
-    // (two work-groups per CU: N = 1000 fp32 18.5 % of the roofline, four: 30.2 %)
-    const int full = f64 ? kTilePoints64 : kTilePoints32;
-    const int cap = full / (n <= full / 2 ? 2 : 1);          // (quarter tiles, eight work-groups per CU: 29.0 against 30.2 %)
-    int W = cap / n;
-    if (W < 1) W = 1;
-    if (W > rows) W = (int)rows;
-    if (a.inner > 1) {
-        // a tile's W lines are adjacent and share one o: the largest W <= cap / n that divides `inner`
-        while (W > 1 && a.inner % W) --W;
+    int W;
+    if (mode == 0) {
+        // tiles of half the capacity (32 KiB of LDS, four work-groups per CU) whenever a row fits one: the kernel is latency-bound
+        // (full tiles: N = 1000 fp32 39 % of the roofline, half: 49 %, quarter: 40 %)
+        const int full = f64 ? kTilePoints64 : kTilePoints32;
+        const int cap = full / (n <= full / 2 ? 2 : 1);
+        W = cap / n;
+        if (W < 1) W = 1;
+        if (W > rows) W = (int)rows;
+    } else {
+        W = lines_per_tile(f64, n, a.inner, mode == 2);
     }
     a.W = W;
     const long long blocks = (rows + W - 1) / W;
     if (blocks <= 0) return 0;
     if (blocks > 2147483647ll) return -1;
-    const size_t lds_bytes = 2 * (size_t)W * n * (f64 ? 16 : 8);
-    const bool lines = a.inner > 1;
-    if (f64 && lines) hipLaunchKernelGGL((fft_mixed_kernel<double, kThreads, true, OCC64>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, a);
-    else if (f64) hipLaunchKernelGGL((fft_mixed_kernel<double, kThreads, false, OCC64>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, a);
-    else if (lines) hipLaunchKernelGGL((fft_mixed_kernel<float, kThreads, true, OCC32>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, a);
-    else hipLaunchKernelGGL((fft_mixed_kernel<float, kThreads, false, OCC32>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, a);
+    const size_t lds_bytes = 2 * (size_t)(mode == 2 ? (W | 1) : W) * n * (f64 ? 16 : 8);
+    const dim3 g((unsigned)blocks), b(kThreads);
+    if (f64) {
+        if (mode == 2) hipLaunchKernelGGL((fft_mixed_kernel<double, kThreads, 2, OCC64>), g, b, lds_bytes, s, a);
+        else if (mode == 1) hipLaunchKernelGGL((fft_mixed_kernel<double, kThreads, 1, OCC64>), g, b, lds_bytes, s, a);
+        else hipLaunchKernelGGL((fft_mixed_kernel<double, kThreads, 0, OCC64>), g, b, lds_bytes, s, a);
+    } else {
+        if (mode == 2) hipLaunchKernelGGL((fft_mixed_kernel<float, kThreads, 2, OCC32>), g, b, lds_bytes, s, a);
+        else if (mode == 1) hipLaunchKernelGGL((fft_mixed_kernel<float, kThreads, 1, OCC32>), g, b, lds_bytes, s, a);
+        else hipLaunchKernelGGL((fft_mixed_kernel<float, kThreads, 0, OCC32>), g, b, lds_bytes, s, a);
+    }
     return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// flags: bit 0 conjugate on load, bit 1 conjugate on store (inverse transform = 3).  inner > 1: lines of a strided axis.
+extern "C" int mifft_mixed_launch(int f64, int n, long long rows, long long stride_in, long long stride_out, long long inner,
+                                  const void* in, void* out, const void* tw, int flags, double scale, hipStream_t s) {
+    return mixed_launch_impl(f64, n, rows, stride_in, stride_out, inner, in, out, tw, flags, scale, inner > 1 ? 1 : 0, nullptr, nullptr, 0, s);
+}
+
+// LONG smooth transforms, N = n1 * n2 beyond one tile, as two launches (four-step form, no separate transposition):
+//     x[i1 * n2 + i2]  --lines of n1 points, n2 apart; stored as ROWS, times w(N)^(k1 * i2)-->  t[i2 * n1 + k1]
+//                      --lines of n2 points, n1 apart, in place order-->                        X[k1 + n1 * k2]
+// The split: both factors fit a tile with as many adjacent lines as possible (the lines of a tile are what makes either pass
+// coalesced); 0 and the factors if both passes get >= 8 lines (fp64: 4) per tile, else unsupported.
+extern "C" int mifft_mixed_long_split_impl(int f64, long long n, int* n1, int* n2) {
+    const int full = f64 ? kTilePoints64 : kTilePoints32;
+    if (n < 4 || n > (1ll << 24)) return -2;
+    long long m = n;
+    for (int c : {2, 3, 5, 7}) while (m % c == 0) m /= c;
+    if (m != 1) return -2;
+    int best = 0, b1 = 0, b2 = 0;
+    for (long long d = 2; d <= full; ++d) {
+        if (n % d) continue;
+        const long long e = n / d;
+        if (e < 2 || e > full) continue;
+        const int wa = lines_per_tile(f64, (int)d, e, true), wb = lines_per_tile(f64, (int)e, d, false);
+        const int score = wa < wb ? wa : wb;
+        if (score > best) { best = score; b1 = (int)d; b2 = (int)e; }
+    }
+    if (best < (f64 ? 4 : 8)) return -2;
+    *n1 = b1; *n2 = b2;
+    return 0;
+}
+
+// `mid`: where the first pass leaves the transposed array -- `out` itself for an out-of-place transform (the second pass then runs in
+// place), a scratch array of the same size for an in-place one.
+extern "C" int mifft_mixed_long_launch(int f64, int n1, int n2, long long batch, const void* in, void* mid, void* out, const void* tw1,
+                                       const void* tw2, const void* tw_lo, const void* tw_hi, int tw_shift, int flags, double scale,
+                                       hipStream_t s) {
+    int rc = mixed_launch_impl(f64, n1, batch * n2, n1, n1, n2, in, mid, tw1, flags & 1, 1.0, 2, tw_lo, tw_hi, tw_shift, s);
+    if (rc) return rc;
+    return mixed_launch_impl(f64, n2, batch * n1, n2, n2, n1, mid, out, tw2, flags & 2, scale, 1, nullptr, nullptr, 0, s);
 }

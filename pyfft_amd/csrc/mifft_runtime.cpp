@@ -861,6 +861,31 @@ int mifft_launch_mixed_lines(int32_t precision, int32_t n, int64_t outer, int64_
     return 0;
 }
 
+int mifft_mixed_long_split(int32_t precision, int64_t n, int32_t* n1, int32_t* n2) {
+    if (precision != MIFFT_F32 && precision != MIFFT_F64) return MIFFT_E_UNSUPPORTED;
+    if (!n1 || !n2) return set_err(MIFFT_E_INVALID, "mixed long: null result pointer");
+    int a = 0, b = 0;
+    if (mifft_mixed_long_split_impl(precision == MIFFT_F64, n, &a, &b) != 0) return MIFFT_E_UNSUPPORTED;
+    *n1 = a; *n2 = b;
+    return 0;
+}
+
+int mifft_launch_mixed_long(int32_t precision, int32_t n1, int32_t n2, int64_t batch, const void* in, void* mid, void* out, const void* tw1,
+                            const void* tw2, const void* tw_lo, const void* tw_hi, int32_t tw_shift, int32_t inverse, double scale,
+                            mifft_stream_t stream) {
+    if (mifft_mixed_supported(precision, n1) != 0 || mifft_mixed_supported(precision, n2) != 0)
+        return set_err(MIFFT_E_UNSUPPORTED, "mixed long: no kernel for %d x %d", n1, n2);
+    if (!in || !mid || !out || !tw1 || !tw2 || !tw_lo || !tw_hi) return set_err(MIFFT_E_INVALID, "mixed long: null buffer");
+    if (mid == in) return set_err(MIFFT_E_INVALID, "mixed long: the first pass transposes, `mid` must not be the input");
+    if (batch < 0 || tw_shift < 1 || tw_shift > 23) return set_err(MIFFT_E_INVALID, "mixed long: bad batch / table shift");
+    if (batch == 0) return 0;
+    const int rc = mifft_mixed_long_launch(precision == MIFFT_F64, n1, n2, batch, in, mid, out, tw1, tw2, tw_lo, tw_hi, tw_shift,
+                                           inverse ? 3 : 0, scale, (hipStream_t)stream);
+    if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
+    if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
+    return 0;
+}
+
 int mifft_time_chain(const mifft_pass* passes, int32_t npasses, void* const bufs0[3], void* const bufs1[3], mifft_stream_t stream,
                      int32_t repeats, float* ms_total) {
     if (!ms_total || repeats < 1) return set_err(MIFFT_E_INVALID, "bad timing arguments");

@@ -144,6 +144,7 @@ class GenericFFTPlan(object):
                 self._tiled = True
         self._tables = []
         self._axes = []
+        self._direct_long = None
         for n in self._xyz:
             ax = _Axis()
             ax.n = n
@@ -157,6 +158,15 @@ class GenericFFTPlan(object):
                 ax.m, ax.plan, ax.chirp, ax.bhat = n, None, None, None
                 self._axes.append(ax)
                 continue
+            if not ax.pow2 and self._xyz[1] == 1 and self._xyz[2] == 1 and not self._split and self._ntiles == 1:
+                # 1-D smooth length beyond one tile: n = n1 * n2 in TWO mixed-radix launches (lines of n1 stored as rows and
+                # twiddled, then lines of n2: csrc/fft_mixed.hip, mifft_launch_mixed_long) instead of Bluestein
+                n1, n2 = ctypes.c_int32(0), ctypes.c_int32(0)
+                if N.lib.mifft_mixed_long_split(self._precision, n, ctypes.byref(n1), ctypes.byref(n2)) == 0:
+                    self._direct_long = self._long_tables(n, n1.value, n2.value)
+                    ax.m, ax.plan, ax.chirp, ax.bhat = n, None, None, None
+                    self._axes.append(ax)
+                    continue
             ax.m = n if ax.pow2 else 1 << int(numpy.ceil(numpy.log2(2 * n - 1)))
             ax.plan = self._rowplan(ax.m) if ax.m > 1 else None
             ax.chirp = ax.bhat = None
@@ -236,12 +246,25 @@ class GenericFFTPlan(object):
         work = (1, tx, tx * ty, tile, tile * cx, tile * cx * cy)
         return dims, user, work
 
+    def _long_tables(self, n, n1, n2):
+        """(n1, n2, w(n1)^m, w(n2)^m, lo, hi, shift) for mifft_launch_mixed_long: w(n)^e = lo[e & (2^shift - 1)] * hi[e >> shift],
+        every entry evaluated in float64."""
+        def roots(count, step, period):
+            k = numpy.arange(count, dtype=numpy.float64) * float(step)
+            ang = -2.0 * numpy.pi * numpy.fmod(k, float(period)) / float(period)
+            return self._upload((numpy.cos(ang) + 1j * numpy.sin(ang)).astype(self._cdtype))
+        shift = max(1, (int(n - 1).bit_length() + 1) // 2)
+        lo = roots(1 << shift, 1, n)
+        hi = roots(((n - 1) >> shift) + 1, 1 << shift, n)
+        return (n1, n2, roots(n1, 1, n1), roots(n2, 1, n2), lo, hi, shift)
+
     def _prepare(self, batch):
         if batch == self._last_batch:
             return
         self._last_batch = batch
-        if self._tiled or self._direct_mixed or self._direct_nd is not None:
-            return                      # no work arrays
+        if self._tiled or self._direct_mixed or self._direct_nd is not None or self._direct_long is not None:
+            self._work = None           # no work arrays (a long smooth transform in place allocates its scratch on demand)
+            return
         isz = self._cdtype.itemsize
         nt = batch * self._ntiles
         self._work = self._context.allocate(nt * self._size * isz)
@@ -275,6 +298,25 @@ class GenericFFTPlan(object):
                                                            factor if last else 1.0, ctx.stream_handle()), "mifft_launch_mixed_lines")
                     src = ptr(outs[0])
                 inner *= ax.n
+            wait = self._wait_for_finish if wait_for_finish is None else wait_for_finish
+            if wait:
+                self.finish()
+                return None
+            ctx.flush()
+            return ctx.getQueue()
+        if self._direct_long is not None:
+            n1, n2, tw1, tw2, lo, hi, shift = self._direct_long
+            n = n1 * n2
+            inv = bool(inverse)
+            factor = self._scale if not inv else 1.0 / ((n if self._normalize else 1.0) * self._scale)
+            src, dst = ptr(ins[0]), ptr(outs[0])
+            mid = dst
+            if src == dst:                  # in place: the transposing first pass needs somewhere else to write
+                if self._work is None:
+                    self._work = ctx.allocate(batch * n * self._cdtype.itemsize)
+                mid = ptr(self._work)
+            N.check(N.lib.mifft_launch_mixed_long(self._precision, n1, n2, batch, src, mid, dst, tw1, tw2, lo, hi, shift,
+                                                  1 if inv else 0, factor, ctx.stream_handle()), "mifft_launch_mixed_long")
             wait = self._wait_for_finish if wait_for_finish is None else wait_for_finish
             if wait:
                 self.finish()

@@ -285,6 +285,38 @@ def test_mixed_radix_is_what_smooth_any_size_plans_run(ctx):
     assert ctx.getPlan((1000,), dtype=numpy.complex64, any_size=True)._direct_mixed
 
 
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
+@pytest.mark.parametrize("n", [4800, 5000, 6000, 10000, 30000, 50000, 40960, 196608, 2100 * 3])
+def test_long_smooth_lengths_two_launches(ctx, n, dtype):
+    """Smooth lengths beyond one tile of the mixed-radix kernel: n = n1 * n2 in two launches (lines of n1 stored as rows and
+    twiddled, lines of n2), no Bluestein -- against numpy with the reference's thresholds, out of place (input untouched), in place
+    (bit-identical to out of place), the normalised inverse, a ragged batch; the scale."""
+    cd = numpy.dtype(dtype)
+    double = cd == numpy.complex128
+    eps, mx = (1e-11, 1e-10) if double else (1.1e-6, 1e-5)
+    if n <= (2048 if double else 4096):
+        pytest.skip("one tile")
+    plan = ctx.getPlan((n,), dtype=dtype, any_size=True, scale=3.0)
+    assert plan._direct_long is not None and plan._direct_long[0] * plan._direct_long[1] == n
+    batch = 7
+    rng = numpy.random.default_rng(n)
+    x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(cd)
+    ref = 3.0 * numpy.fft.fft(x.astype(numpy.complex128), axis=1)
+    a, b = ctx.toGpu(x), ctx.allocate(x.shape, cd)
+    plan.execute(a, b, batch=batch)
+    got = b.get()
+    assert numpy.abs(got - ref).sum() / numpy.abs(ref).sum() < eps
+    assert numpy.abs(got - ref).max() <= mx * numpy.abs(ref).max()
+    assert numpy.array_equal(a.get(), x) and plan._work is None
+    plan.execute(a, batch=batch)                                   # in place: through the scratch array
+    assert numpy.array_equal(a.get(), got) and plan._work is not None
+    plan.execute(a, batch=batch, inverse=True)
+    assert numpy.abs(a.get() - x).sum() / numpy.abs(x).sum() < 2 * eps
+    c = ctx.toGpu(x[:3])
+    plan.execute(c, batch=3)                                       # another batch: scratch re-sized on demand
+    assert numpy.array_equal(c.get(), got[:3])
+
+
 # ---- the sharded path with more than one rank --------------------------------------------------------------------------
 def test_two_ranks_share_one_gpu_sharded_path(tmp_path):
     """`bench.py --gpus 2` for real: two processes (one plan, stream and scratch each) on ONE device, gloo as the control

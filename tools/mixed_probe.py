@@ -7,3 +7,6 @@ for n in (1000, 100, 60, 360, 2000, 3000, 1024):
     run((n,), numpy.complex64, (1<<27)//n)
 run((1000,), numpy.complex128, 1<<16)
 run((100, 100), numpy.complex64, 8192); run((60, 60, 60), numpy.complex64, 512); run((100, 100), numpy.complex128, 4096)
+for n in (5000, 10000, 30000, 50000, 196608):
+    run((n,), numpy.complex64, (1 << 27) // n)
+run((30000,), numpy.complex128, 2048)
