@@ -416,6 +416,17 @@ def test_round3_entry_points_reject_bad_arguments_without_touching_the_gpu():
     assert N.lib.mifft_launch_mixed_rows(N.F32, 1023, 4, 1023, 1023, 16, 16, 16, 0, 1.0, None) == N.E_UNSUPPORTED
     assert N.lib.mifft_launch_mixed_rows(N.F32, 1000, 4, 999, 1000, 16, 16, 16, 0, 1.0, None) == N.E_INVALID     # stride < n
     assert N.lib.mifft_launch_mixed_lines(N.F32, 1000, 4, 0, 16, 16, 16, 0, 0, 1.0, None) == N.E_INVALID
+    # long smooth lengths: a split n1 * n2 whose factors both fit a tile with enough adjacent lines, or unsupported
+    n1, n2 = ctypes.c_int32(0), ctypes.c_int32(0)
+    for prec, n in ((N.F32, 30000), (N.F32, 5000), (N.F64, 30000), (N.F32, 196608), (N.F64, 3000)):
+        assert N.lib.mifft_mixed_long_split(prec, n, ctypes.byref(n1), ctypes.byref(n2)) == 0
+        assert n1.value * n2.value == n
+        assert N.lib.mifft_mixed_supported(prec, n1.value) == 0 and N.lib.mifft_mixed_supported(prec, n2.value) == 0
+    for n in (12289, 4098, 1000000, 3, 1 << 25):              # a large prime factor; no split with 8 lines per tile; tiny; beyond 2^24
+        assert N.lib.mifft_mixed_long_split(N.F32, n, ctypes.byref(n1), ctypes.byref(n2)) == N.E_UNSUPPORTED
+    assert N.lib.mifft_launch_mixed_long(N.F32, 120, 250, 4, 16, 16, 32, 16, 16, 16, 16, 8, 0, 1.0, None) == N.E_INVALID   # mid == in
+    assert N.lib.mifft_launch_mixed_long(N.F32, 121, 250, 4, 16, 32, 32, 16, 16, 16, 16, 8, 0, 1.0, None) == N.E_UNSUPPORTED
+    assert N.lib.mifft_launch_mixed_long(N.F32, 120, 250, 4, 16, 32, 32, 16, 16, 16, None, 8, 0, 1.0, None) == N.E_INVALID
     # the fp64 strided passes of 2048 points exist, the pair split answers per layout
     assert N.lib.mifft_pass_supported(N.PASS_COL, N.F64, 2048, 0) == 0
     assert N.lib.mifft_pair_split(N.F64, N.SPLIT, 256, 256, 256) == 64 and N.lib.mifft_pair_split(N.F32, N.INTERLEAVED, 128, 128, 128) == 32
