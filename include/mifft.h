@@ -364,6 +364,15 @@ int mifft_mixed_long_split(int32_t precision, int64_t n, int32_t *n1, int32_t *n
 int mifft_launch_mixed_long(int32_t precision, int32_t n1, int32_t n2, int64_t batch, const void *in, void *mid, void *out,
                             const void *tw1, const void *tw2, const void *tw_lo, const void *tw_hi, int32_t tw_shift,
                             int32_t inverse, double scale, mifft_stream_t stream);
+/* Bluestein's algorithm in ONE launch for rows of ANY length n whose padded length fits a tile (2 n - 1 <= 4096 fp32 / 2048 fp64):
+ * both m-point transforms of the convolution run inside LDS (csrc/fft_mixed.hip).
+ *   mifft_bluestein_padded   0 and the padded length m (smooth, >= 2 n - 1, the cheapest one) or MIFFT_E_UNSUPPORTED
+ *   tables: tw = w(m)^j (m entries); chirp c[j] = exp(-i pi j^2 / n) (n entries); bhat = FFT_m(b) / m with b[j] = conj(c[j]) for
+ *   j < n, b[m - j] = b[j], zero between (m entries).  out = scale * DFT(in) (inverse: conjugated in and out). */
+int mifft_bluestein_padded(int32_t precision, int32_t n, int32_t *m);
+int mifft_launch_bluestein_rows(int32_t precision, int32_t n, int32_t m, int64_t rows, int64_t stride_in, int64_t stride_out,
+                                const void *in, void *out, const void *tw, const void *chirp, const void *bhat, int32_t inverse,
+                                double scale, mifft_stream_t stream);
 
 /* Same as mifft_launch_chain but brackets the chain with two events on `stream` and, after
  * synchronising, reports the elapsed device time of `repeats` back-to-back chains. (bench/test helper) */

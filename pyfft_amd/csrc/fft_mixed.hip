@@ -428,6 +428,192 @@ int mixed_launch_impl(int f64, int n, long long rows, long long stride_in, long 
 
 }  // namespace
 
+// ---- Bluestein's algorithm in ONE launch -------------------------------------------------------------------------------------
+// Rows of ANY length n whose padded length m >= 2 n - 1 (smooth, chosen below) fits a tile: with the chirp c[j] = exp(-i pi j^2 / n)
+//     X[k] = c[k] * sum_j (x[j] c[j]) conj(c[k - j])  =  c[k] * IFFT_m( FFT_m(x c, zero-padded) * bhat )[k],   bhat = FFT_m(conj c, wrapped)
+// and both transforms of m points are the stage loop above inside LDS: the first stage of the first transform reads HBM (times the
+// chirp, zeros beyond n), its last stage multiplies by bhat / m and conjugates (the second transform is conj -> forward -> conj),
+// the last stage of the second one multiplies by the chirp and stores the n results.  One HBM round trip instead of the three
+// transforms and four streaming copies of pyfft_amd/generic.py.
+namespace {
+
+struct BlueArgs {
+    const void* in;
+    void* out;
+    const void* tw;        // m entries w(m)^j
+    const void* chirp;     // n entries
+    const void* bhat;      // m entries, already divided by m
+    long long rows, stride_in, stride_out;
+    int n, m, W, nstages;
+    int conj_in, conj_out;
+    int radix[kMaxStages];
+    float inv_per_row[kMaxStages], inv_ns[kMaxStages];
+    double scale;
+};
+
+// PHASE 0: HBM -> LDS (first transform, first stage).  1: LDS -> LDS.  2: LDS -> LDS, times bhat, conjugated (first transform, last
+// stage).  3: LDS -> HBM (second transform, last stage).
+template <int R, typename T, int NT, int PHASE>
+__device__ __forceinline__ void blue_stage(const BlueArgs& a, long long row0, int nrows, const cplx<T>* src, cplx<T>* dst, int Ns, float ipr,
+                                           float ins) {
+    const int n = a.n, m = a.m, LR = m / R, total = nrows * LR;
+    const cplx<T>* tw = reinterpret_cast<const cplx<T>*>(a.tw);
+    const cplx<T>* chirp = reinterpret_cast<const cplx<T>*>(a.chirp);
+    for (int j = threadIdx.x; j < total; j += NT) {
+        const int r = fast_div(j, ipr), jb = j - r * LR;
+        const int jm = jb - fast_div(jb, ins) * Ns;
+        cplx<T> v[R];
+        if constexpr (PHASE == 0) {
+            const cplx<T>* x = reinterpret_cast<const cplx<T>*>(a.in) + (row0 + r) * a.stride_in;
+            const T cs = a.conj_in ? (T)-1 : (T)1;
+            static_for<R>([&](auto kk) {
+                const int i = jb + kk * LR;
+                cplx<T> p = {(T)0, (T)0};
+                if (i < n) {
+                    p = x[i];
+                    p.y *= cs;
+                    p = cmul<T>(p, chirp[i]);
+                }
+                v[kk] = p;
+            });
+        } else {
+            static_for<R>([&](auto kk) { v[kk] = src[r * m + jb + kk * LR]; });
+        }
+        if (Ns > 1) {
+            const int step = jm * (LR / Ns);
+            static_for<R - 1>([&](auto kk) {
+                constexpr int k = kk + 1;
+                v[k] = cmul<T>(v[k], tw[k * step]);
+            });
+        }
+        dft_any<R, T>(v);
+        const int q0 = (jb - jm) * R + jm;
+        if constexpr (PHASE == 3) {
+            cplx<T>* y = reinterpret_cast<cplx<T>*>(a.out) + (row0 + r) * a.stride_out;
+            const T sx = (T)a.scale, sy = a.conj_out ? -sx : sx;
+            static_for<R>([&](auto kk) {
+                const int q = q0 + kk * Ns;
+                if (q < n) {
+                    cplx<T> p = v[kk];
+                    p.y = -p.y;
+                    p = cmul<T>(p, chirp[q]);
+                    p.x *= sx;
+                    p.y *= sy;
+                    y[q] = p;
+                }
+            });
+        } else {
+            static_for<R>([&](auto kk) {
+                const int q = q0 + kk * Ns;
+                cplx<T> p = v[kk];
+                if constexpr (PHASE == 2) {
+                    p = cmul<T>(p, reinterpret_cast<const cplx<T>*>(a.bhat)[q]);
+                    p.y = -p.y;
+                }
+                dst[r * m + q] = p;
+            });
+        }
+    }
+}
+
+template <typename T, int NT, int PHASE, typename... Args>
+__device__ __forceinline__ void blue_switch(int R, Args&&... args) {
+    switch (R) {
+        case 2: blue_stage<2, T, NT, PHASE>(args...); break;
+        case 3: blue_stage<3, T, NT, PHASE>(args...); break;
+        case 4: blue_stage<4, T, NT, PHASE>(args...); break;
+        case 5: blue_stage<5, T, NT, PHASE>(args...); break;
+        case 6: blue_stage<6, T, NT, PHASE>(args...); break;
+        case 7: blue_stage<7, T, NT, PHASE>(args...); break;
+        case 8: blue_stage<8, T, NT, PHASE>(args...); break;
+        case 9: blue_stage<9, T, NT, PHASE>(args...); break;
+        case 10: blue_stage<10, T, NT, PHASE>(args...); break;
+        case 12: blue_stage<12, T, NT, PHASE>(args...); break;
+        case 14: blue_stage<14, T, NT, PHASE>(args...); break;
+        case 15: blue_stage<15, T, NT, PHASE>(args...); break;
+        default: blue_stage<16, T, NT, PHASE>(args...); break;
+    }
+}
+
+template <typename T, int NT, int OCC>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) fft_bluestein_kernel(const BlueArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cplx<T>* lds = reinterpret_cast<cplx<T>*>(smem);
+    const int W = a.W, half = W * a.m, ns = a.nstages;
+    const long long row0 = (long long)blockIdx.x * W;
+    const int nrows = (int)((a.rows - row0) < W ? (a.rows - row0) : W);
+    int cur = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        int Ns = 1;
+        for (int s = 0; s < ns; ++s) {
+            const int R = a.radix[s];
+            const float ipr = a.inv_per_row[s], ins = a.inv_ns[s];
+            const cplx<T>* src = lds + cur * half;
+            cplx<T>* dst = lds + (cur ^ 1) * half;
+            const bool first = pass == 0 && s == 0, turn = pass == 0 && s == ns - 1, last = pass == 1 && s == ns - 1;
+            if (first) blue_switch<T, NT, 0>(R, a, row0, nrows, src, dst, Ns, ipr, ins);
+            else if (turn) blue_switch<T, NT, 2>(R, a, row0, nrows, src, dst, Ns, ipr, ins);
+            else if (last) blue_switch<T, NT, 3>(R, a, row0, nrows, src, dst, Ns, ipr, ins);
+            else blue_switch<T, NT, 1>(R, a, row0, nrows, src, dst, Ns, ipr, ins);
+            if (!last) __syncthreads();
+            Ns *= R;
+            cur ^= 1;
+        }
+    }
+}
+
+}  // namespace
+
+// padded length for rows of n points: the smooth m in [2 n - 1, tile] with the least m * stages, a power of two at a 12 % discount (at least two stages: the first
+// and the last stage of a transform are different code); 0 if none
+extern "C" int mifft_bluestein_padded_impl(int f64, int n) {
+    const int full = f64 ? kTilePoints64 : kTilePoints32;
+    if (n < 2 || 2 * (long long)n - 1 > full) return 0;
+    int radix[kMaxStages], best = 0;
+    double best_cost = 1e30;
+    const int lo = 2 * n - 1 < 4 ? 4 : 2 * n - 1;
+    for (int m = lo; m <= full; ++m) {
+        const int ns = factor(m, radix);
+        if (ns < 2) continue;
+        // (a power of two's radix-16 / 8 stages are cheaper per point than radix 15 / 14 / 9 ones: n = 1009 measured 9.3 % of the
+        // roofline padded to 2048 against 8.2 % padded to 2025; n = 513: 5.4 % padded to 2048, 8.2 % padded to 1050)
+        const double cost = (double)m * ns * ((m & (m - 1)) ? 1.0 : 0.88);
+        if (cost < best_cost) { best_cost = cost; best = m; }
+        if ((m & (m - 1)) == 0) break;           // nothing beyond the first power of two can be cheaper
+    }
+    return best;
+}
+
+extern "C" int mifft_bluestein_launch(int f64, int n, int m, long long rows, long long stride_in, long long stride_out, const void* in,
+                                      void* out, const void* tw, const void* chirp, const void* bhat, int flags, double scale, hipStream_t s) {
+    BlueArgs a;
+    a.nstages = factor(m, a.radix);
+    if (a.nstages < 2 || m < 2 * n - 1) return -2;
+    a.in = in; a.out = out; a.tw = tw; a.chirp = chirp; a.bhat = bhat;
+    a.rows = rows; a.stride_in = stride_in; a.stride_out = stride_out;
+    a.n = n; a.m = m; a.scale = scale;
+    a.conj_in = flags & 1; a.conj_out = (flags >> 1) & 1;
+    for (int i = 0, nsx = 1; i < a.nstages; ++i) {
+        a.inv_per_row[i] = 1.0f / (float)(m / a.radix[i]);
+        a.inv_ns[i] = 1.0f / (float)nsx;
+        nsx *= a.radix[i];
+    }
+    const int full = f64 ? kTilePoints64 : kTilePoints32;
+    if (m > full) return -2;
+    const int cap = full / (m <= full / 2 ? 2 : 1);
+    int W = cap / m;
+    if (W < 1) W = 1;
+    if (W > rows) W = (int)rows;
+    a.W = W;
+    const long long blocks = (rows + W - 1) / W;
+    if (blocks <= 0) return 0;
+    if (blocks > 2147483647ll) return -1;
+    const size_t lds_bytes = 2 * (size_t)W * m * (f64 ? 16 : 8);
+    if (f64) hipLaunchKernelGGL((fft_bluestein_kernel<double, kThreads, OCC64>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, a);
+    else hipLaunchKernelGGL((fft_bluestein_kernel<float, kThreads, OCC32>), dim3((unsigned)blocks), dim3(kThreads), lds_bytes, s, a);
+    return (int)hipGetLastError();
+}
+
 // flags: bit 0 conjugate on load, bit 1 conjugate on store (inverse transform = 3).  inner > 1: lines of a strided axis.
 extern "C" int mifft_mixed_launch(int f64, int n, long long rows, long long stride_in, long long stride_out, long long inner,
                                   const void* in, void* out, const void* tw, int flags, double scale, hipStream_t s) {

@@ -42,6 +42,9 @@ int mifft_mixed_launch(int f64, int n, long long rows, long long stride_in, long
 int mifft_mixed_long_split_impl(int f64, long long n, int* n1, int* n2);
 int mifft_mixed_long_launch(int f64, int n1, int n2, long long batch, const void* in, void* mid, void* out, const void* tw1, const void* tw2,
                             const void* tw_lo, const void* tw_hi, int tw_shift, int flags, double scale, hipStream_t s);
+int mifft_bluestein_padded_impl(int f64, int n);
+int mifft_bluestein_launch(int f64, int n, int m, long long rows, long long stride_in, long long stride_out, const void* in, void* out,
+                           const void* tw, const void* chirp, const void* bhat, int flags, double scale, hipStream_t s);
 int mifft_xcd2_f32_launch(const mifft::Xcd2Args* f, int split, int prefetch, int mode, unsigned grid, hipStream_t s);
 }
 

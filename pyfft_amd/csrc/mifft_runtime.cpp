@@ -886,6 +886,32 @@ int mifft_launch_mixed_long(int32_t precision, int32_t n1, int32_t n2, int64_t b
     return 0;
 }
 
+int mifft_bluestein_padded(int32_t precision, int32_t n, int32_t* m) {
+    if (precision != MIFFT_F32 && precision != MIFFT_F64) return MIFFT_E_UNSUPPORTED;
+    if (!m) return set_err(MIFFT_E_INVALID, "bluestein: null result pointer");
+    const int v = mifft_bluestein_padded_impl(precision == MIFFT_F64, n);
+    if (v <= 0) return MIFFT_E_UNSUPPORTED;
+    *m = v;
+    return 0;
+}
+
+int mifft_launch_bluestein_rows(int32_t precision, int32_t n, int32_t m, int64_t rows, int64_t stride_in, int64_t stride_out, const void* in,
+                                void* out, const void* tw, const void* chirp, const void* bhat, int32_t inverse, double scale,
+                                mifft_stream_t stream) {
+    if (precision != MIFFT_F32 && precision != MIFFT_F64) return MIFFT_E_UNSUPPORTED;
+    if (n < 2 || m < 2 * (int64_t)n - 1 || mifft_mixed_supported(precision, m) != 0)
+        return set_err(MIFFT_E_UNSUPPORTED, "bluestein rows: no kernel for n = %d padded to %d", n, m);
+    if (!in || !out || !tw || !chirp || !bhat) return set_err(MIFFT_E_INVALID, "bluestein rows: null buffer");
+    if (rows < 0 || stride_in < n || stride_out < n) return set_err(MIFFT_E_INVALID, "bluestein rows: bad row count / stride");
+    if (rows == 0) return 0;
+    const int rc = mifft_bluestein_launch(precision == MIFFT_F64, n, m, rows, stride_in, stride_out, in, out, tw, chirp, bhat,
+                                          inverse ? 3 : 0, scale, (hipStream_t)stream);
+    if (rc == -2) return set_err(MIFFT_E_UNSUPPORTED, "bluestein rows: no kernel for n = %d padded to %d", n, m);
+    if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
+    if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
+    return 0;
+}
+
 int mifft_time_chain(const mifft_pass* passes, int32_t npasses, void* const bufs0[3], void* const bufs1[3], mifft_stream_t stream,
                      int32_t repeats, float* ms_total) {
     if (!ms_total || repeats < 1) return set_err(MIFFT_E_INVALID, "bad timing arguments");

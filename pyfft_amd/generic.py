@@ -45,7 +45,7 @@ def _chirp(n, complex_dtype):
 
 
 class _Axis(object):
-    __slots__ = ("n", "m", "plan", "chirp", "bhat", "pow2", "mixed_tw")
+    __slots__ = ("n", "m", "plan", "chirp", "bhat", "pow2", "mixed_tw", "blue")
 
 
 class _SubContext(object):
@@ -150,6 +150,7 @@ class GenericFFTPlan(object):
             ax.n = n
             ax.pow2 = _is_pow2(n)
             ax.mixed_tw = None
+            ax.blue = None
             if not ax.pow2 and N.lib.mifft_mixed_supported(self._precision, n) == 0:
                 # smooth length (2^a 3^b 5^c 7^d): ONE mixed-radix launch on the dense rows instead of Bluestein's three transforms
                 k = numpy.arange(n, dtype=numpy.float64)
@@ -167,6 +168,22 @@ class GenericFFTPlan(object):
                     ax.m, ax.plan, ax.chirp, ax.bhat = n, None, None, None
                     self._axes.append(ax)
                     continue
+            mb = ctypes.c_int32(0)
+            if not ax.pow2 and N.lib.mifft_bluestein_padded(self._precision, n, ctypes.byref(mb)) == 0:
+                # any other length whose padded rows fit a tile: Bluestein's algorithm in ONE launch (both m-point transforms
+                # inside LDS, csrc/fft_mixed.hip) instead of three batched transforms and four streaming copies
+                m = mb.value
+                c = _chirp(n, self._cdtype)
+                b = numpy.zeros(m, numpy.complex128)
+                b[:n] = numpy.conj(c)
+                b[m - n + 1:] = numpy.conj(c[1:][::-1])
+                k = numpy.arange(m, dtype=numpy.float64)
+                ang = -2.0 * numpy.pi * k / float(m)
+                ax.blue = (m, self._upload((numpy.cos(ang) + 1j * numpy.sin(ang)).astype(self._cdtype)),
+                           self._upload(c.astype(self._cdtype)), self._upload((numpy.fft.fft(b) / m).astype(self._cdtype)))
+                ax.m, ax.plan, ax.chirp, ax.bhat = n, None, None, None
+                self._axes.append(ax)
+                continue
             ax.m = n if ax.pow2 else 1 << int(numpy.ceil(numpy.log2(2 * n - 1)))
             ax.plan = self._rowplan(ax.m) if ax.m > 1 else None
             ax.chirp = ax.bhat = None
@@ -182,6 +199,9 @@ class GenericFFTPlan(object):
         # (conjugation of the inverse direction and the scale included): one HBM round trip, no work array
         self._direct_mixed = (self._xyz[1] == 1 and self._xyz[2] == 1 and self._axes[0].mixed_tw is not None
                               and not self._split and self._ntiles == 1)
+        # ... and a 1-D length with the one-launch Bluestein kernel likewise
+        self._direct_blue = (self._xyz[1] == 1 and self._xyz[2] == 1 and self._axes[0].blue is not None
+                             and not self._split and self._ntiles == 1)
         # N-D, every axis a smooth length the mixed-radix kernel takes (powers of two included), at least one of them not a power of
         # two, interleaved, dense: ONE launch per axis straight on the user's buffers -- the x axis as rows from input to output,
         # the slower axes as lines of the output array in place (mifft_launch_mixed_lines); no gather, no scatter, no work array
@@ -262,7 +282,7 @@ class GenericFFTPlan(object):
         if batch == self._last_batch:
             return
         self._last_batch = batch
-        if self._tiled or self._direct_mixed or self._direct_nd is not None or self._direct_long is not None:
+        if self._tiled or self._direct_mixed or self._direct_blue or self._direct_nd is not None or self._direct_long is not None:
             self._work = None           # no work arrays (a long smooth transform in place allocates its scratch on demand)
             return
         isz = self._cdtype.itemsize
@@ -323,6 +343,19 @@ class GenericFFTPlan(object):
                 return None
             ctx.flush()
             return ctx.getQueue()
+        if self._direct_blue:
+            n = self._xyz[0]
+            m, tw, chirp, bhat = self._axes[0].blue
+            inv = bool(inverse)
+            factor = self._scale if not inv else 1.0 / ((n if self._normalize else 1.0) * self._scale)
+            N.check(N.lib.mifft_launch_bluestein_rows(self._precision, n, m, batch, n, n, ptr(ins[0]), ptr(outs[0]), tw, chirp, bhat,
+                                                      1 if inv else 0, factor, ctx.stream_handle()), "mifft_launch_bluestein_rows")
+            wait = self._wait_for_finish if wait_for_finish is None else wait_for_finish
+            if wait:
+                self.finish()
+                return None
+            ctx.flush()
+            return ctx.getQueue()
         if self._direct_mixed:
             n = self._xyz[0]
             inv = bool(inverse)
@@ -364,6 +397,16 @@ class GenericFFTPlan(object):
                         self._copy(lines, wstride, rstride, work, None, rows, None)
                         N.check(N.lib.mifft_launch_mixed_rows(self._precision, n, outer * inner, n, n, rows, rows, ax.mixed_tw, 0, 1.0,
                                                               ctx.stream_handle()), "mifft_launch_mixed_rows")
+                        self._copy(lines, rstride, wstride, rows, None, work, None)
+                elif ax.blue is not None:
+                    bm, btw, bchirp, bbhat = ax.blue
+                    if inner == 1:
+                        N.check(N.lib.mifft_launch_bluestein_rows(self._precision, n, bm, outer, n, n, work, work, btw, bchirp, bbhat, 0, 1.0,
+                                                                  ctx.stream_handle()), "mifft_launch_bluestein_rows")
+                    else:
+                        self._copy(lines, wstride, rstride, work, None, rows, None)
+                        N.check(N.lib.mifft_launch_bluestein_rows(self._precision, n, bm, outer * inner, n, n, rows, rows, btw, bchirp, bbhat,
+                                                                  0, 1.0, ctx.stream_handle()), "mifft_launch_bluestein_rows")
                         self._copy(lines, rstride, wstride, rows, None, work, None)
                 elif ax.pow2 and inner == 1:
                     ax.plan.execute(work, batch=outer, wait_for_finish=False)

@@ -427,6 +427,16 @@ def test_round3_entry_points_reject_bad_arguments_without_touching_the_gpu():
     assert N.lib.mifft_launch_mixed_long(N.F32, 120, 250, 4, 16, 16, 32, 16, 16, 16, 16, 8, 0, 1.0, None) == N.E_INVALID   # mid == in
     assert N.lib.mifft_launch_mixed_long(N.F32, 121, 250, 4, 16, 32, 32, 16, 16, 16, 16, 8, 0, 1.0, None) == N.E_UNSUPPORTED
     assert N.lib.mifft_launch_mixed_long(N.F32, 120, 250, 4, 16, 32, 32, 16, 16, 16, None, 8, 0, 1.0, None) == N.E_INVALID
+    # Bluestein in one launch: a smooth padded length >= 2 n - 1 inside one tile, or unsupported
+    m = ctypes.c_int32(0)
+    for prec, n in ((N.F32, 1009), (N.F32, 17), (N.F32, 2048), (N.F64, 1023), (N.F32, 2)):
+        assert N.lib.mifft_bluestein_padded(prec, n, ctypes.byref(m)) == 0
+        assert m.value >= 2 * n - 1 and N.lib.mifft_mixed_supported(prec, m.value) == 0
+    assert N.lib.mifft_bluestein_padded(N.F32, 2049, ctypes.byref(m)) == N.E_UNSUPPORTED
+    assert N.lib.mifft_bluestein_padded(N.F64, 1025, ctypes.byref(m)) == N.E_UNSUPPORTED
+    assert N.lib.mifft_launch_bluestein_rows(N.F32, 1009, 2000, 4, 1009, 1009, 16, 16, 16, 16, 16, 0, 1.0, None) == N.E_UNSUPPORTED  # m < 2n-1
+    assert N.lib.mifft_launch_bluestein_rows(N.F32, 1009, 2048, 4, 1000, 1009, 16, 16, 16, 16, 16, 0, 1.0, None) == N.E_INVALID      # stride < n
+    assert N.lib.mifft_launch_bluestein_rows(N.F32, 1009, 2048, 4, 1009, 1009, 16, 16, 16, None, 16, 0, 1.0, None) == N.E_INVALID
     # the fp64 strided passes of 2048 points exist, the pair split answers per layout
     assert N.lib.mifft_pass_supported(N.PASS_COL, N.F64, 2048, 0) == 0
     assert N.lib.mifft_pair_split(N.F64, N.SPLIT, 256, 256, 256) == 64 and N.lib.mifft_pair_split(N.F32, N.INTERLEAVED, 128, 128, 128) == 32

@@ -317,6 +317,57 @@ def test_long_smooth_lengths_two_launches(ctx, n, dtype):
     assert numpy.array_equal(c.get(), got[:3])
 
 
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
+@pytest.mark.parametrize("n", [2, 3, 11, 17, 97, 127, 513, 1009, 1023, 1100, 2039, 2048])
+def test_bluestein_in_one_launch(ctx, n, dtype):
+    """Rows of ANY length whose padded length fits a tile: Bluestein's algorithm in one launch (both m-point transforms in LDS).
+    The C entry point with padded row strides against numpy (reference thresholds), input untouched, in place, inverse; then the
+    any_size plan, which must take this path for a 1-D non-smooth length."""
+    import ctypes
+    from pyfft_amd import _native as N
+    from pyfft_amd.generic import _chirp
+    cd = numpy.dtype(dtype)
+    prec = N.F64 if cd == numpy.complex128 else N.F32
+    mm = ctypes.c_int32(0)
+    if N.lib.mifft_bluestein_padded(prec, n, ctypes.byref(mm)) != 0:
+        assert 2 * n - 1 > (2048 if prec == N.F64 else 4096)
+        return
+    m = mm.value
+    assert m >= 2 * n - 1 and N.lib.mifft_mixed_supported(prec, m) == 0
+    eps, mx = (1e-11, 1e-10) if prec == N.F64 else (1.1e-6, 1e-5)
+    rows, pad = 29, 3
+    rng = numpy.random.default_rng(n)
+    x = (rng.standard_normal((rows, n + pad)) + 1j * rng.standard_normal((rows, n + pad))).astype(cd)
+    c = _chirp(n, cd)
+    b = numpy.zeros(m, numpy.complex128)
+    b[:n] = numpy.conj(c)
+    b[m - n + 1:] = numpy.conj(c[1:][::-1])
+    tw = ctx.toGpu(numpy.exp(-2j * numpy.pi * numpy.arange(m) / m).astype(cd))
+    chirp, bhat = ctx.toGpu(c.astype(cd)), ctx.toGpu((numpy.fft.fft(b) / m).astype(cd))
+    a, o = ctx.toGpu(x), ctx.allocate((rows, n), cd)
+    N.check(N.lib.mifft_launch_bluestein_rows(prec, n, m, rows, n + pad, n, a.ptr, o.ptr, tw.ptr, chirp.ptr, bhat.ptr, 0, 2.0, None), "blue")
+    N.check(N.lib.mifft_device_sync(), "sync")
+    ref = 2.0 * numpy.fft.fft(x[:, :n].astype(numpy.complex128), axis=1)
+    got = o.get()
+    assert numpy.abs(got - ref).sum() / numpy.abs(ref).sum() < eps
+    assert numpy.abs(got - ref).max() <= mx * numpy.abs(ref).max()
+    assert numpy.array_equal(a.get(), x)
+    N.check(N.lib.mifft_launch_bluestein_rows(prec, n, m, rows, n, n, o.ptr, o.ptr, tw.ptr, chirp.ptr, bhat.ptr, 1, 0.5 / n, None), "blue")
+    N.check(N.lib.mifft_device_sync(), "sync")
+    assert numpy.abs(o.get() - x[:, :n]).sum() / numpy.abs(x[:, :n]).sum() < 2 * eps
+    smooth = N.lib.mifft_mixed_supported(prec, n) == 0
+    if not smooth:
+        plan = ctx.getPlan((n,), dtype=dtype, any_size=True)
+        assert plan._direct_blue and plan._axes[0].blue[0] == m
+        y = numpy.ascontiguousarray(x[:, :n])
+        d = ctx.toGpu(y)
+        plan.execute(d, batch=rows)
+        assert numpy.abs(d.get() - ref / 2.0).sum() / numpy.abs(ref).sum() * 2.0 < eps
+        plan.execute(d, batch=rows, inverse=True)
+        assert numpy.abs(d.get() - y).sum() / numpy.abs(y).sum() < 2 * eps
+        assert plan._work is None
+
+
 # ---- the sharded path with more than one rank --------------------------------------------------------------------------
 def test_two_ranks_share_one_gpu_sharded_path(tmp_path):
     """`bench.py --gpus 2` for real: two processes (one plan, stream and scratch each) on ONE device, gloo as the control

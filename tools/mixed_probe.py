@@ -10,3 +10,6 @@ run((100, 100), numpy.complex64, 8192); run((60, 60, 60), numpy.complex64, 512);
 for n in (5000, 10000, 30000, 50000, 196608):
     run((n,), numpy.complex64, (1 << 27) // n)
 run((30000,), numpy.complex128, 2048)
+for n in (1009, 127, 17, 2039, 513):
+    run((n,), numpy.complex64, (1 << 27) // n)
+run((1009,), numpy.complex128, 1 << 16); run((1009, 64), numpy.complex64, 2048); run((4099,), numpy.complex64, 1 << 15)
