@@ -71,6 +71,11 @@ extern "C" {
    buffer `src` of this pass and writes the buffer `dst` of the next one; the chain launchers skip the second descriptor.
    Only set where mifft_pass_pair_supported() says so. */
 #define MIFFT_FLAG_PAIR_WITH_NEXT 16
+/* small launches: store the destination WRITE-THROUGH.  A kernel's plain stores stay dirty in the eight L2s (32 MiB) until the
+   end-of-kernel write-back, which runs alone: ~4 us behind a launch whose whole output fits the L2s -- a third of a 32 MiB
+   launch (profiles/r03_l_small_launch_write_through.log).  Set by the planner for launches of <= 128 MiB; kernels without a
+   write-through form ignore it.  Results are unaffected. */
+#define MIFFT_FLAG_WRITE_THROUGH 32
 
 /* pass kinds */
 #define MIFFT_PASS_COL 0  /* strided pass: [outer][L][M*S] -> [outer][M][L][S]  (kernel.mako:805-1047) */

@@ -24,6 +24,7 @@ VARIANT_INTERLEAVED_ONLY = 2
 PASS_COL, PASS_ROW, PASS_ND = 0, 1, 2
 FLAG_SRC_INTERLEAVED, FLAG_DST_INTERLEAVED = 1, 2
 FLAG_STREAM_SRC, FLAG_STREAM_DST = 4, 8
+FLAG_WRITE_THROUGH = 32
 FLAG_PAIR_WITH_NEXT = 16
 XCD2_SCRATCH_BYTES = 8 * 64 * 16 * 256 * 8
 XCD2_CONTROL_BYTES = (64 + 2 * 512 * 32) * 4

@@ -28,13 +28,14 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 // written to the fabric at once and not kept in the XCD's L2.  For STREAMED output (nobody on this XCD re-reads it) a copy kernel
 // measured 6.1 TB/s with these stores against 5.6 TB/s with non-temporal and 5.3 TB/s with plain ones
 // (profiles/r03_a_l2_resident_probe.log).  HIP has no builtin for a 16-byte agent-scope store, so the encoding is spelled out; the
-// s_nop is the wait state gfx9 needs between a store of more than 64 bits and a VALU write of its data registers (the compiler's
-// hazard recogniser does not look inside inline assembly).
+// s_nop 1 = the TWO wait states gfx940+ needs between a store of more than 64 bits and a VALU write of its data registers (the
+// compiler's hazard recogniser does not look inside inline assembly; with one wait state the nd2 fp64 inverse kernels stored a
+// later value in a few lanes).
 template <typename T> __device__ __forceinline__ void store_wt(char* sbase, unsigned voff, cplx<T> r) {
     if constexpr (sizeof(cplx<T>) == 16) {
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
         const u4 v = __builtin_bit_cast(u4, r);
-        asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 0" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
     } else {
         typedef unsigned u2 __attribute__((ext_vector_type(2)));
         const u2 v = __builtin_bit_cast(u2, r);
@@ -47,11 +48,30 @@ template <typename T> __device__ __forceinline__ void store_wt_ptr(void* p, cplx
     if constexpr (sizeof(cplx<T>) == 16) {
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
         const u4 v = __builtin_bit_cast(u4, r);
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
     } else {
         typedef unsigned u2 __attribute__((ext_vector_type(2)));
         const u2 v = __builtin_bit_cast(u2, r);
         asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    }
+}
+
+// ... and of any 8 / 16 / 32-byte vector at a per-lane address (the small-launch store policy, MIFFT_FLAG_WRITE_THROUGH)
+template <typename VT> __device__ __forceinline__ void store_vec_wt(VT* p, const VT& w) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    if constexpr (sizeof(VT) == 8) {
+        const u2 v = __builtin_bit_cast(u2, w);
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    } else if constexpr (sizeof(VT) == 16) {
+        const u4 v = __builtin_bit_cast(u4, w);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    } else {
+        static_assert(sizeof(VT) == 32, "8, 16 or 32 bytes");
+        struct Halves { u4 lo, hi; };
+        const Halves h = __builtin_bit_cast(Halves, w);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(h.lo) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off offset:16 sc1\n\ts_nop 1" ::"v"(p), "v"(h.hi) : "memory");
     }
 }
 

@@ -304,9 +304,11 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
             if constexpr (!SPLIT_OUT) {
                 char* p = reinterpret_cast<char*>(reinterpret_cast<cplx<T>*>(a.out0) + gu);
                 if constexpr (WT) {
-                    static_assert(!WT || sizeof(cplx<T>) == 8, "write-through path is fp32 interleaved only");
-                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p + ovoff * (unsigned)sizeof(cplx<T>)),
-                                       __builtin_bit_cast(unsigned long long, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if constexpr (sizeof(cplx<T>) == 8)
+                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(p + ovoff * (unsigned)sizeof(cplx<T>)),
+                                           __builtin_bit_cast(unsigned long long, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        store_wt<T>(p, ovoff * (unsigned)sizeof(cplx<T>), r);
                 } else if constexpr (NTOUT) {
                     __builtin_nontemporal_store(r, reinterpret_cast<cplx<T>*>(p + ovoff * (unsigned)sizeof(cplx<T>)));
                 } else {
@@ -332,11 +334,14 @@ __global__ void __launch_bounds__(256, 2) fft_col2_kernel(const TileArgs a) {
     const long long rem0 = col0 & ((1ll << a.logMS) - 1);
     // streaming hints (MIFFT_FLAG_STREAM_*): a transposing pass is the first pass of a plan (its input is read once), a
     // plain one the last pass of an axis (when it is the plan's last, nobody re-reads its output)
+    // (MIFFT_FLAG_WRITE_THROUGH, small launches: write-through stores whatever the other hints say)
     if constexpr (TR && !SPLIT) {
-        if (a.nt & 1) col2_tile<T, A, TR, TW, SPLIT, false, true, false, SPLIT_OUT>(a, o, o, rem0, lds);
+        if (a.nt & 4) col2_tile<T, A, TR, TW, SPLIT, true, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
+        else if (a.nt & 1) col2_tile<T, A, TR, TW, SPLIT, false, true, false, SPLIT_OUT>(a, o, o, rem0, lds);
         else col2_tile<T, A, TR, TW, SPLIT, false, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
     } else if constexpr (!TR && !SPLIT_OUT) {
-        if (a.nt & 2) col2_tile<T, A, TR, TW, SPLIT, false, false, true, SPLIT_OUT>(a, o, o, rem0, lds);
+        if (a.nt & 4) col2_tile<T, A, TR, TW, SPLIT, true, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
+        else if (a.nt & 2) col2_tile<T, A, TR, TW, SPLIT, false, false, true, SPLIT_OUT>(a, o, o, rem0, lds);
         else col2_tile<T, A, TR, TW, SPLIT, false, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
     } else {
         col2_tile<T, A, TR, TW, SPLIT, false, false, false, SPLIT_OUT>(a, o, o, rem0, lds);

@@ -71,7 +71,7 @@ template <typename T, bool TR> struct Col3Lds {
 __device__ __forceinline__ void col3_store_wt16(void* p, const cplx<double>& r) {
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     const u4 v = __builtin_bit_cast(u4, r);
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 // WT: write the result with write-through (agent-coherent) stores: the intermediate of the fused two-pass kernel (interleaved)
@@ -284,10 +284,12 @@ __global__ void __launch_bounds__(512, 2) fft_col3_kernel(const TileArgs a) {
     const long long o = col0 >> a.logMS;
     const long long rem0 = col0 & ((1ll << a.logMS) - 1);
     if constexpr (TR && !SPLIT) {
-        if (a.nt & 1) col3_tile<T, A, TR, TW, SPLIT, true, false, SPLIT_OUT>(a, o, o, rem0, lds);
+        if (a.nt & 4) col3_tile<T, A, TR, TW, SPLIT, false, false, SPLIT_OUT, true>(a, o, o, rem0, lds);
+        else if (a.nt & 1) col3_tile<T, A, TR, TW, SPLIT, true, false, SPLIT_OUT>(a, o, o, rem0, lds);
         else col3_tile<T, A, TR, TW, SPLIT, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
     } else if constexpr (!TR && !SPLIT_OUT) {
-        if (a.nt & 2) col3_tile<T, A, TR, TW, SPLIT, false, true, SPLIT_OUT>(a, o, o, rem0, lds);
+        if (a.nt & 4) col3_tile<T, A, TR, TW, SPLIT, false, false, SPLIT_OUT, true>(a, o, o, rem0, lds);
+        else if (a.nt & 2) col3_tile<T, A, TR, TW, SPLIT, false, true, SPLIT_OUT>(a, o, o, rem0, lds);
         else col3_tile<T, A, TR, TW, SPLIT, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
     } else {
         col3_tile<T, A, TR, TW, SPLIT, false, false, SPLIT_OUT>(a, o, o, rem0, lds);

@@ -66,11 +66,12 @@ __global__ void __launch_bounds__(256) fft_colr_kernel(const TileArgs a) {
                 w[2 * j + 1] = v[j][q].y * sy;
             });
             VT* p = reinterpret_cast<VT*>(out + ((long long)q << logS));
-            if constexpr (decltype(ntc)::value != 0) __builtin_nontemporal_store(w, p);
+            if constexpr (decltype(ntc)::value == 2) store_vec_wt(p, w);
+            else if constexpr (decltype(ntc)::value == 1) __builtin_nontemporal_store(w, p);
             else *p = w;
         });
     };
-    if (a.nt & 2) stores(IC<1>{}); else stores(IC<0>{});
+    if (a.nt & 4) stores(IC<2>{}); else if (a.nt & 2) stores(IC<1>{}); else stores(IC<0>{});
 }
 
 template <typename T, int L, int V> static inline int launch_colr(const TileArgs* a, hipStream_t s) {

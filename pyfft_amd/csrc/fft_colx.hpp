@@ -96,6 +96,7 @@ __device__ __forceinline__ void colx_tile(const TileArgs& a, const long long o_i
     };
     auto sink = [&](auto stc, const cplx<T>* vv) __attribute__((always_inline)) {
         if constexpr (WT) stores(stc, IC<2>{}, vv);
+        else if (nt & 4) stores(stc, IC<2>{}, vv);
         else if (nt & 2) stores(stc, IC<1>{}, vv);
         else stores(stc, IC<0>{}, vv);
     };

@@ -60,20 +60,27 @@ template <typename T, bool NT = false> __device__ __forceinline__ void load_pair
     }
 }
 
-template <typename T, bool NT = false> __device__ __forceinline__ void store_pair(const TileArgs& a, long long g, cplx<T> p0,
-                                                                                  cplx<T> p1) {
+// NT: 0 plain, 1 non-temporal (interleaved side only), 2 write-through
+template <typename T, int NT = 0> __device__ __forceinline__ void store_pair(const TileArgs& a, long long g, cplx<T> p0,
+                                                                                 cplx<T> p1) {
     using V4 = T __attribute__((ext_vector_type(4)));
     if (!a.split_out) {
         V4 t;
         t.x = p0.x; t.y = p0.y; t.z = p1.x; t.w = p1.y;
         V4* q = reinterpret_cast<V4*>(reinterpret_cast<cplx<T>*>(a.out0) + g);
-        if constexpr (NT) __builtin_nontemporal_store(t, q);
+        if constexpr (NT == 2) store_vec_wt(q, t);
+        else if constexpr (NT == 1) __builtin_nontemporal_store(t, q);
         else *q = t;
     } else {
         cplx<T> re, im;
         re.x = p0.x; re.y = p1.x; im.x = p0.y; im.y = p1.y;
-        *reinterpret_cast<cplx<T>*>(reinterpret_cast<T*>(a.out0) + g) = re;
-        *reinterpret_cast<cplx<T>*>(reinterpret_cast<T*>(a.out1) + g) = im;
+        if constexpr (NT == 2) {
+            store_vec_wt(reinterpret_cast<cplx<T>*>(reinterpret_cast<T*>(a.out0) + g), re);
+            store_vec_wt(reinterpret_cast<cplx<T>*>(reinterpret_cast<T*>(a.out1) + g), im);
+        } else {
+            *reinterpret_cast<cplx<T>*>(reinterpret_cast<T*>(a.out0) + g) = re;
+            *reinterpret_cast<cplx<T>*>(reinterpret_cast<T*>(a.out1) + g) = im;
+        }
     }
 }
 
@@ -90,7 +97,7 @@ template <typename T, int V, bool NT = false> __device__ __forceinline__ void lo
         p[2].x = re.z; p[2].y = im.z; p[3].x = re.w; p[3].y = im.w;
     }
 }
-template <typename T, int V, bool NT = false> __device__ __forceinline__ void store_vec(const TileArgs& a, long long g, const cplx<T>* p) {
+template <typename T, int V, int NT = 0> __device__ __forceinline__ void store_vec(const TileArgs& a, long long g, const cplx<T>* p) {
     if constexpr (V == 2) {
         store_pair<T, NT>(a, g, p[0], p[1]);
     } else {
@@ -302,7 +309,7 @@ __global__ void __launch_bounds__(NT) fft_tile_kernel(const TileArgs a) {
     const T sy = a.inverse ? -sx : sx;
     auto store_phase = [&](auto vv, auto ntc) {
         constexpr int V = vv;
-        constexpr bool NTS = (int)ntc != 0;
+        constexpr int NTS = (int)ntc;
         static_for<PPT / V>([&](auto ii) {
             constexpr int it = ii;
             const int e = (it * NT + tid) * V;
@@ -339,10 +346,12 @@ __global__ void __launch_bounds__(NT) fft_tile_kernel(const TileArgs a) {
     };
     if constexpr (kQuadShape) {
         if (quad_out) store_phase(IC<4>{}, IC<0>{});
+        else if (a.nt & 4) store_phase(IC<2>{}, IC<2>{});
         else if (a.nt & 2) store_phase(IC<2>{}, IC<1>{});
         else store_phase(IC<2>{}, IC<0>{});
     } else {
-        if (a.nt & 2) store_phase(IC<2>{}, IC<1>{});
+        if (a.nt & 4) store_phase(IC<2>{}, IC<2>{});
+        else if (a.nt & 2) store_phase(IC<2>{}, IC<1>{});
         else store_phase(IC<2>{}, IC<0>{});
     }
 }

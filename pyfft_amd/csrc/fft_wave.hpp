@@ -138,7 +138,8 @@ __global__ void __launch_bounds__(256) fft_wave_kernel(const WaveArgs a) {
                 constexpr int j = jj;
                 const long long p = (ch + u) * (64 * G) + lane + j * 64;
                 if (p < a.pieces) {
-                    if (a.nt & 2) __builtin_nontemporal_store(w[u][j], dst + p);
+                    if (a.nt & 4) store_vec_wt(dst + p, w[u][j]);
+                    else if (a.nt & 2) __builtin_nontemporal_store(w[u][j], dst + p);
                     else dst[p] = w[u][j];
                 }
             });
@@ -217,7 +218,8 @@ __global__ void __launch_bounds__(256) fft_wave_16x16_kernel(const WaveArgs a) {
         static_for<16>([&](auto jj) {
             constexpr int j = jj;
             if (live) {
-                if (a.nt & 2) __builtin_nontemporal_store(w[j], dst + p0 + j * 8);
+                if (a.nt & 4) store_vec_wt(dst + p0 + j * 8, w[j]);
+                else if (a.nt & 2) __builtin_nontemporal_store(w[j], dst + p0 + j * 8);
                 else dst[p0 + j * 8] = w[j];
             }
         });

@@ -75,6 +75,7 @@ int validate(const mifft_pass* p) {
 // (development switch MIFFT_DEBUG_STORE overrides the store side for A/B measurements)
 int stream_policy(int flags) {
     int nt = ((flags & MIFFT_FLAG_STREAM_SRC) ? 1 : 0) | ((flags & MIFFT_FLAG_STREAM_DST) ? 2 : 0);
+    if (flags & MIFFT_FLAG_WRITE_THROUGH) nt = (nt & 1) | 4;
     if (g_debug[MIFFT_DEBUG_STORE] == 1) nt = (nt & 1) | 2;
     else if (g_debug[MIFFT_DEBUG_STORE] == 2) nt = (nt & 1) | 4;
     else if (g_debug[MIFFT_DEBUG_STORE] == 3) nt = nt & 1;
@@ -153,7 +154,7 @@ int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0,
         w.in = in0; w.out = out0;
         w.pieces = p->outer * 128;
         w.inverse = p->inverse ? 1 : 0;
-        w.nt = ((p->flags & MIFFT_FLAG_STREAM_SRC) ? 1 : 0) | ((p->flags & MIFFT_FLAG_STREAM_DST) ? 2 : 0);
+        w.nt = stream_policy(p->flags);
         w.scale = p->scale;
         const int rc = mifft_wave_16x16_launch(&w, wave_max_blocks(), s);
         if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
@@ -530,6 +531,7 @@ int mifft_launch_pass_pair(const mifft_pass* p0, const mifft_pass* p1, const voi
     // box: plain 13.31 ms, write-through 14.44 ms; non-temporal stores measured below plain ones at batch 16 --
     // profiles/r03_c_store_policy.log)
     a.nt = (p0->flags & MIFFT_FLAG_STREAM_SRC) ? 1 : 0;
+    if (p1->flags & MIFFT_FLAG_WRITE_THROUGH) a.nt |= 4;
     if (g_debug[MIFFT_DEBUG_STORE] == 1) a.nt = (a.nt & 1) | 2;
     else if (g_debug[MIFFT_DEBUG_STORE] == 2) a.nt = (a.nt & 1) | 4;
     else if (g_debug[MIFFT_DEBUG_STORE] == 3) a.nt = a.nt & 1;

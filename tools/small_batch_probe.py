@@ -1,6 +1,6 @@
 """The multi-pass rows of the reference's 32 MiB table (test/test_performance.py:11,22-30) one by one: passes, strategy, time per
 execute (10 back-to-back executes between two events, best of 5) and the fraction of the 8 TB/s roofline.
-    python3 tools/small_batch_probe.py [sp|dp]            run it under `rocprofv3 --kernel-trace --stats` for per-kernel times"""
+    [BUF_MB=32] python3 tools/small_batch_probe.py [sp|dp]            run it under `rocprofv3 --kernel-trace --stats` for per-kernel times"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,7 @@ double = len(sys.argv) > 1 and sys.argv[1] == "dp"
 dtype = numpy.complex128 if double else numpy.complex64
 for shape in SHAPES:
     size = int(numpy.prod(shape))
-    batch = (32 << 20) // (size * numpy.dtype(dtype).itemsize)
+    batch = (int(os.environ.get("BUF_MB", "32")) << 20) // (size * numpy.dtype(dtype).itemsize)
     rng = numpy.random.default_rng(5)
     data = (rng.standard_normal(size * batch) + 1j * rng.standard_normal(size * batch)).astype(dtype)
     a = DeviceArray((size * batch,), dtype).set(data)
