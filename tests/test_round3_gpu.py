@@ -368,6 +368,56 @@ def test_bluestein_in_one_launch(ctx, n, dtype):
         assert plan._work is None
 
 
+WT_CASES = [((16,), 4096), ((16, 16), 512), ((64,), 999), ((1024,), 33), ((8192,), 5), ((256, 256), 3), ((1024, 1024), 2),
+            ((32, 32, 128), 3), ((16, 16, 16), 37), ((128, 128, 128), 1), ((1 << 21,), 1), ((4, 2048), 9), ((512, 8), 7)]
+
+
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128, numpy.float32], ids=["c64", "c128", "f32"])
+@pytest.mark.parametrize("shape,batch", WT_CASES, ids=[str(c[0]) for c in WT_CASES])
+def test_small_launch_write_through_is_bit_identical(ctx, shape, batch, dtype, monkeypatch):
+    """Executes of <= 128 MiB per side store write-through (MIFFT_FLAG_WRITE_THROUGH on every pass): every kernel family's
+    write-through form against its plain stores, bit for bit, out of place and in place, forward and inverse."""
+    from pyfft_amd import _native as N
+    split = numpy.dtype(dtype).kind == "f"
+    cd = numpy.complex128 if dtype == numpy.complex128 else numpy.complex64
+    data = oracle.get_test_data(shape, cd, batch, 77)
+
+    def run(hints):
+        if hints:
+            monkeypatch.delenv("PYFFT_AMD_NO_STREAM_HINTS", raising=False)
+        else:
+            monkeypatch.setenv("PYFFT_AMD_NO_STREAM_HINTS", "1")
+        plan = ctx.getPlan(shape, dtype=dtype, wait_for_finish=True)
+        flags = [d.flags for d in plan._descriptors(batch, False, False)]
+        outs = []
+        for inverse in (False, True):
+            if split:
+                a = [ctx.toGpu(numpy.ascontiguousarray(data.real)), ctx.toGpu(numpy.ascontiguousarray(data.imag))]
+                b = [ctx.allocate(data.shape, dtype), ctx.allocate(data.shape, dtype)]
+                plan.execute(a[0], a[1], b[0], b[1], batch=batch, inverse=inverse)
+                plan.execute(a[0], a[1], batch=batch, inverse=inverse)
+                outs += [b[0].get(), b[1].get(), a[0].get(), a[1].get()]
+            else:
+                a, b = ctx.toGpu(data), ctx.allocate(data.shape, cd)
+                plan.execute(a, b, batch=batch, inverse=inverse)
+                plan.execute(a, batch=batch, inverse=inverse)
+                outs += [b.get(), a.get()]
+        return flags, outs
+
+    f1, o1 = run(True)
+    f0, o0 = run(False)
+    assert all(f & N.FLAG_WRITE_THROUGH for f in f1) and not any(f & N.FLAG_WRITE_THROUGH for f in f0)
+    for x, y in zip(o1, o0):
+        assert numpy.array_equal(x, y)
+
+
+def test_write_through_rule_stops_at_128_mib(ctx):
+    from pyfft_amd import _native as N
+    plan = ctx.getPlan((1024,), dtype=numpy.complex64)
+    assert all(d.flags & N.FLAG_WRITE_THROUGH for d in plan._descriptors(16384, False, False))          # 128 MiB
+    assert not any(d.flags & N.FLAG_WRITE_THROUGH for d in plan._descriptors(16385, False, False))
+
+
 # ---- the sharded path with more than one rank --------------------------------------------------------------------------
 def test_two_ranks_share_one_gpu_sharded_path(tmp_path):
     """`bench.py --gpus 2` for real: two processes (one plan, stream and scratch each) on ONE device, gloo as the control
