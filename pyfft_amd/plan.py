@@ -9,7 +9,6 @@ whole pass list is enqueued by one native call (mifft_launch_chain) instead of a
 
 import ctypes
 
-import os
 import numpy
 
 from . import _debug as D
