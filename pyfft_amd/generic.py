@@ -278,6 +278,15 @@ class GenericFFTPlan(object):
         hi = roots(((n - 1) >> shift) + 1, 1 << shift, n)
         return (n1, n2, roots(n1, 1, n1), roots(n2, 1, n2), lo, hi, shift)
 
+    def _epilogue(self, wait_for_finish):
+        """The end of every execute (plan.py:250-259): wait (and check for errors) or hand the stream back."""
+        wait = self._wait_for_finish if wait_for_finish is None else wait_for_finish
+        if wait:
+            self.finish()
+            return None
+        self._context.flush()
+        return self._context.getQueue()
+
     def _prepare(self, batch):
         if batch == self._last_batch:
             return
@@ -318,12 +327,7 @@ class GenericFFTPlan(object):
                                                            factor if last else 1.0, ctx.stream_handle()), "mifft_launch_mixed_lines")
                     src = ptr(outs[0])
                 inner *= ax.n
-            wait = self._wait_for_finish if wait_for_finish is None else wait_for_finish
-            if wait:
-                self.finish()
-                return None
-            ctx.flush()
-            return ctx.getQueue()
+            return self._epilogue(wait_for_finish)
         if self._direct_long is not None:
             n1, n2, tw1, tw2, lo, hi, shift = self._direct_long
             n = n1 * n2
@@ -337,12 +341,7 @@ class GenericFFTPlan(object):
                 mid = ptr(self._work)
             N.check(N.lib.mifft_launch_mixed_long(self._precision, n1, n2, batch, src, mid, dst, tw1, tw2, lo, hi, shift,
                                                   1 if inv else 0, factor, ctx.stream_handle()), "mifft_launch_mixed_long")
-            wait = self._wait_for_finish if wait_for_finish is None else wait_for_finish
-            if wait:
-                self.finish()
-                return None
-            ctx.flush()
-            return ctx.getQueue()
+            return self._epilogue(wait_for_finish)
         if self._direct_blue:
             n = self._xyz[0]
             m, tw, chirp, bhat = self._axes[0].blue
@@ -350,24 +349,14 @@ class GenericFFTPlan(object):
             factor = self._scale if not inv else 1.0 / ((n if self._normalize else 1.0) * self._scale)
             N.check(N.lib.mifft_launch_bluestein_rows(self._precision, n, m, batch, n, n, ptr(ins[0]), ptr(outs[0]), tw, chirp, bhat,
                                                       1 if inv else 0, factor, ctx.stream_handle()), "mifft_launch_bluestein_rows")
-            wait = self._wait_for_finish if wait_for_finish is None else wait_for_finish
-            if wait:
-                self.finish()
-                return None
-            ctx.flush()
-            return ctx.getQueue()
+            return self._epilogue(wait_for_finish)
         if self._direct_mixed:
             n = self._xyz[0]
             inv = bool(inverse)
             factor = self._scale if not inv else 1.0 / ((n if self._normalize else 1.0) * self._scale)
             N.check(N.lib.mifft_launch_mixed_rows(self._precision, n, batch, n, n, ptr(ins[0]), ptr(outs[0]), self._axes[0].mixed_tw,
                                                   1 if inv else 0, factor, ctx.stream_handle()), "mifft_launch_mixed_rows")
-            wait = self._wait_for_finish if wait_for_finish is None else wait_for_finish
-            if wait:
-                self.finish()
-                return None
-            ctx.flush()
-            return ctx.getQueue()
+            return self._epilogue(wait_for_finish)
         nt = batch * self._ntiles
         work, rows = ptr(self._work), ptr(self._rows)
         in0, in1 = ptr(ins[0]), (ptr(ins[1]) if self._split else None)
@@ -430,14 +419,7 @@ class GenericFFTPlan(object):
             factor = 1.0 / ((self._size if self._normalize else 1.0) * self._scale)
         self._copy(dims, dense, user, work, None, out0, out1, conj_out=inverse, scale=factor, dst_split=self._split)
 
-        wait = self._wait_for_finish
-        if wait_for_finish is not None:
-            wait = wait_for_finish
-        if wait:
-            self.finish()
-        else:
-            ctx.flush()
-            return ctx.getQueue()
+        return self._epilogue(wait_for_finish)
 
     def _execute_tiled(self, wait_for_finish, inverse, batch, src, dst):
         """Every tile transformed where it lies: one MIFFT_PASS_ND launch over batch * tiles transforms with the parent's pitches."""
@@ -457,12 +439,7 @@ class GenericFFTPlan(object):
         t.pitch_y, t.pitch_z, t.parent_elems = px, px * py, px * py * pz
         t.cx, t.cy, t.cz = cx, cy, cz
         N.check(N.lib.mifft_launch_nd_tiled(ctypes.byref(d), ctypes.byref(t), src, dst, ctx.stream_handle()), "mifft_launch_nd_tiled")
-        wait = self._wait_for_finish if wait_for_finish is None else wait_for_finish
-        if wait:
-            self.finish()
-        else:
-            ctx.flush()
-            return ctx.getQueue()
+        return self._epilogue(wait_for_finish)
 
     def _inner_plans(self):
         plans = [self._ndplan] if self._ndplan is not None else []
