@@ -418,6 +418,52 @@ def test_write_through_rule_stops_at_128_mib(ctx):
     assert not any(d.flags & N.FLAG_WRITE_THROUGH for d in plan._descriptors(16385, False, False))
 
 
+def _random_lengths(seed, count):
+    rng = numpy.random.default_rng(seed)
+    lens = set()
+    while len(lens) < count:
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            n = int(rng.integers(2, 5000))                                   # anything: mostly Bluestein
+        elif kind == 1:
+            n = int(2 ** rng.integers(0, 5) * 3 ** rng.integers(0, 4) * 5 ** rng.integers(0, 3) * 7 ** rng.integers(0, 3))   # smooth
+        elif kind == 2:
+            n = int(rng.integers(4097, 70000))                               # beyond one tile: long smooth or multi-launch Bluestein
+        else:
+            n = int(rng.integers(2, 130)) * int(rng.integers(2, 130))        # composite, often smooth-ish
+        if 2 <= n <= 70000:
+            lens.add(n)
+    return sorted(lens)
+
+
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
+def test_any_size_random_lengths(ctx, dtype):
+    """A seeded sample of 1-D lengths through Plan(any_size=True) -- whichever form each one takes (dense plan, mixed-radix rows,
+    two-launch long smooth, one-launch or multi-launch Bluestein) -- against numpy with the reference's thresholds: forward out of
+    place with a ragged batch, inverse in place."""
+    double = numpy.dtype(dtype) == numpy.complex128
+    eps, mx = (1e-11, 1e-10) if double else (1.1e-6, 1e-5)
+    forms = {}
+    for n in _random_lengths(20261003 + double, 48):
+        batch = 1 + n % 5
+        rng = numpy.random.default_rng(n)
+        x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(dtype)
+        plan = ctx.getPlan((n,), dtype=dtype, any_size=True)
+        form = ("dense" if not hasattr(plan, "_direct_long") else "long" if plan._direct_long is not None else "blue1" if plan._direct_blue
+                else "mixed" if plan._direct_mixed else "bluestein")
+        forms[form] = forms.get(form, 0) + 1
+        a, b = ctx.toGpu(x), ctx.allocate(x.shape, dtype)
+        plan.execute(a, b, batch=batch)
+        ref = numpy.fft.fft(x.astype(numpy.complex128), axis=1)
+        got = b.get()
+        assert numpy.abs(got - ref).sum() / numpy.abs(ref).sum() < eps, (n, form)
+        assert numpy.abs(got - ref).max() <= mx * numpy.abs(ref).max(), (n, form)
+        assert numpy.array_equal(a.get(), x), (n, form)
+        plan.execute(b, batch=batch, inverse=True)
+        assert numpy.abs(b.get() - x).sum() / numpy.abs(x).sum() < 2 * eps, (n, form)
+    assert len(forms) >= 4, forms            # the sample reaches the different forms
+
+
 # ---- the sharded path with more than one rank --------------------------------------------------------------------------
 def test_two_ranks_share_one_gpu_sharded_path(tmp_path):
     """`bench.py --gpus 2` for real: two processes (one plan, stream and scratch each) on ONE device, gloo as the control
