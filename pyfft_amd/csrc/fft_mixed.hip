@@ -327,7 +327,20 @@ bool search(int n, int depth, int first, int* pick, int at, int sum, int* best, 
     return found;
 }
 
+int factor_search(int n, int* radix);
+
+// (the search costs microseconds; a launch loop asks for the same length again and again)
 int factor(int n, int* radix) {
+    static thread_local int last_n = 0, last_ns = 0, last_radix[kMaxStages];
+    if (n != last_n) {
+        last_ns = factor_search(n, last_radix);
+        last_n = n;
+    }
+    for (int i = 0; i < last_ns; ++i) radix[i] = last_radix[i];
+    return last_ns;
+}
+
+int factor_search(int n, int* radix) {
     int m = n;
     for (int c : {2, 3, 5, 7}) while (m % c == 0) m /= c;
     if (n < 2 || m != 1) return 0;
