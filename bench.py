@@ -389,6 +389,7 @@ def main():
 
     from pyfft_amd import _native as N
     from pyfft_amd.hip import Plan, DeviceArray, Event, device_props
+    from pyfft_amd.passes import launch_units
     N.check(N.lib.mifft_set_device(device), "set_device")
     props = device_props(device)
 
@@ -437,7 +438,9 @@ def main():
     if not args.inplace:
         step()
         plan.finish()
-        samples = sorted(set([0, 1 % batch, (blk - 1) % batch, blk % batch, batch // 2, batch - 1]))
+        # >= 8 sampled batch items including the first and the last one (all of them when the batch is smaller)
+        samples = sorted(set([0, 1 % batch, 2 % batch, (blk - 1) % batch, blk % batch, batch // 3, batch // 2, (2 * batch) // 3,
+                              (batch - blk) % batch, max(0, batch - 2), batch - 1]))
         worst_diff, worst_max = 0.0, 0.0
         isz = dtype.itemsize
         for s in samples:
@@ -540,24 +543,33 @@ def main():
             b1 = [None, None, None]
         pass_ms = []
         reps = 3
-        for i in range(npass):
+        # one entry per LAUNCH of the plan: a pass, or a pass pair (two descriptors, one kernel; both carry the unit's src / dst)
+        i = 0
+        for unit, count in launch_units(plan.pass_list()):
             d = descs[i]
+            dl = descs[i + count - 1]
             e0, e1 = Event(), Event()
             e0.record(stream)
             for _ in range(reps):
-                N.check(N.lib.mifft_launch_pass(ctypes.byref(d), b0[d.src], b1[d.src], b0[d.dst], b1[d.dst],
-                                                plan._context.stream_handle()), "launch_pass")
+                if count == 2:
+                    N.check(N.lib.mifft_launch_pass_pair(ctypes.byref(d), ctypes.byref(dl), b0[d.src], b1[d.src], b0[dl.dst], b1[dl.dst],
+                                                         plan._context.stream_handle()), "launch_pass_pair")
+                else:
+                    N.check(N.lib.mifft_launch_pass(ctypes.byref(d), b0[d.src], b1[d.src], b0[d.dst], b1[d.dst],
+                                                    plan._context.stream_handle()), "launch_pass")
             e1.record(stream)
             e1.synchronize()
             pass_ms.append(e1.time_since(e0) / reps)
+            i += count
+    nlaunch = len(launch_units(plan.pass_list()))
     if strategy[0] == "chain":
-        launches = "%d launches per step" % npass
+        launches = "%d launches per step" % nlaunch
     elif strategy[0] == "fused2":
         launches = "1 persistent launch per step (both passes, lag %s, ring %s)" % tuple(strategy[1:3])
     elif strategy[0] == "xcd2":
         launches = "1 persistent launch per step (both passes, XCD-resident intermediate)"
     else:
-        launches = "%d launches per chunk, chunks of %s items on %s streams" % ((npass,) + tuple(strategy[1:3]))
+        launches = "%d launches per chunk, chunks of %s items on %s streams" % ((nlaunch,) + tuple(strategy[1:3]))
 
     total_xforms = batch * world * args.steps
     ms_per_step = elapsed * 1e3 / args.steps
@@ -578,6 +590,13 @@ def main():
         except Exception:
             traffic = None
 
+    c5_note = None
+    if args.config == "c5" and not args.batch:
+        # BASELINE.json configs[4]: 65536 transforms of 2^22 points over 8 GPUs = 8192 per GPU = 256 GiB per side, run as a streaming
+        # loop over resident chunks: one step of this line is ONE 256-transform chunk (8 GiB in + 8 GiB out)
+        c5_note = {"chunk_transforms": batch, "chunks_per_gpu_for_stated_config": 8192 // batch,
+                   "ms_per_gpu_for_stated_config": ms_per_step * (8192 // batch),
+                   "stated_config": "1-D c2c fp32 N=2^22 batch=65536 sharded across 8 GPUs (8192 per GPU)"}
     result = {
         "metric": "batched_c2c_fft_gflops_5NlogN_1d_n2^20" if args.config == "c2" else "batched_c2c_fft_gflops_5NlogN_" + args.config,
         "value": gflops,
@@ -611,6 +630,8 @@ def main():
         "device": "%s (%s), %d CUs" % (props.name.decode(), props.gcn_arch.decode(), props.compute_units),
         "cpu_baseline": cpu,
     }
+    if c5_note is not None:
+        result["config"].update(c5_note)
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

@@ -40,6 +40,14 @@ def fused_lag_factor(default):
     return int(os.environ.get("PYFFT_AMD_FUSED_LAGF", "0")) or default
 
 
+def fused_ring(lag, ring):
+    """PYFFT_AMD_FUSED_RING = lag,ring of the fused two-pass kernel, any size (development sweep, tools/fused_sweep.py)"""
+    v = os.environ.get("PYFFT_AMD_FUSED_RING")
+    if v:
+        lag, ring = (int(t) for t in v.split(","))
+    return lag, ring
+
+
 def fused3_lag_ring(lag, ring):
     """PYFFT_AMD_FUSED3 = lag,ring (development sweep of the 2048 x 2048 fused kernel)"""
     v = os.environ.get("PYFFT_AMD_FUSED3")

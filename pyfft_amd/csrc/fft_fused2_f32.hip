@@ -9,14 +9,16 @@ template <int A0, int A1> int launch(const mifft::FusedArgs* f, int split, unsig
     // intermediate ring: C2 35.0 -> 36.6 % (development switch to turn it off)
     const bool nt = mifft_debug_get(MIFFT_DEBUG_FUSED_NO_NT) == 0;
     const bool wt = mifft_debug_get(MIFFT_DEBUG_STORE) == 2;   // A/B: write-through stores of the output
+    // (round 4: every interleaved size streams non-temporally, not only 1024 x 1024 -- the XCD-local development kernel always
+    // did, which was part of its lead at 2^19; the plain and write-through forms stay as A/B instances of 1024 x 1024)
     if (split)
         hipLaunchKernelGGL((mifft::fft_fused2_kernel<float, A0, A1, true, 0>), dim3(grid), dim3(256), 0, s, *f);
     else if (nt && wt && A0 == 4 && A1 == 4)
         hipLaunchKernelGGL((mifft::fft_fused2_kernel<float, A0, A1, false, 2>), dim3(grid), dim3(256), 0, s, *f);
-    else if (nt && A0 == 4 && A1 == 4)
-        hipLaunchKernelGGL((mifft::fft_fused2_kernel<float, A0, A1, false, 1>), dim3(grid), dim3(256), 0, s, *f);
-    else
+    else if (!nt && A0 == 4 && A1 == 4)
         hipLaunchKernelGGL((mifft::fft_fused2_kernel<float, A0, A1, false, 0>), dim3(grid), dim3(256), 0, s, *f);
+    else
+        hipLaunchKernelGGL((mifft::fft_fused2_kernel<float, A0, A1, false, 1>), dim3(grid), dim3(256), 0, s, *f);
     return (int)hipGetLastError();
 }
 }  // namespace

@@ -31,6 +31,23 @@ int hip_check(hipError_t e, const char* what) {
 }
 
 bool is_pow2(long long v) { return v > 0 && (v & (v - 1)) == 0; }
+// a * b * c (all >= 0) without overflow, or -1
+long long mul3_checked(long long a, long long b, long long c) {
+    long long ab, abc;
+    if (__builtin_mul_overflow(a, b, &ab) || __builtin_mul_overflow(ab, c, &abc)) return -1;
+    return abc;
+}
+// rows of the mixed-radix / Bluestein launchers: interleaved complex numbers, 8-byte (fp32) / 16-byte (fp64) aligned; an in-place call
+// must keep every row where it is (a work-group stores its rows while others have not loaded theirs yet)
+const char* check_rows(int precision, const void* in, const void* out, long long rows, long long n, long long stride_in, long long stride_out) {
+    const uintptr_t mask = precision == MIFFT_F64 ? 15 : 7;
+    if (((uintptr_t)in | (uintptr_t)out) & mask) return "data buffers must be aligned to one complex number";
+    if (in == out && stride_in != stride_out) return "an in-place call needs equal row strides on both sides";
+    const long long esz = precision == MIFFT_F64 ? 16 : 8;
+    if (mul3_checked(rows, stride_in > stride_out ? stride_in : stride_out, esz) < 0) return "rows * stride overflows";
+    (void)n;
+    return nullptr;
+}
 int ilog2(long long v) {
     int r = 0;
     while (v > 1) {
@@ -288,7 +305,6 @@ int classify_pair(const mifft_pass* p0, const mifft_pass* p1, int* kind, int key
 }
 
 int pair_call(int precision, int kind, const int key[3], int split, const mifft::PairArgs* a, hipStream_t s, int query, int* width) {
-    if (g_debug[MIFFT_DEBUG_PAIR] == 1) return MIFFT_E_UNSUPPORTED;
     if (precision == MIFFT_F64) return mifft_pair_f64(kind, key[0], key[1], key[2], split, a, s, query, width);
     if (precision == MIFFT_F32) return mifft_pair_f32(kind, key[0], key[1], key[2], split, a, s, query, width);
     return MIFFT_E_UNSUPPORTED;
@@ -471,6 +487,9 @@ int mifft_launch_pass(const mifft_pass* p, const void* in0, const void* in1, voi
 int mifft_pair_split(int32_t precision, int32_t layout, int32_t x, int32_t y, int32_t z) {
     if (x < 2 || y < 2 || z < 2 || !is_pow2(x) || !is_pow2(y) || !is_pow2(z)) return 0;
     const int split = layout == MIFFT_SPLIT ? 1 : 0;
+    // the development switch "no pass pairs" acts HERE, when a plan is built, and nowhere else: a plan that was built with pairs
+    // keeps launching them whatever the switch says later
+    if (g_debug[MIFFT_DEBUG_PAIR] == 1) return 0;
     // candidates in order of preference (measured: profiles/r03_b_c4_pair_split.log); MIFFT_DEBUG_PAIR = 2 swaps them
     int cand[2] = {32, 64};
     if (g_debug[MIFFT_DEBUG_PAIR] == 2) { cand[0] = 64; cand[1] = 32; }
@@ -843,6 +862,7 @@ int mifft_launch_mixed_rows(int32_t precision, int32_t n, int64_t rows, int64_t 
     if (mifft_mixed_supported(precision, n) != 0) return set_err(MIFFT_E_UNSUPPORTED, "mixed rows: no kernel for n = %d", n);
     if (!in || !out || !tw) return set_err(MIFFT_E_INVALID, "mixed rows: null buffer");
     if (rows < 0 || stride_in < n || stride_out < n) return set_err(MIFFT_E_INVALID, "mixed rows: bad row count / stride");
+    if (const char* why = check_rows(precision, in, out, rows, n, stride_in, stride_out)) return set_err(MIFFT_E_INVALID, "mixed rows: %s", why);
     if (rows == 0) return 0;
     const int rc = mifft_mixed_launch(precision == MIFFT_F64, n, rows, stride_in, stride_out, 1, in, out, tw, inverse ? 3 : 0, scale, (hipStream_t)stream);
     if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
@@ -855,6 +875,9 @@ int mifft_launch_mixed_lines(int32_t precision, int32_t n, int64_t outer, int64_
     if (mifft_mixed_supported(precision, n) != 0) return set_err(MIFFT_E_UNSUPPORTED, "mixed lines: no kernel for n = %d", n);
     if (!in || !out || !tw) return set_err(MIFFT_E_INVALID, "mixed lines: null buffer");
     if (outer < 0 || inner < 1) return set_err(MIFFT_E_INVALID, "mixed lines: bad index space");
+    if (mul3_checked(outer, inner, (long long)n * (precision == MIFFT_F64 ? 16 : 8)) < 0)
+        return set_err(MIFFT_E_INVALID, "mixed lines: outer * inner * n overflows");
+    if (const char* why = check_rows(precision, in, out, 0, n, n, n)) return set_err(MIFFT_E_INVALID, "mixed lines: %s", why);
     if (outer == 0) return 0;
     const int flags = (conj_in ? 1 : 0) | (conj_out ? 2 : 0);
     const int rc = mifft_mixed_launch(precision == MIFFT_F64, n, outer * inner, n, n, inner, in, out, tw, flags, scale, (hipStream_t)stream);
@@ -880,6 +903,12 @@ int mifft_launch_mixed_long(int32_t precision, int32_t n1, int32_t n2, int64_t b
     if (!in || !mid || !out || !tw1 || !tw2 || !tw_lo || !tw_hi) return set_err(MIFFT_E_INVALID, "mixed long: null buffer");
     if (mid == in) return set_err(MIFFT_E_INVALID, "mixed long: the first pass transposes, `mid` must not be the input");
     if (batch < 0 || tw_shift < 1 || tw_shift > 23) return set_err(MIFFT_E_INVALID, "mixed long: bad batch / table shift");
+    if ((long long)n1 * n2 > (1ll << 24)) return set_err(MIFFT_E_INVALID, "mixed long: n1 * n2 = %lld exceeds 2^24", (long long)n1 * n2);
+    if (mul3_checked(batch, (long long)n1 * n2, precision == MIFFT_F64 ? 16 : 8) < 0) return set_err(MIFFT_E_INVALID, "mixed long: batch * n overflows");
+    {
+        const uintptr_t mask = precision == MIFFT_F64 ? 15 : 7;
+        if (((uintptr_t)in | (uintptr_t)mid | (uintptr_t)out) & mask) return set_err(MIFFT_E_INVALID, "mixed long: data buffers must be aligned to one complex number");
+    }
     if (batch == 0) return 0;
     const int rc = mifft_mixed_long_launch(precision == MIFFT_F64, n1, n2, batch, in, mid, out, tw1, tw2, tw_lo, tw_hi, tw_shift,
                                            inverse ? 3 : 0, scale, (hipStream_t)stream);
@@ -905,6 +934,7 @@ int mifft_launch_bluestein_rows(int32_t precision, int32_t n, int32_t m, int64_t
         return set_err(MIFFT_E_UNSUPPORTED, "bluestein rows: no kernel for n = %d padded to %d", n, m);
     if (!in || !out || !tw || !chirp || !bhat) return set_err(MIFFT_E_INVALID, "bluestein rows: null buffer");
     if (rows < 0 || stride_in < n || stride_out < n) return set_err(MIFFT_E_INVALID, "bluestein rows: bad row count / stride");
+    if (const char* why = check_rows(precision, in, out, rows, n, stride_in, stride_out)) return set_err(MIFFT_E_INVALID, "bluestein rows: %s", why);
     if (rows == 0) return 0;
     const int rc = mifft_bluestein_launch(precision == MIFFT_F64, n, m, rows, stride_in, stride_out, in, out, tw, chirp, bhat,
                                           inverse ? 3 : 0, scale, (hipStream_t)stream);

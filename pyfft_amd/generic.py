@@ -29,7 +29,7 @@ import ctypes
 import numpy
 
 from . import _native as N
-from .plan import FFTPlan, normalize_shape, on_plan_device
+from .plan import FFTPlan, normalize_shape, on_plan_device, _twiddle_table
 
 
 def _is_pow2(n):
@@ -127,22 +127,24 @@ class GenericFFTPlan(object):
             self._counts = (1, 1, 1)
         self._ntiles = self._counts[0] * self._counts[1] * self._counts[2]
 
-        # one batched 1-D power-of-two plan per distinct row length; they share this plan's context (= stream)
+        # Which path runs is decided FIRST; the inner power-of-two plans (one batched 1-D plan per distinct row length, or one N-D
+        # plan over all tiles; they share this plan's context = stream) are built only for the work-array path, at the end
         self._sub = _SubContext(context)
         self._rowplans = {}
-        # every axis a power of two (tiles of a parent array): ONE N-D plan on the dense work array
         self._ndplan = None
-        if all(_is_pow2(v) for v in self._xyz):
-            self._ndplan = FFTPlan(self._sub, shape, dtype=self._cdtype, normalize=True, wait_for_finish=False)
-        # ... and, for the tile shapes that have such a kernel, ONE launch straight on the parent array (csrc/fft_nd2t.hpp): no
-        # gather, no scatter, no work array
-        self._tiled = False
-        if self._ndplan is not None and not self._split and parent_shape is not None:
-            k = self._ndplan.pass_list()
-            tx, ty, tz = self._xyz
-            if len(k) == 1 and k[0].kind == N.PASS_ND and N.lib.mifft_nd_tiled_supported(self._precision, tx, ty, tz) == 0:
-                self._tiled = True
+        self._shape_arg = shape
         self._tables = []
+        all_pow2 = all(_is_pow2(v) for v in self._xyz)
+        # tiles of a parent array whose shape has such a kernel: ONE launch straight on the parent array (csrc/fft_nd2t.hpp): no
+        # gather, no scatter, no work array -- only the three w(len)^k tables of a MIFFT_PASS_ND pass
+        self._tiled = False
+        self._tiled_tables = None
+        tx, ty, tz = self._xyz
+        if all_pow2 and not self._split and parent_shape is not None and (tx > 1) + (ty > 1) + (tz > 1) >= 2 and \
+                N.lib.mifft_nd_shape_supported(self._precision, tx, ty, tz, N.VARIANT_INTERLEAVED_ONLY) == 0 and \
+                N.lib.mifft_nd_tiled_supported(self._precision, tx, ty, tz) == 0:
+            self._tiled = True
+            self._tiled_tables = tuple(self._upload(_twiddle_table(n, n, 1, self._cdtype)) if n > 1 else None for n in self._xyz)
         self._axes = []
         self._direct_long = None
         for n in self._xyz:
@@ -185,9 +187,9 @@ class GenericFFTPlan(object):
                 self._axes.append(ax)
                 continue
             ax.m = n if ax.pow2 else 1 << int(numpy.ceil(numpy.log2(2 * n - 1)))
-            ax.plan = self._rowplan(ax.m) if ax.m > 1 else None
+            ax.plan = None                    # a batched ROW plan of ax.m points, built below if the work-array path runs
             ax.chirp = ax.bhat = None
-            if not ax.pow2:
+            if not ax.pow2 and not self._tiled:
                 c = _chirp(n, self._cdtype)
                 b = numpy.zeros(ax.m, numpy.complex128)
                 b[:n] = numpy.conj(c)
@@ -219,6 +221,16 @@ class GenericFFTPlan(object):
                     ang = -2.0 * numpy.pi * k / float(ax.n)
                     tabs.append(self._upload((numpy.cos(ang) + 1j * numpy.sin(ang)).astype(self._cdtype)))
             self._direct_nd = tabs
+        self._uses_work = not (self._tiled or self._direct_mixed or self._direct_blue or self._direct_nd is not None
+                               or self._direct_long is not None)
+        if self._uses_work:
+            if all_pow2:
+                # every axis a power of two (tiles of a parent array): ONE N-D plan on the dense work array
+                self._ndplan = FFTPlan(self._sub, shape, dtype=self._cdtype, normalize=True, wait_for_finish=False)
+            else:
+                for ax in self._axes:
+                    if ax.m > 1 and ax.mixed_tw is None and ax.blue is None:
+                        ax.plan = self._rowplan(ax.m)
         self._work = None
         self._rows = None
         self._last_batch = 0
@@ -291,7 +303,7 @@ class GenericFFTPlan(object):
         if batch == self._last_batch:
             return
         self._last_batch = batch
-        if self._tiled or self._direct_mixed or self._direct_blue or self._direct_nd is not None or self._direct_long is not None:
+        if not self._uses_work:
             self._work = None           # no work arrays (a long smooth transform in place allocates its scratch on demand)
             return
         isz = self._cdtype.itemsize
@@ -433,8 +445,7 @@ class GenericFFTPlan(object):
         d.outer = batch * self._ntiles
         d.outer_stride_in = d.outer_stride_out = self._size
         d.scale = self._scale if not inverse else 1.0 / ((self._size if self._normalize else 1.0) * self._scale)
-        twx, twy, twz, _ = self._ndplan._table_ptrs[0]
-        d.tw_L, d.tw_lo, d.tw_hi = twx, twy, twz
+        d.tw_L, d.tw_lo, d.tw_hi = self._tiled_tables
         t = N.MifftTiling()
         t.pitch_y, t.pitch_z, t.parent_elems = px, px * py, px * py * pz
         t.cx, t.cy, t.cz = cx, cy, cz

@@ -417,18 +417,21 @@ def Plan(*args, **kwds):
     if device_count() < 1:
         raise RuntimeError("pyfft_amd: no HIP device visible (there is no CPU fallback)")
 
+    # the device comes from `context` whether or not a stream is given (Plan(stream=s, context=i): the stream only decides the
+    # default wait policy, cuda.py:129-134; tables, scratch and launches belong to device i -- the stream must live there too)
     device = None
-    if stream_obj is not None:
-        wait_for_finish = False
-    elif context_obj is not None:
-        if isinstance(context_obj, (int, numpy.integer)):
+    if context_obj is not None:
+        if isinstance(context_obj, (int, numpy.integer)) and not isinstance(context_obj, bool):
             device = int(context_obj)
         elif hasattr(context_obj, "device"):
             device = context_obj.device
-        wait_for_finish = True
-        stream_obj = None
-    else:
-        wait_for_finish = True
+    wait_for_finish = stream_obj is None
+    if stream_obj is not None and device is not None:
+        sdev = getattr(stream_obj, "device_index", None)       # torch.cuda.Stream knows its device; raw handles do not
+        if sdev is None:
+            sdev = getattr(getattr(stream_obj, "device", None), "index", None)
+        if sdev is not None and int(sdev) != int(device):
+            raise ValueError("pyfft_amd: stream belongs to device %d but context=%d" % (int(sdev), int(device)))
 
     if 'wait_for_finish' not in kwds or kwds['wait_for_finish'] is None:
         kwds['wait_for_finish'] = wait_for_finish

@@ -38,14 +38,15 @@ def on_plan_device(method):
 class _FFTParams(object):
     """Plan parameters derived from shape and dtype (plan.py:10-63)."""
 
-    def __init__(self, shape, dtype, context, fast_math):
+    def __init__(self, shape, dtype, context):
+        # (the reference's fast_math parameter has no counterpart here -- twiddles come from float64-evaluated tables, hip.Plan's
+        # docstring -- so the plan accepts the keyword for signature parity and keeps no state for it)
         self.x, self.y, self.z = shape
         for v in shape:
             if not isinstance(v, (int, numpy.integer)) or isinstance(v, bool) or v < 1:
                 raise ValueError("Wrong shape")
         self.size = int(self.x) * int(self.y) * int(self.z)
         self.context = context
-        self.fast_math = fast_math
 
         # the reference only checks the product (plan.py:23-24); every axis is checked here
         if not all(P.is_pow2(int(v)) for v in shape):
@@ -104,14 +105,14 @@ class FFTPlan(object):
     def validate(shape, dtype=numpy.complex64, normalize=True, wait_for_finish=None, fast_math=True, scale=1.0):
         """Raise the reference's ValueErrors (plan.py:24,48,87,89) without touching a device."""
         _, xyz = normalize_shape(shape)
-        _FFTParams(xyz, dtype, None, fast_math)
+        _FFTParams(xyz, dtype, None)
 
     def __init__(self, context, shape, dtype=numpy.complex64, normalize=True,
                  wait_for_finish=None, fast_math=True, scale=1.0):
         self._dim, shape = normalize_shape(shape)
 
         self._context = context
-        self._params = _FFTParams(shape, dtype, context, fast_math)
+        self._params = _FFTParams(shape, dtype, context)
         self._normalize = normalize
         self._scale = float(scale)
         self._wait_for_finish = wait_for_finish
@@ -346,6 +347,7 @@ class FFTPlan(object):
                 slots = (224 << 20) // item_bytes
                 lag, ring = D.fused3_lag_ring(4 * slots // 7, slots)
                 big = True
+            lag, ring = D.fused_ring(lag, ring)
             if forced == "fused" and batch < 2 * ring and batch >= 8:   # on request: a shorter pipeline for a small batch
                 lag = batch // 4
                 ring = 2 * lag
