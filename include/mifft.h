@@ -39,8 +39,10 @@ extern "C" {
 #endif
 
 /* 2: mifft_launch_fused2's counter buffer is MIFFT_FUSED2_COUNTER_BYTES (one 256-byte line per counter) and is zeroed by the
- * call; streams are blocking streams; mifft_stream_wait_event */
-#define MIFFT_ABI_VERSION 2
+ * call; streams are blocking streams; mifft_stream_wait_event
+ * 3: the persistent launches take a mifft_fused_sync: two alternating counter sets, error word anywhere the device can write;
+ * mifft_device_props carries the last-level cache size and the XCD count; mifft_launch_fused_pair */
+#define MIFFT_ABI_VERSION 3
 
 /* negative library error codes (positive values are hipError_t) */
 #define MIFFT_E_INVALID      (-1)  /* malformed descriptor / argument              */
@@ -137,7 +139,12 @@ typedef struct mifft_device_props {
     int64_t lds_bytes_per_block;
     int64_t total_mem_bytes;
     int32_t clock_khz;
-    int32_t l2_bytes;
+    int32_t l2_bytes;        /* L2 of ONE XCD (hipDeviceProp_t::l2CacheSize) */
+    int64_t llc_bytes;       /* last-level cache in front of HBM (the Infinity Cache / MALL: 256 MiB on MI355X) from the HSA agent
+                                (HSA_AGENT_INFO_CACHE_SIZE[2]); 0 = none or unknown.  The planner sizes the rings of the persistent
+                                launches, the pipelined chunks and the write-through rule from it instead of from literals */
+    int32_t num_xcc;         /* XCDs (chiplets with their own L2) the device spans (HSA_AMD_AGENT_INFO_NUM_XCC); 1 if unknown */
+    int32_t reserved0;
 } mifft_device_props;
 
 /* ---- library ------------------------------------------------------------------------------------- */
@@ -256,25 +263,56 @@ int mifft_launch_chain_pipelined(const mifft_pass *passes, int32_t npasses, void
  *             1-D form: p0 = the transposing first pass (COL, S == 1, M == p1->L), p1 = the plain strided last pass
  *             (COL, M == 1, S == p0->L).  2-D form (the squares 512 / 1024 / 2048 in fp32, 1024 in fp64): p0 = the ROW
  *             pass, p1 = the strided COL pass of the plan.  Anything else: MIFFT_E_UNSUPPORTED.
- *   counters  caller-owned device buffer of at least MIFFT_FUSED2_COUNTER_BYTES(outer) bytes, zeroed by this call on
- *             `stream` (one 256-byte line per counter, csrc/fft_fused2.hpp).  After completion
- *             ((uint32_t*)counters)[1] != 0 reports a dependency time-out (results invalid).
+ *   sync      counters + error word, see mifft_fused_sync below (one 256-byte line per counter, csrc/fft_fused2.hpp).  After
+ *             completion a non-zero error word reports a dependency time-out (results invalid).
  *   ring      always interleaved (ring0; ring1 is ignored), also for split-plane in/out buffers.
  */
 #define MIFFT_FUSED2_COUNTER_STRIDE 64u /* uint32 words between two counters */
 #define MIFFT_FUSED2_COUNTER_BYTES(outer) ((size_t)MIFFT_FUSED2_COUNTER_STRIDE * 4u * (9u + 2u * (size_t)(outer)))
+/*
+ * Synchronisation state of one persistent launch (all caller-owned device-accessible memory):
+ *   counters       MIFFT_FUSED2_COUNTER_BYTES(outer) bytes.  With counters_next == NULL the call zeroes them on `stream` in front
+ *                  of the launch (a memset node: ~5 us, what a 32 MiB execute cannot afford).
+ *   counters_next  a second buffer of the same size: the caller guarantees that `counters` is ALL ZERO when the launch starts, and
+ *                  THIS launch zeroes `counters_next` -- a plan that alternates between two sets (set A zeroes B, B zeroes A) after
+ *                  one initial mifft_memset of both never pays the memset again.
+ *   error_word     a uint32 the kernel sets (system-scope store) when a bounded dependency wait times out = results INVALID; any
+ *                  address the device can write: pinned host memory from mifft_host_alloc (device-accessible under the same
+ *                  pointer; the host then reads it without a copy), or NULL = word [1] of `counters`.  Never cleared by the library.
+ */
+typedef struct mifft_fused_sync {
+    void *counters;
+    void *counters_next;
+    void *error_word;
+} mifft_fused_sync;
+/* lag == 0 selects the SEQUENTIAL work list for tiny batches (ring_slots == outer): every first-pass tile of every transform,
+ * then every second-pass tile -- two dependent launches folded into one, without the launch gap and the end-of-kernel
+ * write-back between them (the reference's own 32 MiB benchmark protocol, test/test_performance.py:11,22-30). */
 int mifft_launch_fused2(const mifft_pass *p0, const mifft_pass *p1, const void *in0, const void *in1, void *out0,
-                        void *out1, void *ring0, void *ring1, int32_t ring_slots, int32_t lag, void *counters,
+                        void *out1, void *ring0, void *ring1, int32_t ring_slots, int32_t lag, const mifft_fused_sync *sync,
                         int32_t grid, mifft_stream_t stream);
 
 /*
- * Development (strategy `fusedx`, csrc/fft_fused2.hpp): the same launch with one work list PER XCD -- XCD x owns the transforms
- * x, x + 8, ... and the ring slots [x * ring_slots, (x + 1) * ring_slots), so the ring holds 8 * ring_slots transforms; with
- * write_through == 0 the intermediate is written with plain stores and can stay in the XCD's L2.  Interleaved fp32 1-D pairs
- * only.  After completion counters[1] bit 0 = dependency time-out, bit 2 = an XCD received no work-group (results invalid).
+ * The same launch with one work list PER XCD (strategy `fusedx`, csrc/fft_fused2.hpp): XCD x owns the transforms x, x + 8, ... and
+ * the ring slots [x * ring_slots, (x + 1) * ring_slots), so the ring holds 8 * ring_slots transforms.  A work-group whose own
+ * list is exhausted drains the other XCDs' lists, so the result does not depend on where the work-groups land (the
+ * intermediate is written write-through, like the global form's).  Interleaved fp32 1-D pairs with p0->L >= p1->L in
+ * {256, 512, 1024}.
  */
 int mifft_launch_fused2x(const mifft_pass *p0, const mifft_pass *p1, const void *in0, void *out0, void *ring0, int32_t ring_slots,
-                         int32_t lag, void *counters, int32_t grid, int32_t write_through, mifft_stream_t stream);
+                         int32_t lag, const mifft_fused_sync *sync, int32_t grid, mifft_stream_t stream);
+
+/*
+ * Persistent form of a 3-D plan made of two PASS PAIRS (mifft_pair_split > 0): passes[0..3] = ROW x | COL y (R0) | COL y (R1) |
+ * COL z as the chain holds them.  Work list as in mifft_launch_fused2 with the (ROW x, COL y R0) tiles as first-pass items and the
+ * (COL y R1, COL z) tiles as second-pass items; the buffer between the two pairs is a ring of `ring_slots` whole transforms
+ * (interleaved) that stays in the last-level cache.  Exists for the cubes whose transform is a fraction of that cache:
+ *   mifft_fused_pair_supported   0 if (precision, x, y, z) has such a kernel for interleaved data, else MIFFT_E_UNSUPPORTED
+ * Reference shape of the work: pyfft/plan.py:160-167 (one chain per axis), published row doc/source/index.rst:373 (128^3).
+ */
+int mifft_fused_pair_supported(int32_t precision, int32_t x, int32_t y, int32_t z);
+int mifft_launch_fused_pair(const mifft_pass *passes, const void *in0, void *out0, void *ring0, int32_t ring_slots, int32_t lag,
+                            const mifft_fused_sync *sync, int32_t grid, mifft_stream_t stream);
 
 /*
  * XCD-cooperative form of the same two-pass axis for N = 1024 * 1024, fp32 (csrc/fft_xcd2.hpp): ONE persistent launch of

@@ -7,7 +7,7 @@ import os
 
 
 def forced_strategy():
-    """PYFFT_AMD_STRATEGY = auto | chain | pipelined | fused | xcd"""
+    """PYFFT_AMD_STRATEGY = auto | chain | pipelined | fused | fusedx | xcd"""
     return os.environ.get("PYFFT_AMD_STRATEGY", "auto")
 
 
@@ -48,6 +48,21 @@ def fused_ring(lag, ring):
     return lag, ring
 
 
+def fused_memset():
+    """PYFFT_AMD_FUSED_MEMSET=1: one counter set zeroed by a memset in front of every persistent launch (rounds 1-3; A/B)"""
+    return bool(os.environ.get("PYFFT_AMD_FUSED_MEMSET"))
+
+
+def no_fusedx():
+    """PYFFT_AMD_NO_FUSEDX=1: never choose the per-XCD work lists by default (A/B)"""
+    return bool(os.environ.get("PYFFT_AMD_NO_FUSEDX"))
+
+
+def no_tiled_kernel():
+    """PYFFT_AMD_NO_TILED=1: tiled-batch plans gather / transform / scatter even where a one-launch tile kernel exists (A/B, tests)"""
+    return bool(os.environ.get("PYFFT_AMD_NO_TILED"))
+
+
 def fused3_lag_ring(lag, ring):
     """PYFFT_AMD_FUSED3 = lag,ring (development sweep of the 2048 x 2048 fused kernel)"""
     v = os.environ.get("PYFFT_AMD_FUSED3")
@@ -57,7 +72,8 @@ def fused3_lag_ring(lag, ring):
 
 
 def fusedx():
-    """PYFFT_AMD_FUSEDX = lag,ring,write_through of the XCD-local fused form (development strategy `fusedx`)"""
+    """PYFFT_AMD_FUSEDX = lag,ring (per XCD) of the XCD-local fused form forced by PYFFT_AMD_STRATEGY=fusedx (a third field,
+    round 3's write-through switch, is accepted and ignored)"""
     v = os.environ.get("PYFFT_AMD_FUSEDX", "1,2,0")
     return tuple(int(t) for t in v.split(","))
 

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmifft.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 E_INVALID = -1
 E_UNSUPPORTED = -2
@@ -110,6 +110,18 @@ class MifftDeviceProps(ctypes.Structure):
         ("total_mem_bytes", ctypes.c_int64),
         ("clock_khz", ctypes.c_int32),
         ("l2_bytes", ctypes.c_int32),
+        ("llc_bytes", ctypes.c_int64),
+        ("num_xcc", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
+    ]
+
+
+class MifftFusedSync(ctypes.Structure):
+    """struct mifft_fused_sync (include/mifft.h): counters of this launch, the set it zeroes for the next one, the error word."""
+    _fields_ = [
+        ("counters", ctypes.c_void_p),
+        ("counters_next", ctypes.c_void_p),
+        ("error_word", ctypes.c_void_p),
     ]
 
 
@@ -118,6 +130,7 @@ _vpp = ctypes.POINTER(ctypes.c_void_p)
 _i32 = ctypes.c_int32
 _sz = ctypes.c_size_t
 _pass_p = ctypes.POINTER(MifftPass)
+_sync_p = ctypes.POINTER(MifftFusedSync)
 _buf3 = ctypes.c_void_p * 3
 
 # name -> (restype, argtypes); every symbol include/mifft.h declares
@@ -160,8 +173,10 @@ PROTOTYPES = {
     "mifft_launch_chain": (ctypes.c_int, [_pass_p, _i32, _vpp, _vpp, _vp]),
     "mifft_launch_chain_pipelined": (ctypes.c_int, [_pass_p, _i32, _vpp, _vpp, ctypes.c_int64, ctypes.c_int64,
                                                       ctypes.c_int64, _vp, _vpp, _i32, _vpp]),
-    "mifft_launch_fused2": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
-    "mifft_launch_fused2x": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "mifft_launch_fused2": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _sync_p, _i32, _vp]),
+    "mifft_launch_fused2x": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp, _i32, _i32, _sync_p, _i32, _vp]),
+    "mifft_fused_pair_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
+    "mifft_launch_fused_pair": (ctypes.c_int, [_pass_p, _vp, _vp, _vp, _i32, _i32, _sync_p, _i32, _vp]),
     "mifft_launch_xcd2": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "mifft_nd_tiled_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
     "mifft_launch_nd_tiled": (ctypes.c_int, [_pass_p, ctypes.POINTER(MifftTiling), _vp, _vp, _vp]),

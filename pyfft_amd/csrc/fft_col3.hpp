@@ -142,7 +142,7 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
             __builtin_amdgcn_sched_barrier(0);
         });
     }
-    {
+    if constexpr (A > 1) {                     // (A == 1: L = 512 = 2 x 256, no radix-A stage -- the rectangles of round 4)
         cplx<T> twA[A - 1];
         static_for<A - 1>([&](auto qq) {
             constexpr int qa = qq + 1;

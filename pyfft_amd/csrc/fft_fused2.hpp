@@ -27,24 +27,37 @@ namespace mifft {
 
 constexpr unsigned kFusedCS = 64u;   // words between two counters (= MIFFT_FUSED2_COUNTER_STRIDE)
 
+// the work list and its synchronisation state (shared by every persistent kernel: fft_fused2 / fused3 / fused2x / fusedp)
+struct FusedCtl {
+    unsigned* counters;  // [0] ticket, [1] error (when `err` points here), then one counter per CS = 64 words (256 bytes): wdone[t] at
+                         // CS * (1 + t), rdone[t] at CS * (1 + batch + t), the ticket counters of the per-XCD lists behind them; ALL ZERO
+                         // when the launch starts
+    unsigned* counters_next;   // nullptr, or a second counter set that THIS launch zeroes for the next one (round 4: a plan alternates
+                               // between two sets, so no memset node precedes the launch)
+    unsigned* err;       // error word, set on a dependency time-out (device-accessible: counters + 1, or pinned host memory)
+    unsigned lines;      // counter lines per set (9 + 2 * batch)
+    unsigned batch;      // number of transforms
+    unsigned lag;        // pass 1 of transform t is queued with pass 0 of transform t + lag; 0 = the SEQUENTIAL list of a tiny batch:
+                         // every pass-0 tile of every transform, then every pass-1 tile (ring = batch slots, no slot is reused)
+    unsigned ring;       // scratch ring slots (transforms); ring > lag
+    unsigned tiles0;     // tiles per transform in pass 0
+    unsigned tiles1;     // tiles per transform in pass 1
+};
+
 struct FusedArgs {
     TileArgs p0;         // pass 0: in = user input,  out = scratch ring (matrix index = ring slot)
     TileArgs p1;         // pass 1: in = scratch ring, out = user output
-    unsigned* counters;  // [0] ticket, [1] error, then one counter per CS = 64 words (256 bytes): wdone[t] at CS * (1 + t),
-                         // rdone[t] at CS * (1 + batch + t)  (zeroed per launch)
-    unsigned batch;      // number of transforms
-    unsigned lag;        // pass 1 of transform t is queued with pass 0 of transform t + lag
-    unsigned ring;       // scratch ring slots (transforms); ring > lag
-    unsigned tiles0;     // 16-column tiles per transform in pass 0 (= L1 / 16)
-    unsigned tiles1;     // 16-column tiles per transform in pass 1 (= L0 / 16)
+    FusedCtl c;
 };
 
-// XCD-local form (development strategy `fusedx`, round 3): one work list PER XCD (chiplet).  A work-group reads its XCD from
-// HW_REG_XCC_ID and draws tickets from that XCD's counter; XCD x owns the transforms t = x + 8 i, its ring slots are
-// [x * ring, (x + 1) * ring), so a transform's intermediate is written and read by work-groups of ONE XCD and -- written with
-// plain stores -- can stay in that XCD's 4 MiB L2 (tools/l2_resident_probe.hip: ~1 MiB stays next to non-temporal streams, 2 MiB
-// leaks 44 % of its writes).  Same dependency order per list, so the same no-deadlock argument; an XCD that receives no
-// work-group at all would leave its transforms undone, which the launch detects (a census word per XCD, error bit 2).
+// XCD-local form (strategy `fusedx`, round 3; a default since round 4): one work list PER XCD (chiplet).  A work-group reads its XCD
+// from HW_REG_XCC_ID and draws tickets from that XCD's counter; XCD x owns the transforms t = x + 8 i, its ring slots are
+// [x * ring, (x + 1) * ring).  (Round 3 measured that the intermediate still crosses the fabric twice -- an XCD's L2 keeps ~1 MiB
+// next to the streams, a stall-free list needs 4-32 MiB -- so what the form buys is eight short pipelines with eight ticket
+// counters instead of one long one: + 2 points at 2^16 / 2^17, profiles/r04_a_fused_sweep.log.)  Same dependency order per list, so
+// the same no-deadlock argument.  Round 4: a work-group that finds its own list exhausted moves on to the lists other XCDs have
+// not finished (work stealing, in list order), so every list is drained whatever the placement of the work-groups -- a launch
+// that leaves an XCD without work-groups (a CU mask, a shared device) is slower, not wrong.
 __device__ __forceinline__ unsigned fused_xcc_id() {
     unsigned v;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
@@ -76,7 +89,7 @@ template <bool ACQ> __device__ __forceinline__ void fused_wait_ge(unsigned* ctr,
             if (seen >= target) break;
             __builtin_amdgcn_s_sleep(32);
             if (++spins > (1u << 22)) {  // ~ seconds: never hang the GPU
-                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (may be pinned host memory)
                 break;
             }
         }
@@ -125,14 +138,31 @@ struct FusedItem {
 // xs = 8 and x = the XCD for the XCD-local lists (group g of the list = transform x + 8 g, `nb` = transforms of this list);
 // xs = 1, x = 0, nb = batch for the one global list.  it.t is the GLOBAL transform, it.slot its ring slot.
 template <unsigned PER0, unsigned PER1>
-__device__ __forceinline__ FusedItem fused_decode(const FusedArgs& f, unsigned item, unsigned gsize, unsigned* wdone, unsigned* rdone,
+__device__ __forceinline__ FusedItem fused_decode(const FusedCtl& f, unsigned item, unsigned gsize, unsigned* wdone, unsigned* rdone,
                                                   unsigned x = 0u, unsigned xs = 1u, unsigned nb = 0xffffffffu) {
-    constexpr unsigned period = PER0 + PER1;
-    const unsigned g = item / gsize, k = item % gsize, j = k / period, m = k % period;
-    if (xs == 1u) nb = f.batch;
     FusedItem it;
     it.dep = nullptr;
     it.target = 0;
+    if (f.lag == 0u) {
+        // sequential list (tiny batches): no empty item, no ring reuse; a pass-1 tile still waits for its transform's pass-0 tiles
+        const unsigned n0 = f.batch * f.tiles0;
+        if (item < n0) {
+            it.pass = 0u;
+            it.t = item / f.tiles0;
+            it.tile = item % f.tiles0;
+        } else {
+            it.pass = 1u;
+            it.t = (item - n0) / f.tiles1;
+            it.tile = (item - n0) % f.tiles1;
+            it.dep = wdone + kFusedCS * it.t;
+            it.target = f.tiles0;
+        }
+        it.slot = it.t;
+        return it;
+    }
+    constexpr unsigned period = PER0 + PER1;
+    const unsigned g = item / gsize, k = item % gsize, j = k / period, m = k % period;
+    if (xs == 1u) nb = f.batch;
     if (m < PER0) {
         it.pass = g < nb ? 0u : 2u;
         it.t = x + xs * g;
@@ -155,22 +185,23 @@ __device__ __forceinline__ FusedItem fused_decode(const FusedArgs& f, unsigned i
     return it;
 }
 
-// lane 0 only: hand out this item's ticket and its early poll, draw the next ticket
-// (tmul, tadd): a drawn ticket k is item k * tmul + tadd -- (1, 0) for one ticket counter; (8, x) when the counter is sharded per
-// XCD and XCD x owns the items x, x + 8, ... of the SAME global list (development switch, see fused_loop)
-__device__ __forceinline__ unsigned fused_advance(FusedQueue& q, unsigned& seen, unsigned total, unsigned* next, unsigned tmul = 1u,
-                                                  unsigned tadd = 0u) {
+// lane 0 only: hand out this item's ticket and its early poll, draw the next ticket.  `stat`: the sequential list of a tiny batch is
+// dealt out STATICALLY (work-group w takes the items w, w + grid, ...): with every work-group of the launch resident (grid <= 2 per
+// CU, checked by the host) nothing can deadlock -- a work-group runs all its first-pass items, which never wait, before its first
+// second-pass item -- and 512 work-groups do not queue up twice at one ticket counter (measured: 53 against 25 us for two plain
+// launches at (1024, 1024) x 4 with tickets, profiles/r04_b_small_batch_sequential.log).
+__device__ __forceinline__ unsigned fused_advance(FusedQueue& q, unsigned& seen, unsigned total, unsigned* next, bool stat) {
     const unsigned item = q.t1;
     seen = q.seen1;
     q.seen1 = 0u;     // "not polled yet" (the hook of this item's tile sets it)
-    if (item < total) q.t1 = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * tmul + tadd;
+    if (item < total) q.t1 = stat ? item + gridDim.x : __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return item;
 }
 
 // The early poll.  A dependency is typically 20-50 us old when its consumer arrives (measured: 2 % younger than 10 us), so a
 // poll from the middle of the previous tile (~8 us earlier) almost always sees it; one item earlier it fails three times in four.
 template <unsigned PER0, unsigned PER1> struct FusedHook {
-    const FusedArgs& f;
+    const FusedCtl& f;
     FusedQueue& q;
     unsigned total, gsize;
     unsigned *wdone, *rdone;
@@ -183,23 +214,11 @@ template <unsigned PER0, unsigned PER1> struct FusedHook {
     }
 };
 
-// one persistent work-group: TILE0(t, slot, tile, hook) / TILE1(slot, t, tile, hook) run one tile of pass 0 / pass 1
-// XCD = 1: one work list per XCD.  XCD = 2 (development): the ONE global list with its ticket counter sharded per XCD -- XCD x draws
-// the items x, x + 8, ...; every dependency still points to a lower item of the same list, and the lowest unfinished item is
-// either running or the next ticket of its XCD, so the order argument holds as long as every XCD has a resident work-group.
-template <unsigned PER0, unsigned PER1, bool EARLY, typename TILE0, typename TILE1, int XCD = 0>
-__device__ __forceinline__ void fused_loop(const FusedArgs& f, unsigned* s_item, TILE0&& tile0, TILE1&& tile1) {
-    // XCD-local lists: ticket counter of XCD x on its own line behind the dependency counters, census word beside it
-    const unsigned xq = XCD ? fused_xcc_id() : 0u;
-    const unsigned x = XCD == 1 ? xq : 0u;
-    constexpr unsigned xs = XCD == 1 ? 8u : 1u;
-    const unsigned tmul = XCD == 2 ? 8u : 1u, tadd = XCD == 2 ? xq : 0u;
-    const unsigned nb = XCD == 1 ? (f.batch + 7u - x) >> 3 : f.batch;
-    unsigned* const next = XCD ? f.counters + kFusedCS * (1u + 2u * f.batch + xq) : f.counters;
-    unsigned* const err = f.counters + 1;
-    if constexpr (XCD) {
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(next + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // census
-    }
+// one work list (the global one, or the list of XCD x), drained by this work-group together with whoever else draws from `next`
+template <unsigned PER0, unsigned PER1, bool EARLY, typename TILE0, typename TILE1>
+__device__ __forceinline__ void fused_list(const FusedCtl& f, unsigned* s_item, TILE0& tile0, TILE1& tile1, FusedPending& pend,
+                                           const unsigned x, const unsigned xs, const unsigned nb, unsigned* const next) {
+    unsigned* const err = f.err;
     // One counter per 256-byte line: the counters of the few transforms in flight are polled and bumped by all 512 work-groups,
     // and packed 32 to a line they shared one memory channel's atomic unit (C2 with no polls at all -- wrong results, same
     // traffic -- ran 15 % faster; hiding the poll LATENCY changed nothing: it is the rate of same-line agent-scope accesses).
@@ -208,16 +227,16 @@ __device__ __forceinline__ void fused_loop(const FusedArgs& f, unsigned* s_item,
     // a group = the tiles0 pass-0 tiles of transform g and the tiles1 pass-1 tiles of transform g - lag, interleaved in their
     // ratio (tiles0 : tiles1 = PER0 : PER1), so that no ticket is an empty item
     const unsigned gsize = f.tiles0 + f.tiles1;
-    const unsigned total = (nb + f.lag) * gsize;
+    const unsigned total = f.lag == 0u ? f.batch * gsize : (nb + f.lag) * gsize;
 
-    FusedPending pend = {nullptr};
+    const bool stat = f.lag == 0u;
     FusedQueue q = {0u, 0u};
-    if (threadIdx.x == 0) q.t1 = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * tmul + tadd;
+    if (threadIdx.x == 0) q.t1 = stat ? blockIdx.x : __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const FusedHook<PER0, PER1> hook = {f, q, total, gsize, wdone, rdone, x, xs, nb};
     for (;;) {
         __syncthreads();  // the previous item's LDS traffic and its s_item read are over
         unsigned seen = 0;
-        if (threadIdx.x == 0) *s_item = fused_advance(q, seen, total, next, tmul, tadd);
+        if (threadIdx.x == 0) *s_item = fused_advance(q, seen, total, next, stat);
         __syncthreads();
         const unsigned item = *s_item;
         if (item >= total) break;
@@ -241,7 +260,55 @@ __device__ __forceinline__ void fused_loop(const FusedArgs& f, unsigned* s_item,
             fused_signal_read(rdone + kFusedCS * it.t);
         }
     }
-    fused_flush(pend);
+    fused_flush(pend);   // never carry a publish into another list (or out of the kernel)
+}
+
+// one persistent work-group: TILE0(t, slot, tile, hook) / TILE1(slot, t, tile, hook) run one tile of pass 0 / pass 1
+// XCD = 1: one work list per XCD, own list first, then the unfinished lists of the other XCDs.
+template <unsigned PER0, unsigned PER1, bool EARLY, typename TILE0, typename TILE1, int XCD = 0>
+__device__ __forceinline__ void fused_loop(const FusedCtl& f, unsigned* s_item, TILE0&& tile0, TILE1&& tile1) {
+    // the counter set of the NEXT launch (words 0 and 1 of every line: a counter, or ticket + error / census)
+    if (f.counters_next != nullptr) {
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < f.lines; i += gridDim.x * blockDim.x) {
+            f.counters_next[i * kFusedCS] = 0u;
+            f.counters_next[i * kFusedCS + 1u] = 0u;
+        }
+    }
+    FusedPending pend = {nullptr};
+    if constexpr (XCD == 0) {
+        fused_list<PER0, PER1, EARLY>(f, s_item, tile0, tile1, pend, 0u, 1u, f.batch, f.counters);
+    } else {
+        // ticket counter of XCD x on its own line behind the dependency counters
+        const unsigned home = fused_xcc_id();
+        unsigned* const tickets = f.counters + kFusedCS * (1u + 2u * f.batch);
+        const unsigned gsize = f.tiles0 + f.tiles1;
+        unsigned visit = 1u;     // bit h: drain the list of XCD (home + h) & 7
+        for (unsigned h = 0; h < 8u; ++h) {
+            if (visit & (1u << h)) {
+                const unsigned x = (home + h) & 7u;
+                fused_list<PER0, PER1, EARLY>(f, s_item, tile0, tile1, pend, x, 8u, (f.batch + 7u - x) >> 3, tickets + kFusedCS * x);
+            }
+            if (h == 0u) {
+                // own list exhausted: which other lists still have tickets?  (seven loads in flight at once, one lane)
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    unsigned v[7];
+#pragma unroll
+                    for (unsigned k = 0; k < 7u; ++k)
+                        v[k] = __hip_atomic_load(tickets + kFusedCS * ((home + 1u + k) & 7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned mask = 1u;
+#pragma unroll
+                    for (unsigned k = 0; k < 7u; ++k) {
+                        const unsigned x = (home + 1u + k) & 7u;
+                        if (v[k] < (((f.batch + 7u - x) >> 3) + f.lag) * gsize) mask |= 2u << k;
+                    }
+                    *s_item = mask;
+                }
+                __syncthreads();
+                visit = *s_item;
+            }
+        }
+    }
 }
 
 // NT: 0 = plain accesses on the streamed side, 1 = non-temporal loads of the input and stores of the output, 2 = non-temporal
@@ -254,7 +321,7 @@ __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
     constexpr unsigned per0 = A0 > A1 ? 1u : (unsigned)(A1 / A0);   // tiles0 : tiles1 = L1 : L0 = A1 : A0
     constexpr unsigned per1 = A1 > A0 ? 1u : (unsigned)(A0 / A1);
     fused_loop<per0, per1, !SPLIT>(   // early poll: C2 19.49 -> 19.32 ms; split planes 26.7 -> 25.6 ms WITHOUT it
-        f, &s_item,
+        f.c, &s_item,
         [&](unsigned t, unsigned slot, unsigned tile, auto hook) {
             col2_tile<T, A0, true, true, SPLIT, true, NT != 0, false, false>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);
         },
@@ -263,9 +330,11 @@ __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
         });
 }
 
-// XCD-local lists (see FusedArgs above).  WT0: write the intermediate with write-through stores (as the global form must) or
-// with plain ones (it then lives in the XCD's L2 and is written back only when evicted).
-template <typename T, int A0, int A1, bool WT0, int XCD = 1>
+// XCD-local lists (see fused_xcc_id above).  The intermediate is written WRITE-THROUGH, as in the global form: a work-group that
+// drains another XCD's list (work stealing) produces and consumes across XCDs, and only write-through stores + the consumer's
+// acquire are coherent between two L2s.  (Round 3's plain-store variant -- the intermediate in the owning XCD's L2 -- measured
+// 0-2 points more and was placement-dependent: removed.)
+template <typename T, int A0, int A1>
 __global__ void __launch_bounds__(256, 2) fft_fused2x_kernel(const FusedArgs f) {
     constexpr int E0 = Col2Lds<A0, true>::ELEMS, E1 = Col2Lds<A1, false>::ELEMS;
     __shared__ __attribute__((aligned(16))) cplx<T> lds[E0 > E1 ? E0 : E1];
@@ -273,28 +342,33 @@ __global__ void __launch_bounds__(256, 2) fft_fused2x_kernel(const FusedArgs f) 
     constexpr unsigned per0 = A0 > A1 ? 1u : (unsigned)(A1 / A0);
     constexpr unsigned per1 = A1 > A0 ? 1u : (unsigned)(A0 / A1);
     auto t0 = [&](unsigned t, unsigned slot, unsigned tile, auto hook) {
-        col2_tile<T, A0, true, true, false, WT0, true, false, false>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);
+        col2_tile<T, A0, true, true, false, true, true, false, false>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);
     };
     auto t1 = [&](unsigned slot, unsigned t, unsigned tile, auto hook) {
         col2_tile<T, A1, false, false, false, false, false, true, false>(f.p1, (long long)slot, (long long)t, (long long)tile * 16, lds, hook);
     };
-    fused_loop<per0, per1, true, decltype(t0)&, decltype(t1)&, XCD>(f, &s_item, t0, t1);
+    fused_loop<per0, per1, true, decltype(t0)&, decltype(t1)&, 1>(f.c, &s_item, t0, t1);
 }
 
 // The 2-D form (BASELINE config 3: 1024 x 1024): a 2-D transform is two TRANSPOSING column passes without an inter-pass twiddle
 // -- pass 0 transforms the y axis of in[y][x] and writes ring[x][ky], pass 1 transforms the x axis of that and writes
 // out[ky][kx] -- i.e. the 1-D kernel above minus the twiddle, with contiguous 8 KiB runs on the output side.
-template <typename T, int A, bool SPLIT, bool NT>
+// Round 4: rectangles.  A0 = ny / 256 (pass 0 transforms the y axis over nx / 16 tiles), A1 = nx / 256 (pass 1 the x axis over
+// ny / 16 tiles); the two passes look their w(L) up in different tables (TileArgs.tw_L of p0 / p1).
+template <typename T, int A0, int A1, bool SPLIT, bool NT>
 __global__ void __launch_bounds__(256, 2) fft_fused2d_kernel(const FusedArgs f) {
-    __shared__ __attribute__((aligned(16))) cplx<T> lds[Col2Lds<A, true>::ELEMS];
+    constexpr int E0 = Col2Lds<A0, true>::ELEMS, E1 = Col2Lds<A1, true>::ELEMS;
+    __shared__ __attribute__((aligned(16))) cplx<T> lds[E0 > E1 ? E0 : E1];
     __shared__ unsigned s_item;
-    fused_loop<1, 1, !SPLIT>(
-        f, &s_item,
+    constexpr unsigned per0 = A0 > A1 ? 1u : (unsigned)(A1 / A0);   // tiles0 : tiles1 = nx : ny = A1 : A0
+    constexpr unsigned per1 = A1 > A0 ? 1u : (unsigned)(A0 / A1);
+    fused_loop<per0, per1, !SPLIT>(
+        f.c, &s_item,
         [&](unsigned t, unsigned slot, unsigned tile, auto hook) {
-            col2_tile<T, A, true, false, SPLIT, true, NT, false, false>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);
+            col2_tile<T, A0, true, false, SPLIT, true, NT, false, false>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);
         },
         [&](unsigned slot, unsigned t, unsigned tile, auto hook) {
-            col2_tile<T, A, true, false, false, false, false, NT, SPLIT>(f.p1, (long long)slot, (long long)t, (long long)tile * 16, lds, hook);
+            col2_tile<T, A1, true, false, false, false, false, NT, SPLIT>(f.p1, (long long)slot, (long long)t, (long long)tile * 16, lds, hook);
         });
 }
 
@@ -309,7 +383,7 @@ __global__ void __launch_bounds__(512, 2) fft_fused3_kernel(const FusedArgs f) {
     constexpr unsigned per0 = A0 > A1 ? 1u : (unsigned)(A1 / A0);
     constexpr unsigned per1 = A1 > A0 ? 1u : (unsigned)(A0 / A1);
     fused_loop<per0, per1, false>(   // no early poll: the fp64 tiles have no register to spare for it, the fp32 ones measured equal
-        f, &s_item,
+        f.c, &s_item,
         [&](unsigned t, unsigned slot, unsigned tile, auto hook) {
             col3_tile<T, A0, true, true, SPLIT, NT, false, false, true>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);
         },
@@ -318,18 +392,21 @@ __global__ void __launch_bounds__(512, 2) fft_fused3_kernel(const FusedArgs f) {
         });
 }
 
-// 2-D 1024 x 1024 in fp64 on the 512-thread tiles (the published (1024, 1024) double-precision shape): fft_fused2d_kernel's data flow
-template <typename T, int A, bool SPLIT, bool NT>
+// 2-D shapes on the 512-thread tiles (axis length 512 * A): fp64 1024 x 1024 (the published double-precision shape), fp32 with a
+// 2048-point axis -- fft_fused2d_kernel's data flow
+template <typename T, int A0, int A1, bool SPLIT, bool NT>
 __global__ void __launch_bounds__(512, 2) fft_fused3d_kernel(const FusedArgs f) {
     __shared__ __attribute__((aligned(16))) T lds[Col3Lds<T, true>::SCALARS];
     __shared__ unsigned s_item;
-    fused_loop<1, 1, false>(
-        f, &s_item,
+    constexpr unsigned per0 = A0 > A1 ? 1u : (unsigned)(A1 / A0);
+    constexpr unsigned per1 = A1 > A0 ? 1u : (unsigned)(A0 / A1);
+    fused_loop<per0, per1, false>(
+        f.c, &s_item,
         [&](unsigned t, unsigned slot, unsigned tile, auto hook) {
-            col3_tile<T, A, true, false, SPLIT, NT, false, false, true>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);
+            col3_tile<T, A0, true, false, SPLIT, NT, false, false, true>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);
         },
         [&](unsigned slot, unsigned t, unsigned tile, auto hook) {
-            col3_tile<T, A, true, false, false, false, NT, SPLIT>(f.p1, (long long)slot, (long long)t, (long long)tile * 16, lds, hook);
+            col3_tile<T, A1, true, false, false, false, NT, SPLIT>(f.p1, (long long)slot, (long long)t, (long long)tile * 16, lds, hook);
         });
 }
 

@@ -49,42 +49,40 @@ extern "C" int mifft_fused2_f32_launch(int L0, int L1, const mifft::FusedArgs* f
     return -2;
 }
 
-// XCD-local work lists (development strategy `fusedx`): interleaved fp32, L0, L1 in {256, 512, 1024}; wt = write-through intermediate
-namespace {
-template <int A0, int A1> int launchx(const mifft::FusedArgs* f, int wt, unsigned grid, hipStream_t s) {
-    // wt == 2: the GLOBAL list with a per-XCD sharded ticket counter (write-through intermediate, as the global form needs)
-    if (wt == 2) hipLaunchKernelGGL((mifft::fft_fused2x_kernel<float, A0, A1, true, 2>), dim3(grid), dim3(256), 0, s, *f);
-    else if (wt) hipLaunchKernelGGL((mifft::fft_fused2x_kernel<float, A0, A1, true>), dim3(grid), dim3(256), 0, s, *f);
-    else hipLaunchKernelGGL((mifft::fft_fused2x_kernel<float, A0, A1, false>), dim3(grid), dim3(256), 0, s, *f);
-    return (int)hipGetLastError();
-}
-}  // namespace
-extern "C" int mifft_fused2x_f32_launch(int L0, int L1, const mifft::FusedArgs* f, int wt, unsigned grid, hipStream_t s) {
-    const int key = (L0 / 256) * 10 + (L1 / 256);
-    switch (key) {
-        case 11: return launchx<1, 1>(f, wt, grid, s);
-        case 21: return launchx<2, 1>(f, wt, grid, s);
-        case 22: return launchx<2, 2>(f, wt, grid, s);
-        case 42: return launchx<4, 2>(f, wt, grid, s);
-        case 44: return launchx<4, 4>(f, wt, grid, s);
+// XCD-local work lists (strategy `fusedx`): interleaved fp32, L0 >= L1 in {256, 512, 1024}
+extern "C" int mifft_fused2x_f32_launch(int L0, int L1, const mifft::FusedArgs* f, unsigned grid, hipStream_t s) {
+#define XL(A0, A1)                                                                                                  \
+    if (L0 == 256 * A0 && L1 == 256 * A1) {                                                                         \
+        hipLaunchKernelGGL((mifft::fft_fused2x_kernel<float, A0, A1>), dim3(grid), dim3(256), 0, s, *f);            \
+        return (int)hipGetLastError();                                                                              \
     }
+    XL(1, 1)
+    XL(2, 1)
+    XL(2, 2)
+    XL(4, 2)
+    XL(4, 4)
+#undef XL
     return -2;
 }
 
-// 2-D squares: 512 and 1024 on the 256-thread tiles (fft_fused2d_kernel), 2048 on the 512-thread ones (fft_fused3d_kernel)
-extern "C" int mifft_fused2d_f32_launch(int L, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s) {
+// 2-D squares: 512 and 1024 on the 256-thread tiles (fft_fused2d_kernel), 2048 on the 512-thread ones (fft_fused3d_kernel);
+// the rectangles live in fft_fused2d_f32.hip
+extern "C" int mifft_fused2d_rect_f32_launch(int ny, int nx, const mifft::FusedArgs* f, unsigned grid, hipStream_t s);
+extern "C" int mifft_fused2d_f32_launch(int ny, int nx, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s) {
+    if (ny != nx) return split ? MIFFT_E_UNSUPPORTED : mifft_fused2d_rect_f32_launch(ny, nx, f, grid, s);
+    const int L = nx;
     if (L == 512) {
-        if (split) hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 2, true, false>), dim3(grid), dim3(256), 0, s, *f);
-        else hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 2, false, true>), dim3(grid), dim3(256), 0, s, *f);
+        if (split) hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 2, 2, true, false>), dim3(grid), dim3(256), 0, s, *f);
+        else hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 2, 2, false, true>), dim3(grid), dim3(256), 0, s, *f);
         return (int)hipGetLastError();
     }
     if (L == 2048) {   // 512-thread tiles
-        if (split) hipLaunchKernelGGL((mifft::fft_fused3d_kernel<float, 4, true, false>), dim3(grid), dim3(512), 0, s, *f);
-        else hipLaunchKernelGGL((mifft::fft_fused3d_kernel<float, 4, false, true>), dim3(grid), dim3(512), 0, s, *f);
+        if (split) hipLaunchKernelGGL((mifft::fft_fused3d_kernel<float, 4, 4, true, false>), dim3(grid), dim3(512), 0, s, *f);
+        else hipLaunchKernelGGL((mifft::fft_fused3d_kernel<float, 4, 4, false, true>), dim3(grid), dim3(512), 0, s, *f);
         return (int)hipGetLastError();
     }
     if (L != 1024) return MIFFT_E_UNSUPPORTED;
-    if (split) hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 4, true, false>), dim3(grid), dim3(256), 0, s, *f);
-    else hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 4, false, true>), dim3(grid), dim3(256), 0, s, *f);
+    if (split) hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 4, 4, true, false>), dim3(grid), dim3(256), 0, s, *f);
+    else hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 4, 4, false, true>), dim3(grid), dim3(256), 0, s, *f);
     return (int)hipGetLastError();
 }

@@ -1,0 +1,28 @@
+// fp32 instances of the fused 2-D kernels for RECTANGLES (fft_fused2.hpp; round 4): (ny, nx) in {512, 1024, 2048}^2, ny != nx,
+// interleaved.  Both sides up to 1024: 256-thread tiles (fft_fused2d_kernel); a 2048-point axis: 512-thread tiles
+// (fft_fused3d_kernel, axis length 512 * A).  -fno-slp-vectorize: see fft_col2_f32.hip.
+#include "../../include/mifft.h"
+#include "mifft_internal.h"
+#include "fft_fused2.hpp"
+
+extern "C" int mifft_fused2d_rect_f32_launch(int ny, int nx, const mifft::FusedArgs* f, unsigned grid, hipStream_t s) {
+#define RECT2(NY, NX)                                                                                                             \
+    if (ny == NY && nx == NX) {                                                                                                   \
+        hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, NY / 256, NX / 256, false, true>), dim3(grid), dim3(256), 0, s, *f); \
+        return (int)hipGetLastError();                                                                                            \
+    }
+#define RECT3(NY, NX)                                                                                                             \
+    if (ny == NY && nx == NX) {                                                                                                   \
+        hipLaunchKernelGGL((mifft::fft_fused3d_kernel<float, NY / 512, NX / 512, false, true>), dim3(grid), dim3(512), 0, s, *f); \
+        return (int)hipGetLastError();                                                                                            \
+    }
+    RECT2(512, 1024)
+    RECT2(1024, 512)
+    RECT3(1024, 2048)
+    RECT3(2048, 1024)
+    RECT3(512, 2048)
+    RECT3(2048, 512)
+#undef RECT2
+#undef RECT3
+    return MIFFT_E_UNSUPPORTED;
+}

@@ -13,7 +13,7 @@ extern "C" int mifft_fused3_f64_launch(int L0, int L1, const mifft::FusedArgs* f
 // 2-D 1024 x 1024 (fft_fused3d_kernel)
 extern "C" int mifft_fused3d_f64_launch(int L, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s) {
     if (L != 1024) return MIFFT_E_UNSUPPORTED;
-    if (split) hipLaunchKernelGGL((mifft::fft_fused3d_kernel<double, 2, true, false>), dim3(grid), dim3(512), 0, s, *f);
-    else hipLaunchKernelGGL((mifft::fft_fused3d_kernel<double, 2, false, true>), dim3(grid), dim3(512), 0, s, *f);
+    if (split) hipLaunchKernelGGL((mifft::fft_fused3d_kernel<double, 2, 2, true, false>), dim3(grid), dim3(512), 0, s, *f);
+    else hipLaunchKernelGGL((mifft::fft_fused3d_kernel<double, 2, 2, false, true>), dim3(grid), dim3(512), 0, s, *f);
     return (int)hipGetLastError();
 }

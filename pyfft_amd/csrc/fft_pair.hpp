@@ -167,23 +167,18 @@ struct PairChain<T, P, NT, HALF, FIRST, MAP, TWOUT, SPLIT_OUT, Nd2StageList<D, R
     }
 };
 
+// One tile: `bin` / `bout` = element offset of the tile's first point on the input / output side, `lrow` = the tile's row index l in
+// the inter-pass twiddle of an XY tile.  Shared by the plain launch below and the persistent two-pair kernel (fft_fusedp.hpp).
 // CFG: P, NT, HALF, OCC, MAP, SL (stage list over the tile-local space), TWOUT, SPLIT_IN, SPLIT_OUT
-template <typename T, typename CFG>
-__global__ void __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::OCC))) fft_pair_kernel(const PairArgs a) {
+template <typename T, typename CFG, typename LdsT>
+__device__ __forceinline__ void pair_tile(const PairArgs& a, const long long bin, const long long bout, const int lrow, LdsT* lds,
+                                          const int tid, const bool nt_in, const int nt_out) {
     using MAP = typename CFG::MAP;
     using SL = typename CFG::SL;
     constexpr int P = CFG::P, NT = CFG::NT, PPT = P / NT;
     constexpr bool HALF = CFG::HALF;
     static_assert(P == MAP::E0 * MAP::E1 * MAP::E2 && PPT * NT == P, "bad tile");
     using First = Nd2Stage<T, P, NT, HALF, typename Nd2First<SL>::type>;
-    using LdsT = typename std::conditional<HALF, T, cplx<T>>::type;
-    __shared__ __attribute__((aligned(16))) LdsT lds[P + P / 16];
-    const int tid = threadIdx.x;
-    const unsigned tile = blockIdx.x;
-    const unsigned c0 = tile % (unsigned)MAP::C0, c1 = (tile / (unsigned)MAP::C0) % (unsigned)MAP::C1;
-    const long long o = tile / (unsigned)(MAP::C0 * MAP::C1);
-    const long long bin = o * MAP::BOUTER + (long long)c0 * MAP::BI0 + (long long)c1 * MAP::BI1;
-    const long long bout = o * MAP::BOUTER + (long long)c0 * MAP::BO0 + (long long)c1 * MAP::BO1;
     constexpr bool SI = CFG::SPLIT_IN, SO = CFG::SPLIT_OUT;
     const char* inb = SI ? reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.in0) + bin)
                          : reinterpret_cast<const char*>(reinterpret_cast<const cplx<T>*>(a.in0) + bin);
@@ -196,11 +191,24 @@ __global__ void __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CF
     const T sx = (T)a.scale;
     const T sy = a.inverse ? -sx : sx;
     cplx<T> v[PPT];
-    if (a.nt & 1) pair_load<T, First, MAP, true, SI>(inb, inb1, v, tid);
+    if (nt_in) pair_load<T, First, MAP, true, SI>(inb, inb1, v, tid);
     else pair_load<T, First, MAP, false, SI>(inb, inb1, v, tid);
     if (a.inverse) static_for<PPT>([&](auto i) { v[i].y = -v[i].y; });
-    PairChain<T, P, NT, HALF, true, MAP, CFG::TWOUT, SO, SL>::run(lds, v, tw, tid, outb, outb1, sx, sy,
-                                                                 (a.nt & 4) ? 2 : ((a.nt & 2) ? 1 : 0), a, (int)c0);
+    PairChain<T, P, NT, HALF, true, MAP, CFG::TWOUT, SO, SL>::run(lds, v, tw, tid, outb, outb1, sx, sy, nt_out, a, lrow);
+}
+
+template <typename T, typename CFG>
+__global__ void __launch_bounds__(CFG::NT) __attribute__((amdgpu_waves_per_eu(CFG::OCC))) fft_pair_kernel(const PairArgs a) {
+    using MAP = typename CFG::MAP;
+    constexpr int P = CFG::P;
+    using LdsT = typename std::conditional<CFG::HALF, T, cplx<T>>::type;
+    __shared__ __attribute__((aligned(16))) LdsT lds[P + P / 16];
+    const unsigned tile = blockIdx.x;
+    const unsigned c0 = tile % (unsigned)MAP::C0, c1 = (tile / (unsigned)MAP::C0) % (unsigned)MAP::C1;
+    const long long o = tile / (unsigned)(MAP::C0 * MAP::C1);
+    const long long bin = o * MAP::BOUTER + (long long)c0 * MAP::BI0 + (long long)c1 * MAP::BI1;
+    const long long bout = o * MAP::BOUTER + (long long)c0 * MAP::BO0 + (long long)c1 * MAP::BO1;
+    pair_tile<T, CFG>(a, bin, bout, (int)c0, lds, (int)threadIdx.x, (a.nt & 1) != 0, (a.nt & 4) ? 2 : ((a.nt & 2) ? 1 : 0));
 }
 
 // ---- the two tile kinds for a (NZ, NY, NX) transform with NY = R0 * R1 ------------------------------------------------

@@ -9,6 +9,7 @@
 #include "fft_wave.hpp"
 #include "fft_pair.hpp"
 #include "fft_nd2t.hpp"
+#include "fft_fusedp.hpp"
 
 // Each returns 0 on success, MIFFT_E_UNSUPPORTED (-2) when no kernel is compiled for (L, tr, variant),
 // or a hipError_t.  With query_only != 0 nothing is launched.
@@ -24,8 +25,8 @@ int mifft_nd2_f32_launch(int x, int y, int z, const mifft::TileArgs* a, hipStrea
 int mifft_nd2_f64_supported(int x, int y, int z);
 int mifft_nd2_f64_launch(int x, int y, int z, const mifft::TileArgs* a, hipStream_t s);
 int mifft_fused2_f32_launch(int L0, int L1, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
-int mifft_fused2x_f32_launch(int L0, int L1, const mifft::FusedArgs* f, int wt, unsigned grid, hipStream_t s);
-int mifft_fused2d_f32_launch(int L, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
+int mifft_fused2x_f32_launch(int L0, int L1, const mifft::FusedArgs* f, unsigned grid, hipStream_t s);
+int mifft_fused2d_f32_launch(int ny, int nx, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
 int mifft_fused3d_f64_launch(int L, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
 int mifft_fused3_f64_launch(int L0, int L1, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
 int mifft_aux_copy_launch(const struct mifft_copy* c, const void* s0, const void* s1, void* d0, void* d1, hipStream_t s);
@@ -35,6 +36,8 @@ int mifft_wave_launch(int f64, int N, const mifft::WaveArgs* a, int max_blocks, 
 int mifft_wave_16x16_launch(const mifft::WaveArgs* a, int max_blocks, hipStream_t s);
 int mifft_pair_f64(int kind, int k0, int k1, int k2, int split, const mifft::PairArgs* a, hipStream_t s, int query, int* width);
 int mifft_pair_f32(int kind, int k0, int k1, int k2, int split, const mifft::PairArgs* a, hipStream_t s, int query, int* width);
+int mifft_fusedp(int f64, int x, int y, int z, const mifft::FusedPairArgs* f, unsigned grid, hipStream_t s, int query, int* r0,
+                 unsigned* tiles0, unsigned* tiles1);
 int mifft_nd2t(int f64, int x, int y, int z, const mifft::TileArgs* a, const mifft::TiledGeom* g, hipStream_t s, int query);
 int mifft_mixed_supported_impl(int f64, int n);
 int mifft_mixed_launch(int f64, int n, long long rows, long long stride_in, long long stride_out, long long inner, const void* in,

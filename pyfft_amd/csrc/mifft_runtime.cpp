@@ -1,6 +1,8 @@
 // C-ABI runtime shim + pass launchers of libmifft.so (see include/mifft.h for the contract and for
 // the reference interfaces each entry point replaces).
 #include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -310,6 +312,71 @@ int pair_call(int precision, int kind, const int key[3], int split, const mifft:
     return MIFFT_E_UNSUPPORTED;
 }
 
+// Last-level cache size and XCD count of a HIP device: HIP has no attribute for either, the HSA agent behind the device has
+// (matched by PCI domain / bus / device / function).  HSA is already initialised by the HIP runtime; hsa_init / hsa_shut_down only
+// move its reference count.
+struct HsaProbe {
+    uint32_t domain, bdf;
+    uint32_t cache[4];
+    uint32_t xcc;
+    bool found;
+};
+hsa_status_t hsa_probe_agent(hsa_agent_t agent, void* data) {
+    HsaProbe* p = static_cast<HsaProbe*>(data);
+    hsa_device_type_t type;
+    if (hsa_agent_get_info(agent, HSA_AGENT_INFO_DEVICE, &type) != HSA_STATUS_SUCCESS || type != HSA_DEVICE_TYPE_GPU) return HSA_STATUS_SUCCESS;
+    uint32_t bdf = 0, domain = 0;
+    if (hsa_agent_get_info(agent, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    (void)hsa_agent_get_info(agent, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
+    if (bdf != p->bdf || domain != p->domain) return HSA_STATUS_SUCCESS;
+    uint32_t cache[4] = {0, 0, 0, 0}, xcc = 0;
+    if (hsa_agent_get_info(agent, HSA_AGENT_INFO_CACHE_SIZE, cache) == HSA_STATUS_SUCCESS) memcpy(p->cache, cache, sizeof(cache));
+    if (hsa_agent_get_info(agent, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_NUM_XCC, &xcc) == HSA_STATUS_SUCCESS) p->xcc = xcc;
+    p->found = true;
+    return HSA_STATUS_INFO_BREAK;
+}
+void probe_memory_system(const hipDeviceProp_t& hp, int64_t* llc_bytes, int32_t* num_xcc) {
+    HsaProbe probe;
+    memset(&probe, 0, sizeof(probe));
+    probe.domain = (uint32_t)hp.pciDomainID;
+    probe.bdf = ((uint32_t)hp.pciBusID << 8) | ((uint32_t)hp.pciDeviceID << 3);
+    if (hsa_init() == HSA_STATUS_SUCCESS) {
+        (void)hsa_iterate_agents(hsa_probe_agent, &probe);
+        (void)hsa_shut_down();
+    }
+    *llc_bytes = probe.found ? (int64_t)probe.cache[2] : 0;
+    *num_xcc = (probe.found && probe.xcc >= 1) ? (int32_t)probe.xcc : 0;
+    if (*llc_bytes == 0 && (strncmp(hp.gcnArchName, "gfx94", 5) == 0 || strncmp(hp.gcnArchName, "gfx95", 5) == 0)) {
+        // no answer from HSA on a CDNA3/4 part: the documented 256 MiB per 8 XCDs, scaled to the partition this device is
+        *llc_bytes = (int64_t)(256ll << 20) * (hp.multiProcessorCount >= 228 ? 8 : (hp.multiProcessorCount + 37) / 38) / 8;
+    }
+    if (*num_xcc == 0) *num_xcc = hp.multiProcessorCount >= 228 ? 8 : (hp.multiProcessorCount >= 64 ? hp.multiProcessorCount / 32 : 1);
+}
+
+// work-list control block of a persistent launch from the caller's mifft_fused_sync (include/mifft.h): validates, zeroes the
+// counters on `stream` when the caller does not alternate between two sets
+int fill_ctl(mifft::FusedCtl* c, const mifft_fused_sync* sync, long long outer, int lag, int ring_slots, unsigned tiles0, unsigned tiles1,
+             hipStream_t stream, const char* who) {
+    static_assert(mifft::kFusedCS == MIFFT_FUSED2_COUNTER_STRIDE, "counter stride");
+    if (!sync || !sync->counters) return set_err(MIFFT_E_INVALID, "%s: null counters", who);
+    if (((uintptr_t)sync->counters | (uintptr_t)sync->counters_next) & 255) return set_err(MIFFT_E_INVALID, "%s: counter buffers must be 256-byte aligned", who);
+    if ((uintptr_t)sync->error_word & 3) return set_err(MIFFT_E_INVALID, "%s: misaligned error word", who);
+    if (sync->counters_next == sync->counters) return set_err(MIFFT_E_INVALID, "%s: counters_next must be a second buffer", who);
+    if (outer > 0x3fffffff) return set_err(MIFFT_E_INVALID, "%s: batch too large", who);
+    c->counters = (unsigned*)sync->counters;
+    c->counters_next = (unsigned*)sync->counters_next;
+    c->err = sync->error_word ? (unsigned*)sync->error_word : (unsigned*)sync->counters + 1;
+    c->lines = (unsigned)(9 + 2 * outer);
+    c->batch = (unsigned)outer;
+    c->lag = (unsigned)lag;
+    c->ring = (unsigned)ring_slots;
+    c->tiles0 = tiles0;
+    c->tiles1 = tiles1;
+    if (!sync->counters_next)
+        return hip_check(hipMemsetAsync(sync->counters, 0, MIFFT_FUSED2_COUNTER_BYTES(outer), stream), "hipMemsetAsync");
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -352,6 +419,7 @@ int mifft_device_props_get(int device, mifft_device_props* props) {
     props->total_mem_bytes = (int64_t)p.totalGlobalMem;
     props->clock_khz = p.clockRate;
     props->l2_bytes = p.l2CacheSize;
+    probe_memory_system(p, &props->llc_bytes, &props->num_xcc);
     return 0;
 }
 
@@ -594,7 +662,7 @@ int mifft_launch_chain(const mifft_pass* passes, int32_t npasses, void* const bu
 }
 
 int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* in0, const void* in1, void* out0, void* out1,
-                        void* ring0, void* ring1, int32_t ring_slots, int32_t lag, void* counters, int32_t grid,
+                        void* ring0, void* ring1, int32_t ring_slots, int32_t lag, const mifft_fused_sync* sync, int32_t grid,
                         mifft_stream_t stream) {
     int rc = validate(p0);
     if (rc) return rc;
@@ -602,13 +670,15 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     if (rc) return rc;
     if (p0->precision != p1->precision) return set_err(MIFFT_E_INVALID, "fused2: passes of two precisions");
     const bool f64 = p0->precision == MIFFT_F64;
-    // 2-D form: the ROW pass and the strided COL pass of a square 1024 x 1024 fp32 transform, run as two transposing column passes
+    // 2-D form: the ROW pass (x axis, length nx) and the strided COL pass (y axis, length ny) of a 2-D plan, run as two
+    // transposing column passes; fp32: nx, ny in {512, 1024, 2048} (split planes: squares only), fp64: 1024 x 1024
     const bool twod = p0->kind == MIFFT_PASS_ROW;
     if (twod) {
-        const bool okL = f64 ? p1->L == 1024 : (p1->L == 512 || p1->L == 1024 || p1->L == 2048);
-        if (p1->kind != MIFFT_PASS_COL || !okL || p0->L != p1->L || p1->S != p1->L || p1->M != 1 ||
+        auto side = [](int L) { return L == 512 || L == 1024 || L == 2048; };
+        const bool okL = f64 ? (p1->L == 1024 && p0->L == 1024) : (side(p0->L) && side(p1->L) && (p0->L == p1->L || p0->layout != MIFFT_SPLIT));
+        if (p1->kind != MIFFT_PASS_COL || !okL || p1->S != p0->L || p1->M != 1 ||
             p0->outer != p1->outer * p1->L || p0->layout != p1->layout || p0->inverse != p1->inverse)
-            return set_err(MIFFT_E_UNSUPPORTED, "fused2: the 2-D form is a square of 512, 1024 or 2048 (fp32) / 1024 (fp64)");
+            return set_err(MIFFT_E_UNSUPPORTED, "fused2: the 2-D form takes (ny, nx) in {512, 1024, 2048}^2 (fp32; split planes: squares) / 1024 x 1024 (fp64)");
     } else {
     if (p0->kind != MIFFT_PASS_COL || p1->kind != MIFFT_PASS_COL || p0->S != 1 || p0->M != p1->L || p1->M != 1 ||
         p1->S != p0->L || p0->outer != p1->outer || p0->layout != p1->layout || p0->inverse != p1->inverse)
@@ -618,13 +688,15 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     if (f64 ? (p0->L != 1024 || p1->L != 1024) : (!big && (!ok_len(p0->L) || !ok_len(p1->L)))) return set_err(MIFFT_E_UNSUPPORTED, "fused2: no kernel for %d x %d", p0->L, p1->L);
     }
     const bool split = p0->layout == MIFFT_SPLIT;
-    if (!in0 || !out0 || !ring0 || !counters || (split && (!in1 || !out1))) return set_err(MIFFT_E_INVALID, "fused2: null buffer");
+    if (!in0 || !out0 || !ring0 || (split && (!in1 || !out1))) return set_err(MIFFT_E_INVALID, "fused2: null buffer");
     (void)ring1;  // the ring is always interleaved
-    if (ring_slots < 2 || lag < 1 || lag >= ring_slots || grid < 1) return set_err(MIFFT_E_INVALID, "fused2: need 1 <= lag < ring_slots, grid >= 1");
+    if (grid < 1) return set_err(MIFFT_E_INVALID, "fused2: grid >= 1");
+    // lag == 0: the sequential list of a tiny batch, one ring slot per transform
+    if (lag == 0 ? ring_slots != p1->outer && p1->outer > 0 : (ring_slots < 2 || lag < 1 || lag >= ring_slots))
+        return set_err(MIFFT_E_INVALID, "fused2: need 1 <= lag < ring_slots, or lag == 0 with ring_slots == outer");
     if (((uintptr_t)in0 | (uintptr_t)out0 | (uintptr_t)ring0 | (uintptr_t)in1 | (uintptr_t)out1) & 15)
         return set_err(MIFFT_E_INVALID, "data buffers must be 16-byte aligned");
     if (p1->outer == 0) return 0;
-    if (p1->outer > 0x3fffffff) return set_err(MIFFT_E_INVALID, "fused2: batch too large");
     const int64_t n = (int64_t)p0->L * p1->L;
     mifft::FusedArgs f;
     fill_args(p0, in0, in1, ring0, nullptr, &f.p0);
@@ -632,24 +704,21 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     f.p0.ostride_out = n;  // ring slot pitch
     f.p1.ostride_in = n;
     if (twod) {
-        // pass 0 = the y axis as a transposing column pass over in[y][x] (L rows of M = L columns, S = 1), pass 1 = the x axis as
-        // the same pass over ring[x][ky]; both take w(L) from the COL pass's table
+        // pass 0 = the y axis as a transposing column pass over in[y][x] (ny rows of M = nx columns, S = 1) -> ring[x][ky], with the
+        // COL pass's table w(ny); pass 1 = the x axis as the same pass over ring[x][ky] (nx rows of ny columns) -> out[ky][kx],
+        // with the ROW pass's table w(nx)
         f.p0.tw_L = p1->tw_L;
+        f.p1.tw_L = p0->tw_L;
         f.p0.ostride_in = p1->outer_stride_in;
-        f.p0.logMS = ilog2(p1->L); f.p0.logS = 0; f.p0.has_tw = 0; f.p0.total = p1->outer * p1->L;
+        f.p0.logMS = ilog2(p0->L); f.p0.logS = 0; f.p0.has_tw = 0; f.p0.total = p1->outer * p0->L;
         f.p1.logMS = ilog2(p1->L); f.p1.logS = 0; f.p1.has_tw = 0; f.p1.total = p1->outer * p1->L;
     }
-    f.counters = (unsigned*)counters;
-    f.batch = (unsigned)p1->outer;
-    f.lag = (unsigned)lag;
-    f.ring = (unsigned)ring_slots;
-    f.tiles0 = twod ? (unsigned)(p1->L / 16) : (unsigned)(p0->M / 16);
-    f.tiles1 = (unsigned)(p1->S / 16);
-    static_assert(mifft::kFusedCS == MIFFT_FUSED2_COUNTER_STRIDE, "counter stride");
-    rc = hip_check(hipMemsetAsync(counters, 0, MIFFT_FUSED2_COUNTER_BYTES(p1->outer), (hipStream_t)stream), "hipMemsetAsync");
+    // tiles per transform: 2-D: nx / 16 column tiles in pass 0, ny / 16 in pass 1; 1-D: L1 / 16 and L0 / 16
+    rc = fill_ctl(&f.c, sync, p1->outer, lag, ring_slots, twod ? (unsigned)(p0->L / 16) : (unsigned)(p0->M / 16),
+                  twod ? (unsigned)(p1->L / 16) : (unsigned)(p1->S / 16), (hipStream_t)stream, "fused2");
     if (rc) return rc;
     rc = twod ? (f64 ? mifft_fused3d_f64_launch(p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)
-                     : mifft_fused2d_f32_launch(p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream))
+                     : mifft_fused2d_f32_launch(p1->L, p0->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream))
        : f64 ? mifft_fused3_f64_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)
              : mifft_fused2_f32_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream);
     if (rc == MIFFT_E_UNSUPPORTED) return set_err(rc, "fused2: no kernel for %d x %d", p0->L, p1->L);
@@ -658,7 +727,7 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
 }
 
 int mifft_launch_fused2x(const mifft_pass* p0, const mifft_pass* p1, const void* in0, void* out0, void* ring0, int32_t ring_slots,
-                         int32_t lag, void* counters, int32_t grid, int32_t write_through, mifft_stream_t stream) {
+                         int32_t lag, const mifft_fused_sync* sync, int32_t grid, mifft_stream_t stream) {
     int rc = validate(p0);
     if (rc) return rc;
     rc = validate(p1);
@@ -668,27 +737,77 @@ int mifft_launch_fused2x(const mifft_pass* p0, const mifft_pass* p1, const void*
     if (p0->kind != MIFFT_PASS_COL || p1->kind != MIFFT_PASS_COL || p0->S != 1 || p0->M != p1->L || p1->M != 1 ||
         p1->S != p0->L || p0->outer != p1->outer || p0->inverse != p1->inverse)
         return set_err(MIFFT_E_INVALID, "fused2x: passes are not the two passes of one long contiguous axis");
-    if (!in0 || !out0 || !ring0 || !counters) return set_err(MIFFT_E_INVALID, "fused2x: null buffer");
-    if (ring_slots < 2 || lag < 1 || lag >= ring_slots || grid < 8) return set_err(MIFFT_E_INVALID, "fused2x: need 1 <= lag < ring_slots, grid >= 8");
+    if (!in0 || !out0 || !ring0) return set_err(MIFFT_E_INVALID, "fused2x: null buffer");
+    if (ring_slots < 2 || lag < 1 || lag >= ring_slots || grid < 1) return set_err(MIFFT_E_INVALID, "fused2x: need 1 <= lag < ring_slots, grid >= 1");
     if (((uintptr_t)in0 | (uintptr_t)out0 | (uintptr_t)ring0) & 15) return set_err(MIFFT_E_INVALID, "data buffers must be 16-byte aligned");
     if (p1->outer == 0) return 0;
-    if (p1->outer > 0x3fffffff) return set_err(MIFFT_E_INVALID, "fused2x: batch too large");
     const int64_t n = (int64_t)p0->L * p1->L;
     mifft::FusedArgs f;
     fill_args(p0, in0, nullptr, ring0, nullptr, &f.p0);
     fill_args(p1, ring0, nullptr, out0, nullptr, &f.p1);
     f.p0.ostride_out = n;
     f.p1.ostride_in = n;
-    f.counters = (unsigned*)counters;
-    f.batch = (unsigned)p1->outer;
-    f.lag = (unsigned)lag;
-    f.ring = (unsigned)ring_slots;
-    f.tiles0 = (unsigned)(p0->M / 16);
-    f.tiles1 = (unsigned)(p1->S / 16);
-    rc = hip_check(hipMemsetAsync(counters, 0, MIFFT_FUSED2_COUNTER_BYTES(p1->outer), (hipStream_t)stream), "hipMemsetAsync");
+    rc = fill_ctl(&f.c, sync, p1->outer, lag, ring_slots, (unsigned)(p0->M / 16), (unsigned)(p1->S / 16), (hipStream_t)stream, "fused2x");
     if (rc) return rc;
-    rc = mifft_fused2x_f32_launch(p0->L, p1->L, &f, write_through, (unsigned)grid, (hipStream_t)stream);
+    rc = mifft_fused2x_f32_launch(p0->L, p1->L, &f, (unsigned)grid, (hipStream_t)stream);
     if (rc == MIFFT_E_UNSUPPORTED) return set_err(rc, "fused2x: no kernel for %d x %d", p0->L, p1->L);
+    if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
+    return 0;
+}
+
+int mifft_fused_pair_supported(int32_t precision, int32_t x, int32_t y, int32_t z) {
+    if (precision != MIFFT_F32 && precision != MIFFT_F64) return MIFFT_E_UNSUPPORTED;
+    return mifft_fusedp(precision == MIFFT_F64, x, y, z, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr) == 0 ? 0 : MIFFT_E_UNSUPPORTED;
+}
+
+int mifft_launch_fused_pair(const mifft_pass* passes, const void* in0, void* out0, void* ring0, int32_t ring_slots, int32_t lag,
+                            const mifft_fused_sync* sync, int32_t grid, mifft_stream_t stream) {
+    if (!passes) return set_err(MIFFT_E_INVALID, "fused pair: null pass list");
+    for (int i = 0; i < 4; ++i) {
+        const int rc = validate(&passes[i]);
+        if (rc) return rc;
+    }
+    const mifft_pass *px = &passes[0], *py0 = &passes[1], *py1 = &passes[2], *pz = &passes[3];
+    int kxy, kyz, keyxy[3], keyyz[3], sxy, syz;
+    if (classify_pair(px, py0, &kxy, keyxy, &sxy) != 0 || classify_pair(py1, pz, &kyz, keyyz, &syz) != 0 || kxy != 0 || kyz != 1 || sxy || syz ||
+        px->layout != MIFFT_INTERLEAVED || py1->S != (int64_t)px->L * py0->L || py1->L != py0->M || pz->outer != py0->outer / pz->L ||
+        py1->inverse != px->inverse)
+        return set_err(MIFFT_E_INVALID, "fused pair: not the (ROW x, COL y R0) + (COL y R1, COL z) pairs of one dense interleaved 3-D batch");
+    const int nx = px->L, ny = py0->L * (int)py0->M, nz = pz->L;
+    const bool f64 = px->precision == MIFFT_F64;
+    int r0 = 0;
+    unsigned tiles0 = 0, tiles1 = 0;
+    if (mifft_fusedp(f64, nx, ny, nz, nullptr, 0, nullptr, 1, &r0, &tiles0, &tiles1) != 0 || r0 != py0->L)
+        return set_err(MIFFT_E_UNSUPPORTED, "fused pair: no kernel for %d x %d x %d with y = %d x %lld", nz, ny, nx, py0->L, (long long)py0->M);
+    if (!in0 || !out0 || !ring0) return set_err(MIFFT_E_INVALID, "fused pair: null buffer");
+    if (((uintptr_t)in0 | (uintptr_t)out0 | (uintptr_t)ring0) & 15) return set_err(MIFFT_E_INVALID, "data buffers must be 16-byte aligned");
+    if (ring0 == in0 || ring0 == out0) return set_err(MIFFT_E_INVALID, "fused pair: the ring must be a buffer of its own");
+    if (grid < 1) return set_err(MIFFT_E_INVALID, "fused pair: grid >= 1");
+    const long long batch = pz->outer;
+    if (lag == 0 ? ring_slots != batch && batch > 0 : (ring_slots < 2 || lag < 1 || lag >= ring_slots))
+        return set_err(MIFFT_E_INVALID, "fused pair: need 1 <= lag < ring_slots, or lag == 0 with ring_slots == outer");
+    if (batch == 0) return 0;
+    mifft::FusedPairArgs f;
+    memset(&f, 0, sizeof(f));
+    f.n = (long long)nx * ny * nz;
+    f.a0.in0 = in0;
+    f.a0.out0 = ring0;
+    f.a0.tw[0] = px->tw_L;     // w(nx)
+    f.a0.tw[1] = py0->tw_L;    // w(R0)
+    f.a0.tw_lo = py0->tw_lo;   // w(ny), two-level
+    f.a0.tw_hi = py0->tw_hi;
+    f.a0.tw_shift = py0->tw_shift;
+    f.a0.inverse = px->inverse ? 1 : 0;
+    f.a0.scale = px->scale * py0->scale;
+    f.a1.in0 = ring0;
+    f.a1.out0 = out0;
+    f.a1.tw[1] = py1->tw_L;    // w(R1)
+    f.a1.tw[2] = pz->tw_L;     // w(nz)
+    f.a1.inverse = f.a0.inverse;
+    f.a1.scale = py1->scale * pz->scale;
+    int rc = fill_ctl(&f.c, sync, batch, lag, ring_slots, tiles0, tiles1, (hipStream_t)stream, "fused pair");
+    if (rc) return rc;
+    rc = mifft_fusedp(f64, nx, ny, nz, &f, (unsigned)grid, (hipStream_t)stream, 0, nullptr, nullptr, nullptr);
     if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
     return 0;
 }

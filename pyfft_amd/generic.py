@@ -28,6 +28,7 @@ import ctypes
 
 import numpy
 
+from . import _debug as D
 from . import _native as N
 from .plan import FFTPlan, normalize_shape, on_plan_device, _twiddle_table
 
@@ -57,6 +58,7 @@ class _SubContext(object):
     def __init__(self, ctx):
         self._ctx = ctx
         self.compute_units = ctx.compute_units
+        self.machine = ctx.machine
         self.allocate = ctx.allocate
         self.allocate_raw = ctx.allocate_raw
         self.upload = ctx.upload
@@ -140,7 +142,7 @@ class GenericFFTPlan(object):
         self._tiled = False
         self._tiled_tables = None
         tx, ty, tz = self._xyz
-        if all_pow2 and not self._split and parent_shape is not None and (tx > 1) + (ty > 1) + (tz > 1) >= 2 and \
+        if all_pow2 and not self._split and parent_shape is not None and (tx > 1) + (ty > 1) + (tz > 1) >= 2 and not D.no_tiled_kernel() and \
                 N.lib.mifft_nd_shape_supported(self._precision, tx, ty, tz, N.VARIANT_INTERLEAVED_ONLY) == 0 and \
                 N.lib.mifft_nd_tiled_supported(self._precision, tx, ty, tz) == 0:
             self._tiled = True

@@ -20,6 +20,7 @@ import numpy
 
 from . import _native as N
 from .plan import FFTPlan
+from .machine import Machine
 
 
 def device_pointer(obj):
@@ -239,6 +240,35 @@ class ErrorMailbox(object):
             pass
 
 
+class ErrorWord(object):
+    """A pinned host word the persistent kernels write (system-scope store) when a bounded dependency wait times out: the
+    kernel's mifft_fused_sync.error_word.  The host reads it without a copy, an event or a synchronisation -- a non-zero value
+    means some launch since the last clear produced invalid results (round 4; rounds 2-3 copied a device word back behind every
+    launch, which a 32 MiB execute cannot afford)."""
+
+    def __init__(self):
+        p = ctypes.c_void_p()
+        N.check(N.lib.mifft_host_alloc(ctypes.byref(p), 64), "mifft_host_alloc")
+        self.ptr = p.value
+        self._word = ctypes.c_uint32.from_address(p.value)
+        self._word.value = 0
+
+    def take(self):
+        """The word's value; clears it when non-zero."""
+        v = int(self._word.value)
+        if v:
+            self._word.value = 0
+        return v
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                N.lib.mifft_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
 def _torch_current_stream(args):
     """torch's current stream if one of the buffers is a torch device tensor, else None (f1: a plan built without
     stream= runs where the producing framework runs, cuda.py:116-134 current-context semantics)."""
@@ -294,6 +324,7 @@ class Context(object):
         self.device_name = props.name.decode()
         self.gcn_arch = props.gcn_arch.decode()
         self.compute_units = props.compute_units
+        self.machine = Machine.from_props(props)      # what the planner sizes rings / chunks / thresholds from
         self.max_block_size = props.max_threads_per_block
         self.max_shared_mem = props.lds_bytes_per_block
         self.max_grid_x = props.max_grid_x

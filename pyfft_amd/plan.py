@@ -121,7 +121,11 @@ class FFTPlan(object):
         self._last_batch_size = 0
         self._desc_cache = {}
         self._strategy = ("chain",)
-        self._counters = None
+        self._counters = None        # two alternating counter sets of the persistent launches (mifft_fused_sync)
+        self._counter_bytes = 0
+        self._counter_set = 0
+        self._counters_clean = False
+        self._errword = None         # pinned host word the persistent kernels report a dependency time-out in
         self._xcd2_scratch = None
         self._xcd2_disabled = False
         self._mailbox = None
@@ -154,7 +158,8 @@ class FFTPlan(object):
         # slab by slab (a few z planes) through the pipelined launcher before the z passes run over whole transforms --
         # the x -> y intermediate then stays on die.  (_slab_passes leading passes, every pass in place capable.)
         self._slab_passes = 0
-        if int(p.z) > 1 and not self._temp_buffer_needed and not self._paired and p.size * p.complex_nbytes > self.PIPELINE_TARGET_BYTES:
+        if int(p.z) > 1 and not self._temp_buffer_needed and not self._paired and \
+                p.size * p.complex_nbytes > max(1, self._context.machine.pipeline_chunk_bytes):
             k = 0
             while k < len(self._kernels) and self._kernels[k].kind != N.PASS_ND and \
                     self._kernels[k].axis in (P.X_DIRECTION, P.Y_DIRECTION):
@@ -208,6 +213,7 @@ class FFTPlan(object):
         if d is not None:
             return d
         p = self._params
+        mach = self._context.machine
         _, sched = P.buffer_schedule(self._kernels, is_inplace, self._via_temp)
         arr = (N.MifftPass * max(1, len(self._kernels)))()
         last = len(self._kernels) - 1
@@ -242,7 +248,7 @@ class FFTPlan(object):
             # multi-pass plans: the first pass reads the input once, nobody re-reads what the last pass writes.  Only
             # while a transform's intermediate can stay in the 256 MiB Infinity Cache (256^3 fp64: 256 MiB per transform,
             # measured 1 % slower with the hints)
-            if last >= 1 and (p.size * p.complex_nbytes <= (64 << 20) or self._slab_passes or self._paired) and not D.no_stream_hints():
+            if last >= 1 and (p.size * p.complex_nbytes <= mach.stream_hint_item_bytes or self._slab_passes or self._paired) and not D.no_stream_hints():
                 if i == 0:
                     d.flags |= N.FLAG_STREAM_SRC
                 if i == last:
@@ -250,11 +256,11 @@ class FFTPlan(object):
             # one-launch N-D plans on buffers beyond the Infinity Cache: non-temporal stores of the result (nobody finds it in a
             # cache anyway): (16, 16, 16) 70.4 -> 72.6 %, (128, 128) 64.8 -> 68.1 %, fp64 (128, 128) 58.6 -> 59.9 % at 1 GiB
             # (profiles/r03_c_store_policy.log; the long ROW kernels measured better with plain stores and keep them)
-            if last == 0 and k.kind == N.PASS_ND and batch * p.size * p.complex_nbytes > self.CHAIN_MAX_BYTES and not D.no_stream_hints():
+            if last == 0 and k.kind == N.PASS_ND and batch * p.size * p.complex_nbytes > mach.chain_max_bytes and not D.no_stream_hints():
                 d.flags |= N.FLAG_STREAM_DST
             # small launches: write-through stores, so that the output does not wait dirty in the L2s for the end-of-kernel
             # write-back (32 MiB launches: (16, 16, 16) 14.3 -> 9.1 us, (1024,) 13.5 -> 10.5 us; neutral from 256 MiB on)
-            if batch * p.size * p.complex_nbytes <= self.WRITE_THROUGH_MAX_BYTES and not D.no_stream_hints():
+            if batch * p.size * p.complex_nbytes <= mach.write_through_max_bytes and not D.no_stream_hints():
                 d.flags = (d.flags & ~N.FLAG_STREAM_DST) | N.FLAG_WRITE_THROUGH
         if len(self._desc_cache) > 64:
             self._desc_cache.clear()
@@ -262,35 +268,39 @@ class FFTPlan(object):
         return arr
 
     # ------------------------------------------------------------------------------------
-    # ------------------------------------------------------------------------------------
     # execution strategies (all enqueue the same passes; they differ in how the batch is cut and overlapped)
     #   chain      one launch per pass over the whole batch (the reference's loop, plan.py:217-248)
-    #   pipelined  batch cut into Infinity-Cache-sized chunks, chunk i on side stream i % n with its own temp
-    #              slot (mifft_launch_chain_pipelined)
-    #   fused2     both passes of a long 1-D fp32 transform in one persistent launch (mifft_launch_fused2)
+    #   pipelined  batch cut into cache-sized chunks, chunk i on side stream i % n with its own temp slot
+    #              (mifft_launch_chain_pipelined)
+    #   fused2     both passes of a long 1-D transform / a big 2-D one in one persistent launch (mifft_launch_fused2)
+    #   fused2x    the same with one work list per XCD (mifft_launch_fused2x): 2^16 / 2^17, where eight short pipelines beat one
+    #   fusedp     both pass PAIRS of a cache-sized 3-D cube in one persistent launch (mifft_launch_fused_pair)
     #   xcd2       1024 x 1024 fp32: one persistent launch, each transform stays on one XCD between its two HBM
-    #              crossings (mifft_launch_xcd2); needs no temp buffer, in place or out of place
-    PIPELINE_TARGET_BYTES = 64 << 20
-    SLAB_TARGET_BYTES = 128 << 20      # slabs of the leading passes of a big 3-D transform (C4: 24.7 % at 64 MiB, 25.5 % at 128)
+    #              crossings (mifft_launch_xcd2); development only
+    # Every size below comes from the device (pyfft_amd/machine.py: fractions of the last-level cache, multiples of the CU count).
     PIPELINE_STREAMS = 2
-    CHAIN_MAX_BYTES = 256 << 20        # per side (batch x transform): below this the plain launch chain wins
-    WRITE_THROUGH_MAX_BYTES = 128 << 20   # per side: below this every launch stores write-through (_descriptors)
     XCD2_MIN_BATCH = 64                # 8 transforms per XCD: below that the pipelined chunks win
     SMALL_FUSED_LAG_DIV = 0            # small-batch fused form: off (see _select_strategy)
+    FUSEDX_LAG_RING = (8, 16)          # per XCD (profiles/r04_a_fused_sweep.log: 4 / 8 loses 3-6 points at 2^16 / 2^17)
 
     def _fused2d_eligible(self):
-        """2-D 1024 x 1024 (BASELINE config 3, and the published double-precision shape): ROW + strided COL, run by the fused
-        kernel as two transposing passes."""
+        """2-D (ny, nx) in {512, 1024, 2048}^2 (fp32; BASELINE config 3 is the 1024 square) and the published double-precision
+        1024 x 1024: ROW + strided COL, run by the fused kernel as two transposing passes.  Round 4: rectangles (interleaved)."""
         p = self._params
         k = self._kernels
-        # (split planes: 29 % against 35 % for the pipelined chunks -- only on request)
-        side = int(p.x)
-        if side not in ((1024,) if p.precision == N.F64 else (512, 1024, 2048)):
+        nx, ny = int(p.x), int(p.y)
+        sides = (1024,) if p.precision == N.F64 else (512, 1024, 2048)
+        if nx not in sides or ny not in sides or int(p.z) != 1 or len(k) != 2:
             return False
-        return (int(p.y) == side and int(p.z) == 1 and len(k) == 2
-                and (not p.split or D.forced_strategy() == "fused")
-                and k[0].kind == N.PASS_ROW and k[0].L == side and k[1].kind == N.PASS_COL and k[1].L == side
-                and k[1].M == 1 and k[1].S == side)
+        if p.split and (nx != ny or D.forced_strategy() != "fused"):
+            return False      # (split planes: 29 % against 35 % for the pipelined chunks -- squares, on request only)
+        return (k[0].kind == N.PASS_ROW and k[0].L == nx and k[1].kind == N.PASS_COL and k[1].L == ny
+                and k[1].M == 1 and k[1].S == nx)
+
+    def _fused_wide_tiles(self):
+        """The plan's persistent kernel runs on the 512-thread tiles (one work-group per CU): fp64, or a 2048-point pass."""
+        k = self._kernels
+        return self._params.precision == N.F64 or k[1].L == 2048 or (self._fused2d_eligible() and k[0].L == 2048)
 
     def _fused2_eligible(self):
         p = self._params
@@ -304,75 +314,104 @@ class FFTPlan(object):
             return k[0].L == 1024 and k[1].L == 1024
         return (k[0].L in (256, 512, 1024) and k[1].L in (256, 512, 1024)) or (k[0].L == 2048 and k[1].L in (1024, 2048))
 
+    def _fusedx_eligible(self):
+        """Per-XCD work lists: interleaved fp32 1-D, both passes on the 256-thread tiles, a device with 8 XCDs."""
+        p = self._params
+        k = self._kernels
+        return (self._fused2_eligible() and not self._fused2d_eligible() and not p.split and p.precision == N.F32
+                and k[0].L <= 1024 and k[0].L >= k[1].L and self._context.machine.xcd_cooperative)
+
+    def _fusedp_eligible(self):
+        """3-D plans made of two pass pairs whose transform is a fraction of the last-level cache (128^3)."""
+        p = self._params
+        return (self._paired and len(self._kernels) == 4 and not p.split
+                and N.lib.mifft_fused_pair_supported(p.precision, int(p.x), int(p.y), int(p.z)) == 0)
+
     def _xcd2_eligible(self):
         k = self._kernels
         return (self._fused2_eligible() and not self._fused2d_eligible() and self._params.precision == N.F32
-                and k[0].L == 1024 and k[1].L == 1024 and self._context.compute_units == 256
+                and k[0].L == 1024 and k[1].L == 1024 and self._context.machine.xcd_cooperative
                 and not self._xcd2_disabled)
+
+    def _fused_tiles0(self):
+        """First-pass tiles per transform of the plan's persistent form (what the lag is counted in)."""
+        k = self._kernels
+        if self._fusedp_eligible():
+            return int(self._params.z) * int(k[1].M)             # planes x R1
+        if self._fused2d_eligible():
+            return k[0].L // 16                                  # nx / 16 column tiles of the y pass
+        return k[0].M // 16
 
     def _select_strategy(self, batch):
         forced = D.forced_strategy()
         p = self._params
+        mach = self._context.machine
         item_bytes = p.size * p.complex_nbytes
-        target = D.pipeline_chunk_bytes(self.PIPELINE_TARGET_BYTES)
+        target = D.pipeline_chunk_bytes(mach.pipeline_chunk_bytes)
         nstreams = D.pipeline_streams(self.PIPELINE_STREAMS)
         chunk = max(1, target // item_bytes)
         strat = ("chain",)
-        # up to 256 MiB per side one launch per pass over the whole batch is the fastest form: the side-stream fork / join of the
-        # pipelined chunks and the fill / drain of the persistent kernels only pay beyond it (profiles/r03_d_pipeline_threshold.log:
+        # up to the cache size per side one launch per pass over the whole batch is the fastest form: the side-stream fork / join of
+        # the pipelined chunks and the fill / drain of the persistent kernels only pay beyond it (profiles/r03_d_pipeline_threshold.log:
         # (1024, 1024) x 32 chain 0.348 / pipelined 0.317, 2^18 x 128 chain 0.374 / fused 0.329, 2^16 x 512 0.387 / 0.343,
         # 128^3 x 16 0.346 / 0.299; at twice the size the order flips)
-        if forced == "auto" and batch * item_bytes <= self.CHAIN_MAX_BYTES:
+        small = forced == "auto" and batch * item_bytes <= mach.chain_max_bytes
+        if small or target < 1:
+            # tiny batches of a shape with a persistent kernel: both passes in ONE launch on the sequential work list (every
+            # first-pass tile, then every second-pass tile; one ring slot per transform) -- PYFFT_AMD_SMALL_FUSED, see DESIGN.md
+            if small and D.small_fused(self.SMALL_FUSED_LAG_DIV) and batch >= 1 and not p.split and \
+                    (self._fused2_eligible() or self._fusedp_eligible()):
+                huge = not self._fusedp_eligible() and self._fused_wide_tiles()
+                # statically dealt list: every work-group must be resident (1 or 2 per CU by the kernels' resources)
+                grid = (1 if huge else 2) * mach.compute_units
+                return ("fusedp" if self._fusedp_eligible() else "fused2", 0, batch, grid)
             return strat
-        if forced == "fusedx" and self._fused2_eligible() and not self._fused2d_eligible() and not p.split and p.precision == N.F32 \
-                and self._kernels[0].L <= 1024 and batch >= 64:
-            lag, ring, wt = D.fusedx()            # development: one work list per XCD, ring slots per XCD
-            return ("fused2x", lag, ring, 2 * self._context.compute_units, wt)
-        if forced == "xcd" and self._xcd2_eligible() and batch >= self.XCD2_MIN_BATCH:   # not the default yet: DESIGN.md section 4
+        if forced == "fusedx" and self._fusedx_eligible() and batch >= 64:
+            lag, ring = D.fusedx()[:2]            # development: explicit lag / ring slots per XCD
+            return ("fused2x", lag, ring, 2 * mach.compute_units)
+        if forced == "xcd" and self._xcd2_eligible() and batch >= self.XCD2_MIN_BATCH:   # not the default: DESIGN.md section 4
             return ("xcd2", D.xcd2_flags(N.XCD2_PREFETCH))
+        # per-XCD lists where they win: the two-pass sizes below 2^18, whose 16-tile passes leave one global list short of slack
+        if forced == "auto" and self._fusedx_eligible() and self._kernels[0].L * self._kernels[1].L < (1 << 18) and not D.no_fusedx():
+            lag, ring = self.FUSEDX_LAG_RING
+            if batch >= 8 * 2 * ring and 8 * ring * item_bytes <= mach.ring_bytes:
+                return ("fused2x", lag, ring, 2 * mach.compute_units)
+        if forced in ("auto", "fused") and self._fusedp_eligible():
+            geo = mach.fused_geometry(item_bytes, self._fused_tiles0(), D.fused_grid_per_cu(2), fill_cache=True)
+            if geo is not None:
+                lag, ring, grid = geo
+                lag, ring = D.fused_ring(lag, ring)
+                if batch >= 2 * ring:
+                    return ("fusedp", lag, ring, grid)
         if (self._temp_buffer_needed or self._fused2d_eligible()) and forced in ("auto", "fused") and self._fused2_eligible():
-            huge = self._kernels[1].L == 2048 or p.precision == N.F64   # 512-thread tiles: one work-group per CU
-            grid = D.fused_grid_per_cu(1 if huge else 2) * self._context.compute_units   # (four per CU for L <= 512: no gain)
-            gsize = 2 * max(max(self._kernels[0].M, self._kernels[0].L if self._fused2d_eligible() else 1) // 16, self._kernels[1].S // 16)
-            # producers run `lag` transforms ahead of the consumers; ring = 2 * lag slots (1024 x 1024: lag 14, 224 MiB --
-            # the largest ring that still fits the 256 MiB Infinity Cache measured best: fused_probe.py wide)
+            huge = self._fused_wide_tiles()   # 512-thread tiles: one work-group per CU
             # measured on MI355X (end of round 2, counters on their own lines): the persistent kernel beats the stream-pipelined
             # chunks from N = 2^18 up (2^18: 42.0 vs 39.5 %, 2^19: 37.2 vs 36.2 %; 2^17: 39.1 vs 39.5, 2^16: 33 vs 40)
             big = self._kernels[0].L * self._kernels[1].L >= (1 << 18)
-            lag = max(2, -(-D.fused_lag_factor(14) * grid // (4 * gsize)))
-            ring = 2 * lag
-            if huge:
-                # fp32 2048 x 2048: 32 MiB per transform, fp64 1024 x 1024: 16 MiB; the ring that fits the Infinity Cache is
-                # 224 MiB, and the consumers follow the producers by a bit more than half of it (measured: lag 4 of 7 / 8 of 14)
-                slots = (224 << 20) // item_bytes
-                lag, ring = D.fused3_lag_ring(4 * slots // 7, slots)
-                big = True
-            lag, ring = D.fused_ring(lag, ring)
-            if forced == "fused" and batch < 2 * ring and batch >= 8:   # on request: a shorter pipeline for a small batch
-                lag = batch // 4
-                ring = 2 * lag
-            if batch >= 2 * ring and (big or forced == "fused"):
-                return ("fused2", lag, ring, grid)
-            # small batches (the reference's own 32 MiB protocol: (1024, 1024) x 4) through the same persistent launch with one ring
-            # slot per transform and the consumers `lag` transforms behind: MEASURED SLOWER than one launch per pass at every
-            # batch below the normal form's threshold ((1024, 1024) x 4: 64.9 against 28.4 us, x 16: 133 against 85 us; the
-            # launch's counter reset + error-word copy cost ~30 us and a short pipeline never fills: profiles/
-            # r03_small_batch_fused.log) -- development switch only (PYFFT_AMD_SMALL_FUSED = lag divisor), off by default
-            small = D.small_fused(self.SMALL_FUSED_LAG_DIV)
-            if small and 2 <= batch < 2 * ring and (big or forced == "fused") and forced != "pipelined" and \
-                    (batch < 4 * chunk or forced == "fused"):
-                return ("fused2", max(1, batch // small), batch, grid)
+            geo = mach.fused_geometry(item_bytes, self._fused_tiles0(), D.fused_grid_per_cu(1 if huge else 2))   # (four per CU for L <= 512: no gain)
+            if geo is not None:
+                lag, ring, grid = geo
+                if huge:
+                    lag, ring = D.fused3_lag_ring(lag, ring)
+                lag, ring = D.fused_ring(lag, ring)
+                if forced == "fused" and batch < 2 * ring and batch >= 8:   # on request: a shorter pipeline for a small batch
+                    lag = batch // 4
+                    ring = 2 * lag
+                if batch >= 2 * ring and (big or forced == "fused"):
+                    return ("fused2", lag, ring, grid)
         # any multi-pass plan gains from cache-sized chunks (the second pass re-reads what the first just wrote),
         # whether or not it needs a temp buffer
         if len(self._kernels) >= 2 and forced in ("auto", "pipelined") and batch >= 4 * chunk:
             nslab = 0
             if self._slab_passes and not D.no_slabs():
                 plane_bytes = int(p.x) * int(p.y) * p.complex_nbytes
-                slab_target = D.slab_bytes(self.SLAB_TARGET_BYTES // 2 if p.split else self.SLAB_TARGET_BYTES)   # split planes measured best at 64 MiB
+                slab_target = D.slab_bytes(mach.slab_bytes // 2 if p.split else mach.slab_bytes)   # split planes measured best at half
                 planes = min(int(p.z), max(1, slab_target // plane_bytes))
                 nslab = int(p.z) // planes
             return ("pipelined", chunk, nstreams, nslab)
         return strat
+
+    PERSISTENT = ("fused2", "fused2x", "fusedp")
 
     def _prepare(self, batch):
         """(Re)allocate the plan-owned scratch when the batch changes (plan.py:179-192)."""
@@ -393,14 +432,18 @@ class FFTPlan(object):
                 self._xcd2_scratch = ctx.allocate_raw(N.XCD2_SCRATCH_BYTES)
             self._counters = ctx.allocate_raw(N.XCD2_CONTROL_BYTES + N.XCD2_TRACE_BYTES)
             return
-        if not self._temp_buffer_needed and self._strategy[0] not in ("fused2", "fused2x"):
+        if not self._temp_buffer_needed and self._strategy[0] not in self.PERSISTENT:
             return
-        if self._strategy[0] == "fused2x":
-            items = (1 if self._strategy[4] == 2 else 8) * self._strategy[2]     # ring slots per XCD (wt == 2: one global ring)
-            self._counters = ctx.allocate_raw(N.fused2_counter_bytes(batch))
-        elif self._strategy[0] == "fused2":
-            items = self._strategy[2]                     # ring slots
-            self._counters = ctx.allocate_raw(N.fused2_counter_bytes(batch))
+        if self._strategy[0] in self.PERSISTENT:
+            # ring slots: `ring` of them; the per-XCD lists hold `ring` slots for each of the 8 XCDs
+            items = self._strategy[2] * (8 if self._strategy[0] == "fused2x" else 1)
+            # two counter sets: every launch runs on one and zeroes the other (mifft_fused_sync), so no memset precedes a launch
+            self._counter_bytes = N.fused2_counter_bytes(batch)
+            self._counters = ctx.allocate_raw(2 * self._counter_bytes)
+            self._counters_clean = False
+            if self._errword is None:
+                from .hip import ErrorWord
+                self._errword = ErrorWord()
         elif self._strategy[0] == "pipelined":
             items = self._strategy[1] * self._strategy[2]  # chunk * streams
         else:
@@ -408,6 +451,21 @@ class FFTPlan(object):
         # one interleaved buffer for both layouts (the reference allocates two scalar planes for split plans,
         # plan.py:189-190; same total size)
         self._tempmemobj = ctx.allocate(p.size * items * p.complex_nbytes)
+
+    def _fused_sync(self, stream):
+        """mifft_fused_sync of the coming persistent launch: the counter set it runs on (zero: the previous launch cleared it, or
+        the memset below), the set it clears for the next launch, the pinned error word."""
+        base = self._context.pointer_of(self._counters)
+        nb = self._counter_bytes
+        if D.fused_memset():            # development A/B: one counter set, zeroed by a memset in front of every launch
+            return N.MifftFusedSync(base, None, self._errword.ptr)
+        if not self._counters_clean:
+            N.check(N.lib.mifft_memset(base, 0, 2 * nb, stream), "mifft_memset")
+            self._counters_clean = True
+            self._counter_set = 0
+        cur = self._counter_set
+        self._counter_set = 1 - cur
+        return N.MifftFusedSync(base + cur * nb, base + (1 - cur) * nb, self._errword.ptr)
 
     def _enqueue(self, batch, is_inplace, inverse, bufs0, bufs1):
         ctx = self._context
@@ -422,22 +480,30 @@ class FFTPlan(object):
                                             ctx.pointer_of(self._xcd2_scratch), ctx.pointer_of(self._counters),
                                             strat[1], stream), "mifft_launch_xcd2")
             self._post_error_word(stream)
-        elif strat[0] == "fused2x":
-            _, lag, ring, grid, wt = strat
-            d0, d1 = descs[0], descs[1]
-            N.check(N.lib.mifft_launch_fused2x(ctypes.byref(d0), ctypes.byref(d1), bufs0[d0.src], bufs0[d1.dst], bufs0[2], ring, lag,
-                                               ctx.pointer_of(self._counters), grid, wt, stream), "mifft_launch_fused2x")
-            self._post_error_word(stream)
-        elif strat[0] == "fused2":
-            _, lag, ring, grid = strat
-            d0, d1 = descs[0], descs[1]
-            # the two-pass schedule is in -> temp -> out for both in-place and out-of-place calls
-            in1 = bufs1[d0.src] if bufs1 is not None else None
-            out1 = bufs1[d1.dst] if bufs1 is not None else None
-            N.check(N.lib.mifft_launch_fused2(ctypes.byref(d0), ctypes.byref(d1), bufs0[d0.src], in1, bufs0[d1.dst], out1,
-                                              bufs0[2], None, ring, lag, ctx.pointer_of(self._counters), grid, stream),
-                    "mifft_launch_fused2")
-            self._post_error_word(stream)
+        elif strat[0] in self.PERSISTENT:
+            sync = self._fused_sync(stream)
+            try:
+                if strat[0] == "fused2x":
+                    _, lag, ring, grid = strat
+                    d0, d1 = descs[0], descs[1]
+                    N.check(N.lib.mifft_launch_fused2x(ctypes.byref(d0), ctypes.byref(d1), bufs0[d0.src], bufs0[d1.dst], bufs0[2], ring, lag,
+                                                       ctypes.byref(sync), grid, stream), "mifft_launch_fused2x")
+                elif strat[0] == "fusedp":
+                    _, lag, ring, grid = strat
+                    N.check(N.lib.mifft_launch_fused_pair(descs, bufs0[descs[0].src], bufs0[descs[3].dst], bufs0[2], ring, lag,
+                                                          ctypes.byref(sync), grid, stream), "mifft_launch_fused_pair")
+                else:
+                    _, lag, ring, grid = strat
+                    d0, d1 = descs[0], descs[1]
+                    # the two-pass schedule is in -> temp -> out for both in-place and out-of-place calls
+                    in1 = bufs1[d0.src] if bufs1 is not None else None
+                    out1 = bufs1[d1.dst] if bufs1 is not None else None
+                    N.check(N.lib.mifft_launch_fused2(ctypes.byref(d0), ctypes.byref(d1), bufs0[d0.src], in1, bufs0[d1.dst], out1,
+                                                      bufs0[2], None, ring, lag, ctypes.byref(sync), grid, stream),
+                            "mifft_launch_fused2")
+            except Exception:
+                self._counters_clean = False     # a launch that did not start cleared nothing
+                raise
         elif strat[0] == "pipelined":
             _, chunk, nside, nslab = strat
             side = (ctypes.c_void_p * nside)(*[s.handle for s in self._side_streams])
@@ -457,20 +523,28 @@ class FFTPlan(object):
         else:
             N.check(N.lib.mifft_launch_chain(descs, len(self._kernels), bufs0, bufs1, stream), "mifft_launch_chain")
 
-    # ---- error word of the persistent kernels (fused2 / xcd2): word [1] of their control block --------------------
-    # Every launch is followed, on the same stream, by an asynchronous copy of that word into pinned host memory and an
-    # event.  check() looks at the copies whose event has completed (never blocks); finish() synchronises first.  execute()
-    # calls check() on entry, so an asynchronous caller learns of a time-out at its next call at the latest, and the
-    # waiting path / Stream users call finish().
+    # ---- error reporting of the persistent kernels --------------------------------------------------------------------
+    # fused2 / fused2x / fusedp write a PINNED HOST word (hip.ErrorWord) when a bounded dependency wait times out; the host looks
+    # at it on entry of every execute() (check(), never blocks) and after synchronising (finish()): an asynchronous caller learns
+    # of invalid results at its next call at the latest.  The development strategy xcd2 keeps rounds 2-3's mechanism: word [1] of
+    # its control block copied into pinned memory behind every launch (hip.ErrorMailbox).
     def _post_error_word(self, stream):
         if self._mailbox is None:
             from .hip import ErrorMailbox
             self._mailbox = ErrorMailbox()
         self._mailbox.post(self._context.pointer_of(self._counters) + 4, stream, self._strategy[0])
 
+    def _take_error_word(self):
+        if self._errword is not None:
+            word = self._errword.take()
+            if word:
+                self._counters_clean = False
+                raise RuntimeError("pyfft_amd: %s kernel dependency time-out (results invalid)" % (self._strategy[0],))
+
     @on_plan_device
     def check(self):
         """Raise if a completed asynchronous execute() reported invalid results (non-blocking)."""
+        self._take_error_word()
         if self._mailbox is not None:
             self._handle_errors(self._mailbox.collect(False))
 
@@ -478,6 +552,7 @@ class FFTPlan(object):
     def finish(self):
         """Wait for the plan's stream, then raise if any execute() since the last check reported invalid results."""
         self._context.wait()
+        self._take_error_word()
         if self._mailbox is not None:
             self._handle_errors(self._mailbox.collect(True))
 
@@ -490,8 +565,6 @@ class FFTPlan(object):
                 self._last_batch_size = 0
                 raise RuntimeError("pyfft_amd: XCD-cooperative launch found no full XCD residency; results of that execute() "
                                    "are invalid -- the plan has switched strategy, run it again")
-            if strategy == "fused2x" and (word & 4):
-                raise RuntimeError("pyfft_amd: the XCD-local launch left an XCD without work-groups (results invalid)")
             raise RuntimeError("pyfft_amd: %s kernel dependency time-out (results invalid)" % strategy)
 
     def _buffers(self, is_inplace, args):
@@ -521,7 +594,7 @@ class FFTPlan(object):
         batch = int(batch)
         if batch < 1:
             raise ValueError("batch must be positive")
-        if self._mailbox is not None:
+        if self._mailbox is not None or self._errword is not None:
             self.check()
         if self._last_batch_size != batch:
             self._prepare(batch)
@@ -584,6 +657,7 @@ class FFTPlan(object):
             self._side_streams = None
             self._side_events = None
             self._mailbox = None
+            self._errword = None
             self._last_batch_size = 0
             self._last_call_key = None
 

@@ -440,3 +440,146 @@ def test_round3_entry_points_reject_bad_arguments_without_touching_the_gpu():
     # the fp64 strided passes of 2048 points exist, the pair split answers per layout
     assert N.lib.mifft_pass_supported(N.PASS_COL, N.F64, 2048, 0) == 0
     assert N.lib.mifft_pair_split(N.F64, N.SPLIT, 256, 256, 256) == 64 and N.lib.mifft_pair_split(N.F32, N.INTERLEAVED, 128, 128, 128) == 32
+
+
+# ---- round 4: the planner sizes everything from the device's properties (pyfft_amd/machine.py) --------------------------
+class _FakeContext(object):
+    """A context without a device: tables are "uploaded" nowhere.  What FFTPlan._select_strategy reads is `machine`."""
+    _guard = False
+
+    def __init__(self, machine):
+        self.machine = machine
+        self.compute_units = machine.compute_units
+
+    def allocate_raw(self, nbytes):
+        return 4096
+
+    allocate = allocate_raw
+
+    def upload(self, mem, host):
+        pass
+
+    @staticmethod
+    def pointer_of(obj):
+        return obj
+
+
+def _strategy_on(machine, shape, dtype, batch):
+    from pyfft_amd.plan import FFTPlan
+    plan = FFTPlan(_FakeContext(machine), shape, dtype=dtype)
+    return plan, plan._select_strategy(batch)
+
+
+def test_planner_constants_come_from_the_device():
+    """On the full part (256 CUs, 8 XCDs, 256 MiB last-level cache) the machine model gives back the measured constants of
+    rounds 1-3 and the round-4 ring rule; on a partition (32 CUs, one XCD, 32 MiB of cache) every ring, chunk and threshold
+    shrinks with the cache, the XCD-cooperative strategies disappear, and nothing is sized for a machine that is not there;
+    without a last-level cache every plan is the plain chain (the reference's loop, pyfft/plan.py:217-248)."""
+    import numpy
+    from pyfft_amd.machine import Machine
+    full = Machine(256, 8, 4 << 20, 256 << 20)
+    assert (full.ring_bytes, full.pipeline_chunk_bytes, full.slab_bytes, full.chain_max_bytes, full.write_through_max_bytes) == \
+        (224 << 20, 64 << 20, 128 << 20, 256 << 20, 128 << 20)
+    assert full.xcd_cooperative
+    c64, c128 = numpy.complex64, numpy.complex128
+    assert _strategy_on(full, (1 << 20,), c64, 4096)[1] == ("fused2", 14, 28, 512)            # BASELINE config 2, as in rounds 2-3
+    assert _strategy_on(full, (1 << 19,), c64, 2048)[1] == ("fused2", 28, 56, 512)            # round 4: the ring fills the cache
+    assert _strategy_on(full, (1 << 18,), c64, 4096)[1] == ("fused2", 28, 56, 512)
+    assert _strategy_on(full, (1 << 22,), c64, 256)[1] == ("fused2", 4, 7, 256)               # BASELINE config 5's chunk
+    assert _strategy_on(full, (1 << 21,), c64, 512)[1] == ("fused2", 8, 14, 512)              # 16 MiB transforms: the cache caps the ring
+    assert _strategy_on(full, (1 << 17,), c64, 8192)[1] == ("fused2x", 8, 16, 512)         # per-XCD lists below 2^18
+    assert _strategy_on(full, (1 << 16,), c64, 16384)[1] == ("fused2x", 8, 16, 512)
+    assert _strategy_on(full, (1024, 1024), c64, 512)[1] == ("fused2", 14, 28, 512)           # BASELINE config 3
+    assert _strategy_on(full, (128, 128, 128), c64, 64)[1][0] == "fusedp"
+    assert _strategy_on(full, (128, 128, 128), c128, 32)[1][0] == "fusedp"
+    assert _strategy_on(full, (256, 256, 256), c128, 64)[1][0] == "pipelined"                 # BASELINE config 4 (256 MiB per transform)
+    assert _strategy_on(full, (1024, 1024), c64, 4)[1] == ("chain",)                          # 32 MiB: below the chain threshold
+    assert _strategy_on(full, (1 << 20,), c64, 32)[1] == ("chain",)                           # exactly the cache size per side
+
+    part = Machine(32, 1, 4 << 20, 32 << 20)
+    assert not part.xcd_cooperative and part.ring_bytes == 28 << 20 and part.chain_max_bytes == 32 << 20
+    for shape, dtype, batch in (((1 << 20,), c64, 4096), ((1 << 19,), c64, 2048), ((1 << 18,), c64, 4096), ((1 << 17,), c64, 8192),
+                                ((1 << 22,), c64, 256), ((1024, 1024), c64, 512), ((128, 128, 128), c64, 64), ((256, 256, 256), c128, 8),
+                                ((1 << 20,), c128, 512), ((1024,), c64, 1 << 16)):
+        plan, st = _strategy_on(part, shape, dtype, batch)
+        item = plan._params.size * plan._params.complex_nbytes
+        assert st[0] in ("chain", "pipelined", "fused2", "fusedp"), (shape, st)                # never xcd2 / per-XCD lists
+        if st[0] in ("fused2", "fusedp"):
+            lag, ring, grid = st[1:4]
+            assert ring * item <= part.ring_bytes and 1 <= lag < ring and grid in (32, 64) and batch >= 2 * ring, (shape, st)
+        if st[0] == "pipelined":
+            assert st[1] * item <= max(item, part.pipeline_chunk_bytes), (shape, st)
+    assert _strategy_on(part, (1 << 20,), c64, 4096)[1] == ("pipelined", 1, 2, 0)              # an 8 MiB transform: three ring slots are no ring
+    assert _strategy_on(part, (1 << 18,), c64, 4096)[1] == ("fused2", 4, 8, 64)                # 2 MiB transforms: 8 of 14 slots
+    assert _strategy_on(part, (1 << 20,), c64, 4)[1] == ("chain",)                             # 32 MiB per side = this device's cache
+    assert _strategy_on(part, (1 << 20,), c64, 16)[1] == ("pipelined", 1, 2, 0)                # (the full part runs the chain here)
+
+    bare = Machine(64, 2, 4 << 20, 0)
+    for shape, dtype, batch in (((1 << 20,), c64, 4096), ((1024, 1024), c64, 512), ((128, 128, 128), c64, 64), ((1 << 17,), c64, 8192)):
+        assert _strategy_on(bare, shape, dtype, batch)[1] == ("chain",)
+    # the model's geometry helper: no ring below four slots, lag counted in first-pass tiles per work-group wave
+    assert full.fused_geometry(8 << 20, 64, 2) == (14, 28, 512) and full.fused_geometry(64 << 20, 128, 1) is None
+    assert full.fused_geometry(32 << 20, 128, 1) == (4, 7, 256)
+
+
+def test_round4_entry_points_reject_bad_arguments_without_touching_the_gpu():
+    """mifft_fused_sync validation and the fused pass-pair launcher (host side of the C ABI; every call returns before HIP)."""
+    import ctypes
+    from pyfft_amd import _native as N
+
+    def col(L, M, S, outer, stride, prec=N.F32):
+        p = N.MifftPass()
+        p.kind, p.precision, p.layout, p.L, p.M, p.S, p.outer = N.PASS_COL, prec, N.INTERLEAVED, L, M, S, outer
+        p.outer_stride_in = p.outer_stride_out = stride
+        p.scale, p.tw_L, p.tw_lo, p.tw_hi, p.tw_shift = 1.0, 16, 16, 16, 10
+        return p
+
+    p0, p1 = col(1024, 1024, 1, 64, 1 << 20), col(1024, 1, 1024, 64, 1 << 20)
+    ok = N.MifftFusedSync(4096, 8192, None)
+    byref = ctypes.byref
+    # null / misaligned / aliased counter sets, bad lag / ring combinations
+    for sync, what in ((N.MifftFusedSync(None, None, None), "null counters"), (N.MifftFusedSync(4096 + 64, None, None), "256-byte"),
+                       (N.MifftFusedSync(4096, 4096, None), "second buffer"), (N.MifftFusedSync(4096, 8192, 4098), "error word")):
+        assert N.lib.mifft_launch_fused2(byref(p0), byref(p1), 16, None, 32, None, 64, None, 28, 14, byref(sync), 512, None) == N.E_INVALID
+        assert what in N.last_error(), N.last_error()
+    assert N.lib.mifft_launch_fused2(byref(p0), byref(p1), 16, None, 32, None, 64, None, 28, 14, None, 512, None) == N.E_INVALID
+    assert N.lib.mifft_launch_fused2(byref(p0), byref(p1), 16, None, 32, None, 64, None, 14, 14, byref(ok), 512, None) == N.E_INVALID   # lag == ring
+    assert N.lib.mifft_launch_fused2(byref(p0), byref(p1), 16, None, 32, None, 64, None, 28, 0, byref(ok), 512, None) == N.E_INVALID    # sequential list: ring == outer
+    assert N.lib.mifft_launch_fused2x(byref(p0), byref(p1), 16, 32, 64, 8, 4, None, 512, None) == N.E_INVALID
+    assert N.lib.mifft_launch_fused2x(byref(p0), byref(p1), 16, 32, 64, 8, 4, byref(N.MifftFusedSync(4096, 4096, None)), 512, None) == N.E_INVALID
+    # the persistent pass-pair form exists for the 128^3 cubes, interleaved
+    assert N.lib.mifft_fused_pair_supported(N.F32, 128, 128, 128) == 0 and N.lib.mifft_fused_pair_supported(N.F64, 128, 128, 128) == 0
+    assert N.lib.mifft_fused_pair_supported(N.F32, 256, 256, 256) == N.E_UNSUPPORTED
+    assert N.lib.mifft_fused_pair_supported(7, 128, 128, 128) == N.E_UNSUPPORTED
+    from pyfft_amd import passes as P
+    chain = P.build_chain(128, 128, 128, N.F32, interleaved=True)
+    assert [k.pair_with_next for k in chain] == [True, False, True, False]
+    descs = (N.MifftPass * 4)()
+    for d, k in zip(descs, chain):
+        d.kind, d.precision, d.layout, d.L, d.M, d.S = k.kind, N.F32, N.INTERLEAVED, k.L, k.M, k.S
+        d.outer, d.outer_stride_in, d.outer_stride_out, d.scale = k.outer_per_batch * 20, k.outer_stride, k.outer_stride, 1.0
+        d.tw_L, d.tw_lo, d.tw_hi, d.tw_shift = 16, 16, 16, 4
+    assert N.lib.mifft_launch_fused_pair(descs, 16, 32, 32, 4, 2, byref(ok), 512, None) == N.E_INVALID and "ring" in N.last_error()
+    assert N.lib.mifft_launch_fused_pair(descs, 16, 32, 64, 4, 4, byref(ok), 512, None) == N.E_INVALID
+    assert N.lib.mifft_launch_fused_pair(descs, 16, 32, 64, 4, 2, None, 512, None) == N.E_INVALID
+    descs[1].L, descs[1].M = 64, 2                      # not the split the library's kernels use
+    assert N.lib.mifft_launch_fused_pair(descs, 16, 32, 64, 4, 2, byref(ok), 512, None) in (N.E_INVALID, N.E_UNSUPPORTED)
+    # device properties carry the memory-system fields the planner reads
+    assert {"llc_bytes", "num_xcc"} <= {f[0] for f in N.MifftDeviceProps._fields_}
+
+
+def test_pyfft_import_name():
+    """importable as `pyfft`, VERSION kept (pyfft/__init__.py:1 of the reference); the backend module is pyfft.hip,
+    and there is no pyfft.cuda compatibility alias."""
+    import importlib
+    import pyfft
+    assert pyfft.VERSION == (0, 3, 9) and all(isinstance(v, int) for v in pyfft.VERSION)
+    from pyfft.hip import Plan
+    import pyfft_amd.hip
+    assert Plan is pyfft_amd.hip.Plan
+    try:
+        importlib.import_module("pyfft.cuda")
+    except ImportError:
+        pass
+    else:
+        raise AssertionError("pyfft.cuda must not exist")

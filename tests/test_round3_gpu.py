@@ -140,7 +140,7 @@ TILED = [((8, 8), (24, 40)), ((16, 16), (48, 80)), ((32, 32), (96, 64)), ((64, 6
 
 @pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
 @pytest.mark.parametrize("shape,parent", TILED + [((32, 32, 32), (64, 32, 96))], ids=str)
-def test_tiled_batch_single_launch(ctx, shape, parent, dtype):
+def test_tiled_batch_single_launch(ctx, shape, parent, dtype, monkeypatch):
     """Every tile shape of the tiled N-D kernel: the tiles of 3 parent arrays transformed where they lie (one launch, no work
     array), tile counts that leave the last work-group ragged -- against numpy tile by tile (reference thresholds), against the
     gather / dense plan / scatter form of the same plan, out of place with the input untouched, in place, and the inverse."""
@@ -168,11 +168,12 @@ def test_tiled_batch_single_launch(ctx, shape, parent, dtype):
     plan.execute(c, inverse=True, batch=batch)
     assert numpy.abs(c.get() - x).sum() / numpy.abs(x).sum() < 2 * eps
     assert plan._work is None                                 # never needed a work array
-    # the three-round-trip form of the same plan
-    plan._tiled = False
-    plan._last_batch = 0
+    # the three-round-trip form of the same plan (round 4: a one-launch plan no longer builds the inner N-D plan it does not run)
+    monkeypatch.setenv("PYFFT_AMD_NO_TILED", "1")
+    plan3 = ctx.getPlan(shape, dtype=dtype, parent_shape=parent)
+    assert not plan3._tiled and len(plan3._inner_plans()) == 1 and plan._inner_plans() == []
     d = ctx.allocate(full, cd)
-    plan.execute(a, d, batch=batch)
+    plan3.execute(a, d, batch=batch)
     assert numpy.abs(d.get() - got).sum() / numpy.abs(got).sum() < eps
 
 

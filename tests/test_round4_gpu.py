@@ -1,0 +1,254 @@
+"""Round-4 GPU tests: the persistent two-pair kernel of the cache-sized cubes (128^3), the per-XCD work lists as a default
+strategy, the sequential single-launch form of tiny batches, launches without memset / copy-back (two alternating counter sets,
+pinned error word), the device properties the planner sizes everything from, Plan(stream=, context=i)."""
+import ctypes
+
+import numpy
+import pytest
+
+import pyfft_oracle as oracle
+from test_errors_gpu import run_protocol
+
+pytestmark = pytest.mark.gpu
+
+
+def _execute(ctx, shape, dtype, batch, data, inplace=False, inverse=False, expect=None):
+    plan = ctx.getPlan(shape, dtype=dtype)
+    if expect is not None:
+        assert plan.strategy(batch)[0] == expect, plan.strategy(batch)
+    a = ctx.toGpu(data)
+    if inplace:
+        plan.execute(a, batch=batch, inverse=inverse)
+        return a.get()
+    b = ctx.allocate(data.shape, data.dtype)
+    plan.execute(a, b, batch=batch, inverse=inverse)
+    assert numpy.array_equal(a.get(), data), "an out-of-place execute touched its input"
+    return b.get()
+
+
+def test_device_properties_describe_the_memory_system(ctx):
+    """mifft_device_props carries what the planner needs (include/mifft.h): on an MI355X 256 CUs in 8 XCDs with 4 MiB of L2
+    each and the 256 MiB Infinity Cache -- read from the HSA agent, not hard-wired."""
+    props = ctx.hip.device_props()
+    m = ctx.hip.Machine.from_props(props)
+    assert props.compute_units >= 1 and props.num_xcc >= 1 and props.llc_bytes >= 0
+    if props.gcn_arch.decode().startswith("gfx950") and props.compute_units == 256:
+        assert props.num_xcc == 8 and props.llc_bytes == 256 << 20 and props.l2_bytes == 4 << 20, (props.num_xcc, props.llc_bytes, props.l2_bytes)
+        assert m.xcd_cooperative and m.ring_bytes == 224 << 20
+
+
+# ---- persistent two-pair kernel: 128^3 -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,batch", [(numpy.complex64, 21), (numpy.complex128, 11)], ids=lambda v: str(numpy.dtype(v).name) if isinstance(v, type) else str(v))
+def test_fused_pair_cube_128(ctx, monkeypatch, dtype, batch):
+    """(128, 128, 128) beyond the chain threshold: both pass pairs of every transform in ONE persistent launch
+    (mifft_launch_fused_pair).  Same tile arithmetic as the two plain pair launches -> the bits of the chain; in place ==
+    out of place; the reference's accuracy thresholds against numpy (test/test_errors.py:20-23) on sampled transforms; inverse
+    round trip.  Published shape: doc/source/index.rst:373."""
+    shape = (128, 128, 128)
+    n = 128 ** 3
+    cdt = numpy.dtype(dtype)
+    tol, tol_max = (1.1e-6, 1e-5) if cdt == numpy.complex64 else (1e-11, 1e-10)
+    rng = numpy.random.default_rng(77)
+    data = (rng.standard_normal((batch * 128, 128, 128)) + 1j * rng.standard_normal((batch * 128, 128, 128))).astype(cdt)
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
+    want = _execute(ctx, shape, dtype, batch, data, expect="chain")
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    got = _execute(ctx, shape, dtype, batch, data, expect="fusedp")
+    assert numpy.array_equal(want, got), "persistent two-pair launch differs from the two plain pair launches"
+    got_ip = _execute(ctx, shape, dtype, batch, data, inplace=True, expect="fusedp")
+    assert numpy.array_equal(got, got_ip), "in place differs from out of place"
+    for item in (0, batch // 2, batch - 1):
+        sl = slice(item * 128, (item + 1) * 128)
+        ref = numpy.fft.fftn(data[sl].astype(numpy.complex128))
+        assert numpy.abs(ref - got[sl]).sum() / numpy.abs(ref).sum() < tol
+        assert numpy.abs(ref - got[sl]).max() <= tol_max * numpy.abs(ref).max()
+    back = _execute(ctx, shape, dtype, batch, got, inverse=True, expect="fusedp")
+    assert oracle.difference(data, back, batch) < tol
+    # many executes in a row alternate between the two counter sets; a forced ring / lag keeps the results
+    monkeypatch.setenv("PYFFT_AMD_FUSED_RING", "3,5")
+    plan = ctx.getPlan(shape, dtype=dtype)
+    assert plan.strategy(batch)[:3] == ("fusedp", 3, 5)
+    a, b = ctx.toGpu(data), ctx.allocate(data.shape, data.dtype)
+    for _ in range(5):
+        plan.execute(a, b, batch=batch, wait_for_finish=False)
+    plan.finish()
+    assert numpy.array_equal(b.get(), got)
+
+
+# ---- per-XCD work lists as a default ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,batch", [(1 << 16, 1040), (1 << 17, 520)], ids=str)
+def test_per_xcd_lists_are_the_default_below_2_18(ctx, monkeypatch, n, batch):
+    """2^16 / 2^17 beyond the chain threshold run the fused kernel with one work list per XCD (mifft_launch_fused2x; pyfft/
+    kernel.py:259-283 chain semantics): the bits of the chain, in place == out of place, the plan's choice without any switch;
+    a batch that is not a multiple of 8 leaves the lists uneven, work stealing drains them."""
+    if not ctx.hip.Machine.from_props(ctx.hip.device_props()).xcd_cooperative:
+        pytest.skip("needs 8 XCDs x 32 CUs")
+    data = oracle.get_test_data((n,), numpy.complex64, batch, 91)
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
+    want = _execute(ctx, (n,), numpy.complex64, batch, data, expect="chain")
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    got = _execute(ctx, (n,), numpy.complex64, batch, data, expect="fused2x")
+    assert numpy.array_equal(want, got)
+    assert numpy.array_equal(_execute(ctx, (n,), numpy.complex64, batch, data, inplace=True, expect="fused2x"), got)
+    odd = batch - 3
+    got_odd = _execute(ctx, (n,), numpy.complex64, odd, data[:odd * n], expect="fused2x")
+    assert numpy.array_equal(got_odd, want[:odd * n])
+    monkeypatch.setenv("PYFFT_AMD_NO_FUSEDX", "1")
+    assert ctx.getPlan((n,), dtype=numpy.complex64).strategy(batch)[0] == "pipelined"
+
+
+def test_fused_ring_rule_2_19(ctx, monkeypatch):
+    """2^19 = 1024 x 512 has 32 first-pass tiles per transform: the ring rule counts the lag in tiles (28 transforms, ring 56 =
+    224 MiB), not in transforms (round 3: 14 / 28, four points lower) -- and the bits stay the chain's."""
+    n, batch = 1 << 19, 130
+    plan = ctx.getPlan((n,), dtype=numpy.complex64)
+    if ctx.hip.Machine.from_props(ctx.hip.device_props()).llc_bytes == 256 << 20 and plan._context.compute_units == 256:
+        assert plan.strategy(batch) == ("fused2", 28, 56, 512)
+    data = oracle.get_test_data((n,), numpy.complex64, batch, 92)
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
+    want = _execute(ctx, (n,), numpy.complex64, batch, data, expect="chain")
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    assert numpy.array_equal(_execute(ctx, (n,), numpy.complex64, batch, data, expect="fused2"), want)
+
+
+# ---- tiny batches: the sequential work list (one launch instead of two) ------------------------------------------------------
+@pytest.mark.parametrize("shape,dtype,batch", [((1024, 1024), numpy.complex64, 4), ((1 << 20,), numpy.complex64, 3), ((1 << 18,), numpy.complex64, 7),
+                                               ((128, 128, 128), numpy.complex64, 2), ((128, 128, 128), numpy.complex128, 1),
+                                               ((1024, 1024), numpy.complex128, 2), ((1 << 22,), numpy.complex64, 1)],
+                         ids=lambda v: str(numpy.dtype(v).name) if isinstance(v, type) else str(v).replace(" ", ""))
+def test_sequential_single_launch_of_tiny_batches(ctx, monkeypatch, shape, dtype, batch):
+    """The reference's own benchmark protocol runs 32 MiB buffers (test/test_performance.py:11,22-30): there the two passes of a
+    transform are two dependent launches.  The sequential work list runs them in ONE persistent launch (lag 0: every first-pass
+    tile, then every second-pass tile); it must give the chain's bits, in place and out of place, forward and inverse."""
+    data = oracle.get_test_data(shape, dtype, batch, 93)
+    monkeypatch.setenv("PYFFT_AMD_SMALL_FUSED", "0")
+    want = _execute(ctx, shape, dtype, batch, data, expect="chain")
+    monkeypatch.setenv("PYFFT_AMD_SMALL_FUSED", "1")
+    plan = ctx.getPlan(shape, dtype=dtype)
+    st = plan.strategy(batch)
+    assert st[0] in ("fused2", "fusedp") and st[1] == 0 and st[2] == batch, st
+    got = _execute(ctx, shape, dtype, batch, data)
+    assert numpy.array_equal(want, got)
+    assert numpy.array_equal(_execute(ctx, shape, dtype, batch, data, inplace=True), got)
+    tol = 1.1e-6 if numpy.dtype(dtype) == numpy.complex64 else 1e-11
+    back = _execute(ctx, shape, dtype, batch, got, inverse=True)
+    assert oracle.difference(data, back, batch) < tol
+    ref = oracle.numpy_fft(numpy.fft.fftn, data, batch)
+    assert oracle.difference(ref, got, batch) < tol
+
+
+# ---- launches without memset / copy-back -----------------------------------------------------------------------------------
+def test_alternating_counter_sets_and_memset_form_agree(ctx, monkeypatch):
+    """A plan's persistent launches alternate between two counter sets (each launch zeroes the other one: mifft_fused_sync), so
+    no memset node precedes a launch; the round-3 form (one set, zeroed by the call) is kept behind a switch.  Both give the same
+    bits over many back-to-back executes, with a batch change in between (new sets) and alternating directions."""
+    n = 1 << 20
+    data = oracle.get_test_data((n,), numpy.complex64, 70, 94)
+    outs = {}
+    for memset in ("", "1"):
+        if memset:
+            monkeypatch.setenv("PYFFT_AMD_FUSED_MEMSET", memset)
+        plan = ctx.getPlan((n,), dtype=numpy.complex64, wait_for_finish=False)
+        res = []
+        for batch in (70, 60, 70):
+            assert plan.strategy(batch)[0] == "fused2"
+            a, b = ctx.toGpu(data[:batch * n]), ctx.allocate((batch * n,), numpy.complex64)
+            for rep in range(5):
+                plan.execute(a, b, batch=batch)
+                plan.execute(b, a, batch=batch, inverse=True)         # back to the data (to rounding)
+            plan.execute(a, b, batch=batch)
+            plan.finish()
+            res.append(b.get())
+        outs[memset] = res
+    for x, y in zip(outs[""], outs["1"]):
+        assert numpy.array_equal(x, y)
+    ref = oracle.numpy_fft(numpy.fft.fft, data[:2 * n], 2)
+    assert oracle.difference(ref, outs[""][0][:2 * n], 2) < 2e-6      # (eleven transforms deep)
+
+
+def test_plan_with_stream_and_context_index(ctx):
+    """Plan(stream=s, context=i): the device comes from `context` also when a stream is given (cuda.py:121-134); the plan is
+    asynchronous by default and guarded for device i.  With several GPUs the last one is used from device 0."""
+    hip = ctx.hip
+    N = hip.N
+    ndev = hip.device_count()
+    dev = ndev - 1
+    cur = ctypes.c_int()
+    N.check(N.lib.mifft_get_device(ctypes.byref(cur)), "get")
+    home = cur.value
+    N.check(N.lib.mifft_set_device(dev), "set")
+    stream = hip.Stream()
+    data = oracle.get_test_data((8192,), numpy.complex64, 3, 95)
+    a = ctx.toGpu(data)
+    N.check(N.lib.mifft_set_device(home), "set")
+    plan = ctx.getPlan((8192,), dtype=numpy.complex64, stream=stream, context=dev)
+    assert plan._context.device == dev and plan._context._guard and plan._wait_for_finish is False
+    assert plan.execute(a, batch=3) is stream
+    plan.finish()
+    N.check(N.lib.mifft_get_device(ctypes.byref(cur)), "get")
+    assert cur.value == home
+    N.check(N.lib.mifft_set_device(dev), "set")
+    got = a.get()
+    N.check(N.lib.mifft_set_device(home), "set")
+    assert oracle.difference(oracle.numpy_fft(numpy.fft.fft, data, 3), got, 3) < 1.1e-6
+
+    class FakeTorchStream(object):                 # a stream that knows its device (torch.cuda.Stream.device_index)
+        cuda_stream = stream.handle
+        device_index = dev + 1
+    with pytest.raises(ValueError, match="stream belongs to device"):
+        ctx.getPlan((8192,), dtype=numpy.complex64, stream=FakeTorchStream(), context=dev)
+
+
+def test_generic_plans_build_only_what_they_run(ctx):
+    """a tiled-batch plan with a one-launch kernel and an all-smooth N-D plan hold no inner power-of-two plans
+    (nothing to allocate, nothing for finish() / check() to walk); the work-array paths still build theirs."""
+    tiled = ctx.getPlan((16, 16), parent_shape=(64, 64), dtype=numpy.complex64)
+    assert tiled._tiled and tiled._inner_plans() == [] and tiled._tiled_tables[0] and tiled._tiled_tables[2] is None
+    nd = ctx.getPlan((60, 16), dtype=numpy.complex64, any_size=True)
+    assert nd._direct_nd is not None and nd._inner_plans() == [] and nd._rowplans == {}
+    work = ctx.getPlan((16, 16), parent_shape=(64, 64), dtype=numpy.float32)            # split planes: gather / N-D plan / scatter
+    assert not work._tiled and len(work._inner_plans()) == 1
+    blue = ctx.getPlan((4099, 4), dtype=numpy.complex64, any_size=True)                 # a long prime axis: padded power-of-two rows
+    assert len(blue._inner_plans()) >= 1
+    for plan, shape, batch in ((tiled, (64, 64), 2), (nd, (60, 16), 3)):
+        data = oracle.get_test_data(shape, numpy.complex64, batch, 96)
+        a = ctx.toGpu(data)
+        plan.execute(a, batch=batch)
+        got = a.get().reshape((batch,) + shape)
+        src = data.reshape((batch,) + shape).astype(numpy.complex128)
+        if plan is tiled:
+            ref = numpy.empty_like(src)
+            for i in range(4):
+                for j in range(4):
+                    ref[:, 16 * i:16 * i + 16, 16 * j:16 * j + 16] = numpy.fft.fft2(src[:, 16 * i:16 * i + 16, 16 * j:16 * j + 16])
+        else:
+            ref = numpy.fft.fft2(src)
+        assert numpy.abs(ref - got).sum() / numpy.abs(ref).sum() < 1.1e-6
+
+
+# ---- rectangular 2-D shapes on the fused kernel ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,batch", [((512, 1024), 66), ((1024, 512), 113), ((1024, 2048), 18), ((2048, 1024), 29), ((512, 2048), 33),
+                                         ((2048, 512), 57)], ids=str)
+def test_fused_2d_rectangles(ctx, monkeypatch, shape, batch):
+    """(ny, nx) in {512, 1024, 2048}^2 with ny != nx, fp32 interleaved, beyond the chain threshold: one persistent launch of two
+    transposing passes (round 3: squares only; pyfft/kernel.mako:857-874 vertical mode, plan.py:135-171).  The reference's
+    thresholds against numpy on sampled transforms, input untouched, in place == out of place, inverse round trip, and the
+    chain's result within fp32 rounding (another operation order: ROW + strided COL)."""
+    ny, nx = shape
+    data = oracle.get_test_data(shape, numpy.complex64, batch, 1100 + ny // 512 + nx // 128)
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    got = _execute(ctx, shape, numpy.complex64, batch, data, expect="fused2")
+    assert numpy.array_equal(_execute(ctx, shape, numpy.complex64, batch, data, inplace=True, expect="fused2"), got)
+    for item in (0, batch // 2, batch - 1):
+        sl = slice(item * ny, (item + 1) * ny)
+        ref = numpy.fft.fft2(data[sl].astype(numpy.complex128))
+        assert numpy.abs(ref - got[sl]).sum() / numpy.abs(ref).sum() < 1.1e-6
+        assert numpy.abs(ref - got[sl]).max() <= 1e-5 * numpy.abs(ref).max()
+    back = _execute(ctx, shape, numpy.complex64, batch, got, inverse=True, expect="fused2")
+    assert oracle.difference(data, back, batch) < 1.1e-6
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
+    want = _execute(ctx, shape, numpy.complex64, batch, data, expect="chain")
+    assert oracle.difference(want, got, batch) < 5e-7
+    # split planes keep the pipelined chunks (rectangles have no split form of the fused kernel)
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    assert ctx.getPlan(shape, dtype=numpy.float32).strategy(batch)[0] in ("pipelined", "chain")

@@ -34,11 +34,12 @@ def probe(n, B, combos, iters=3, check=True):
     descs = plan._descriptors(B, False, False)
     refh = ref.get() if check else None
     counters = DeviceAllocation(N.fused2_counter_bytes(B))
+    sync = N.MifftFusedSync(counters.ptr, None, None)       # one counter set, zeroed by the call; error word = counters[1]
     for lag, ring, grid in combos:
         scratch = DeviceAllocation(ring * n * isz)
         def once():
             N.check(N.lib.mifft_launch_fused2(ctypes.byref(descs[0]), ctypes.byref(descs[1]), a.ptr, None, b.ptr, None,
-                                              scratch.ptr, None, ring, lag, counters.ptr, grid, st.handle), "fused2")
+                                              scratch.ptr, None, ring, lag, ctypes.byref(sync), grid, st.handle), "fused2")
         N.check(N.lib.mifft_memset(b.ptr, 0, b.nbytes, st.handle))
         once(); st.synchronize()
         cnt = numpy.zeros(2, numpy.uint32)

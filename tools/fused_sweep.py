@@ -3,7 +3,8 @@ profiles/r04_fused_sweep.log): every variant builds a fresh plan in this process
 pyfft_amd/_debug.py set, checks sampled transforms against numpy and times back-to-back executes between two HIP events.
 
     python3 tools/fused_sweep.py [SHAPE DTYPE GIB VARIANTS]...      e.g.  524288 complex64 1 auto,f:14:28,x:4:8:0
-    variants: auto | chain | pipelined | f:LAG:RING (fused2) | x:LAG:RING:WT (fusedx, per XCD) | any of them + @ENV=VALUE
+    variants: auto | chain | pipelined | f:LAG:RING (fused2 / fusedp) | x:LAG:RING:WT (fusedx, per XCD) | seq | any of them + @ENV=VALUE
+    GIB may be a fraction (0.03125 = the reference's 32 MiB protocol)
 """
 import os
 import sys
@@ -12,7 +13,8 @@ import numpy
 from pyfft_amd.hip import Plan, DeviceArray, Event
 from pyfft_amd import _native as N
 
-KEYS = ("PYFFT_AMD_STRATEGY", "PYFFT_AMD_FUSED_RING", "PYFFT_AMD_FUSEDX", "PYFFT_AMD_FUSED3", "PYFFT_AMD_FUSED_WGS", "PYFFT_AMD_PIPE_MB")
+KEYS = ("PYFFT_AMD_STRATEGY", "PYFFT_AMD_FUSED_RING", "PYFFT_AMD_FUSEDX", "PYFFT_AMD_FUSED3", "PYFFT_AMD_FUSED_WGS", "PYFFT_AMD_PIPE_MB",
+        "PYFFT_AMD_FUSED_MEMSET", "PYFFT_AMD_NO_FUSEDX", "PYFFT_AMD_SMALL_FUSED")
 
 
 def variant_env(v):
@@ -31,6 +33,8 @@ def variant_env(v):
         env["PYFFT_AMD_STRATEGY"] = "fused"
         env["PYFFT_AMD_FUSED_RING"] = "%s,%s" % (t[1], t[2])
         env["PYFFT_AMD_FUSED3"] = "%s,%s" % (t[1], t[2])
+    elif t[0] == "seq":          # tiny batches: the sequential single-launch work list
+        env["PYFFT_AMD_SMALL_FUSED"] = "1"
     elif t[0] == "x":
         env["PYFFT_AMD_STRATEGY"] = "fusedx"
         env["PYFFT_AMD_FUSEDX"] = "%s,%s,%s" % (t[1], t[2], t[3])
@@ -51,7 +55,7 @@ def fill(buf, blk):
     N.check(N.lib.mifft_device_sync())
 
 
-def sweep(shape, dtype, gib, variants, reps=3, iters=5):
+def sweep(shape, dtype, gib, variants, reps=5, iters=10):
     dt = numpy.dtype(dtype)
     size = int(numpy.prod(shape))
     batch = max(1, int(gib * (1 << 30)) // (size * dt.itemsize))
