@@ -407,8 +407,9 @@ int mifft_mixed_long_split(int32_t precision, int64_t n, int32_t *n1, int32_t *n
 int mifft_launch_mixed_long(int32_t precision, int32_t n1, int32_t n2, int64_t batch, const void *in, void *mid, void *out,
                             const void *tw1, const void *tw2, const void *tw_lo, const void *tw_hi, int32_t tw_shift,
                             int32_t inverse, double scale, mifft_stream_t stream);
-/* Bluestein's algorithm in ONE launch for rows of ANY length n whose padded length fits a tile (2 n - 1 <= 4096 fp32 / 2048 fp64):
- * both m-point transforms of the convolution run inside LDS (csrc/fft_mixed.hip).
+/* Bluestein's algorithm in ONE launch for rows of ANY length n whose padded length fits the LDS of a CU twice (2 n - 1 <= 10000 fp32 /
+ * 5000 fp64; up to 4096 / 2048 several rows share a work-group): both m-point transforms of the convolution run inside LDS
+ * (csrc/fft_mixed.hip).
  *   mifft_bluestein_padded   0 and the padded length m (smooth, >= 2 n - 1, the cheapest one) or MIFFT_E_UNSUPPORTED
  *   tables: tw = w(m)^j (m entries); chirp c[j] = exp(-i pi j^2 / n) (n entries); bhat = FFT_m(b) / m with b[j] = conj(c[j]) for
  *   j < n, b[m - j] = b[j], zero between (m entries).  out = scale * DFT(in) (inverse: conjugated in and out). */
@@ -416,6 +417,15 @@ int mifft_bluestein_padded(int32_t precision, int32_t n, int32_t *m);
 int mifft_launch_bluestein_rows(int32_t precision, int32_t n, int32_t m, int64_t rows, int64_t stride_in, int64_t stride_out,
                                 const void *in, void *out, const void *tw, const void *chirp, const void *bhat, int32_t inverse,
                                 double scale, mifft_stream_t stream);
+
+/* Whole SMOOTH 2-D / 3-D transforms in one launch (csrc/fft_mixed_nd.hip): every axis of the (z, y, x) shape a smooth length (or 1), at
+ * least two axes longer than 1, x * y * z <= 10240 points (fp32) / 5120 (fp64) -- the transform, or several, lives in one work-group's
+ * LDS between its first load and its last store.  `transforms` dense arrays one after the other, interleaved, in place or out of place;
+ * tw_x / tw_y / tw_z = device tables w(len)^m of the axis lengths (NULL for an axis of length 1).  out = scale * DFT3(in).
+ *   mifft_mixed_nd_supported  0 if the shape has this form, else MIFFT_E_UNSUPPORTED */
+int mifft_mixed_nd_supported(int32_t precision, int32_t x, int32_t y, int32_t z);
+int mifft_launch_mixed_nd(int32_t precision, int32_t x, int32_t y, int32_t z, int64_t transforms, const void *in, void *out,
+                          const void *tw_x, const void *tw_y, const void *tw_z, int32_t inverse, double scale, mifft_stream_t stream);
 
 /* Same as mifft_launch_chain but brackets the chain with two events on `stream` and, after
  * synchronising, reports the elapsed device time of `repeats` back-to-back chains. (bench/test helper) */

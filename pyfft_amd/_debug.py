@@ -63,6 +63,11 @@ def no_tiled_kernel():
     return bool(os.environ.get("PYFFT_AMD_NO_TILED"))
 
 
+def no_mixed_nd():
+    """PYFFT_AMD_NO_MIXED_ND=1: smooth N-D shapes one launch per axis even where the whole transform fits one tile (A/B, tests)"""
+    return bool(os.environ.get("PYFFT_AMD_NO_MIXED_ND"))
+
+
 def fused3_lag_ring(lag, ring):
     """PYFFT_AMD_FUSED3 = lag,ring (development sweep of the 2048 x 2048 fused kernel)"""
     v = os.environ.get("PYFFT_AMD_FUSED3")

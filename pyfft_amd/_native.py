@@ -191,6 +191,8 @@ PROTOTYPES = {
     "mifft_bluestein_padded": (ctypes.c_int, [_i32, _i32, ctypes.POINTER(ctypes.c_int32)]),
     "mifft_launch_bluestein_rows": (ctypes.c_int, [_i32, _i32, _i32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp,
                                                    _i32, ctypes.c_double, _vp]),
+    "mifft_mixed_nd_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
+    "mifft_launch_mixed_nd": (ctypes.c_int, [_i32, _i32, _i32, _i32, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _i32, ctypes.c_double, _vp]),
     "mifft_time_chain": (ctypes.c_int, [_pass_p, _i32, _vpp, _vpp, _vp, _i32, ctypes.POINTER(ctypes.c_float)]),
 }
 

@@ -25,8 +25,13 @@ __device__ __forceinline__ void colx_tile(const TileArgs& a, const long long o_i
     using SL = typename Nd2AxisStages<1, L, W, 1, RL, Nd2StageList<>>::type;
     using First = Nd2Stage<T, P, NT, HALF, typename Nd2First<SL>::type>;
     static_assert(First::AX == 1 && First::SA == W && First::LA == L, "stage list of the strided axis");
-    const int tid = threadIdx.x;
+    // (opaque copies: inside the persistent loop of fft_fusedx_f64.hip the wave-uniform offsets derived from the shifts and the
+    // per-thread ones derived from the thread index are recomputed per tile instead of being hoisted out of the loop for both
+    // tile kinds and spilled -- as in fft_col2.hpp)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     int logMS = a.logMS, logS = a.logS;
+    asm volatile("" : "+s"(logMS), "+s"(logS));
     const cplx<T>* tw[3] = {nullptr, reinterpret_cast<const cplx<T>*>(a.tw_L), nullptr};
 
     // ---- first stage: v[b*R + k] = in[(jb + k*LR) rows][column c]

@@ -28,6 +28,7 @@ int mifft_fused2_f32_launch(int L0, int L1, const mifft::FusedArgs* f, int split
 int mifft_fused2x_f32_launch(int L0, int L1, const mifft::FusedArgs* f, unsigned grid, hipStream_t s);
 int mifft_fused2d_f32_launch(int ny, int nx, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
 int mifft_fused3d_f64_launch(int L, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
+int mifft_fusedx_f64(int L0, int L1, const mifft::FusedArgs* f, unsigned grid, hipStream_t s, int query, unsigned* tiles0, unsigned* tiles1);
 int mifft_fused3_f64_launch(int L0, int L1, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
 int mifft_aux_copy_launch(const struct mifft_copy* c, const void* s0, const void* s1, void* d0, void* d1, hipStream_t s);
 int mifft_aux_mul_rows_launch(int f64, void* a, const void* b, long long rows, long long n, hipStream_t s);
@@ -46,6 +47,10 @@ int mifft_mixed_long_split_impl(int f64, long long n, int* n1, int* n2);
 int mifft_mixed_long_launch(int f64, int n1, int n2, long long batch, const void* in, void* mid, void* out, const void* tw1, const void* tw2,
                             const void* tw_lo, const void* tw_hi, int tw_shift, int flags, double scale, hipStream_t s);
 int mifft_bluestein_padded_impl(int f64, int n);
+int mifft_bluestein_len_supported_impl(int f64, int m);
+int mifft_mixed_nd_supported_impl(int f64, int nx, int ny, int nz);
+int mifft_mixed_nd_launch(int f64, int nx, int ny, int nz, long long transforms, const void* in, void* out, const void* twx, const void* twy,
+                          const void* twz, int flags, double scale, hipStream_t s);
 int mifft_bluestein_launch(int f64, int n, int m, long long rows, long long stride_in, long long stride_out, const void* in, void* out,
                            const void* tw, const void* chirp, const void* bhat, int flags, double scale, hipStream_t s);
 int mifft_xcd2_f32_launch(const mifft::Xcd2Args* f, int split, int prefetch, int mode, unsigned grid, hipStream_t s);

@@ -685,8 +685,10 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
         return set_err(MIFFT_E_INVALID, "fused2: passes are not the two passes of one long contiguous axis");
     auto ok_len = [](int L) { return L == 256 || L == 512 || L == 1024; };
     const bool big = p0->L == 2048 && (p1->L == 2048 || p1->L == 1024);   // 512-thread tiles (fft_col3.hpp)
-    if (f64 ? (p0->L != 1024 || p1->L != 1024) : (!big && (!ok_len(p0->L) || !ok_len(p1->L)))) return set_err(MIFFT_E_UNSUPPORTED, "fused2: no kernel for %d x %d", p0->L, p1->L);
+    const bool wide64 = f64 && p0->L == 2048 && (p1->L == 2048 || p1->L == 1024) && p0->layout == MIFFT_INTERLEAVED;   // fft_fusedx_f64.hip
+    if (f64 ? (!wide64 && (p0->L != 1024 || p1->L != 1024)) : (!big && (!ok_len(p0->L) || !ok_len(p1->L)))) return set_err(MIFFT_E_UNSUPPORTED, "fused2: no kernel for %d x %d", p0->L, p1->L);
     }
+    const bool wide64 = !twod && f64 && p0->L == 2048;
     const bool split = p0->layout == MIFFT_SPLIT;
     if (!in0 || !out0 || !ring0 || (split && (!in1 || !out1))) return set_err(MIFFT_E_INVALID, "fused2: null buffer");
     (void)ring1;  // the ring is always interleaved
@@ -713,11 +715,14 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
         f.p0.logMS = ilog2(p0->L); f.p0.logS = 0; f.p0.has_tw = 0; f.p0.total = p1->outer * p0->L;
         f.p1.logMS = ilog2(p1->L); f.p1.logS = 0; f.p1.has_tw = 0; f.p1.total = p1->outer * p1->L;
     }
-    // tiles per transform: 2-D: nx / 16 column tiles in pass 0, ny / 16 in pass 1; 1-D: L1 / 16 and L0 / 16
-    rc = fill_ctl(&f.c, sync, p1->outer, lag, ring_slots, twod ? (unsigned)(p0->L / 16) : (unsigned)(p0->M / 16),
-                  twod ? (unsigned)(p1->L / 16) : (unsigned)(p1->S / 16), (hipStream_t)stream, "fused2");
+    // tiles per transform: 2-D: nx / 16 column tiles in pass 0, ny / 16 in pass 1; 1-D: L1 / 16 and L0 / 16 (fp64 2048-point
+    // passes: the tile widths of fft_fusedx_f64.hip)
+    unsigned tiles0 = twod ? (unsigned)(p0->L / 16) : (unsigned)(p0->M / 16), tiles1 = twod ? (unsigned)(p1->L / 16) : (unsigned)(p1->S / 16);
+    if (wide64 && mifft_fusedx_f64(p0->L, p1->L, nullptr, 0, nullptr, 1, &tiles0, &tiles1) != 0)
+        return set_err(MIFFT_E_UNSUPPORTED, "fused2: no kernel for %d x %d", p0->L, p1->L);
+    rc = fill_ctl(&f.c, sync, p1->outer, lag, ring_slots, tiles0, tiles1, (hipStream_t)stream, "fused2");
     if (rc) return rc;
-    rc = twod ? (f64 ? mifft_fused3d_f64_launch(p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)
+    rc = wide64 ? mifft_fusedx_f64(p0->L, p1->L, &f, (unsigned)grid, (hipStream_t)stream, 0, nullptr, nullptr) : twod ? (f64 ? mifft_fused3d_f64_launch(p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)
                      : mifft_fused2d_f32_launch(p1->L, p0->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream))
        : f64 ? mifft_fused3_f64_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)
              : mifft_fused2_f32_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream);
@@ -1049,7 +1054,7 @@ int mifft_launch_bluestein_rows(int32_t precision, int32_t n, int32_t m, int64_t
                                 void* out, const void* tw, const void* chirp, const void* bhat, int32_t inverse, double scale,
                                 mifft_stream_t stream) {
     if (precision != MIFFT_F32 && precision != MIFFT_F64) return MIFFT_E_UNSUPPORTED;
-    if (n < 2 || m < 2 * (int64_t)n - 1 || mifft_mixed_supported(precision, m) != 0)
+    if (n < 2 || m < 2 * (int64_t)n - 1 || mifft_bluestein_len_supported_impl(precision == MIFFT_F64, m) != 0)
         return set_err(MIFFT_E_UNSUPPORTED, "bluestein rows: no kernel for n = %d padded to %d", n, m);
     if (!in || !out || !tw || !chirp || !bhat) return set_err(MIFFT_E_INVALID, "bluestein rows: null buffer");
     if (rows < 0 || stride_in < n || stride_out < n) return set_err(MIFFT_E_INVALID, "bluestein rows: bad row count / stride");
@@ -1058,6 +1063,26 @@ int mifft_launch_bluestein_rows(int32_t precision, int32_t n, int32_t m, int64_t
     const int rc = mifft_bluestein_launch(precision == MIFFT_F64, n, m, rows, stride_in, stride_out, in, out, tw, chirp, bhat,
                                           inverse ? 3 : 0, scale, (hipStream_t)stream);
     if (rc == -2) return set_err(MIFFT_E_UNSUPPORTED, "bluestein rows: no kernel for n = %d padded to %d", n, m);
+    if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
+    if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
+    return 0;
+}
+
+int mifft_mixed_nd_supported(int32_t precision, int32_t x, int32_t y, int32_t z) {
+    if (precision != MIFFT_F32 && precision != MIFFT_F64) return MIFFT_E_UNSUPPORTED;
+    return mifft_mixed_nd_supported_impl(precision == MIFFT_F64, x, y, z) == 0 ? 0 : MIFFT_E_UNSUPPORTED;
+}
+
+int mifft_launch_mixed_nd(int32_t precision, int32_t x, int32_t y, int32_t z, int64_t transforms, const void* in, void* out, const void* tw_x,
+                          const void* tw_y, const void* tw_z, int32_t inverse, double scale, mifft_stream_t stream) {
+    if (mifft_mixed_nd_supported(precision, x, y, z) != 0) return set_err(MIFFT_E_UNSUPPORTED, "mixed nd: no kernel for %d x %d x %d", z, y, x);
+    if (!in || !out || (x > 1 && !tw_x) || (y > 1 && !tw_y) || (z > 1 && !tw_z)) return set_err(MIFFT_E_INVALID, "mixed nd: null buffer");
+    if (const char* why = check_rows(precision, in, out, 0, 0, 0, 0)) return set_err(MIFFT_E_INVALID, "mixed nd: %s", why);
+    if (transforms < 0 || mul3_checked(transforms, (long long)x * y * z, precision == MIFFT_F64 ? 16 : 8) < 0)
+        return set_err(MIFFT_E_INVALID, "mixed nd: bad transform count");
+    if (transforms == 0) return 0;
+    const int rc = mifft_mixed_nd_launch(precision == MIFFT_F64, x, y, z, transforms, in, out, tw_x, tw_y, tw_z, inverse ? 3 : 0, scale, (hipStream_t)stream);
+    if (rc == -2) return set_err(MIFFT_E_UNSUPPORTED, "mixed nd: no kernel for %d x %d x %d", z, y, x);
     if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
     if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
     return 0;

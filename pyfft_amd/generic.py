@@ -210,6 +210,7 @@ class GenericFFTPlan(object):
         # two, interleaved, dense: ONE launch per axis straight on the user's buffers -- the x axis as rows from input to output,
         # the slower axes as lines of the output array in place (mifft_launch_mixed_lines); no gather, no scatter, no work array
         self._direct_nd = None
+        self._direct_nd1 = False
         if not self._direct_mixed and not self._split and self._ntiles == 1 and any(ax.mixed_tw is not None for ax in self._axes) and \
                 all(ax.n == 1 or N.lib.mifft_mixed_supported(self._precision, ax.n) == 0 for ax in self._axes):
             tabs = []
@@ -223,6 +224,11 @@ class GenericFFTPlan(object):
                     ang = -2.0 * numpy.pi * k / float(ax.n)
                     tabs.append(self._upload((numpy.cos(ang) + 1j * numpy.sin(ang)).astype(self._cdtype)))
             self._direct_nd = tabs
+            # ... and the whole transform in ONE launch when it fits a work-group's LDS (csrc/fft_mixed_nd.hip, round 4): (100, 100)
+            # is 80 KB; one HBM round trip instead of one per axis
+            x, y, z = self._xyz
+            if N.lib.mifft_mixed_nd_supported(self._precision, x, y, z) == 0 and not D.no_mixed_nd():
+                self._direct_nd1 = True
         self._uses_work = not (self._tiled or self._direct_mixed or self._direct_blue or self._direct_nd is not None
                                or self._direct_long is not None)
         if self._uses_work:
@@ -327,6 +333,14 @@ class GenericFFTPlan(object):
         ctx.order_scratch()
         if self._tiled:
             return self._execute_tiled(wait_for_finish, bool(inverse), batch, ptr(ins[0]), ptr(outs[0]))
+        if self._direct_nd1:
+            inv = bool(inverse)
+            factor = self._scale if not inv else 1.0 / ((self._size if self._normalize else 1.0) * self._scale)
+            x, y, z = self._xyz
+            twx, twy, twz = self._direct_nd
+            N.check(N.lib.mifft_launch_mixed_nd(self._precision, x, y, z, batch, ptr(ins[0]), ptr(outs[0]), twx, twy, twz, 1 if inv else 0,
+                                                factor, ctx.stream_handle()), "mifft_launch_mixed_nd")
+            return self._epilogue(wait_for_finish)
         if self._direct_nd is not None:
             inv = bool(inverse)
             factor = self._scale if not inv else 1.0 / ((self._size if self._normalize else 1.0) * self._scale)

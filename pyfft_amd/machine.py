@@ -59,14 +59,14 @@ class Machine(object):
         return self.llc_bytes // 4
 
     # ---- persistent launches -----------------------------------------------------------------------------------------
-    def fused_geometry(self, item_bytes, tiles0, groups_per_cu, fill_cache=False):
+    def fused_geometry(self, item_bytes, tiles0, groups_per_cu, fill_cache=False, min_slots=None):
         """(lag, ring, grid) of a persistent two-pass launch, or None when the cache holds no useful ring.
         lag: the producers stay 1.75 work-group waves of first-pass tiles ahead of the consumers (C2: 14 transforms of 64 tiles
         on 512 work-groups; 2^19 has 32 tiles per transform and ran 4 points low on 14: profiles/r04_a_fused_sweep.log);
         ring = 2 * lag, capped by the cache -- then the consumers follow by 4/7 of the ring (measured on the 32 MiB transforms)."""
         grid = groups_per_cu * self.compute_units
         slots = self.ring_bytes // max(1, item_bytes)
-        if slots < self.MIN_RING_SLOTS or grid < 1:
+        if slots < (min_slots or self.MIN_RING_SLOTS) or grid < 1:
             return None
         lag = max(2, -(-7 * grid // (4 * max(1, tiles0))))
         ring = 2 * lag

@@ -273,7 +273,7 @@ class FFTPlan(object):
     #   pipelined  batch cut into cache-sized chunks, chunk i on side stream i % n with its own temp slot
     #              (mifft_launch_chain_pipelined)
     #   fused2     both passes of a long 1-D transform / a big 2-D one in one persistent launch (mifft_launch_fused2)
-    #   fused2x    the same with one work list per XCD (mifft_launch_fused2x): 2^16 / 2^17, where eight short pipelines beat one
+    #   fused2x    the same with one work list per XCD (mifft_launch_fused2x): 2^17, where eight short pipelines beat one
     #   fusedp     both pass PAIRS of a cache-sized 3-D cube in one persistent launch (mifft_launch_fused_pair)
     #   xcd2       1024 x 1024 fp32: one persistent launch, each transform stays on one XCD between its two HBM
     #              crossings (mifft_launch_xcd2); development only
@@ -294,6 +294,10 @@ class FFTPlan(object):
             return False
         if p.split and (nx != ny or D.forced_strategy() != "fused"):
             return False      # (split planes: 29 % against 35 % for the pipelined chunks -- squares, on request only)
+        if (ny, nx) == (512, 2048) and D.forced_strategy() != "fused":
+            # 512-point columns on the 512-thread tiles (16 points per thread, 64 KiB tiles, one work-group per CU): 0.355 against
+            # 0.392 for the pipelined chunks -- the one rectangle that loses (profiles/r04_c_rect_sweep.log); on request only
+            return False
         return (k[0].kind == N.PASS_ROW and k[0].L == nx and k[1].kind == N.PASS_COL and k[1].L == ny
                 and k[1].M == 1 and k[1].S == nx)
 
@@ -311,7 +315,8 @@ class FFTPlan(object):
                 and k[0].S == 1 and k[0].M == k[1].L and k[1].M == 1):
             return False
         if p.precision == N.F64:
-            return k[0].L == 1024 and k[1].L == 1024
+            # 1024 x 1024 on the 512-thread tiles; round 4: 2048 x 2048 / 2048 x 1024 on the stage-chain tiles (interleaved)
+            return (k[0].L == 1024 and k[1].L == 1024) or (k[0].L == 2048 and k[1].L in (1024, 2048) and not p.split)
         return (k[0].L in (256, 512, 1024) and k[1].L in (256, 512, 1024)) or (k[0].L == 2048 and k[1].L in (1024, 2048))
 
     def _fusedx_eligible(self):
@@ -340,6 +345,8 @@ class FFTPlan(object):
             return int(self._params.z) * int(k[1].M)             # planes x R1
         if self._fused2d_eligible():
             return k[0].L // 16                                  # nx / 16 column tiles of the y pass
+        if self._params.precision == N.F64 and k[0].L == 2048:
+            return k[0].M // 8                                   # 8-column tiles (csrc/fft_fusedx_f64.hip)
         return k[0].M // 16
 
     def _select_strategy(self, batch):
@@ -371,8 +378,9 @@ class FFTPlan(object):
             return ("fused2x", lag, ring, 2 * mach.compute_units)
         if forced == "xcd" and self._xcd2_eligible() and batch >= self.XCD2_MIN_BATCH:   # not the default: DESIGN.md section 4
             return ("xcd2", D.xcd2_flags(N.XCD2_PREFETCH))
-        # per-XCD lists where they win: the two-pass sizes below 2^18, whose 16-tile passes leave one global list short of slack
-        if forced == "auto" and self._fusedx_eligible() and self._kernels[0].L * self._kernels[1].L < (1 << 18) and not D.no_fusedx():
+        # per-XCD lists where they win: 2^17 = 512 x 256 (+ 2 points over the pipelined chunks at 0.5 / 2 / 8 GiB; 2^16 is within
+        # +- 0.5 of them, 2^18 and up within +- 0.5 of the global list: profiles/r04_d_list_sweep.log)
+        if forced == "auto" and self._fusedx_eligible() and self._kernels[0].L * self._kernels[1].L == (1 << 17) and not D.no_fusedx():
             lag, ring = self.FUSEDX_LAG_RING
             if batch >= 8 * 2 * ring and 8 * ring * item_bytes <= mach.ring_bytes:
                 return ("fused2x", lag, ring, 2 * mach.compute_units)
@@ -388,7 +396,9 @@ class FFTPlan(object):
             # measured on MI355X (end of round 2, counters on their own lines): the persistent kernel beats the stream-pipelined
             # chunks from N = 2^18 up (2^18: 42.0 vs 39.5 %, 2^19: 37.2 vs 36.2 %; 2^17: 39.1 vs 39.5, 2^16: 33 vs 40)
             big = self._kernels[0].L * self._kernels[1].L >= (1 << 18)
-            geo = mach.fused_geometry(item_bytes, self._fused_tiles0(), D.fused_grid_per_cu(1 if huge else 2))   # (four per CU for L <= 512: no gain)
+            # (fp64 2^22: 64 MiB per transform, three ring slots are all the cache holds)
+            geo = mach.fused_geometry(item_bytes, self._fused_tiles0(), D.fused_grid_per_cu(1 if huge else 2),   # (four per CU for L <= 512: no gain)
+                                      min_slots=3 if (p.precision == N.F64 and self._kernels[0].L == 2048) else None)
             if geo is not None:
                 lag, ring, grid = geo
                 if huge:

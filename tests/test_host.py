@@ -432,8 +432,18 @@ def test_round3_entry_points_reject_bad_arguments_without_touching_the_gpu():
     for prec, n in ((N.F32, 1009), (N.F32, 17), (N.F32, 2048), (N.F64, 1023), (N.F32, 2)):
         assert N.lib.mifft_bluestein_padded(prec, n, ctypes.byref(m)) == 0
         assert m.value >= 2 * n - 1 and N.lib.mifft_mixed_supported(prec, m.value) == 0
-    assert N.lib.mifft_bluestein_padded(N.F32, 2049, ctypes.byref(m)) == N.E_UNSUPPORTED
-    assert N.lib.mifft_bluestein_padded(N.F64, 1025, ctypes.byref(m)) == N.E_UNSUPPORTED
+    # round 4: padded rows up to 10000 (fp32) / 5000 (fp64) points -- one row per work-group in up to 160 KB of LDS
+    for prec, n in ((N.F32, 2049), (N.F32, 4099), (N.F32, 5000), (N.F64, 1025), (N.F64, 2500)):
+        assert N.lib.mifft_bluestein_padded(prec, n, ctypes.byref(m)) == 0 and m.value >= 2 * n - 1
+        assert m.value <= (10000 if prec == N.F32 else 5000)
+    assert N.lib.mifft_bluestein_padded(N.F32, 5001, ctypes.byref(m)) == N.E_UNSUPPORTED
+    assert N.lib.mifft_bluestein_padded(N.F64, 2501, ctypes.byref(m)) == N.E_UNSUPPORTED
+    # smooth N-D shapes in one launch: every axis smooth, at least two axes, the transform inside one tile
+    assert [N.lib.mifft_mixed_nd_supported(N.F32, *xyz) == 0 for xyz in ((100, 100, 1), (60, 60, 1), (30, 20, 10), (100, 101, 1), (1000, 1, 1),
+                                                                            (128, 100, 1), (60, 60, 60))] == [True, True, True, False, False, False, False]
+    assert N.lib.mifft_mixed_nd_supported(N.F64, 100, 100, 1) == N.E_UNSUPPORTED and N.lib.mifft_mixed_nd_supported(N.F64, 70, 70, 1) == 0
+    assert N.lib.mifft_launch_mixed_nd(N.F32, 100, 100, 1, 4, 16, 16, None, 16, None, 0, 1.0, None) == N.E_INVALID        # x table missing
+    assert N.lib.mifft_launch_mixed_nd(N.F32, 100, 101, 1, 4, 16, 16, 16, 16, None, 0, 1.0, None) == N.E_UNSUPPORTED
     assert N.lib.mifft_launch_bluestein_rows(N.F32, 1009, 2000, 4, 1009, 1009, 16, 16, 16, 16, 16, 0, 1.0, None) == N.E_UNSUPPORTED  # m < 2n-1
     assert N.lib.mifft_launch_bluestein_rows(N.F32, 1009, 2048, 4, 1000, 1009, 16, 16, 16, 16, 16, 0, 1.0, None) == N.E_INVALID      # stride < n
     assert N.lib.mifft_launch_bluestein_rows(N.F32, 1009, 2048, 4, 1009, 1009, 16, 16, 16, None, 16, 0, 1.0, None) == N.E_INVALID
@@ -488,7 +498,10 @@ def test_planner_constants_come_from_the_device():
     assert _strategy_on(full, (1 << 22,), c64, 256)[1] == ("fused2", 4, 7, 256)               # BASELINE config 5's chunk
     assert _strategy_on(full, (1 << 21,), c64, 512)[1] == ("fused2", 8, 14, 512)              # 16 MiB transforms: the cache caps the ring
     assert _strategy_on(full, (1 << 17,), c64, 8192)[1] == ("fused2x", 8, 16, 512)         # per-XCD lists below 2^18
-    assert _strategy_on(full, (1 << 16,), c64, 16384)[1] == ("fused2x", 8, 16, 512)
+    assert _strategy_on(full, (1 << 16,), c64, 16384)[1] == ("pipelined", 128, 2, 0)          # (per-XCD lists: +- 0.5 points there)
+    assert _strategy_on(full, (1 << 22,), numpy.complex128, 64)[1] == ("fused2", 1, 3, 256)   # fp64 2^22: 64 MiB transforms, 3 slots
+    assert _strategy_on(full, (1 << 21,), numpy.complex128, 128)[1] == ("fused2", 4, 7, 256)
+    assert _strategy_on(full, (1 << 22,), numpy.float64, 64)[1][0] == "pipelined"             # (split planes: no kernel)
     assert _strategy_on(full, (1024, 1024), c64, 512)[1] == ("fused2", 14, 28, 512)           # BASELINE config 3
     assert _strategy_on(full, (128, 128, 128), c64, 64)[1][0] == "fusedp"
     assert _strategy_on(full, (128, 128, 128), c128, 32)[1][0] == "fusedp"

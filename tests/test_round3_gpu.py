@@ -331,10 +331,11 @@ def test_bluestein_in_one_launch(ctx, n, dtype):
     prec = N.F64 if cd == numpy.complex128 else N.F32
     mm = ctypes.c_int32(0)
     if N.lib.mifft_bluestein_padded(prec, n, ctypes.byref(mm)) != 0:
-        assert 2 * n - 1 > (2048 if prec == N.F64 else 4096)
+        assert 2 * n - 1 > (5000 if prec == N.F64 else 10000)        # (round 4: padded rows up to the whole LDS of a CU)
         return
     m = mm.value
-    assert m >= 2 * n - 1 and N.lib.mifft_mixed_supported(prec, m) == 0
+    # a smooth padded length: inside one 64 KiB tile the mixed-radix row kernel takes it too; beyond (round 4) only Bluestein does
+    assert m >= 2 * n - 1 and (N.lib.mifft_mixed_supported(prec, m) == 0 or m > (2048 if prec == N.F64 else 4096))
     eps, mx = (1e-11, 1e-10) if prec == N.F64 else (1.1e-6, 1e-5)
     rows, pad = 29, 3
     rng = numpy.random.default_rng(n)
@@ -557,7 +558,9 @@ def test_generic_plan_reports_inner_plan_errors(ctx):
     """GenericFFTPlan.finish()/check() drain the mailboxes of the inner power-of-two plans (a persistent kernel inside a tiled
     or Bluestein plan posts its dependency time-outs there)."""
     hip = ctx.hip
-    plan = ctx.getPlan((16, 16), parent_shape=(64, 64), dtype=numpy.complex64, wait_for_finish=True)
+    # (a tile shape WITHOUT a one-launch kernel: gather, one inner N-D plan, scatter -- since round 4 a plan that runs the tile
+    # kernel builds no inner plan at all)
+    plan = ctx.getPlan((16, 4), parent_shape=(64, 64), dtype=numpy.complex64, wait_for_finish=True)
     data = oracle.get_test_data((64, 64), numpy.complex64, 2, 5)
     a = ctx.toGpu(data)
     plan.execute(a, batch=2)                                  # fine

@@ -38,7 +38,7 @@ def test_device_properties_describe_the_memory_system(ctx):
 
 
 # ---- persistent two-pair kernel: 128^3 -----------------------------------------------------------------------------------
-@pytest.mark.parametrize("dtype,batch", [(numpy.complex64, 21), (numpy.complex128, 11)], ids=lambda v: str(numpy.dtype(v).name) if isinstance(v, type) else str(v))
+@pytest.mark.parametrize("dtype,batch", [(numpy.complex64, 19), (numpy.complex128, 10)], ids=lambda v: str(numpy.dtype(v).name) if isinstance(v, type) else str(v))
 def test_fused_pair_cube_128(ctx, monkeypatch, dtype, batch):
     """(128, 128, 128) beyond the chain threshold: both pass pairs of every transform in ONE persistent launch
     (mifft_launch_fused_pair).  Same tile arithmetic as the two plain pair launches -> the bits of the chain; in place ==
@@ -53,6 +53,9 @@ def test_fused_pair_cube_128(ctx, monkeypatch, dtype, batch):
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
     want = _execute(ctx, shape, dtype, batch, data, expect="chain")
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    full = ctx.getPlan(shape, dtype=dtype).strategy(64)
+    assert full[0] == "fusedp" and full[2] * n * cdt.itemsize <= 224 << 20, full      # the plan's own choice: a ring that fills the cache
+    monkeypatch.setenv("PYFFT_AMD_FUSED_RING", "4,8" if cdt == numpy.complex64 else "2,4")   # (a ring the test's batch can fill twice)
     got = _execute(ctx, shape, dtype, batch, data, expect="fusedp")
     assert numpy.array_equal(want, got), "persistent two-pair launch differs from the two plain pair launches"
     got_ip = _execute(ctx, shape, dtype, batch, data, inplace=True, expect="fusedp")
@@ -77,22 +80,27 @@ def test_fused_pair_cube_128(ctx, monkeypatch, dtype, batch):
 
 # ---- per-XCD work lists as a default ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,batch", [(1 << 16, 1040), (1 << 17, 520)], ids=str)
-def test_per_xcd_lists_are_the_default_below_2_18(ctx, monkeypatch, n, batch):
-    """2^16 / 2^17 beyond the chain threshold run the fused kernel with one work list per XCD (mifft_launch_fused2x; pyfft/
-    kernel.py:259-283 chain semantics): the bits of the chain, in place == out of place, the plan's choice without any switch;
-    a batch that is not a multiple of 8 leaves the lists uneven, work stealing drains them."""
+def test_per_xcd_lists(ctx, monkeypatch, n, batch):
+    """2^17 beyond the chain threshold runs the fused kernel with one work list per XCD (mifft_launch_fused2x; pyfft/
+    kernel.py:259-283 chain semantics) by the plan's own choice, 2^16 on request: the bits of the chain, in place == out of
+    place; a batch that is not a multiple of 8 leaves the lists uneven, work stealing drains them."""
     if not ctx.hip.Machine.from_props(ctx.hip.device_props()).xcd_cooperative:
         pytest.skip("needs 8 XCDs x 32 CUs")
     data = oracle.get_test_data((n,), numpy.complex64, batch, 91)
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
     want = _execute(ctx, (n,), numpy.complex64, batch, data, expect="chain")
-    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    if n == 1 << 17:
+        monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    else:
+        monkeypatch.setenv("PYFFT_AMD_STRATEGY", "fusedx")
+        monkeypatch.setenv("PYFFT_AMD_FUSEDX", "8,16")
     got = _execute(ctx, (n,), numpy.complex64, batch, data, expect="fused2x")
     assert numpy.array_equal(want, got)
     assert numpy.array_equal(_execute(ctx, (n,), numpy.complex64, batch, data, inplace=True, expect="fused2x"), got)
     odd = batch - 3
     got_odd = _execute(ctx, (n,), numpy.complex64, odd, data[:odd * n], expect="fused2x")
     assert numpy.array_equal(got_odd, want[:odd * n])
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
     monkeypatch.setenv("PYFFT_AMD_NO_FUSEDX", "1")
     assert ctx.getPlan((n,), dtype=numpy.complex64).strategy(batch)[0] == "pipelined"
 
@@ -128,7 +136,12 @@ def test_sequential_single_launch_of_tiny_batches(ctx, monkeypatch, shape, dtype
     st = plan.strategy(batch)
     assert st[0] in ("fused2", "fusedp") and st[1] == 0 and st[2] == batch, st
     got = _execute(ctx, shape, dtype, batch, data)
-    assert numpy.array_equal(want, got)
+    if len(shape) == 2:
+        # the 2-D persistent form is two TRANSPOSING passes, the chain a ROW pass and a strided one: the same transform in another
+        # operation order (as in test_fused_2d_1024)
+        assert oracle.difference(want, got, batch) < (5e-7 if numpy.dtype(dtype) == numpy.complex64 else 1e-14)
+    else:
+        assert numpy.array_equal(want, got)
     assert numpy.array_equal(_execute(ctx, shape, dtype, batch, data, inplace=True), got)
     tol = 1.1e-6 if numpy.dtype(dtype) == numpy.complex64 else 1e-11
     back = _execute(ctx, shape, dtype, batch, got, inverse=True)
@@ -228,7 +241,7 @@ def test_generic_plans_build_only_what_they_run(ctx):
 
 # ---- rectangular 2-D shapes on the fused kernel ---------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape,batch", [((512, 1024), 66), ((1024, 512), 113), ((1024, 2048), 18), ((2048, 1024), 29), ((512, 2048), 33),
-                                         ((2048, 512), 57)], ids=str)
+                                         ((2048, 512), 57)], ids=str)   # ((512, 2048) runs the kernel on request only: pipelined is faster)
 def test_fused_2d_rectangles(ctx, monkeypatch, shape, batch):
     """(ny, nx) in {512, 1024, 2048}^2 with ny != nx, fp32 interleaved, beyond the chain threshold: one persistent launch of two
     transposing passes (round 3: squares only; pyfft/kernel.mako:857-874 vertical mode, plan.py:135-171).  The reference's
@@ -236,7 +249,7 @@ def test_fused_2d_rectangles(ctx, monkeypatch, shape, batch):
     chain's result within fp32 rounding (another operation order: ROW + strided COL)."""
     ny, nx = shape
     data = oracle.get_test_data(shape, numpy.complex64, batch, 1100 + ny // 512 + nx // 128)
-    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto" if shape != (512, 2048) else "fused")
     got = _execute(ctx, shape, numpy.complex64, batch, data, expect="fused2")
     assert numpy.array_equal(_execute(ctx, shape, numpy.complex64, batch, data, inplace=True, expect="fused2"), got)
     for item in (0, batch // 2, batch - 1):
@@ -252,3 +265,82 @@ def test_fused_2d_rectangles(ctx, monkeypatch, shape, batch):
     # split planes keep the pipelined chunks (rectangles have no split form of the fused kernel)
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
     assert ctx.getPlan(shape, dtype=numpy.float32).strategy(batch)[0] in ("pipelined", "chain")
+
+
+# ---- f4 tails: smooth N-D shapes in one launch, Bluestein rows up to 5000 points in one launch ----------------------------------
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
+@pytest.mark.parametrize("shape,batch", [((100, 100), 5), ((60, 60), 7), ((30, 20, 10), 3), ((12, 20), 301), ((6, 10, 14), 33), ((100, 64), 2),
+                                         ((70, 70), 3), ((9, 1, 25), 11), ((15, 16), 64)], ids=str)
+def test_smooth_nd_single_launch(ctx, monkeypatch, shape, dtype, batch):
+    """Every axis a smooth length and the transform inside one tile (csrc/fft_mixed_nd.hip; the reference's TODO.txt:8): ONE launch
+    against numpy with the reference's thresholds, out of place (input untouched), the inverse in place, ragged last work-group,
+    and against the round-3 form (one launch per axis) -- the same butterflies in the same order, so the same bits."""
+    from test_round2_gpu import _run_generic
+    N = ctx.hip.N
+    prec = N.F32 if numpy.dtype(dtype) == numpy.complex64 else N.F64
+    x, y, z = (tuple(reversed(shape)) + (1, 1))[:3]
+    plan = ctx.getPlan(shape, dtype=dtype, any_size=True)
+    one = N.lib.mifft_mixed_nd_supported(prec, x, y, z) == 0
+    assert plan._direct_nd1 == one and plan._inner_plans() == []
+    if shape == (100, 100):
+        assert one == (prec == N.F32)                  # 10000 points: one fp32 tile (80 KB per LDS buffer), two launches in fp64
+    _run_generic(ctx, shape, dtype, batch, seed=sum(shape))
+    if one:
+        rng = numpy.random.default_rng(5)
+        full = (batch * shape[0],) + tuple(shape[1:])
+        data = (rng.standard_normal(full) + 1j * rng.standard_normal(full)).astype(dtype)
+        a = ctx.toGpu(data)
+        plan.execute(a, batch=batch)
+        monkeypatch.setenv("PYFFT_AMD_NO_MIXED_ND", "1")
+        per_axis = ctx.getPlan(shape, dtype=dtype, any_size=True)
+        assert not per_axis._direct_nd1 and per_axis._direct_nd is not None
+        b = ctx.toGpu(data)
+        per_axis.execute(b, batch=batch)
+        assert numpy.array_equal(a.get(), b.get())
+
+
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
+@pytest.mark.parametrize("n,batch", [(2049, 9), (4099, 5), (5000, 3), (3001, 4), (2500, 7)], ids=str)
+def test_bluestein_rows_beyond_one_small_tile(ctx, n, batch, dtype):
+    """Lengths with a large prime factor whose padded rows take up to the whole LDS of a CU (n <= 5000 fp32 / 2500 fp64): ONE launch
+    (round 3: five launches at 0.029 of the roofline for n = 4099); longer ones keep the composition.  numpy, reference thresholds."""
+    from test_round2_gpu import _run_generic
+    N = ctx.hip.N
+    prec = N.F32 if numpy.dtype(dtype) == numpy.complex64 else N.F64
+    m = ctypes.c_int32(0)
+    one = N.lib.mifft_bluestein_padded(prec, n, ctypes.byref(m)) == 0
+    assert one == (n <= (5000 if prec == N.F32 else 2500))
+    plan = ctx.getPlan((n,), dtype=dtype, any_size=True)
+    smooth = N.lib.mifft_mixed_supported(prec, n) == 0 or plan._direct_long is not None
+    assert plan._direct_blue == (one and not smooth)
+    _run_generic(ctx, (n,), dtype, batch, seed=n)
+
+
+# ---- fp64 2^21 / 2^22 on the persistent kernel (stage-chain strided tiles) ------------------------------------------------------
+@pytest.mark.parametrize("n,batch", [(1 << 22, 6), (1 << 21, 14)], ids=str)
+def test_fused_long_fp64(ctx, monkeypatch, n, batch):
+    """fp64 N = 2^22 = 2048 x 2048 and 2^21 = 2048 x 1024 beyond the chain threshold: both passes in one persistent launch on the
+    8-column stage-chain tiles (csrc/fft_fusedx_f64.hip; round 3: two launches per 64 MiB chunk).  2^22 runs the chain's own two
+    tile kinds -> the chain's bits; 2^21 runs its 1024-point pass on 16-column stage-chain tiles instead of the 512-thread ones ->
+    the same transform in another operation order.  numpy on sampled transforms (reference thresholds), in place, inverse."""
+    rng = numpy.random.default_rng(n % 1000)
+    blk = (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))).astype(numpy.complex128)
+    data = numpy.concatenate([blk[i % 2] for i in range(batch)])
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
+    want = _execute(ctx, (n,), numpy.complex128, batch, data, expect="chain")
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    got = _execute(ctx, (n,), numpy.complex128, batch, data, expect="fused2")
+    if n == 1 << 22:
+        assert numpy.array_equal(want, got)
+    else:
+        assert oracle.difference(want, got, batch) < 1e-14
+    assert numpy.array_equal(_execute(ctx, (n,), numpy.complex128, batch, data, inplace=True, expect="fused2"), got)
+    for item in (0, 1, batch - 1):
+        ref = numpy.fft.fft(blk[item % 2])
+        g = got[item * n:(item + 1) * n]
+        assert numpy.abs(ref - g).sum() / numpy.abs(ref).sum() < 1e-11
+        assert numpy.abs(ref - g).max() <= 1e-10 * numpy.abs(ref).max()
+    back = _execute(ctx, (n,), numpy.complex128, batch, got, inverse=True, expect="fused2")
+    assert oracle.difference(data, back, batch) < 1e-11
+    # split planes have no such kernel: the pipelined chunks
+    assert ctx.getPlan((n,), dtype=numpy.float64).strategy(batch)[0] in ("pipelined", "chain")

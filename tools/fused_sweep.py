@@ -37,7 +37,7 @@ def variant_env(v):
         env["PYFFT_AMD_SMALL_FUSED"] = "1"
     elif t[0] == "x":
         env["PYFFT_AMD_STRATEGY"] = "fusedx"
-        env["PYFFT_AMD_FUSEDX"] = "%s,%s,%s" % (t[1], t[2], t[3])
+        env["PYFFT_AMD_FUSEDX"] = "%s,%s" % (t[1], t[2])
     else:
         raise ValueError(v)
     return env

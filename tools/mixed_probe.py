@@ -13,3 +13,10 @@ run((30000,), numpy.complex128, 2048)
 for n in (1009, 127, 17, 2039, 513):
     run((n,), numpy.complex64, (1 << 27) // n)
 run((1009,), numpy.complex128, 1 << 16); run((1009, 64), numpy.complex64, 2048); run((4099,), numpy.complex64, 1 << 15)
+# round 4: smooth N-D shapes in one launch, Bluestein rows up to 5000 points in one launch
+for shape, batch in (((60, 60), 1 << 15), ((30, 20, 10), 1 << 14), ((70, 70), 1 << 14), ((12, 20), 1 << 19), ((100, 64), 1 << 14)):
+    run(shape, numpy.complex64, batch)
+run((70, 70), numpy.complex128, 1 << 13)
+for n in (2049, 3001, 4099, 5000):
+    run((n,), numpy.complex64, (1 << 27) // n)
+run((2500,), numpy.complex128, 1 << 14)
