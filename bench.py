@@ -41,6 +41,10 @@ CONFIGS = {
     "c4": ((256, 256, 256), "complex128", 64, 1004),
     "c4s": ((256, 256, 256), "float64", 64, 1004),
     "c5": ((1 << 22,), "complex64", 256, 1005),   # per-GPU resident chunk of config 5 (8 GiB in + 8 GiB out)
+    # not BASELINE configurations: the reference's published 128^3 row (doc/source/index.rst:373) at 1 GiB per side, for
+    # tools/pmc_traffic.py and the round-4 evidence of the persistent two-pair kernel
+    "cube": ((128, 128, 128), "complex64", 64, 1006),
+    "cubed": ((128, 128, 128), "complex128", 32, 1007),
 }
 
 
@@ -564,8 +568,9 @@ def main():
     nlaunch = len(launch_units(plan.pass_list()))
     if strategy[0] == "chain":
         launches = "%d launches per step" % nlaunch
-    elif strategy[0] == "fused2":
-        launches = "1 persistent launch per step (both passes, lag %s, ring %s)" % tuple(strategy[1:3])
+    elif strategy[0] in ("fused2", "fused2x", "fusedp"):
+        what = {"fused2": "both passes", "fused2x": "both passes, one work list per XCD", "fusedp": "both pass pairs"}[strategy[0]]
+        launches = "1 persistent launch per step (%s, lag %s, ring %s)" % ((what,) + tuple(strategy[1:3]))
     elif strategy[0] == "xcd2":
         launches = "1 persistent launch per step (both passes, XCD-resident intermediate)"
     else:

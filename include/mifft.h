@@ -157,7 +157,7 @@ const char *mifft_last_error(void);
 #define MIFFT_DEBUG_FORCE_WAVE 3   /* wave-autonomous kernels wherever one exists, whatever the buffer size */
 #define MIFFT_DEBUG_PERSIST 4      /* persistent (prefetching) form of the long fp32 rows (measured: no gain) */
 #define MIFFT_DEBUG_ALT_ROWS 5     /* alternative stage lists of the longest fp32 rows (A/B measurements) */
-#define MIFFT_DEBUG_PAIR 6         /* pass pairs: 0 = default split, 1 = off, 2 = the alternative y split (A/B measurements) */
+#define MIFFT_DEBUG_PAIR 6         /* pass pairs: 0 = default split, 1 = off, 2 = the alternative y split, 3 / 4 / 5 = other tile forms of the persistent two-pair kernel (A/B measurements) */
 #define MIFFT_DEBUG_STORE 7        /* streamed output stores (A/B): 0 = default, 1 = non-temporal, 2 = write-through (sc1), 3 = plain */
 #define MIFFT_DEBUG_KEYS 8
 int mifft_debug_set(int32_t key, int32_t value);

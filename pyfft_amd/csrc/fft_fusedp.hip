@@ -9,8 +9,12 @@ using namespace mifft;
 extern "C" int mifft_fusedp(int f64, int x, int y, int z, const FusedPairArgs* f, unsigned grid, hipStream_t s, int query, int* r0,
                             unsigned* tiles0, unsigned* tiles1) {
 #define RL(...) RadixList<__VA_ARGS__>
-#define CASE(T, F64, NX, NY, NZ, R0, R1, W, XY, YZ)                                               \
-    if (f64 == F64 && x == NX && y == NY && z == NZ) {                                           \
+    // development switch (A/B, MIFFT_PAIR): 3 = the narrow fp64 tiles of the first form of this kernel; 4 / 5 = the two wider forms of the
+    // fp32 cube that measured below the narrow one
+    const int sw = mifft_debug_get(MIFFT_DEBUG_PAIR);
+    const int variant = sw >= 3 ? sw : 0;
+#define CASE(T, F64, NX, NY, NZ, R0, R1, W, XY, YZ, VARIANT)                                      \
+    if (f64 == F64 && x == NX && y == NY && z == NZ && variant == VARIANT) {                     \
         constexpr unsigned t0 = (unsigned)NZ * R1 / (YZ::NT / XY::NT), t1 = (unsigned)NX * R0 / W; \
         constexpr unsigned per0 = t0 >= t1 ? t0 / t1 : 1u, per1 = t1 > t0 ? t1 / t0 : 1u;       \
         static_assert(t0 * per1 == t1 * per0, "item counts must be in a small integer ratio");    \
@@ -19,16 +23,34 @@ extern "C" int mifft_fusedp(int f64, int x, int y, int z, const FusedPairArgs* f
         if (tiles1) *tiles1 = t1;                                                                 \
         return query ? 0 : launch_fusedp<T, XY, YZ, per0, per1>(f, grid, s);                     \
     }
-    // 128^3 fp32: y = 32 x 4; XY tile 128 x 32 = 4096 points on 256 threads, two of them side by side; YZ tile 16 x 4 x 128 = 8192
-    // points on 512 threads (the configurations of fft_pair_f32.hip): 256 + 256 items per transform, 69.6 KiB of LDS, two
-    // work-groups = 16 waves per CU
+    // ---- 128^3 fp64, y = 32 x 4: two XY tiles (128 x 32 = 4096 points on 256 threads each) side by side, YZ tile 16 x 4 x 128 = 8192
+    // points on 512 threads (256-byte segments); half-form exchanges, 69.6 KiB of LDS, two work-groups = 16 waves per CU; every item
+    // moves 128 KiB in and 128 KiB out, like a tile of the 1-D kernel.  256 + 256 items per transform.  The stage lists are those of
+    // fft_pair_f64.hip, so the arithmetic is the plain pair launches'.  0.442 of the roofline at 4 GiB, 0.412 at 1 GiB (pipelined
+    // chunks: 0.357 / 0.338; first form with 64 KiB tiles and 128-byte segments: 0.386 / 0.373 -- profiles/r04_f_cube_wide_tiles.log)
+    using XY128d = PairXY<double, 128, 32, 4, 256, true, 1, RL(8, 16), RL(8, 4), false>;
+    using YZ128d = PairYZ<double, 128 * 32, 4, 128, 16, 512, true, 1, RL(4), RL(8, 16), false>;
+    CASE(double, 1, 128, 128, 128, 32, 4, 16, XY128d, YZ128d, 0)
+    CASE(double, 1, 128, 128, 128, 32, 4, 16, XY128d, YZ128d, 4)
+    CASE(double, 1, 128, 128, 128, 32, 4, 16, XY128d, YZ128d, 5)
+    using XY128dn = PairXY<double, 128, 32, 4, 256, false, 1, RL(8, 16), RL(8, 4), false>;
+    using YZ128dn = PairYZ<double, 128 * 32, 4, 128, 8, 256, false, 1, RL(4), RL(8, 16), false>;
+    CASE(double, 1, 128, 128, 128, 32, 4, 8, XY128dn, YZ128dn, 3)
+    // ---- 128^3 fp32: two XY tiles (4096 points, 32 KiB) side by side on 256 threads each, YZ tile 16 x 4 x 128 = 8192 points on 512
+    // threads (the configurations of fft_pair_f32.hip), full-complex exchanges, 69.6 KiB of LDS, two work-groups per CU: 0.366 at 4 GiB
+    // (pipelined chunks 0.358).  The fp32 cube is bound by its five LDS exchanges per point, not by bytes (11.5 us per 2^21 points
+    // against 9.4 us for the 1-D kernel with two exchanges): wider tiles do not help it -- 32-column YZ tiles at 32 points per thread
+    // (variant 4: 16 spilled registers) 0.354, 1024-thread work-groups with plane-sized items (variant 5) 0.341
+    // (profiles/r04_g_cube_fp32_forms.log)
     using XY128f = PairXY<float, 128, 32, 4, 256, false, 1, RL(8, 16), RL(16, 2), false>;
     using YZ128f = PairYZ<float, 128 * 32, 4, 128, 16, 512, false, 1, RL(4), RL(8, 16), false>;
-    CASE(float, 0, 128, 128, 128, 32, 4, 16, XY128f, YZ128f)
-    // 128^3 fp64: XY tile 4096 points, YZ tile 8 x 4 x 128 = 4096 points (64 KiB each) on 256 threads: 512 + 512 items
-    using XY128d = PairXY<double, 128, 32, 4, 256, false, 1, RL(8, 16), RL(8, 4), false>;
-    using YZ128d = PairYZ<double, 128 * 32, 4, 128, 8, 256, false, 1, RL(4), RL(8, 16), false>;
-    CASE(double, 1, 128, 128, 128, 32, 4, 8, XY128d, YZ128d)
+    CASE(float, 0, 128, 128, 128, 32, 4, 16, XY128f, YZ128f, 0)
+    CASE(float, 0, 128, 128, 128, 32, 4, 16, XY128f, YZ128f, 3)
+    using XY128fh = PairXY<float, 128, 32, 4, 256, true, 1, RL(8, 16), RL(16, 2), false>;
+    using YZ128fh = PairYZ<float, 128 * 32, 4, 128, 32, 512, true, 1, RL(4), RL(8, 16), false>;
+    CASE(float, 0, 128, 128, 128, 32, 4, 32, XY128fh, YZ128fh, 4)
+    using YZ128fw = PairYZ<float, 128 * 32, 4, 128, 32, 1024, false, 1, RL(4), RL(8, 16), false>;
+    CASE(float, 0, 128, 128, 128, 32, 4, 32, XY128f, YZ128fw, 5)
 #undef CASE
 #undef RL
     return -2;

@@ -64,6 +64,13 @@ __global__ void __launch_bounds__(C1::NT, C1::NT >= 512 ? 4 : 2) fft_fusedp_kern
 
 template <typename T, typename C0, typename C1, unsigned PER0, unsigned PER1>
 static inline int launch_fusedp(const FusedPairArgs* f, unsigned grid, hipStream_t s) {
+    // a 1024-thread work-group fills a CU: never more persistent work-groups than CUs
+    if (C1::NT >= 1024) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 &&
+            grid > (unsigned)cus)
+            grid = (unsigned)cus;
+    }
     hipLaunchKernelGGL((fft_fusedp_kernel<T, C0, C1, PER0, PER1>), dim3(grid), dim3(C1::NT), 0, s, *f);
     return (int)hipGetLastError();
 }

@@ -315,8 +315,11 @@ class FFTPlan(object):
                 and k[0].S == 1 and k[0].M == k[1].L and k[1].M == 1):
             return False
         if p.precision == N.F64:
-            # 1024 x 1024 on the 512-thread tiles; round 4: 2048 x 2048 / 2048 x 1024 on the stage-chain tiles (interleaved)
-            return (k[0].L == 1024 and k[1].L == 1024) or (k[0].L == 2048 and k[1].L in (1024, 2048) and not p.split)
+            # 1024 x 1024 on the 512-thread tiles; round 4: 2048 x 1024 on the stage-chain tiles (interleaved): 0.285 -> 0.330.  The same
+            # kernel runs 2048 x 2048 -- 64 MiB per transform, a ring of three -- BELOW the pipelined chunks (0.243 - 0.259 against
+            # 0.269, profiles/r04_e_fp64_long_fused.log): on request only
+            return (k[0].L == 1024 and k[1].L == 1024) or \
+                (k[0].L == 2048 and not p.split and (k[1].L == 1024 or (k[1].L == 2048 and D.forced_strategy() == "fused")))
         return (k[0].L in (256, 512, 1024) and k[1].L in (256, 512, 1024)) or (k[0].L == 2048 and k[1].L in (1024, 2048))
 
     def _fusedx_eligible(self):

@@ -328,13 +328,18 @@ def test_fused_long_fp64(ctx, monkeypatch, n, batch):
     data = numpy.concatenate([blk[i % 2] for i in range(batch)])
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
     want = _execute(ctx, (n,), numpy.complex128, batch, data, expect="chain")
-    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    auto = "auto" if n == 1 << 21 else "fused"        # (2^22: the kernel exists and is tested, the plan prefers the pipelined chunks)
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", auto)
     got = _execute(ctx, (n,), numpy.complex128, batch, data, expect="fused2")
     if n == 1 << 22:
         assert numpy.array_equal(want, got)
     else:
         assert oracle.difference(want, got, batch) < 1e-14
     assert numpy.array_equal(_execute(ctx, (n,), numpy.complex128, batch, data, inplace=True, expect="fused2"), got)
+    if n == 1 << 22:
+        monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+        assert ctx.getPlan((n,), dtype=numpy.complex128).strategy(64)[0] == "pipelined"
+        monkeypatch.setenv("PYFFT_AMD_STRATEGY", auto)
     for item in (0, 1, batch - 1):
         ref = numpy.fft.fft(blk[item % 2])
         g = got[item * n:(item + 1) * n]
@@ -343,4 +348,5 @@ def test_fused_long_fp64(ctx, monkeypatch, n, batch):
     back = _execute(ctx, (n,), numpy.complex128, batch, got, inverse=True, expect="fused2")
     assert oracle.difference(data, back, batch) < 1e-11
     # split planes have no such kernel: the pipelined chunks
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
     assert ctx.getPlan((n,), dtype=numpy.float64).strategy(batch)[0] in ("pipelined", "chain")
