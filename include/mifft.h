@@ -419,8 +419,8 @@ int mifft_launch_bluestein_rows(int32_t precision, int32_t n, int32_t m, int64_t
                                 double scale, mifft_stream_t stream);
 
 /* Whole SMOOTH 2-D / 3-D transforms in one launch (csrc/fft_mixed_nd.hip): every axis of the (z, y, x) shape a smooth length (or 1), at
- * least two axes longer than 1, x * y * z <= 10240 points (fp32) / 5120 (fp64) -- the transform, or several, lives in one work-group's
- * LDS between its first load and its last store.  `transforms` dense arrays one after the other, interleaved, in place or out of place;
+ * least two axes longer than 1, x * y * z <= 16384 points (fp32) / 8192 (fp64) -- the transform, or several, lives in one work-group's
+ * LDS (one buffer; a stage holds its operands in registers across a barrier) between its first load and its last store.  `transforms` dense arrays one after the other, interleaved, in place or out of place;
  * tw_x / tw_y / tw_z = device tables w(len)^m of the axis lengths (NULL for an axis of length 1).  out = scale * DFT3(in).
  *   mifft_mixed_nd_supported  0 if the shape has this form, else MIFFT_E_UNSUPPORTED */
 int mifft_mixed_nd_supported(int32_t precision, int32_t x, int32_t y, int32_t z);

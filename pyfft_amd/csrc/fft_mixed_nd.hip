@@ -10,14 +10,22 @@
 //     line base = o * n * inner + jin,  point i of the line at base + i * inner
 // so that consecutive lanes take consecutive butterflies of a row (inner == 1: the x axis) or adjacent lines (inner > 1):
 // both the HBM side of the first / last stage and the LDS side of every stage are walked with unit stride across the wave.
-// The first stage of all reads HBM (conjugated for the inverse), the last stage of all writes it (scaled, conjugated); the
-// stages in between ping-pong through two LDS buffers of W * P points, one barrier each.
+// The first stage of all reads HBM (conjugated for the inverse), the last stage of all writes it (scaled, conjugated).
+//
+// ONE LDS buffer: in a stage every thread first reads the operands of ALL its butterflies into registers (up to 32 fp32 / 16 fp64
+// points per thread: 32 / R butterflies of radix R), a barrier, then computes and writes the results to their autosort positions
+// in the same buffer, a barrier.  (First form of the round: two ping-pong buffers, one barrier per stage -- a (100, 100) tile then
+// fills the LDS of a CU, one work-group of 1024 threads per CU with nothing to overlap its load, stages and store: 0.303 of the
+// roofline, as slow as the two launches it replaced; profiles/r04_d_mixed_radix.log.)
 #include "fft_mixed.hpp"
 
 namespace {
 
-constexpr int kNdTilePoints32 = 10240, kNdTilePoints64 = 5120;    // two LDS buffers: 2 * 10240 * 8 B = 160 KiB
 constexpr int kNdMaxStages = 3 * 6;
+// points a thread holds across the barrier of a stage
+template <typename T> struct NdRegs { static constexpr int value = sizeof(T) == 4 ? 32 : 16; };
+// the largest tile: every point of it in the registers of 512 threads, and in LDS once
+constexpr int kNdTilePoints32 = 512 * 32, kNdTilePoints64 = 512 * 16;
 
 struct MixedNdArgs {
     const void* in;
@@ -37,37 +45,51 @@ template <int R, typename T, int NT, bool GIN, bool GOUT>
 __device__ __forceinline__ void nd_stage(const cplx<T>* src, cplx<T>* dst, const cplx<T>* tw, const int n, const int inner, const int Ns,
                                          const float inv_inner, const float inv_lr, const float inv_ns, const int total, const T csign,
                                          const T sx, const T sy) {
+    constexpr int B = NdRegs<T>::value / R > 0 ? NdRegs<T>::value / R : 1;     // butterflies per thread (the launcher sizes the tile for it)
     const int LR = n / R;
-    for (int j = threadIdx.x; j < total; j += NT) {
+    cplx<T> v[B][R];
+    int base[B], jbs[B];
+    static_for<B>([&](auto bb) {
+        constexpr int b = bb;
+        const int j = threadIdx.x + b * NT;
         int jin = 0, t = j;
         if (inner > 1) {
             t = fast_div(j, inv_inner);
             jin = j - t * inner;
         }
         const int o = fast_div(t, inv_lr), jb = t - o * LR;
-        const int jm = jb - fast_div(jb, inv_ns) * Ns;
-        const int base = o * n * inner + jin;
-        cplx<T> v[R];
-        static_for<R>([&](auto kk) { v[kk] = src[base + (jb + kk * LR) * inner]; });
-        if constexpr (GIN) static_for<R>([&](auto kk) { v[kk].y *= csign; });
-        if (Ns > 1) {
-            const int step = jm * (LR / Ns);
-            static_for<R - 1>([&](auto kk) {
-                constexpr int k = kk + 1;
-                v[k] = cmul<T>(v[k], tw[k * step]);
+        base[b] = o * n * inner + jin;
+        jbs[b] = jb;
+        if (j < total) static_for<R>([&](auto kk) { v[b][kk] = src[base[b] + (jb + kk * LR) * inner]; });
+    });
+    if constexpr (!GIN) __syncthreads();          // every operand of the stage is in registers: the buffer may be overwritten
+    static_for<B>([&](auto bb) {
+        constexpr int b = bb;
+        const int j = threadIdx.x + b * NT;
+        if (j < total) {
+            const int jb = jbs[b];
+            const int jm = jb - fast_div(jb, inv_ns) * Ns;
+            if constexpr (GIN) static_for<R>([&](auto kk) { v[b][kk].y *= csign; });
+            if (Ns > 1) {
+                const int step = jm * (LR / Ns);
+                static_for<R - 1>([&](auto kk) {
+                    constexpr int k = kk + 1;
+                    v[b][k] = cmul<T>(v[b][k], tw[k * step]);
+                });
+            }
+            dft_any<R, T>(v[b]);
+            const int q0 = (jb - jm) * R + jm;
+            static_for<R>([&](auto kk) {
+                cplx<T> p = v[b][kk];
+                if constexpr (GOUT) {
+                    p.x *= sx;
+                    p.y *= sy;
+                }
+                dst[base[b] + (q0 + kk * Ns) * inner] = p;
             });
         }
-        dft_any<R, T>(v);
-        const int q0 = (jb - jm) * R + jm;
-        static_for<R>([&](auto kk) {
-            cplx<T> p = v[kk];
-            if constexpr (GOUT) {
-                p.x *= sx;
-                p.y *= sy;
-            }
-            dst[base + (q0 + kk * Ns) * inner] = p;
-        });
-    }
+    });
+    if constexpr (!GOUT) __syncthreads();         // the next stage reads what this one wrote
 }
 
 template <typename T, int NT, bool GIN, bool GOUT, typename... Args>
@@ -89,38 +111,39 @@ __device__ __forceinline__ void nd_switch(int R, Args&&... args) {
     }
 }
 
+// (four waves per SIMD = 128 VGPRs: two work-groups of 512 threads, or four of 256, per CU; without the bound the kernels take 139)
 template <typename T, int NT>
-__global__ void __launch_bounds__(NT) fft_mixed_nd_kernel(const MixedNdArgs a) {
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) fft_mixed_nd_kernel(const MixedNdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cplx<T>* lds = reinterpret_cast<cplx<T>*>(smem);
     const long long t0 = (long long)blockIdx.x * a.W;
     const int nw = (int)((a.transforms - t0) < a.W ? (a.transforms - t0) : a.W);
-    const int points = nw * a.P, half = a.W * a.P;
+    const int points = nw * a.P;
     const cplx<T>* gin = reinterpret_cast<const cplx<T>*>(a.in) + t0 * a.P;
     cplx<T>* gout = reinterpret_cast<cplx<T>*>(a.out) + t0 * a.P;
     const T csign = a.conj_in ? (T)-1 : (T)1;
     const T sx = (T)a.scale, sy = a.conj_out ? -sx : sx;
-    int cur = 0;                       // the LDS buffer that holds the data after the stages so far (stage 0 fills buffer 0)
     for (int s = 0; s < a.nstages; ++s) {
         const int R = a.st_radix[s];
         const cplx<T>* tw = reinterpret_cast<const cplx<T>*>(a.tw[a.st_axis[s]]);
         const bool first = s == 0, last = s == a.nstages - 1;
-        const cplx<T>* src = first ? gin : lds + cur * half;
-        cplx<T>* dst = last ? gout : lds + (first ? 0 : (cur ^ 1)) * half;
+        const cplx<T>* src = first ? gin : lds;
+        cplx<T>* dst = last ? gout : lds;
         const int total = points / R;
         if (first && last) nd_switch<T, NT, true, true>(R, src, dst, tw, a.st_n[s], a.st_inner[s], a.st_ns[s], a.inv_inner[s], a.inv_lr[s], a.inv_ns[s], total, csign, sx, sy);
         else if (first) nd_switch<T, NT, true, false>(R, src, dst, tw, a.st_n[s], a.st_inner[s], a.st_ns[s], a.inv_inner[s], a.inv_lr[s], a.inv_ns[s], total, csign, sx, sy);
         else if (last) nd_switch<T, NT, false, true>(R, src, dst, tw, a.st_n[s], a.st_inner[s], a.st_ns[s], a.inv_inner[s], a.inv_lr[s], a.inv_ns[s], total, csign, sx, sy);
         else nd_switch<T, NT, false, false>(R, src, dst, tw, a.st_n[s], a.st_inner[s], a.st_ns[s], a.inv_inner[s], a.inv_lr[s], a.inv_ns[s], total, csign, sx, sy);
-        if (!last) __syncthreads();
-        if (!first) cur ^= 1;
     }
 }
 
-// stage list of a shape: the stages of x, then y, then z; 0 if an axis is not smooth or the list is too long
-int nd_stages(int nx, int ny, int nz, MixedNdArgs* a) {
+// stage list of a shape: the stages of x, then y, then z; 0 if an axis is not smooth or the list is too long.
+// *per_thread = the points one thread can hold in EVERY stage of the list: a stage of radix R keeps floor(regs / R) butterflies per
+// thread, so a tile on NT threads may have at most NT * min_R (floor(regs / R) * R) points (radix 10 in fp64: 10 of the 16).
+int nd_stages(int f64, int nx, int ny, int nz, MixedNdArgs* a, int* per_thread) {
     const int dims[3] = {nx, ny, nz};
-    int ns = 0, inner = 1;
+    const int regs = f64 ? NdRegs<double>::value : NdRegs<float>::value;
+    int ns = 0, inner = 1, hold = regs;
     for (int ax = 0; ax < 3; ++ax) {
         const int n = dims[ax];
         if (n > 1) {
@@ -139,12 +162,15 @@ int nd_stages(int nx, int ny, int nz, MixedNdArgs* a) {
                     a->inv_lr[ns] = 1.0f / (float)(n / radix[i]);
                     a->inv_ns[ns] = 1.0f / (float)nsx;
                 }
+                const int h = (regs / radix[i] > 0 ? regs / radix[i] : 1) * radix[i];
+                if (h < hold) hold = h;
                 nsx *= radix[i];
                 ++ns;
             }
         }
         inner *= n;
     }
+    if (per_thread) *per_thread = hold;
     return ns;
 }
 
@@ -171,26 +197,31 @@ extern "C" int mifft_mixed_nd_supported_impl(int f64, int nx, int ny, int nz) {
     if ((nx > 1) + (ny > 1) + (nz > 1) < 2) return -2;
     const long long P = (long long)nx * ny * nz;
     if (P > (f64 ? kNdTilePoints64 : kNdTilePoints32)) return -2;
-    return nd_stages(nx, ny, nz, nullptr) >= 2 ? 0 : -2;
+    int hold = 0;
+    if (nd_stages(f64, nx, ny, nz, nullptr, &hold) < 2) return -2;
+    return P <= 512ll * hold ? 0 : -2;          // the whole transform in the registers of 512 threads in every stage
 }
 
 // flags: bit 0 conjugate on load, bit 1 conjugate on store (inverse transform = 3)
 extern "C" int mifft_mixed_nd_launch(int f64, int nx, int ny, int nz, long long transforms, const void* in, void* out, const void* twx,
                                      const void* twy, const void* twz, int flags, double scale, hipStream_t s) {
     MixedNdArgs a;
-    a.nstages = nd_stages(nx, ny, nz, &a);
-    if (a.nstages < 2) return -2;
+    int hold = 0;
+    a.nstages = nd_stages(f64, nx, ny, nz, &a, &hold);
+    if (a.nstages < 2 || (long long)nx * ny * nz > 512ll * hold) return -2;
     a.in = in; a.out = out;
     a.tw[0] = twx; a.tw[1] = twy; a.tw[2] = twz;
     a.transforms = transforms;
     a.P = nx * ny * nz;
     a.conj_in = flags & 1; a.conj_out = (flags >> 1) & 1;
     a.scale = scale;
-    // tiles of a quarter of the capacity when a transform fits (as the row kernel: more work-groups per CU beat fuller tiles), W whole transforms
+    // W whole transforms per tile: small tiles (<= 4096 fp32 / 2048 fp64 points, 32 KiB of LDS, 256 threads: four to five work-groups
+    // per CU, as the row kernel) when a transform fits one, else tiles of up to 512 threads x the register budget
     const int full = f64 ? kNdTilePoints64 : kNdTilePoints32;
-    int cap = full;
-    if (a.P <= full / 4) cap = full / 4;
-    else if (a.P <= full / 2) cap = full / 2;
+    const int small = full / 4 < 256 * hold ? full / 4 : 256 * hold;          // (both bounded by what the threads can hold in every stage)
+    const bool big = a.P > small;
+    int cap = big ? (a.P <= full / 2 ? full / 2 : full) : small;
+    if (big && cap > 512 * hold) cap = 512 * hold;
     int W = cap / a.P;
     if (W < 1) W = 1;
     if (W > transforms) W = (int)transforms;
@@ -198,8 +229,7 @@ extern "C" int mifft_mixed_nd_launch(int f64, int nx, int ny, int nz, long long 
     const long long blocks = (transforms + W - 1) / W;
     if (blocks <= 0) return 0;
     if (blocks > 2147483647ll) return -1;
-    const size_t lds_bytes = 2 * (size_t)W * a.P * (f64 ? 16 : 8);
-    const bool big = (long long)W * a.P > full / 4;     // more than 40 KiB of points: 1024 threads walk the stages
-    if (f64) return big ? launch_nd_kernel<double, 1024>(a, (unsigned)blocks, lds_bytes, s) : launch_nd_kernel<double, 256>(a, (unsigned)blocks, lds_bytes, s);
-    return big ? launch_nd_kernel<float, 1024>(a, (unsigned)blocks, lds_bytes, s) : launch_nd_kernel<float, 256>(a, (unsigned)blocks, lds_bytes, s);
+    const size_t lds_bytes = (size_t)W * a.P * (f64 ? 16 : 8);
+    if (f64) return big ? launch_nd_kernel<double, 512>(a, (unsigned)blocks, lds_bytes, s) : launch_nd_kernel<double, 256>(a, (unsigned)blocks, lds_bytes, s);
+    return big ? launch_nd_kernel<float, 512>(a, (unsigned)blocks, lds_bytes, s) : launch_nd_kernel<float, 256>(a, (unsigned)blocks, lds_bytes, s);
 }

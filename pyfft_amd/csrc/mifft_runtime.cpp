@@ -157,6 +157,14 @@ int wave_max_blocks() {
     return blocks;
 }
 
+// The statically dealt sequential work list (lag == 0) is deadlock-free only while every work-group of the launch is resident:
+// the grid is capped at `per_cu` work-groups per compute unit (what the kernel's registers and LDS allow), whatever the caller asked for
+int resident_grid(int grid, int per_cu) {
+    const int cus = wave_max_blocks() / 8;
+    const int cap = per_cu * (cus > 0 ? cus : 1);
+    return grid > cap ? cap : grid;
+}
+
 long long wave_bytes(const mifft_pass* p, const mifft::TileArgs* a) {   // bytes of one side of a dense ROW pass
     return a->total * p->L * (p->precision == MIFFT_F64 ? 16ll : 8ll);
 }
@@ -722,6 +730,10 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
         return set_err(MIFFT_E_UNSUPPORTED, "fused2: no kernel for %d x %d", p0->L, p1->L);
     rc = fill_ctl(&f.c, sync, p1->outer, lag, ring_slots, tiles0, tiles1, (hipStream_t)stream, "fused2");
     if (rc) return rc;
+    if (lag == 0) {
+        const bool wide = f64 || p0->L == 2048 || p1->L == 2048;       // 512- / 1024-thread tiles: one work-group per CU
+        grid = resident_grid(grid, wide ? 1 : 2);
+    }
     rc = wide64 ? mifft_fusedx_f64(p0->L, p1->L, &f, (unsigned)grid, (hipStream_t)stream, 0, nullptr, nullptr) : twod ? (f64 ? mifft_fused3d_f64_launch(p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)
                      : mifft_fused2d_f32_launch(p1->L, p0->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream))
        : f64 ? mifft_fused3_f64_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)
@@ -812,6 +824,7 @@ int mifft_launch_fused_pair(const mifft_pass* passes, const void* in0, void* out
     f.a1.scale = py1->scale * pz->scale;
     int rc = fill_ctl(&f.c, sync, batch, lag, ring_slots, tiles0, tiles1, (hipStream_t)stream, "fused pair");
     if (rc) return rc;
+    if (lag == 0) grid = resident_grid(grid, 2);
     rc = mifft_fusedp(f64, nx, ny, nz, &f, (unsigned)grid, (hipStream_t)stream, 0, nullptr, nullptr, nullptr);
     if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
     return 0;

@@ -440,7 +440,7 @@ def test_round3_entry_points_reject_bad_arguments_without_touching_the_gpu():
     assert N.lib.mifft_bluestein_padded(N.F64, 2501, ctypes.byref(m)) == N.E_UNSUPPORTED
     # smooth N-D shapes in one launch: every axis smooth, at least two axes, the transform inside one tile
     assert [N.lib.mifft_mixed_nd_supported(N.F32, *xyz) == 0 for xyz in ((100, 100, 1), (60, 60, 1), (30, 20, 10), (100, 101, 1), (1000, 1, 1),
-                                                                            (128, 100, 1), (60, 60, 60))] == [True, True, True, False, False, False, False]
+                                                                            (128, 100, 1), (160, 128, 1), (60, 60, 60))] == [True, True, True, False, False, True, False, False]
     assert N.lib.mifft_mixed_nd_supported(N.F64, 100, 100, 1) == N.E_UNSUPPORTED and N.lib.mifft_mixed_nd_supported(N.F64, 70, 70, 1) == 0
     assert N.lib.mifft_launch_mixed_nd(N.F32, 100, 100, 1, 4, 16, 16, None, 16, None, 0, 1.0, None) == N.E_INVALID        # x table missing
     assert N.lib.mifft_launch_mixed_nd(N.F32, 100, 101, 1, 4, 16, 16, 16, 16, None, 0, 1.0, None) == N.E_UNSUPPORTED

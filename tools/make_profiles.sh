@@ -1,11 +1,11 @@
 #!/bin/bash
 # Regenerates the round's evidence under profiles/ ON THE GPU BOX (run through gpurun from the repo root):
-#     gpurun --timeout 3000 -- 'bash tools/make_profiles.sh r03'
+#     gpurun --timeout 3000 -- 'bash tools/make_profiles.sh r04'
 # Everything is written to gpurun_out/<tag>/ (scratch, merged back by gpurun); the summaries that are judged are gathered in
 # gpurun_out/<tag>/to_profiles/ under their final names -- back in the build container:
-#     cp gpurun_out/r03/to_profiles/* profiles/  rocprofv3 gets the program directly after `--` (no env/bash hop), counters in their own runs.
+#     cp gpurun_out/r04/to_profiles/* profiles/  rocprofv3 gets the program directly after `--` (no env/bash hop), counters in their own runs.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT/to_profiles profiles
 P=$OUT/to_profiles
@@ -13,16 +13,16 @@ cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 
 # 1. kernel stats + PMC traffic of the same command, per configuration (writes profiles/traffic_<c>.json and
 #    profiles/<tag>_<c>_kernel_stats.csv)
-timeout 2400 python3 tools/pmc_traffic.py --tag $TAG c2 c3 c4 c4s c5 > $OUT/pmc_traffic.log 2>&1
+timeout 2400 python3 tools/pmc_traffic.py --tag $TAG c2 c3 c4 c4s c5 cube cubed > $OUT/pmc_traffic.log 2>&1
 cp $OUT/pmc_traffic.log $P/${TAG}_pmc_traffic.log
 cp profiles/traffic_*.json profiles/${TAG}_*_kernel_stats.csv $P/ 2>/dev/null
 
 # 2. the bench lines (after the traffic files exist, so that every line carries roofline.traffic): default line (c2) and every other BASELINE configuration
 timeout 600 python3 bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
-for c in c1 c3 c4 c4s c5; do
+for c in c1 c3 c4 c4s c5 cube cubed; do
     timeout 600 python3 bench.py --config $c --steps 10 --warmup 2 > $OUT/bench_$c.json 2> $OUT/bench_$c.err
 done
-for c in c1 c2 c3 c4 c4s c5; do cp $OUT/bench_$c.json $P/${TAG}_bench_$c.json; done
+for c in c1 c2 c3 c4 c4s c5 cube cubed; do cp $OUT/bench_$c.json $P/${TAG}_bench_$c.json; done
 
 # 3. the reference's published shapes (test/test_performance.py method), the vendor yardstick (cuda/test.cu counterpart) and its
 #    value cross-check
@@ -36,7 +36,12 @@ timeout 600 python3 tools/hipfft_check.py > $OUT/hipfft_check.log 2>&1; cp $OUT/
 # 5. the long 1-D sizes in both precisions, the small-batch rows of the reference's 32 MiB protocol
 timeout 900 python3 tools/quick_bench.py 1d > $OUT/long_1d.log 2>&1
 timeout 900 python3 tools/quick_bench.py f64 >> $OUT/long_1d.log 2>&1
+echo "# the two-pass fp32 sizes at 1 GiB and at 8 GiB per side" >> $OUT/long_1d.log
+timeout 900 python3 tools/quick_bench.py 1d1g >> $OUT/long_1d.log 2>&1
+timeout 900 python3 tools/quick_bench.py 1d8g >> $OUT/long_1d.log 2>&1
 cp $OUT/long_1d.log $P/${TAG}_long_1d_sizes.log
+timeout 900 python3 tools/quick_bench.py r4 > $OUT/r4_shapes.log 2>&1; cp $OUT/r4_shapes.log $P/${TAG}_cubes_rectangles_fp64.log
+timeout 600 python3 tools/mixed_probe.py > $OUT/mixed.log 2>&1; cp $OUT/mixed.log $P/${TAG}_mixed_radix.log
 timeout 300 python3 tools/small_batch_probe.py sp > $OUT/small_batch.log 2>&1
 timeout 300 python3 tools/small_batch_probe.py dp >> $OUT/small_batch.log 2>&1
 cp $OUT/small_batch.log $P/${TAG}_small_batch_32MiB.log

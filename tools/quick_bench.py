@@ -34,6 +34,10 @@ def run(shape, dtype, batch, iters=5, inplace=False):
             done += n
         N.check(N.lib.mifft_device_sync())
     plan.timed_execute(1, inplace, False, batch, bufs_in, bufs_out)  # warm-up
+    # blocks of at least ~20 ms of back-to-back executes: a burst of a few milliseconds behind a synchronisation measures the
+    # clock ramp, not the kernel (round 4: 2^20 x 128 0.37 in blocks of 5, 0.41 in blocks of 10 x 5 on the same kind of box)
+    est = plan.timed_execute(iters, inplace, False, batch, bufs_in, bufs_out) / iters
+    iters = int(min(200, max(iters, 20.0 / max(est, 1e-3))))
     best = 1e30
     for _ in range(3):
         ms = plan.timed_execute(iters, inplace, False, batch, bufs_in, bufs_out) / iters
@@ -81,6 +85,15 @@ if __name__ == "__main__":
                  ((4096,), c128, 1 << 14), ((16,), c64, 1 << 23), ((16, 16, 16), c64, 1 << 15), ((128, 128), c64, 1 << 13),
                  ((128, 128), c128, 1 << 12), ((1 << 20,), c64, 512), ((1024, 1024), c64, 256), ((256, 256, 256), c128, 16),
                  ((1 << 22,), c64, 128), ((1 << 16,), c64, 8192)]
+    elif len(sys.argv) > 1 and sys.argv[1] in ("1d1g", "1d8g"):      # the two-pass fp32 sizes at 1 GiB / 8 GiB per side (round 4)
+        gib = 1 if sys.argv[1] == "1d1g" else 8
+        cases = [((1 << k,), c64, (gib << 27) >> k) for k in (16, 17, 18, 19, 20, 21, 22)]
+    elif len(sys.argv) > 1 and sys.argv[1] == "r4":                  # round-4 shapes: cubes, rectangles, fp64 2^21 at 1 GiB and 4 GiB
+        cases = []
+        for gib in (1, 4):
+            cases += [((128, 128, 128), c64, gib * 64), ((128, 128, 128), c128, gib * 32), ((512, 1024), c64, gib * 256), ((1024, 512), c64, gib * 256),
+                      ((1024, 2048), c64, gib * 64), ((2048, 1024), c64, gib * 64), ((2048, 512), c64, gib * 128), ((512, 2048), c64, gib * 128),
+                      ((1 << 21,), c128, gib * 32), ((1 << 22,), c128, gib * 16), ((1 << 20,), c128, gib * 64)]
     elif len(sys.argv) > 1 and sys.argv[1] == "1d":
         cases = [((1 << k,), c64, max(64, (1 << 31) >> (k + 3))) for k in (13, 14, 15, 16, 17, 18, 19, 20, 21, 22)]
     else:
