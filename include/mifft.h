@@ -157,9 +157,10 @@ const char *mifft_last_error(void);
 #define MIFFT_DEBUG_FORCE_WAVE 3   /* wave-autonomous kernels wherever one exists, whatever the buffer size */
 #define MIFFT_DEBUG_PERSIST 4      /* persistent (prefetching) form of the long fp32 rows (measured: no gain) */
 #define MIFFT_DEBUG_ALT_ROWS 5     /* alternative stage lists of the longest fp32 rows (A/B measurements) */
-#define MIFFT_DEBUG_PAIR 6         /* pass pairs: 0 = default split, 1 = off, 2 = the alternative y split, 3 / 4 / 5 = other tile forms of the persistent two-pair kernel (A/B measurements) */
+#define MIFFT_DEBUG_PAIR 6         /* pass pairs: 0 = default split, 1 = off, 2 = the alternative y split, 3 = the first tile forms of the persistent two-pair kernel (A/B measurements) */
 #define MIFFT_DEBUG_STORE 7        /* streamed output stores (A/B): 0 = default, 1 = non-temporal, 2 = write-through (sc1), 3 = plain */
-#define MIFFT_DEBUG_KEYS 8
+#define MIFFT_DEBUG_ROWS_ND 8      /* dense smooth rows: 0 = default, 1 = two-buffer row kernel only, 2 = single-buffer tile kernel wherever it fits (A/B) */
+#define MIFFT_DEBUG_KEYS 9
 int mifft_debug_set(int32_t key, int32_t value);
 int mifft_debug_get(int32_t key);
 
@@ -421,7 +422,9 @@ int mifft_launch_bluestein_rows(int32_t precision, int32_t n, int32_t m, int64_t
 /* Whole SMOOTH 2-D / 3-D transforms in one launch (csrc/fft_mixed_nd.hip): every axis of the (z, y, x) shape a smooth length (or 1), at
  * least two axes longer than 1, x * y * z <= 16384 points (fp32) / 8192 (fp64) -- the transform, or several, lives in one work-group's
  * LDS (one buffer; a stage holds its operands in registers across a barrier) between its first load and its last store.  `transforms` dense arrays one after the other, interleaved, in place or out of place;
- * tw_x / tw_y / tw_z = device tables w(len)^m of the axis lengths (NULL for an axis of length 1).  out = scale * DFT3(in).
+ * tw_x / tw_y / tw_z = device tables w(len)^m of the axis lengths (NULL for an axis of length 1).  out = scale * DFT3(in);
+ * inverse: 0 forward, 1 inverse (input and output conjugated), 2 / 4 conjugate the input / the output only (the first / last launch
+ * of a composition, e.g. the (y, x) planes of a bigger 3-D shape followed by mifft_launch_mixed_lines along z).
  *   mifft_mixed_nd_supported  0 if the shape has this form, else MIFFT_E_UNSUPPORTED */
 int mifft_mixed_nd_supported(int32_t precision, int32_t x, int32_t y, int32_t z);
 int mifft_launch_mixed_nd(int32_t precision, int32_t x, int32_t y, int32_t z, int64_t transforms, const void *in, void *out,

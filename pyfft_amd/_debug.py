@@ -103,5 +103,7 @@ def apply_native_switches(native):
             native.lib.mifft_debug_set(key, 1)
     if os.environ.get("MIFFT_STORE"):       # streamed output stores: 1 = non-temporal, 2 = write-through, 3 = plain
         native.lib.mifft_debug_set(native.DEBUG_STORE, int(os.environ["MIFFT_STORE"]))
+    if os.environ.get("MIFFT_ROWS_ND"):     # dense smooth rows: 1 = two-buffer row kernel only, 2 = single-buffer tile kernel wherever it fits
+        native.lib.mifft_debug_set(native.DEBUG_ROWS_ND, int(os.environ["MIFFT_ROWS_ND"]))
     if os.environ.get("MIFFT_PAIR"):        # pass pairs: 1 = off, 2 = the alternative y split
         native.lib.mifft_debug_set(native.DEBUG_PAIR, int(os.environ["MIFFT_PAIR"]))

@@ -83,12 +83,24 @@ __device__ __forceinline__ void colx_tile(const TileArgs& a, const long long o_i
             // TR: out[(rem0 + c) * L + q]; plain: out[((l0 * L + q) << logS) + jp0 + c]
             const unsigned voff = (TR ? (c * (unsigned)L + q0) : ((q0 << logS) + c)) * (unsigned)sizeof(cplx<T>);
             const unsigned l = TR ? (unsigned)rem0 + c : (unsigned)l0;
+            // inter-pass twiddle w(L * M)^(l * q), q = q0 + k * Ns (round 4, as fft_pair.hpp): every fourth factor from the two-level
+            // table, the three behind it one multiplication each by the step w^(l * Ns) (rounds 2-3: every factor looked up)
+            cplx<T> wstep = {(T)1, (T)0}, wcur = {(T)1, (T)0};
+            if constexpr (TW && St::R > 1) {
+                const unsigned es = l * (unsigned)St::Ns;
+                wstep = cmul<T>(twlo[es & lomask], twhi[es >> tw_shift]);
+            }
             static_for<St::R>([&](auto kk) {
                 constexpr int k = kk;
                 cplx<T> p = vv[b * St::R + k];
                 if constexpr (TW) {
-                    const unsigned e = l * (q0 + (unsigned)(k * St::Ns));
-                    p = cmul<T>(p, cmul<T>(twlo[e & lomask], twhi[e >> tw_shift]));
+                    if constexpr (k % 4 == 0) {
+                        const unsigned e = l * (q0 + (unsigned)(k * St::Ns));
+                        wcur = cmul<T>(twlo[e & lomask], twhi[e >> tw_shift]);
+                    } else {
+                        wcur = cmul<T>(wcur, wstep);
+                    }
+                    p = cmul<T>(p, wcur);
                 }
                 p.x *= sx;
                 p.y *= sy;

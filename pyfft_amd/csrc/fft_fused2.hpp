@@ -315,12 +315,12 @@ __device__ __forceinline__ void fused_loop(const FusedCtl& f, unsigned* s_item, 
 // loads and write-through (sc1) stores of the output (A/B; non-temporal loads of the RING in pass 1 measured 0.6 % slower on C2)
 template <typename T, int A0, int A1, bool SPLIT, int NT>
 __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
-    constexpr int E0 = Col2Lds<A0, true>::ELEMS, E1 = Col2Lds<A1, false>::ELEMS;
+    constexpr int E0 = Col2Lds<A0, true, sizeof(cplx<T>)>::ELEMS, E1 = Col2Lds<A1, false, sizeof(cplx<T>)>::ELEMS;
     __shared__ __attribute__((aligned(16))) cplx<T> lds[E0 > E1 ? E0 : E1];
     __shared__ unsigned s_item;
     constexpr unsigned per0 = A0 > A1 ? 1u : (unsigned)(A1 / A0);   // tiles0 : tiles1 = L1 : L0 = A1 : A0
     constexpr unsigned per1 = A1 > A0 ? 1u : (unsigned)(A0 / A1);
-    fused_loop<per0, per1, !SPLIT>(   // early poll: C2 19.49 -> 19.32 ms; split planes 26.7 -> 25.6 ms WITHOUT it
+    fused_loop<per0, per1, !SPLIT && sizeof(T) == 4>(   // early poll: C2 19.49 -> 19.32 ms; split planes 26.7 -> 25.6 ms WITHOUT it; fp64: no register to spare
         f.c, &s_item,
         [&](unsigned t, unsigned slot, unsigned tile, auto hook) {
             col2_tile<T, A0, true, true, SPLIT, true, NT != 0, false, false>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
 // 0-2 points more and was placement-dependent: removed.)
 template <typename T, int A0, int A1>
 __global__ void __launch_bounds__(256, 2) fft_fused2x_kernel(const FusedArgs f) {
-    constexpr int E0 = Col2Lds<A0, true>::ELEMS, E1 = Col2Lds<A1, false>::ELEMS;
+    constexpr int E0 = Col2Lds<A0, true, sizeof(cplx<T>)>::ELEMS, E1 = Col2Lds<A1, false, sizeof(cplx<T>)>::ELEMS;
     __shared__ __attribute__((aligned(16))) cplx<T> lds[E0 > E1 ? E0 : E1];
     __shared__ unsigned s_item;
     constexpr unsigned per0 = A0 > A1 ? 1u : (unsigned)(A1 / A0);
@@ -357,12 +357,12 @@ __global__ void __launch_bounds__(256, 2) fft_fused2x_kernel(const FusedArgs f) 
 // ny / 16 tiles); the two passes look their w(L) up in different tables (TileArgs.tw_L of p0 / p1).
 template <typename T, int A0, int A1, bool SPLIT, bool NT>
 __global__ void __launch_bounds__(256, 2) fft_fused2d_kernel(const FusedArgs f) {
-    constexpr int E0 = Col2Lds<A0, true>::ELEMS, E1 = Col2Lds<A1, true>::ELEMS;
+    constexpr int E0 = Col2Lds<A0, true, sizeof(cplx<T>)>::ELEMS, E1 = Col2Lds<A1, true, sizeof(cplx<T>)>::ELEMS;
     __shared__ __attribute__((aligned(16))) cplx<T> lds[E0 > E1 ? E0 : E1];
     __shared__ unsigned s_item;
     constexpr unsigned per0 = A0 > A1 ? 1u : (unsigned)(A1 / A0);   // tiles0 : tiles1 = nx : ny = A1 : A0
     constexpr unsigned per1 = A1 > A0 ? 1u : (unsigned)(A0 / A1);
-    fused_loop<per0, per1, !SPLIT>(
+    fused_loop<per0, per1, !SPLIT && sizeof(T) == 4>(
         f.c, &s_item,
         [&](unsigned t, unsigned slot, unsigned tile, auto hook) {
             col2_tile<T, A0, true, false, SPLIT, true, NT, false, false>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);

@@ -9,10 +9,8 @@ using namespace mifft;
 extern "C" int mifft_fusedp(int f64, int x, int y, int z, const FusedPairArgs* f, unsigned grid, hipStream_t s, int query, int* r0,
                             unsigned* tiles0, unsigned* tiles1) {
 #define RL(...) RadixList<__VA_ARGS__>
-    // development switch (A/B, MIFFT_PAIR): 3 = the narrow fp64 tiles of the first form of this kernel; 4 / 5 = the two wider forms of the
-    // fp32 cube that measured below the narrow one
-    const int sw = mifft_debug_get(MIFFT_DEBUG_PAIR);
-    const int variant = sw >= 3 ? sw : 0;
+    // development switch (A/B, MIFFT_PAIR): 3 = the first form of this kernel (narrow fp64 tiles, the (16, 2) y list in fp32)
+    const int variant = mifft_debug_get(MIFFT_DEBUG_PAIR) == 3 ? 3 : 0;
 #define CASE(T, F64, NX, NY, NZ, R0, R1, W, XY, YZ, VARIANT)                                      \
     if (f64 == F64 && x == NX && y == NY && z == NZ && variant == VARIANT) {                     \
         constexpr unsigned t0 = (unsigned)NZ * R1 / (YZ::NT / XY::NT), t1 = (unsigned)NX * R0 / W; \
@@ -31,26 +29,24 @@ extern "C" int mifft_fusedp(int f64, int x, int y, int z, const FusedPairArgs* f
     using XY128d = PairXY<double, 128, 32, 4, 256, true, 1, RL(8, 16), RL(8, 4), false>;
     using YZ128d = PairYZ<double, 128 * 32, 4, 128, 16, 512, true, 1, RL(4), RL(8, 16), false>;
     CASE(double, 1, 128, 128, 128, 32, 4, 16, XY128d, YZ128d, 0)
-    CASE(double, 1, 128, 128, 128, 32, 4, 16, XY128d, YZ128d, 4)
-    CASE(double, 1, 128, 128, 128, 32, 4, 16, XY128d, YZ128d, 5)
     using XY128dn = PairXY<double, 128, 32, 4, 256, false, 1, RL(8, 16), RL(8, 4), false>;
     using YZ128dn = PairYZ<double, 128 * 32, 4, 128, 8, 256, false, 1, RL(4), RL(8, 16), false>;
     CASE(double, 1, 128, 128, 128, 32, 4, 8, XY128dn, YZ128dn, 3)
-    // ---- 128^3 fp32: two XY tiles (4096 points, 32 KiB) side by side on 256 threads each, YZ tile 16 x 4 x 128 = 8192 points on 512
-    // threads (the configurations of fft_pair_f32.hip), full-complex exchanges, 69.6 KiB of LDS, two work-groups per CU: 0.366 at 4 GiB
-    // (pipelined chunks 0.358).  The fp32 cube is bound by its five LDS exchanges per point, not by bytes (11.5 us per 2^21 points
-    // against 9.4 us for the 1-D kernel with two exchanges): wider tiles do not help it -- 32-column YZ tiles at 32 points per thread
-    // (variant 4: 16 spilled registers) 0.354, 1024-thread work-groups with plane-sized items (variant 5) 0.341
-    // (profiles/r04_g_cube_fp32_forms.log)
-    using XY128f = PairXY<float, 128, 32, 4, 256, false, 1, RL(8, 16), RL(16, 2), false>;
-    using YZ128f = PairYZ<float, 128 * 32, 4, 128, 16, 512, false, 1, RL(4), RL(8, 16), false>;
+    // ---- 128^3 fp32: the XY tile (128 x 32 = 4096 points) on 128 threads x 32 points with the y digit as ONE radix-32 stage -- four LDS
+    // exchanges per point instead of the five of the (16, 2) list -- and FOUR of them side by side: a pass-0 item is a whole 128 KiB
+    // plane; YZ tile 16 x 4 x 128 = 8192 points on 512 threads; half-form exchanges, 69.6 KiB of LDS, two work-groups per CU.
+    // 0.357 (pipelined chunks) -> 0.423 at 4 GiB (profiles/r04_l_anchored_twiddles_fp64_mid.log).  The fp32 cube is bound by work per
+    // POINT, not by bytes (11.5 us per 2^21 points against 9.4 us for the 1-D kernel with two exchanges), so what moved it was
+    // fewer exchanges (this list: + 3 points) and cheaper inter-pass twiddles (fft_pair.hpp pair_store: + 3 points); WIDER tiles did
+    // not: 32-column YZ tiles at 32 points per thread 0.354 (16 spilled registers), 1024-thread work-groups 0.341 against 0.366 for
+    // the list's first form (profiles/r04_g_cube_fp32_forms.log; those two instances are no longer built).
+    using XY128f = PairXY<float, 128, 32, 4, 128, true, 1, RL(8, 16), RL(32), false>;
+    using YZ128f = PairYZ<float, 128 * 32, 4, 128, 16, 512, true, 1, RL(4), RL(8, 16), false>;
     CASE(float, 0, 128, 128, 128, 32, 4, 16, XY128f, YZ128f, 0)
-    CASE(float, 0, 128, 128, 128, 32, 4, 16, XY128f, YZ128f, 3)
-    using XY128fh = PairXY<float, 128, 32, 4, 256, true, 1, RL(8, 16), RL(16, 2), false>;
-    using YZ128fh = PairYZ<float, 128 * 32, 4, 128, 32, 512, true, 1, RL(4), RL(8, 16), false>;
-    CASE(float, 0, 128, 128, 128, 32, 4, 32, XY128fh, YZ128fh, 4)
-    using YZ128fw = PairYZ<float, 128 * 32, 4, 128, 32, 1024, false, 1, RL(4), RL(8, 16), false>;
-    CASE(float, 0, 128, 128, 128, 32, 4, 32, XY128f, YZ128fw, 5)
+    // (MIFFT_PAIR=3: the first form -- two 256-thread XY tiles with the (16, 2) list per item, full-complex exchanges)
+    using XY128fn = PairXY<float, 128, 32, 4, 256, false, 1, RL(8, 16), RL(16, 2), false>;
+    using YZ128fn = PairYZ<float, 128 * 32, 4, 128, 16, 512, false, 1, RL(4), RL(8, 16), false>;
+    CASE(float, 0, 128, 128, 128, 32, 4, 16, XY128fn, YZ128fn, 3)
 #undef CASE
 #undef RL
     return -2;

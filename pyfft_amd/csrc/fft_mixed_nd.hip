@@ -202,13 +202,21 @@ extern "C" int mifft_mixed_nd_supported_impl(int f64, int nx, int ny, int nz) {
     return P <= 512ll * hold ? 0 : -2;          // the whole transform in the registers of 512 threads in every stage
 }
 
+// 0 if dense ROWS of n points (a 1-D smooth length) fit the tile of this kernel: the same stage loop with one axis
+extern "C" int mifft_mixed_nd_rows_ok_impl(int f64, int n) {
+    if (n < 2 || n > (f64 ? kNdTilePoints64 : kNdTilePoints32)) return -2;
+    int hold = 0;
+    if (nd_stages(f64, n, 1, 1, nullptr, &hold) < 1) return -2;
+    return n <= 512 * hold ? 0 : -2;
+}
+
 // flags: bit 0 conjugate on load, bit 1 conjugate on store (inverse transform = 3)
 extern "C" int mifft_mixed_nd_launch(int f64, int nx, int ny, int nz, long long transforms, const void* in, void* out, const void* twx,
                                      const void* twy, const void* twz, int flags, double scale, hipStream_t s) {
     MixedNdArgs a;
     int hold = 0;
     a.nstages = nd_stages(f64, nx, ny, nz, &a, &hold);
-    if (a.nstages < 2 || (long long)nx * ny * nz > 512ll * hold) return -2;
+    if (a.nstages < 1 || (long long)nx * ny * nz > 512ll * hold) return -2;
     a.in = in; a.out = out;
     a.tw[0] = twx; a.tw[1] = twy; a.tw[2] = twz;
     a.transforms = transforms;

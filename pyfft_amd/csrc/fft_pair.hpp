@@ -90,6 +90,15 @@ __device__ __forceinline__ void pair_store(char* outb, char* outb1, const cplx<T
     constexpr long long G = MAP::GO[St::AX];
     constexpr unsigned ESZ = SPLIT ? sizeof(T) : sizeof(cplx<T>);
     static_assert(!TWOUT || St::AX == 1, "the twiddled store belongs to the last stage of tile dimension 1");
+    // Inter-pass twiddle w(ny)^(l * q) of the R results q = q0 + k * Ns of a butterfly (round 4): every FOURTH factor is looked up in
+    // the two-level table, the three behind it are one multiplication each by the step w(ny)^(l * Ns) -- which is the same for the
+    // whole tile (depth <= 3, as the strided kernels of fft_col2.hpp: fp32 error ~2.5e-7 max).  Rounds 2-3 looked every factor up:
+    // two table loads and two complex multiplications per element, 32 cached loads per thread in the XY tile of 128^3.
+    const cplx<T>* lo = reinterpret_cast<const cplx<T>*>(a.tw_lo);
+    const cplx<T>* hi = reinterpret_cast<const cplx<T>*>(a.tw_hi);
+    auto look = [&](unsigned e) { return cmul<T>(lo[e & ((1u << a.tw_shift) - 1u)], hi[e >> a.tw_shift]); };
+    cplx<T> wstep = {(T)1, (T)0};
+    if constexpr (TWOUT && St::R > 1) wstep = look((unsigned)(lrow * St::Ns));
     static_for<St::NB>([&](auto bb) {
         constexpr int b = bb;
         int base, jb;
@@ -97,14 +106,14 @@ __device__ __forceinline__ void pair_store(char* outb, char* outb1, const cplx<T
         const int e0 = base + St::idxd(jb) * St::SA;
         const unsigned voff = MAP::out_off(e0) * ESZ;
         const int q0 = (e0 / MAP::E0) % MAP::E1;
+        cplx<T> wcur = {(T)1, (T)0};
         static_for<St::R>([&](auto kk) {
             constexpr int k = kk;
             cplx<T> p = v[b * St::R + k];
             if constexpr (TWOUT) {
-                const unsigned e = (unsigned)(lrow * (q0 + k * St::Ns));
-                const cplx<T>* lo = reinterpret_cast<const cplx<T>*>(a.tw_lo);
-                const cplx<T>* hi = reinterpret_cast<const cplx<T>*>(a.tw_hi);
-                p = cmul<T>(p, cmul<T>(lo[e & ((1u << a.tw_shift) - 1u)], hi[e >> a.tw_shift]));
+                if constexpr (k % 4 == 0) wcur = look((unsigned)(lrow * (q0 + k * St::Ns)));
+                else wcur = cmul<T>(wcur, wstep);
+                p = cmul<T>(p, wcur);
             }
             p.x *= sx;
             p.y *= sy;

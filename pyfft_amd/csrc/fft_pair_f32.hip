@@ -17,9 +17,11 @@ extern "C" int mifft_pair_f32(int kind, int k0, int k1, int k2, int split, const
 #define RL(...) RadixList<__VA_ARGS__>
     XY(256, 64, 4, 512, true, 4, RL(16, 16), RL(16, 4), false)
     YZ(256 * 64, 4, 256, 16, 512, true, 4, RL(4), RL(16, 16), false)
-    // 128^3: y = 32 x 4; XY tile 4096 points (32 KiB), YZ tile 16 x 4 x 128 = 8192 points (64 KiB) -- against one 16384-point plane
+    // 128^3: y = 32 x 4; XY tile 4096 points (32 KiB; half-form exchange), YZ tile 16 x 4 x 128 = 8192 points (64 KiB) -- against one 16384-point plane
     // tile + a generic 128-point column pass
-    XY(128, 32, 4, 256, false, 1, RL(8, 16), RL(16, 2), false)
+    // (round 4: the y digit as one radix-32 stage on 128 threads x 32 points -- four LDS exchanges per point instead of five; the
+    // persistent two-pair kernel runs the same list, fft_fusedp.hip)
+    XY(128, 32, 4, 128, true, 1, RL(8, 16), RL(32), false)
     YZ(128 * 32, 4, 128, 16, 512, false, 1, RL(4), RL(8, 16), false)
 #undef XY
 #undef YZ

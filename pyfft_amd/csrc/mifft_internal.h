@@ -27,7 +27,7 @@ int mifft_nd2_f64_launch(int x, int y, int z, const mifft::TileArgs* a, hipStrea
 int mifft_fused2_f32_launch(int L0, int L1, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
 int mifft_fused2x_f32_launch(int L0, int L1, const mifft::FusedArgs* f, unsigned grid, hipStream_t s);
 int mifft_fused2d_f32_launch(int ny, int nx, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
-int mifft_fused3d_f64_launch(int L, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
+int mifft_fused3d_f64_launch(int ny, int nx, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
 int mifft_fusedx_f64(int L0, int L1, const mifft::FusedArgs* f, unsigned grid, hipStream_t s, int query, unsigned* tiles0, unsigned* tiles1);
 int mifft_fused3_f64_launch(int L0, int L1, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
 int mifft_aux_copy_launch(const struct mifft_copy* c, const void* s0, const void* s1, void* d0, void* d1, hipStream_t s);
@@ -49,6 +49,7 @@ int mifft_mixed_long_launch(int f64, int n1, int n2, long long batch, const void
 int mifft_bluestein_padded_impl(int f64, int n);
 int mifft_bluestein_len_supported_impl(int f64, int m);
 int mifft_mixed_nd_supported_impl(int f64, int nx, int ny, int nz);
+int mifft_mixed_nd_rows_ok_impl(int f64, int n);
 int mifft_mixed_nd_launch(int f64, int nx, int ny, int nz, long long transforms, const void* in, void* out, const void* twx, const void* twy,
                           const void* twz, int flags, double scale, hipStream_t s);
 int mifft_bluestein_launch(int f64, int n, int m, long long rows, long long stride_in, long long stride_out, const void* in, void* out,

@@ -361,6 +361,13 @@ void probe_memory_system(const hipDeviceProp_t& hp, int64_t* llc_bytes, int32_t*
     if (*num_xcc == 0) *num_xcc = hp.multiProcessorCount >= 228 ? 8 : (hp.multiProcessorCount >= 64 ? hp.multiProcessorCount / 32 : 1);
 }
 
+// which kernel runs dense smooth rows of n points by default (profiles/r04_j_mixed_rows_ab.log): fp64 the single-buffer tile kernel
+// (N = 1000 0.503 -> 0.569, 2000 0.382 -> 0.460, 100 0.661 -> 0.685); fp32 the two-buffer row kernel (N = 1000 0.513 against 0.445)
+// except for the longest rows, which fill its tile alone (N = 4000 0.279 -> 0.337; 3125 0.313 / 0.305, 3000 0.340 / 0.316)
+bool mixed_rows_prefer_nd(bool f64, int n) {
+    return f64 || n > 3200;
+}
+
 // work-list control block of a persistent launch from the caller's mifft_fused_sync (include/mifft.h): validates, zeroes the
 // counters on `stream` when the caller does not alternate between two sets
 int fill_ctl(mifft::FusedCtl* c, const mifft_fused_sync* sync, long long outer, int lag, int ring_slots, unsigned tiles0, unsigned tiles1,
@@ -683,10 +690,12 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     const bool twod = p0->kind == MIFFT_PASS_ROW;
     if (twod) {
         auto side = [](int L) { return L == 512 || L == 1024 || L == 2048; };
-        const bool okL = f64 ? (p1->L == 1024 && p0->L == 1024) : (side(p0->L) && side(p1->L) && (p0->L == p1->L || p0->layout != MIFFT_SPLIT));
+        auto side64 = [](int L) { return L == 512 || L == 1024; };
+        const bool okL = f64 ? (side64(p0->L) && side64(p1->L) && ((p0->L == 1024 && p1->L == 1024) || p0->layout != MIFFT_SPLIT))
+                             : (side(p0->L) && side(p1->L) && (p0->L == p1->L || p0->layout != MIFFT_SPLIT));
         if (p1->kind != MIFFT_PASS_COL || !okL || p1->S != p0->L || p1->M != 1 ||
             p0->outer != p1->outer * p1->L || p0->layout != p1->layout || p0->inverse != p1->inverse)
-            return set_err(MIFFT_E_UNSUPPORTED, "fused2: the 2-D form takes (ny, nx) in {512, 1024, 2048}^2 (fp32; split planes: squares) / 1024 x 1024 (fp64)");
+            return set_err(MIFFT_E_UNSUPPORTED, "fused2: the 2-D form takes (ny, nx) in {512, 1024, 2048}^2 (fp32; split planes: squares) / {512, 1024}^2 (fp64; split planes: 1024 x 1024)");
     } else {
     if (p0->kind != MIFFT_PASS_COL || p1->kind != MIFFT_PASS_COL || p0->S != 1 || p0->M != p1->L || p1->M != 1 ||
         p1->S != p0->L || p0->outer != p1->outer || p0->layout != p1->layout || p0->inverse != p1->inverse)
@@ -694,7 +703,9 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     auto ok_len = [](int L) { return L == 256 || L == 512 || L == 1024; };
     const bool big = p0->L == 2048 && (p1->L == 2048 || p1->L == 1024);   // 512-thread tiles (fft_col3.hpp)
     const bool wide64 = f64 && p0->L == 2048 && (p1->L == 2048 || p1->L == 1024) && p0->layout == MIFFT_INTERLEAVED;   // fft_fusedx_f64.hip
-    if (f64 ? (!wide64 && (p0->L != 1024 || p1->L != 1024)) : (!big && (!ok_len(p0->L) || !ok_len(p1->L)))) return set_err(MIFFT_E_UNSUPPORTED, "fused2: no kernel for %d x %d", p0->L, p1->L);
+    const bool small64 = f64 && p0->layout == MIFFT_INTERLEAVED && (p0->L == 256 || p0->L == 512) && (p1->L == 256 || p1->L == 512) && p0->L >= p1->L;
+    const bool mid64 = f64 && p0->L == 1024 && (p1->L == 1024 || (p1->L == 512 && p0->layout == MIFFT_INTERLEAVED));
+    if (f64 ? (!wide64 && !small64 && !mid64) : (!big && (!ok_len(p0->L) || !ok_len(p1->L)))) return set_err(MIFFT_E_UNSUPPORTED, "fused2: no kernel for %d x %d", p0->L, p1->L);
     }
     const bool wide64 = !twod && f64 && p0->L == 2048;
     const bool split = p0->layout == MIFFT_SPLIT;
@@ -731,10 +742,10 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     rc = fill_ctl(&f.c, sync, p1->outer, lag, ring_slots, tiles0, tiles1, (hipStream_t)stream, "fused2");
     if (rc) return rc;
     if (lag == 0) {
-        const bool wide = f64 || p0->L == 2048 || p1->L == 2048;       // 512- / 1024-thread tiles: one work-group per CU
+        const bool wide = (f64 && (p0->L > 512 || p1->L > 512)) || p0->L == 2048 || p1->L == 2048;       // 512- / 1024-thread tiles: one work-group per CU
         grid = resident_grid(grid, wide ? 1 : 2);
     }
-    rc = wide64 ? mifft_fusedx_f64(p0->L, p1->L, &f, (unsigned)grid, (hipStream_t)stream, 0, nullptr, nullptr) : twod ? (f64 ? mifft_fused3d_f64_launch(p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)
+    rc = wide64 ? mifft_fusedx_f64(p0->L, p1->L, &f, (unsigned)grid, (hipStream_t)stream, 0, nullptr, nullptr) : twod ? (f64 ? mifft_fused3d_f64_launch(p1->L, p0->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)
                      : mifft_fused2d_f32_launch(p1->L, p0->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream))
        : f64 ? mifft_fused3_f64_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)
              : mifft_fused2_f32_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream);
@@ -1001,6 +1012,15 @@ int mifft_launch_mixed_rows(int32_t precision, int32_t n, int64_t rows, int64_t 
     if (rows < 0 || stride_in < n || stride_out < n) return set_err(MIFFT_E_INVALID, "mixed rows: bad row count / stride");
     if (const char* why = check_rows(precision, in, out, rows, n, stride_in, stride_out)) return set_err(MIFFT_E_INVALID, "mixed rows: %s", why);
     if (rows == 0) return 0;
+    // dense rows: the single-buffer tile kernel of fft_mixed_nd.hip (one axis) where it is the faster one (development switch
+    // MIFFT_DEBUG_ROWS_ND: 1 never, 2 wherever it fits)
+    if (stride_in == n && stride_out == n && g_debug[MIFFT_DEBUG_ROWS_ND] != 1 && mifft_mixed_nd_rows_ok_impl(precision == MIFFT_F64, n) == 0 &&
+        (g_debug[MIFFT_DEBUG_ROWS_ND] == 2 || mixed_rows_prefer_nd(precision == MIFFT_F64, n))) {
+        const int rcn = mifft_mixed_nd_launch(precision == MIFFT_F64, n, 1, 1, rows, in, out, tw, nullptr, nullptr, inverse ? 3 : 0, scale, (hipStream_t)stream);
+        if (rcn == -1) return set_err(MIFFT_E_INVALID, "grid too large");
+        if (rcn != 0 && rcn != -2) return hip_check((hipError_t)rcn, "kernel launch");
+        if (rcn == 0) return 0;
+    }
     const int rc = mifft_mixed_launch(precision == MIFFT_F64, n, rows, stride_in, stride_out, 1, in, out, tw, inverse ? 3 : 0, scale, (hipStream_t)stream);
     if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
     if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
@@ -1094,7 +1114,10 @@ int mifft_launch_mixed_nd(int32_t precision, int32_t x, int32_t y, int32_t z, in
     if (transforms < 0 || mul3_checked(transforms, (long long)x * y * z, precision == MIFFT_F64 ? 16 : 8) < 0)
         return set_err(MIFFT_E_INVALID, "mixed nd: bad transform count");
     if (transforms == 0) return 0;
-    const int rc = mifft_mixed_nd_launch(precision == MIFFT_F64, x, y, z, transforms, in, out, tw_x, tw_y, tw_z, inverse ? 3 : 0, scale, (hipStream_t)stream);
+    // inverse: 0 forward, 1 inverse = conjugate on load and on store; 2 / 4: on load / on store only (one end of a composition)
+    const int flags = inverse == 1 ? 3 : inverse == 2 ? 1 : inverse == 4 ? 2 : 0;
+    if (inverse != 0 && inverse != 1 && inverse != 2 && inverse != 4) return set_err(MIFFT_E_INVALID, "mixed nd: inverse must be 0, 1, 2 or 4");
+    const int rc = mifft_mixed_nd_launch(precision == MIFFT_F64, x, y, z, transforms, in, out, tw_x, tw_y, tw_z, flags, scale, (hipStream_t)stream);
     if (rc == -2) return set_err(MIFFT_E_UNSUPPORTED, "mixed nd: no kernel for %d x %d x %d", z, y, x);
     if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
     if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");

@@ -211,6 +211,7 @@ class GenericFFTPlan(object):
         # the slower axes as lines of the output array in place (mifft_launch_mixed_lines); no gather, no scatter, no work array
         self._direct_nd = None
         self._direct_nd1 = False
+        self._direct_nd_planes = False
         if not self._direct_mixed and not self._split and self._ntiles == 1 and any(ax.mixed_tw is not None for ax in self._axes) and \
                 all(ax.n == 1 or N.lib.mifft_mixed_supported(self._precision, ax.n) == 0 for ax in self._axes):
             tabs = []
@@ -229,6 +230,10 @@ class GenericFFTPlan(object):
             x, y, z = self._xyz
             if N.lib.mifft_mixed_nd_supported(self._precision, x, y, z) == 0 and not D.no_mixed_nd():
                 self._direct_nd1 = True
+            elif z > 1 and x > 1 and y > 1 and N.lib.mifft_mixed_nd_supported(self._precision, x, y, 1) == 0 and not D.no_mixed_nd():
+                # a 3-D shape beyond one tile whose (y, x) PLANES fit one: the planes in one launch (they are just more transforms),
+                # then the z lines -- two HBM round trips instead of three ((60, 60, 60): 216000 points)
+                self._direct_nd_planes = True
         self._uses_work = not (self._tiled or self._direct_mixed or self._direct_blue or self._direct_nd is not None
                                or self._direct_long is not None)
         if self._uses_work:
@@ -340,6 +345,16 @@ class GenericFFTPlan(object):
             twx, twy, twz = self._direct_nd
             N.check(N.lib.mifft_launch_mixed_nd(self._precision, x, y, z, batch, ptr(ins[0]), ptr(outs[0]), twx, twy, twz, 1 if inv else 0,
                                                 factor, ctx.stream_handle()), "mifft_launch_mixed_nd")
+            return self._epilogue(wait_for_finish)
+        if self._direct_nd_planes:
+            inv = bool(inverse)
+            factor = self._scale if not inv else 1.0 / ((self._size if self._normalize else 1.0) * self._scale)
+            x, y, z = self._xyz
+            twx, twy, twz = self._direct_nd
+            N.check(N.lib.mifft_launch_mixed_nd(self._precision, x, y, 1, batch * z, ptr(ins[0]), ptr(outs[0]), twx, twy, None, 2 if inv else 0,
+                                                1.0, ctx.stream_handle()), "mifft_launch_mixed_nd")
+            N.check(N.lib.mifft_launch_mixed_lines(self._precision, z, batch, x * y, ptr(outs[0]), ptr(outs[0]), twz, 0, 1 if inv else 0,
+                                                   factor, ctx.stream_handle()), "mifft_launch_mixed_lines")
             return self._epilogue(wait_for_finish)
         if self._direct_nd is not None:
             inv = bool(inverse)

@@ -289,10 +289,10 @@ class FFTPlan(object):
         p = self._params
         k = self._kernels
         nx, ny = int(p.x), int(p.y)
-        sides = (1024,) if p.precision == N.F64 else (512, 1024, 2048)
+        sides = (512, 1024) if p.precision == N.F64 else (512, 1024, 2048)
         if nx not in sides or ny not in sides or int(p.z) != 1 or len(k) != 2:
             return False
-        if p.split and (nx != ny or D.forced_strategy() != "fused"):
+        if p.split and (nx != ny or D.forced_strategy() != "fused" or (p.precision == N.F64 and nx != 1024)):
             return False      # (split planes: 29 % against 35 % for the pipelined chunks -- squares, on request only)
         if (ny, nx) == (512, 2048) and D.forced_strategy() != "fused":
             # 512-point columns on the 512-thread tiles (16 points per thread, 64 KiB tiles, one work-group per CU): 0.355 against
@@ -304,7 +304,9 @@ class FFTPlan(object):
     def _fused_wide_tiles(self):
         """The plan's persistent kernel runs on the 512-thread tiles (one work-group per CU): fp64, or a 2048-point pass."""
         k = self._kernels
-        return self._params.precision == N.F64 or k[1].L == 2048 or (self._fused2d_eligible() and k[0].L == 2048)
+        if self._params.precision == N.F64:
+            return not (k[0].L <= 512 and k[1].L <= 512)     # (fp64 2^16 ... 2^18 and the (512, 512) square: 256-thread tiles)
+        return k[1].L == 2048 or (self._fused2d_eligible() and k[0].L == 2048)
 
     def _fused2_eligible(self):
         p = self._params
@@ -318,8 +320,10 @@ class FFTPlan(object):
             # 1024 x 1024 on the 512-thread tiles; round 4: 2048 x 1024 on the stage-chain tiles (interleaved): 0.285 -> 0.330.  The same
             # kernel runs 2048 x 2048 -- 64 MiB per transform, a ring of three -- BELOW the pipelined chunks (0.243 - 0.259 against
             # 0.269, profiles/r04_e_fp64_long_fused.log): on request only
-            return (k[0].L == 1024 and k[1].L == 1024) or \
-                (k[0].L == 2048 and not p.split and (k[1].L == 1024 or (k[1].L == 2048 and D.forced_strategy() == "fused")))
+            # round 4 also: 2^16 ... 2^18 (L0 >= L1 in {256, 512}) on the 256-thread tiles, interleaved
+            return (k[0].L == 1024 and k[1].L == 1024) or (k[0].L == 1024 and k[1].L == 512 and not p.split) or \
+                (k[0].L == 2048 and not p.split and (k[1].L == 1024 or (k[1].L == 2048 and D.forced_strategy() == "fused"))) or \
+                (not p.split and k[0].L in (256, 512) and k[1].L in (256, 512) and k[0].L >= k[1].L)
         return (k[0].L in (256, 512, 1024) and k[1].L in (256, 512, 1024)) or (k[0].L == 2048 and k[1].L in (1024, 2048))
 
     def _fusedx_eligible(self):
@@ -398,7 +402,10 @@ class FFTPlan(object):
             huge = self._fused_wide_tiles()   # 512-thread tiles: one work-group per CU
             # measured on MI355X (end of round 2, counters on their own lines): the persistent kernel beats the stream-pipelined
             # chunks from N = 2^18 up (2^18: 42.0 vs 39.5 %, 2^19: 37.2 vs 36.2 %; 2^17: 39.1 vs 39.5, 2^16: 33 vs 40)
-            big = self._kernels[0].L * self._kernels[1].L >= (1 << 18)
+            # fp32 from 2^18 (2 MiB) up -- below, the pipelined chunks or the per-XCD lists win; fp64 from 2^16 (1 MiB) up: its 16-column
+            # tiles are 256-byte segments, 2^16 0.422 -> 0.474, 2^17 0.406 -> 0.465, 2^18 0.405 -> 0.470
+            # (profiles/r04_l_anchored_twiddles_fp64_mid.log)
+            big = item_bytes >= ((1 << 20) if p.precision == N.F64 else (2 << 20))
             # (fp64 2^22: 64 MiB per transform, three ring slots are all the cache holds)
             geo = mach.fused_geometry(item_bytes, self._fused_tiles0(), D.fused_grid_per_cu(1 if huge else 2),   # (four per CU for L <= 512: no gain)
                                       min_slots=3 if (p.precision == N.F64 and self._kernels[0].L == 2048) else None)

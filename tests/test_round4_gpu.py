@@ -350,3 +350,70 @@ def test_fused_long_fp64(ctx, monkeypatch, n, batch):
     # split planes have no such kernel: the pipelined chunks
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
     assert ctx.getPlan((n,), dtype=numpy.float64).strategy(batch)[0] in ("pipelined", "chain")
+
+
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
+@pytest.mark.parametrize("shape,batch", [((60, 60, 60), 2), ((24, 100, 100), 3), ((7, 90, 50), 5)], ids=str)
+def test_smooth_3d_as_planes_and_lines(ctx, shape, dtype, batch):
+    """3-D smooth shapes beyond one tile whose (y, x) planes fit one: the planes in ONE launch (they are more transforms of the
+    2-D kernel), then the z lines -- two HBM round trips instead of three (round 3: one launch per axis).  numpy, reference
+    thresholds, out of place with the input untouched, the normalised inverse in place."""
+    from test_round2_gpu import _run_generic
+    N = ctx.hip.N
+    prec = N.F32 if numpy.dtype(dtype) == numpy.complex64 else N.F64
+    z, y, x = shape
+    plan = ctx.getPlan(shape, dtype=dtype, any_size=True)
+    planes = N.lib.mifft_mixed_nd_supported(prec, x, y, z) != 0 and N.lib.mifft_mixed_nd_supported(prec, x, y, 1) == 0
+    assert plan._direct_nd_planes == planes and not plan._direct_nd1 and plan._inner_plans() == []
+    _run_generic(ctx, shape, dtype, batch, seed=sum(shape))
+
+
+@pytest.mark.parametrize("n,batch,forced", [(1 << 19, 34, "auto"), (1 << 18, 66, "auto"), (1 << 17, 130, "auto"), (1 << 16, 260, "auto")], ids=str)
+def test_fused_mid_sizes_fp64(ctx, monkeypatch, n, batch, forced):
+    """fp64 N = 2^16 ... 2^18 (L0 >= L1 in {256, 512}) on the persistent two-pass kernel with the 256-thread two-phase tiles
+    (`fft_fused2_kernel<double>`; round 3: pipelined chunks): the chain's tile code, so the chain's bits; 2^19 = 1024 x 512 on the
+    512-thread tiles (`fft_fused3_kernel<double, 2, 1>`); in place; numpy on sampled
+    transforms with the reference's fp64 thresholds (test/test_errors.py:20-23); inverse round trip."""
+    data = oracle.get_test_data((n,), numpy.complex128, batch, 97)
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
+    want = _execute(ctx, (n,), numpy.complex128, batch, data, expect="chain")
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", forced)
+    monkeypatch.setenv("PYFFT_AMD_FUSED_RING", "8,16")          # (a ring this batch can fill twice)
+    got = _execute(ctx, (n,), numpy.complex128, batch, data, expect="fused2")
+    if n == 1 << 19:
+        # 1024 x 512: the persistent kernel runs the 512-point pass on the 512-thread tiles (2 x 256 by decimation in time), the chain
+        # on the 256-thread ones: the same transform in another operation order
+        assert oracle.difference(want, got, batch) < 1e-14
+    else:
+        assert numpy.array_equal(want, got)
+    assert numpy.array_equal(_execute(ctx, (n,), numpy.complex128, batch, data, inplace=True, expect="fused2"), got)
+    for item in (0, batch // 2, batch - 1):
+        ref = numpy.fft.fft(data[item * n:(item + 1) * n])
+        g = got[item * n:(item + 1) * n]
+        assert numpy.abs(ref - g).sum() / numpy.abs(ref).sum() < 1e-11
+        assert numpy.abs(ref - g).max() <= 1e-10 * numpy.abs(ref).max()
+    back = _execute(ctx, (n,), numpy.complex128, batch, got, inverse=True, expect="fused2")
+    assert oracle.difference(data, back, batch) < 1e-11
+
+
+@pytest.mark.parametrize("shape,batch", [((512, 512), 66), ((512, 1024), 34), ((1024, 512), 34)], ids=str)
+def test_fused_2d_fp64_512_sides(ctx, monkeypatch, shape, batch):
+    """fp64 2-D shapes with a 512-point side on the persistent 2-D kernels (round 4; round 3: 1024 x 1024 only): (512, 512) on the
+    256-thread two-phase tiles, the rectangles on the 512-thread ones.  numpy with the reference's fp64 thresholds on sampled
+    transforms, in place == out of place, inverse, and the chain's result to rounding (two transposing passes against ROW + COL)."""
+    ny, nx = shape
+    data = oracle.get_test_data(shape, numpy.complex128, batch, 1200 + ny // 512 + nx // 256)
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    monkeypatch.setenv("PYFFT_AMD_FUSED_RING", "8,16")
+    got = _execute(ctx, shape, numpy.complex128, batch, data, expect="fused2")
+    assert numpy.array_equal(_execute(ctx, shape, numpy.complex128, batch, data, inplace=True, expect="fused2"), got)
+    for item in (0, batch // 2, batch - 1):
+        sl = slice(item * ny, (item + 1) * ny)
+        ref = numpy.fft.fft2(data[sl])
+        assert numpy.abs(ref - got[sl]).sum() / numpy.abs(ref).sum() < 1e-11
+        assert numpy.abs(ref - got[sl]).max() <= 1e-10 * numpy.abs(ref).max()
+    back = _execute(ctx, shape, numpy.complex128, batch, got, inverse=True, expect="fused2")
+    assert oracle.difference(data, back, batch) < 1e-11
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
+    want = _execute(ctx, shape, numpy.complex128, batch, data, expect="chain")
+    assert oracle.difference(want, got, batch) < 1e-14
