@@ -105,5 +105,7 @@ def apply_native_switches(native):
         native.lib.mifft_debug_set(native.DEBUG_STORE, int(os.environ["MIFFT_STORE"]))
     if os.environ.get("MIFFT_ROWS_ND"):     # dense smooth rows: 1 = two-buffer row kernel only, 2 = single-buffer tile kernel wherever it fits
         native.lib.mifft_debug_set(native.DEBUG_ROWS_ND, int(os.environ["MIFFT_ROWS_ND"]))
+    if os.environ.get("MIFFT_NARROW_TILES"):   # fp32 2^16 ... 2^18 persistent: 16-column tiles (A/B)
+        native.lib.mifft_debug_set(native.DEBUG_NARROW_TILES, int(os.environ["MIFFT_NARROW_TILES"]))
     if os.environ.get("MIFFT_PAIR"):        # pass pairs: 1 = off, 2 = the alternative y split
         native.lib.mifft_debug_set(native.DEBUG_PAIR, int(os.environ["MIFFT_PAIR"]))

@@ -39,6 +39,7 @@ def fused2_counter_bytes(outer):
 XCD2_PREFETCH = 1
 DEBUG_NO_ND2, DEBUG_FUSED_NO_NT, DEBUG_NO_WAVE, DEBUG_FORCE_WAVE, DEBUG_PERSIST, DEBUG_ALT_ROWS, DEBUG_PAIR, DEBUG_STORE = 0, 1, 2, 3, 4, 5, 6, 7
 DEBUG_ROWS_ND = 8
+DEBUG_NARROW_TILES = 9
 XCD2_TRACE = 2
 XCD2_TRACE_BYTES = 512 * 32 * 8
 

@@ -21,6 +21,7 @@
 // Every spin is bounded; on timeout an error word is set (the host checks it) instead of hanging the GPU.
 #pragma once
 #include "fft_col2.hpp"
+#include "fft_col2w.hpp"
 #include "fft_col3.hpp"
 
 namespace mifft {
@@ -348,6 +349,25 @@ __global__ void __launch_bounds__(256, 2) fft_fused2x_kernel(const FusedArgs f) 
         col2_tile<T, A1, false, false, false, false, false, true, false>(f.p1, (long long)slot, (long long)t, (long long)tile * 16, lds, hook);
     };
     fused_loop<per0, per1, true, decltype(t0)&, decltype(t1)&, 1>(f.c, &s_item, t0, t1);
+}
+
+// The 1-D kernel on the 32-column tiles of fft_col2w.hpp (round 4): fp32 interleaved, L0 >= L1 in {256, 512} (N = 2^16 ... 2^18);
+// a tile is 32 columns, so a transform has L1 / 32 first-pass and L0 / 32 second-pass tiles.
+template <int A0, int A1>
+__global__ void __launch_bounds__(256, 2) fft_fused2w_kernel(const FusedArgs f) {
+    constexpr int E0 = Col2wLds<true>::ELEMS, E1 = Col2wLds<false>::ELEMS;
+    __shared__ __attribute__((aligned(16))) cplx<float> lds[E0 > E1 ? E0 : E1];
+    __shared__ unsigned s_item;
+    constexpr unsigned per0 = A0 > A1 ? 1u : (unsigned)(A1 / A0);
+    constexpr unsigned per1 = A1 > A0 ? 1u : (unsigned)(A0 / A1);
+    fused_loop<per0, per1, (A0 == 1)>(     // (the early dependency poll only where registers are to spare: L = 512 sits at the 256-VGPR limit)
+        f.c, &s_item,
+        [&](unsigned t, unsigned slot, unsigned tile, auto hook) {
+            col2w_tile<A0, true, true, true, true, false>(f.p0, (long long)t, (long long)slot, (long long)tile * 32, lds, hook);
+        },
+        [&](unsigned slot, unsigned t, unsigned tile, auto hook) {
+            col2w_tile<A1, false, false, false, false, true>(f.p1, (long long)slot, (long long)t, (long long)tile * 32, lds, hook);
+        });
 }
 
 // The 2-D form (BASELINE config 3: 1024 x 1024): a 2-D transform is two TRANSPOSING column passes without an inter-pass twiddle

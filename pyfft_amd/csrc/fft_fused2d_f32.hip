@@ -26,3 +26,17 @@ extern "C" int mifft_fused2d_rect_f32_launch(int ny, int nx, const mifft::FusedA
 #undef RECT3
     return MIFFT_E_UNSUPPORTED;
 }
+
+// 1-D N = 2^16 ... 2^18 on the 32-column tiles (fft_fused2w_kernel): L0 >= L1 in {256, 512}, interleaved
+extern "C" int mifft_fused2w_f32_launch(int L0, int L1, const mifft::FusedArgs* f, unsigned grid, hipStream_t s) {
+#define WIDE(A0, A1)                                                                                            \
+    if (L0 == 256 * A0 && L1 == 256 * A1) {                                                                     \
+        hipLaunchKernelGGL((mifft::fft_fused2w_kernel<A0, A1>), dim3(grid), dim3(256), 0, s, *f);               \
+        return (int)hipGetLastError();                                                                          \
+    }
+    WIDE(1, 1)
+    WIDE(2, 1)
+    WIDE(2, 2)
+#undef WIDE
+    return MIFFT_E_UNSUPPORTED;
+}

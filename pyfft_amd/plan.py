@@ -273,7 +273,7 @@ class FFTPlan(object):
     #   pipelined  batch cut into cache-sized chunks, chunk i on side stream i % n with its own temp slot
     #              (mifft_launch_chain_pipelined)
     #   fused2     both passes of a long 1-D transform / a big 2-D one in one persistent launch (mifft_launch_fused2)
-    #   fused2x    the same with one work list per XCD (mifft_launch_fused2x): 2^17, where eight short pipelines beat one
+    #   fused2x    the same with one work list per XCD (mifft_launch_fused2x): on request (2^17 on 16-column tiles: + 2 points)
     #   fusedp     both pass PAIRS of a cache-sized 3-D cube in one persistent launch (mifft_launch_fused_pair)
     #   xcd2       1024 x 1024 fp32: one persistent launch, each transform stays on one XCD between its two HBM
     #              crossings (mifft_launch_xcd2); development only
@@ -354,6 +354,9 @@ class FFTPlan(object):
             return k[0].L // 16                                  # nx / 16 column tiles of the y pass
         if self._params.precision == N.F64 and k[0].L == 2048:
             return k[0].M // 8                                   # 8-column tiles (csrc/fft_fusedx_f64.hip)
+        if self._params.precision == N.F32 and not self._params.split and k[0].L <= 512 and k[1].L <= 512 and \
+                N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1:
+            return k[0].M // 32                                  # 32-column tiles (csrc/fft_col2w.hpp)
         return k[0].M // 16
 
     def _select_strategy(self, batch):
@@ -387,7 +390,10 @@ class FFTPlan(object):
             return ("xcd2", D.xcd2_flags(N.XCD2_PREFETCH))
         # per-XCD lists where they win: 2^17 = 512 x 256 (+ 2 points over the pipelined chunks at 0.5 / 2 / 8 GiB; 2^16 is within
         # +- 0.5 of them, 2^18 and up within +- 0.5 of the global list: profiles/r04_d_list_sweep.log)
-        if forced == "auto" and self._fusedx_eligible() and self._kernels[0].L * self._kernels[1].L == (1 << 17) and not D.no_fusedx():
+        # (superseded within round 4 by the 32-column tiles of the global list, 0.410 -> 0.462: the lists remain for the 16-column
+        # tiles, MIFFT_NARROW_TILES=1, and on request)
+        if forced == "auto" and self._fusedx_eligible() and self._kernels[0].L * self._kernels[1].L == (1 << 17) and not D.no_fusedx() \
+                and N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) == 1:
             lag, ring = self.FUSEDX_LAG_RING
             if batch >= 8 * 2 * ring and 8 * ring * item_bytes <= mach.ring_bytes:
                 return ("fused2x", lag, ring, 2 * mach.compute_units)
@@ -405,7 +411,12 @@ class FFTPlan(object):
             # fp32 from 2^18 (2 MiB) up -- below, the pipelined chunks or the per-XCD lists win; fp64 from 2^16 (1 MiB) up: its 16-column
             # tiles are 256-byte segments, 2^16 0.422 -> 0.474, 2^17 0.406 -> 0.465, 2^18 0.405 -> 0.470
             # (profiles/r04_l_anchored_twiddles_fp64_mid.log)
-            big = item_bytes >= ((1 << 20) if p.precision == N.F64 else (2 << 20))
+            # fp32 2^16 ... 2^18 on the 32-column tiles (round 4, csrc/fft_col2w.hpp: 16-byte lanes, 256-byte segments): 2^16 0.403
+            # (pipelined) -> 0.469, 2^17 0.410 (per-XCD lists) -> 0.462, 2^18 0.420 (16-column tiles) -> 0.448
+            # (profiles/r04_o_fp32_wide_tiles.log)
+            wide32 = p.precision == N.F32 and not p.split and not self._fused2d_eligible() and self._kernels[0].L <= 512 and \
+                self._kernels[1].L <= 512 and N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1
+            big = item_bytes >= ((1 << 20) if p.precision == N.F64 else ((1 << 19) if wide32 else (2 << 20)))
             # (fp64 2^22: 64 MiB per transform, three ring slots are all the cache holds)
             geo = mach.fused_geometry(item_bytes, self._fused_tiles0(), D.fused_grid_per_cu(1 if huge else 2),   # (four per CU for L <= 512: no gain)
                                       min_slots=3 if (p.precision == N.F64 and self._kernels[0].L == 2048) else None)
@@ -414,6 +425,11 @@ class FFTPlan(object):
                 if huge:
                     lag, ring = D.fused3_lag_ring(lag, ring)
                 lag, ring = D.fused_ring(lag, ring)
+                # a batch that cannot fill the ring twice: halve the pipeline (2^18 x 160: 28 / 56 instead of 56 / 112) rather than fall
+                # back to the chunks -- down to the 14 slots of the biggest transforms
+                while forced == "auto" and batch < 2 * ring and ring >= 28:
+                    ring //= 2
+                    lag = max(1, ring // 2)
                 if forced == "fused" and batch < 2 * ring and batch >= 8:   # on request: a shorter pipeline for a small batch
                     lag = batch // 4
                     ring = 2 * lag

@@ -494,11 +494,12 @@ def test_planner_constants_come_from_the_device():
     c64, c128 = numpy.complex64, numpy.complex128
     assert _strategy_on(full, (1 << 20,), c64, 4096)[1] == ("fused2", 14, 28, 512)            # BASELINE config 2, as in rounds 2-3
     assert _strategy_on(full, (1 << 19,), c64, 2048)[1] == ("fused2", 28, 56, 512)            # round 4: the ring fills the cache
-    assert _strategy_on(full, (1 << 18,), c64, 4096)[1] == ("fused2", 28, 56, 512)
+    assert _strategy_on(full, (1 << 18,), c64, 4096)[1] == ("fused2", 56, 112, 512)           # 32-column tiles: 16 first-pass tiles per transform
     assert _strategy_on(full, (1 << 22,), c64, 256)[1] == ("fused2", 4, 7, 256)               # BASELINE config 5's chunk
     assert _strategy_on(full, (1 << 21,), c64, 512)[1] == ("fused2", 8, 14, 512)              # 16 MiB transforms: the cache caps the ring
-    assert _strategy_on(full, (1 << 17,), c64, 8192)[1] == ("fused2x", 8, 16, 512)         # per-XCD lists below 2^18
-    assert _strategy_on(full, (1 << 16,), c64, 16384)[1] == ("pipelined", 128, 2, 0)          # (per-XCD lists: +- 0.5 points there)
+    assert _strategy_on(full, (1 << 17,), c64, 8192)[1] == ("fused2", 112, 224, 512)          # 2^16 / 2^17: 8 tiles of 32 columns per pass
+    assert _strategy_on(full, (1 << 16,), c64, 16384)[1] == ("fused2", 112, 224, 512)
+    assert _strategy_on(full, (1 << 17,), numpy.float32, 8192)[1][0] == "pipelined"           # (split planes: no 32-column tiles)
     assert _strategy_on(full, (1 << 22,), numpy.complex128, 64)[1][0] == "pipelined"          # fp64 2^22: a ring of three 64 MiB slots loses
     assert _strategy_on(full, (1 << 21,), numpy.complex128, 128)[1] == ("fused2", 4, 7, 256)
     assert _strategy_on(full, (1 << 22,), numpy.float64, 64)[1][0] == "pipelined"             # (split planes: no kernel)
@@ -523,7 +524,7 @@ def test_planner_constants_come_from_the_device():
         if st[0] == "pipelined":
             assert st[1] * item <= max(item, part.pipeline_chunk_bytes), (shape, st)
     assert _strategy_on(part, (1 << 20,), c64, 4096)[1] == ("pipelined", 1, 2, 0)              # an 8 MiB transform: three ring slots are no ring
-    assert _strategy_on(part, (1 << 18,), c64, 4096)[1] == ("fused2", 4, 8, 64)                # 2 MiB transforms: 8 of 14 slots
+    assert _strategy_on(part, (1 << 18,), c64, 4096)[1] == ("fused2", 7, 14, 64)               # 2 MiB transforms: all 14 slots
     assert _strategy_on(part, (1 << 20,), c64, 4)[1] == ("chain",)                             # 32 MiB per side = this device's cache
     assert _strategy_on(part, (1 << 20,), c64, 16)[1] == ("pipelined", 1, 2, 0)                # (the full part runs the chain here)
 

@@ -81,19 +81,16 @@ def test_fused_pair_cube_128(ctx, monkeypatch, dtype, batch):
 # ---- per-XCD work lists as a default ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,batch", [(1 << 16, 1040), (1 << 17, 520)], ids=str)
 def test_per_xcd_lists(ctx, monkeypatch, n, batch):
-    """2^17 beyond the chain threshold runs the fused kernel with one work list per XCD (mifft_launch_fused2x; pyfft/
-    kernel.py:259-283 chain semantics) by the plan's own choice, 2^16 on request: the bits of the chain, in place == out of
-    place; a batch that is not a multiple of 8 leaves the lists uneven, work stealing drains them."""
+    """The fused kernel with one work list per XCD (mifft_launch_fused2x; pyfft/kernel.py:259-283 chain semantics), on request
+    (within round 4 the 32-column tiles of the global list overtook it at 2^17): the bits of the chain, in place == out of place; a
+    batch that is not a multiple of 8 leaves the lists uneven, work stealing drains them."""
     if not ctx.hip.Machine.from_props(ctx.hip.device_props()).xcd_cooperative:
         pytest.skip("needs 8 XCDs x 32 CUs")
     data = oracle.get_test_data((n,), numpy.complex64, batch, 91)
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
     want = _execute(ctx, (n,), numpy.complex64, batch, data, expect="chain")
-    if n == 1 << 17:
-        monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
-    else:
-        monkeypatch.setenv("PYFFT_AMD_STRATEGY", "fusedx")
-        monkeypatch.setenv("PYFFT_AMD_FUSEDX", "8,16")
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "fusedx")
+    monkeypatch.setenv("PYFFT_AMD_FUSEDX", "8,16")
     got = _execute(ctx, (n,), numpy.complex64, batch, data, expect="fused2x")
     assert numpy.array_equal(want, got)
     assert numpy.array_equal(_execute(ctx, (n,), numpy.complex64, batch, data, inplace=True, expect="fused2x"), got)
@@ -101,8 +98,7 @@ def test_per_xcd_lists(ctx, monkeypatch, n, batch):
     got_odd = _execute(ctx, (n,), numpy.complex64, odd, data[:odd * n], expect="fused2x")
     assert numpy.array_equal(got_odd, want[:odd * n])
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
-    monkeypatch.setenv("PYFFT_AMD_NO_FUSEDX", "1")
-    assert ctx.getPlan((n,), dtype=numpy.complex64).strategy(batch)[0] == "pipelined"
+    assert ctx.getPlan((n,), dtype=numpy.complex64).strategy(batch)[0] == "fused2"           # the plan's own choice: 32-column tiles
 
 
 def test_fused_ring_rule_2_19(ctx, monkeypatch):
@@ -417,3 +413,34 @@ def test_fused_2d_fp64_512_sides(ctx, monkeypatch, shape, batch):
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
     want = _execute(ctx, shape, numpy.complex128, batch, data, expect="chain")
     assert oracle.difference(want, got, batch) < 1e-14
+
+
+@pytest.mark.parametrize("n,batch", [(1 << 16, 1040), (1 << 17, 530), (1 << 18, 260), (1 << 18, 161)], ids=str)
+def test_wide_tiles_fp32_mid_sizes(ctx, monkeypatch, n, batch):
+    """fp32 N = 2^16 ... 2^18 in the persistent kernel on 32-column tiles (csrc/fft_col2w.hpp: a thread owns two adjacent columns,
+    16-byte lanes, 256-byte row segments) by the plan's own choice: the bits of the chain (same butterflies, same table factors) and
+    of the 16-column tiles, in place, numpy with the reference's thresholds, inverse round trip; a batch that fills the ring only
+    once takes half the pipeline instead of falling back to the chunks."""
+    N = ctx.hip.N
+    data = oracle.get_test_data((n,), numpy.complex64, batch, 98)
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
+    want = _execute(ctx, (n,), numpy.complex64, batch, data, expect="chain")
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    got = _execute(ctx, (n,), numpy.complex64, batch, data, expect="fused2")
+    assert numpy.array_equal(want, got)
+    assert numpy.array_equal(_execute(ctx, (n,), numpy.complex64, batch, data, inplace=True, expect="fused2"), got)
+    N.check(N.lib.mifft_debug_set(N.DEBUG_NARROW_TILES, 1), "debug_set")
+    try:
+        monkeypatch.setenv("PYFFT_AMD_STRATEGY", "fused")
+        narrow = _execute(ctx, (n,), numpy.complex64, batch, data, expect="fused2")
+    finally:
+        N.check(N.lib.mifft_debug_set(N.DEBUG_NARROW_TILES, 0), "debug_set")
+    assert numpy.array_equal(narrow, got)
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    for item in (0, batch // 2, batch - 1):
+        ref = numpy.fft.fft(data[item * n:(item + 1) * n].astype(numpy.complex128))
+        g = got[item * n:(item + 1) * n]
+        assert numpy.abs(ref - g).sum() / numpy.abs(ref).sum() < 1.1e-6
+        assert numpy.abs(ref - g).max() <= 1e-5 * numpy.abs(ref).max()
+    back = _execute(ctx, (n,), numpy.complex64, batch, got, inverse=True, expect="fused2")
+    assert oracle.difference(data, back, batch) < 1.1e-6

@@ -14,7 +14,7 @@ from pyfft_amd.hip import Plan, DeviceArray, Event
 from pyfft_amd import _native as N
 
 KEYS = ("PYFFT_AMD_STRATEGY", "PYFFT_AMD_FUSED_RING", "PYFFT_AMD_FUSEDX", "PYFFT_AMD_FUSED3", "PYFFT_AMD_FUSED_WGS", "PYFFT_AMD_PIPE_MB",
-        "PYFFT_AMD_FUSED_MEMSET", "PYFFT_AMD_NO_FUSEDX", "PYFFT_AMD_SMALL_FUSED", "MIFFT_PAIR")
+        "PYFFT_AMD_FUSED_MEMSET", "PYFFT_AMD_NO_FUSEDX", "PYFFT_AMD_SMALL_FUSED", "MIFFT_PAIR", "MIFFT_NARROW_TILES")
 
 
 def variant_env(v):
@@ -71,7 +71,8 @@ def sweep(shape, dtype, gib, variants, reps=5, iters=10):
         for k in KEYS:
             os.environ.pop(k, None)
         os.environ.update(variant_env(v))
-        N.lib.mifft_debug_set(N.DEBUG_PAIR, int(os.environ.get("MIFFT_PAIR", "0")))     # (a library switch: read at import otherwise)
+        N.lib.mifft_debug_set(N.DEBUG_PAIR, int(os.environ.get("MIFFT_PAIR", "0")))     # (library switches: read at import otherwise)
+        N.lib.mifft_debug_set(N.DEBUG_NARROW_TILES, int(os.environ.get("MIFFT_NARROW_TILES", "0")))
         try:
             plan = Plan(shape if len(shape) > 1 else shape[0], dtype=dt, wait_for_finish=True)
             N.check(N.lib.mifft_memset(b.ptr, 0, b.nbytes, None))
