@@ -4,6 +4,7 @@
 // makes it spill (measured: 228 bytes/lane of scratch with SLP, 36 without).
 #include "mifft_internal.h"
 #include "fft_col2.hpp"
+#include "fft_col2w.hpp"
 
 namespace {
 template <int A, bool TR, bool TW> int launch_l(const mifft::TileArgs* a, hipStream_t s) {
@@ -34,7 +35,31 @@ extern "C" int mifft_col2_f32_eligible(int L, int tr, const mifft::TileArgs* a) 
     return tr ? (a->has_tw != 0) : (a->has_tw == 0);
 }
 
+// Round 4: 32-column tiles (fft_col2w.hpp: 16-byte lanes, 256-byte segments) for L = 256 / 512 on interleaved data -- the tile must
+// be 32 whole columns of one matrix and the column pair adjacent in the output (S >= 2 in the plain form).  In the PERSISTENT kernel
+// they are worth 3-6 points (fft_fused2w_kernel); as plain launches of the chain / the pipelined chunks they measure within +- 2 %
+// of the 16-column tiles, in both directions (profiles/r04_r_plain_wide_tiles_ab.log: 2^16 x 512 0.395 / 0.399, 2^18 x 64
+// 0.336 / 0.357, (512, 512) x 128 0.372 / 0.351, pipelined 2^16 0.405 / 0.397), so the plain launches keep the 16 columns; the
+// instances stay for the A/B: MIFFT_DEBUG_NARROW_TILES = 2 runs them wherever they fit.
+namespace {
+template <int A> int launch_w(int tr, const mifft::TileArgs* a, hipStream_t s) {
+    const long long tiles = a->total / 32;
+    if (tiles > 2147483647ll) return -1;
+    const dim3 g((unsigned)tiles), b(256);
+    if (tr) hipLaunchKernelGGL((mifft::fft_col2w_kernel<A, true, true>), g, b, 0, s, *a);
+    else hipLaunchKernelGGL((mifft::fft_col2w_kernel<A, false, false>), g, b, 0, s, *a);
+    return (int)hipGetLastError();
+}
+bool wide_ok(int L, int tr, const mifft::TileArgs* a) {
+    if (L != 256 && L != 512) return false;
+    if (a->split || a->split_out || mifft_debug_get(MIFFT_DEBUG_NARROW_TILES) != 2) return false;
+    if ((a->total & 31) || a->logMS < 5 || (!tr && a->logS < 1)) return false;
+    return a->total / 32 >= 1024;
+}
+}  // namespace
+
 extern "C" int mifft_col2_f32_launch(int L, int tr, const mifft::TileArgs* a, hipStream_t s) {
+    if (wide_ok(L, tr, a)) return L == 512 ? launch_w<2>(tr, a, s) : launch_w<1>(tr, a, s);
     switch (L) {
         case 1024: return launch<4>(tr, a, s);
         case 512: return launch<2>(tr, a, s);

@@ -229,4 +229,18 @@ __device__ __forceinline__ void col2w_tile(const TileArgs& a, const long long o_
     });
 }
 
+// plain launch: one 32-column tile per work-group; nt as fft_col2_kernel (bit 0 non-temporal loads, bit 1 non-temporal stores,
+// bit 2 write-through stores)
+template <int A, bool TR, bool TW>
+__global__ void __launch_bounds__(256, 2) fft_col2w_kernel(const TileArgs a) {
+    __shared__ __attribute__((aligned(16))) cplx<float> lds[Col2wLds<TR>::ELEMS];
+    const long long col0 = (long long)blockIdx.x * 32;
+    const long long o = col0 >> a.logMS;
+    const long long rem0 = col0 & ((1ll << a.logMS) - 1);
+    if (a.nt & 4) col2w_tile<A, TR, TW, true, false, false>(a, o, o, rem0, lds);
+    else if (TR && (a.nt & 1)) col2w_tile<A, TR, TW, false, true, false>(a, o, o, rem0, lds);
+    else if (!TR && (a.nt & 2)) col2w_tile<A, TR, TW, false, false, true>(a, o, o, rem0, lds);
+    else col2w_tile<A, TR, TW, false, false, false>(a, o, o, rem0, lds);
+}
+
 }  // namespace mifft

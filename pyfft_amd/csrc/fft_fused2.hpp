@@ -370,6 +370,23 @@ __global__ void __launch_bounds__(256, 2) fft_fused2w_kernel(const FusedArgs f) 
         });
 }
 
+// N = 2^19 = 1024 x 512 (round 4): the 1024-point pass on the 16-column tiles (64 points per thread: no room for a second column),
+// the 512-point pass on the 32-column ones -- 32 + 32 tiles per transform
+template <int NT>
+__global__ void __launch_bounds__(256, 2) fft_fused2m_kernel(const FusedArgs f) {
+    constexpr int E0 = Col2Lds<4, true>::ELEMS, E1 = Col2wLds<false>::ELEMS;
+    __shared__ __attribute__((aligned(16))) cplx<float> lds[E0 > E1 ? E0 : E1];
+    __shared__ unsigned s_item;
+    fused_loop<1, 1, false>(
+        f.c, &s_item,
+        [&](unsigned t, unsigned slot, unsigned tile, auto hook) {
+            col2_tile<float, 4, true, true, false, true, NT != 0, false, false>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);
+        },
+        [&](unsigned slot, unsigned t, unsigned tile, auto hook) {
+            col2w_tile<2, false, false, false, false, NT != 0>(f.p1, (long long)slot, (long long)t, (long long)tile * 32, lds, hook);
+        });
+}
+
 // The 2-D form (BASELINE config 3: 1024 x 1024): a 2-D transform is two TRANSPOSING column passes without an inter-pass twiddle
 // -- pass 0 transforms the y axis of in[y][x] and writes ring[x][ky], pass 1 transforms the x axis of that and writes
 // out[ky][kx] -- i.e. the 1-D kernel above minus the twiddle, with contiguous 8 KiB runs on the output side.
@@ -389,6 +406,29 @@ __global__ void __launch_bounds__(256, 2) fft_fused2d_kernel(const FusedArgs f) 
         },
         [&](unsigned slot, unsigned t, unsigned tile, auto hook) {
             col2_tile<T, A1, true, false, false, false, false, NT, SPLIT>(f.p1, (long long)slot, (long long)t, (long long)tile * 16, lds, hook);
+        });
+}
+
+// The 2-D form with 32-column tiles for a 512-point axis (round 4): (512, 512), (512, 1024), (1024, 512) fp32 interleaved.  W0 / W1 =
+// columns per tile of pass 0 / pass 1: 32 where the pass transforms 512 points, 16 where it transforms 1024.
+template <int A0, int A1>
+__global__ void __launch_bounds__(256, 2) fft_fused2dw_kernel(const FusedArgs f) {
+    constexpr bool WIDE0 = A0 <= 2, WIDE1 = A1 <= 2;
+    constexpr int E0 = WIDE0 ? Col2wLds<true>::ELEMS : Col2Lds<A0, true>::ELEMS, E1 = WIDE1 ? Col2wLds<true>::ELEMS : Col2Lds<A1, true>::ELEMS;
+    __shared__ __attribute__((aligned(16))) cplx<float> lds[E0 > E1 ? E0 : E1];
+    __shared__ unsigned s_item;
+    // tiles0 : tiles1 = nx / W0 : ny / W1 with nx = 256 A1, ny = 256 A0
+    constexpr unsigned t0 = 256u * A1 / (WIDE0 ? 32u : 16u), t1 = 256u * A0 / (WIDE1 ? 32u : 16u);
+    constexpr unsigned per0 = t0 >= t1 ? t0 / t1 : 1u, per1 = t1 > t0 ? t1 / t0 : 1u;
+    fused_loop<per0, per1, false>(
+        f.c, &s_item,
+        [&](unsigned t, unsigned slot, unsigned tile, auto hook) {
+            if constexpr (WIDE0) col2w_tile<A0, true, false, true, true, false>(f.p0, (long long)t, (long long)slot, (long long)tile * 32, lds, hook);
+            else col2_tile<float, A0, true, false, false, true, true, false, false>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);
+        },
+        [&](unsigned slot, unsigned t, unsigned tile, auto hook) {
+            if constexpr (WIDE1) col2w_tile<A1, true, false, false, false, true>(f.p1, (long long)slot, (long long)t, (long long)tile * 32, lds, hook);
+            else col2_tile<float, A1, true, false, false, false, false, true, false>(f.p1, (long long)slot, (long long)t, (long long)tile * 16, lds, hook);
         });
 }
 

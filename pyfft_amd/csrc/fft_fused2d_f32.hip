@@ -27,6 +27,24 @@ extern "C" int mifft_fused2d_rect_f32_launch(int ny, int nx, const mifft::FusedA
     return MIFFT_E_UNSUPPORTED;
 }
 
+// 2-D shapes with a 512-point axis on 32-column tiles for that axis' pass (fft_fused2dw_kernel); *tiles0 / *tiles1 per transform
+extern "C" int mifft_fused2dw_f32(int ny, int nx, const mifft::FusedArgs* f, unsigned grid, hipStream_t s, int query, unsigned* tiles0,
+                                  unsigned* tiles1) {
+#define WIDE2D(NY, NX)                                                                                                   \
+    if (ny == NY && nx == NX) {                                                                                          \
+        if (tiles0) *tiles0 = NX / (NY <= 512 ? 32 : 16);                                                                \
+        if (tiles1) *tiles1 = NY / (NX <= 512 ? 32 : 16);                                                                \
+        if (query) return 0;                                                                                             \
+        hipLaunchKernelGGL((mifft::fft_fused2dw_kernel<NY / 256, NX / 256>), dim3(grid), dim3(256), 0, s, *f);           \
+        return (int)hipGetLastError();                                                                                   \
+    }
+    WIDE2D(512, 512)
+    WIDE2D(512, 1024)
+    WIDE2D(1024, 512)
+#undef WIDE2D
+    return MIFFT_E_UNSUPPORTED;
+}
+
 // 1-D N = 2^16 ... 2^18 on the 32-column tiles (fft_fused2w_kernel): L0 >= L1 in {256, 512}, interleaved
 extern "C" int mifft_fused2w_f32_launch(int L0, int L1, const mifft::FusedArgs* f, unsigned grid, hipStream_t s) {
 #define WIDE(A0, A1)                                                                                            \
@@ -38,5 +56,9 @@ extern "C" int mifft_fused2w_f32_launch(int L0, int L1, const mifft::FusedArgs* 
     WIDE(2, 1)
     WIDE(2, 2)
 #undef WIDE
+    if (L0 == 1024 && L1 == 512) {      // mixed: 16-column first pass, 32-column second pass
+        hipLaunchKernelGGL((mifft::fft_fused2m_kernel<1>), dim3(grid), dim3(256), 0, s, *f);
+        return (int)hipGetLastError();
+    }
     return MIFFT_E_UNSUPPORTED;
 }

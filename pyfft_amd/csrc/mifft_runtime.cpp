@@ -740,18 +740,23 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     if (wide64 && mifft_fusedx_f64(p0->L, p1->L, nullptr, 0, nullptr, 1, &tiles0, &tiles1) != 0)
         return set_err(MIFFT_E_UNSUPPORTED, "fused2: no kernel for %d x %d", p0->L, p1->L);
     // fp32 interleaved 2^16 ... 2^18: 32-column tiles (fft_col2w.hpp) -- half as many tiles per pass
-    const bool wide32 = !twod && !f64 && !split && p0->L <= 512 && p1->L <= 512 && p0->L >= p1->L && g_debug[MIFFT_DEBUG_NARROW_TILES] != 1;
+    const bool narrow = g_debug[MIFFT_DEBUG_NARROW_TILES] == 1;
+    const bool mixed32 = !twod && !f64 && !split && p0->L == 1024 && p1->L == 512 && !narrow;        // 2^19: the second pass only
+    const bool wide32 = mixed32 || (!twod && !f64 && !split && p0->L <= 512 && p1->L <= 512 && p0->L >= p1->L && !narrow);
     if (wide32) {
-        tiles0 /= 2;
+        if (!mixed32) tiles0 /= 2;
         tiles1 /= 2;
     }
+    // 2-D fp32 interleaved with a 512-point axis: that axis' pass on 32-column tiles (p1->L = ny, p0->L = nx)
+    const bool wide2d = twod && !f64 && !split && !narrow && mifft_fused2dw_f32(p1->L, p0->L, nullptr, 0, nullptr, 1, &tiles0, &tiles1) == 0;
     rc = fill_ctl(&f.c, sync, p1->outer, lag, ring_slots, tiles0, tiles1, (hipStream_t)stream, "fused2");
     if (rc) return rc;
     if (lag == 0) {
         const bool wide = (f64 && (p0->L > 512 || p1->L > 512)) || p0->L == 2048 || p1->L == 2048;       // 512- / 1024-thread tiles: one work-group per CU
         grid = resident_grid(grid, wide ? 1 : 2);
     }
-    rc = wide32 ? mifft_fused2w_f32_launch(p0->L, p1->L, &f, (unsigned)grid, (hipStream_t)stream) :
+    rc = wide2d ? mifft_fused2dw_f32(p1->L, p0->L, &f, (unsigned)grid, (hipStream_t)stream, 0, nullptr, nullptr) :
+         wide32 ? mifft_fused2w_f32_launch(p0->L, p1->L, &f, (unsigned)grid, (hipStream_t)stream) :
          wide64 ? mifft_fusedx_f64(p0->L, p1->L, &f, (unsigned)grid, (hipStream_t)stream, 0, nullptr, nullptr) : twod ? (f64 ? mifft_fused3d_f64_launch(p1->L, p0->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)
                      : mifft_fused2d_f32_launch(p1->L, p0->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream))
        : f64 ? mifft_fused3_f64_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)

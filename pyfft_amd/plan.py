@@ -351,6 +351,9 @@ class FFTPlan(object):
         if self._fusedp_eligible():
             return int(self._params.z) * int(k[1].M)             # planes x R1
         if self._fused2d_eligible():
+            if self._params.precision == N.F32 and not self._params.split and k[1].L == 512 and k[0].L <= 1024 and \
+                    N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1:
+                return k[0].L // 32                              # a 512-point y axis: its pass runs on 32-column tiles
             return k[0].L // 16                                  # nx / 16 column tiles of the y pass
         if self._params.precision == N.F64 and k[0].L == 2048:
             return k[0].M // 8                                   # 8-column tiles (csrc/fft_fusedx_f64.hip)
