@@ -252,6 +252,9 @@ class ErrorWord(object):
         self.ptr = p.value
         self._word = ctypes.c_uint32.from_address(p.value)
         self._word.value = 0
+        d = ctypes.c_int()
+        N.check(N.lib.mifft_get_device(ctypes.byref(d)), "mifft_get_device")
+        self._device = d.value           # the device whose kernels write the word (the plan's: created under on_plan_device)
 
     def take(self):
         """The word's value; clears it when non-zero."""
@@ -263,6 +266,14 @@ class ErrorWord(object):
     def __del__(self):
         try:
             if getattr(self, "ptr", None):
+                # a persistent kernel that is still running may write the word (on a time-out): wait for the device before the
+                # page goes away (plans are rarely destroyed with work in flight; FFTPlan.close() has synchronised already)
+                cur = ctypes.c_int()
+                switched = N.lib.mifft_get_device(ctypes.byref(cur)) == 0 and cur.value != self._device and \
+                    N.lib.mifft_set_device(self._device) == 0
+                N.lib.mifft_device_sync()
+                if switched:
+                    N.lib.mifft_set_device(cur.value)
                 N.lib.mifft_host_free(self.ptr)
                 self.ptr = None
         except Exception:
