@@ -357,6 +357,8 @@ int mifft_launch_xcd2(const mifft_pass *p0, const mifft_pass *p1, const void *in
  * in the parent -- tile g = item*(cx*cy*cz) + (iz*cy + iy)*cx + ix starts at item*parent_elems + iz*z*pitch_z + iy*y*pitch_y + ix*x.
  * In place or out of place (same geometry on both sides).  Exists for a list of tile shapes only:
  *   mifft_nd_tiled_supported  0 if the tile shape has such a kernel, else MIFFT_E_UNSUPPORTED
+ * mifft_launch_nd_tiled_split is the same launch on split-complex parents (pass->layout = MIFFT_SPLIT; re / im planes with the
+ * same element offsets on both sides), for the same list of tile shapes.
  */
 typedef struct mifft_tiling {
     int64_t pitch_y;       /* elements between consecutive y of the parent array (its x extent) */
@@ -366,6 +368,8 @@ typedef struct mifft_tiling {
 } mifft_tiling;
 int mifft_nd_tiled_supported(int32_t precision, int32_t x, int32_t y, int32_t z);
 int mifft_launch_nd_tiled(const mifft_pass *pass, const mifft_tiling *tiling, const void *in, void *out, mifft_stream_t stream);
+int mifft_launch_nd_tiled_split(const mifft_pass *pass, const mifft_tiling *tiling, const void *in_re, const void *in_im, void *out_re,
+                                void *out_im, mifft_stream_t stream);
 
 typedef struct mifft_copy {
     int32_t precision;          /* MIFFT_F32 | MIFFT_F64 */

@@ -7,7 +7,7 @@
 //     item * parent + iz*LZ*pitch_z + iy*LY*pitch_y + ix*LX        (elements; x contiguous, pitch_y = parent x extent, ...)
 // and its point (z, y, x) at + z*pitch_z + y*pitch_y + x.  Every stage works inside one tile, so the k-th operand of a
 // butterfly is a fixed multiple of (1 | pitch_y | pitch_z) away from the first.  In place or out of place (same geometry on
-// both sides), interleaved data.
+// both sides); interleaved data, or split planes (SPLIT: in0 / in1 = re / im planes of the parent, same element offsets -- round 4).
 #pragma once
 #include "fft_nd2.hpp"
 
@@ -34,7 +34,7 @@ template <int LX, int LY, int LZ> struct Nd2tAddr {
     }
 };
 
-template <typename T, int LX, int LY, int LZ, int P, int NT, bool HALF, int OCC, bool EDGE_IN, typename RLX, typename RLY, typename RLZ>
+template <typename T, int LX, int LY, int LZ, int P, int NT, bool HALF, int OCC, bool EDGE_IN, typename RLX, typename RLY, typename RLZ, bool SPLIT = false>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) fft_nd2t_kernel(const TileArgs a, const TiledGeom g) {
     constexpr int PPT = P / NT;
     static_assert(PPT * NT == P && P % (LX * LY * LZ) == 0 && PPT % 2 == 0, "bad tile");
@@ -51,6 +51,10 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) 
     const long long g0 = (long long)blockIdx.x * (P / Addr::N);
     const cplx<T>* in = reinterpret_cast<const cplx<T>*>(a.in0);
     cplx<T>* out = reinterpret_cast<cplx<T>*>(a.out0);
+    const T* in_re = reinterpret_cast<const T*>(a.in0);
+    const T* in_im = reinterpret_cast<const T*>(a.in1);
+    T* out_re = reinterpret_cast<T*>(a.out0);
+    T* out_im = reinterpret_cast<T*>(a.out1);
     const cplx<T>* tw[3] = {reinterpret_cast<const cplx<T>*>(a.tw_L), reinterpret_cast<const cplx<T>*>(a.tw_lo),
                             reinterpret_cast<const cplx<T>*>(a.tw_hi)};
     const long long pitch[3] = {1, g.pitch_y, g.pitch_z};
@@ -68,7 +72,14 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) 
                 constexpr int k = kk;
                 cplx<T> p;
                 p.x = 0; p.y = 0;
-                if (off >= 0) p = in[off + k * step];
+                if (off >= 0) {
+                    if constexpr (SPLIT) {
+                        p.x = in_re[off + k * step];
+                        p.y = in_im[off + k * step];
+                    } else {
+                        p = in[off + k * step];
+                    }
+                }
                 v[b * First::R + k] = p;
             });
         });
@@ -79,7 +90,16 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) 
             constexpr int it = ii;
             const long long off = Addr::at(g, g0, (it * NT + tid) * 2);
             V4 q = {0, 0, 0, 0};
-            if (off >= 0) q = *reinterpret_cast<const V4*>(in + off);
+            if constexpr (SPLIT) {
+                // two x-adjacent points of each plane (tile rows start on even elements: LX and the pitches are even)
+                using V2 = T __attribute__((ext_vector_type(2)));
+                if (off >= 0) {
+                    const V2 re = *reinterpret_cast<const V2*>(in_re + off), im = *reinterpret_cast<const V2*>(in_im + off);
+                    q.x = re.x; q.y = im.x; q.z = re.y; q.w = im.y;
+                }
+            } else {
+                if (off >= 0) q = *reinterpret_cast<const V4*>(in + off);
+            }
             v[2 * it].x = q.x; v[2 * it].y = q.y; v[2 * it + 1].x = q.z; v[2 * it + 1].y = q.w;
         });
         static_for<PPT / 2>([&](auto ii) {
@@ -110,7 +130,12 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) 
                     cplx<T> p = vv[b * St::R + k];
                     p.x *= sx;
                     p.y *= sy;
-                    out[off + k * step] = p;
+                    if constexpr (SPLIT) {
+                        out_re[off + k * step] = p.x;
+                        out_im[off + k * step] = p.y;
+                    } else {
+                        out[off + k * step] = p;
+                    }
                 });
             }
         });
@@ -119,13 +144,13 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) 
 }
 
 // launch with the tile configuration Nd2Auto derives for the dense kernel of the same shape
-template <typename T, int X, int Y, int Z> static inline int launch_nd2t_auto(const TileArgs* a, const TiledGeom* g, hipStream_t s) {
+template <typename T, int X, int Y, int Z, bool SPLIT = false> static inline int launch_nd2t_auto(const TileArgs* a, const TiledGeom* g, hipStream_t s) {
     using C = Nd2Auto<T, X, Y, Z>;
     const long long per_wg = C::P / (X * Y * Z);
     const long long wgs = (g->tiles + per_wg - 1) / per_wg;
     if (wgs <= 0) return 0;
     if (wgs > 2147483647ll) return -1;
-    hipLaunchKernelGGL((fft_nd2t_kernel<T, X, Y, Z, C::P, C::NT, C::HALF, C::OCC, C::EDGE_IN, typename C::RLX, typename C::RLY, typename C::RLZ>),
+    hipLaunchKernelGGL((fft_nd2t_kernel<T, X, Y, Z, C::P, C::NT, C::HALF, C::OCC, C::EDGE_IN, typename C::RLX, typename C::RLY, typename C::RLZ, SPLIT>),
                        dim3((unsigned)wgs), dim3(C::NT), 0, s, *a, *g);
     return (int)hipGetLastError();
 }

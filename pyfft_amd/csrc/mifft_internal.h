@@ -42,6 +42,7 @@ int mifft_pair_f32(int kind, int k0, int k1, int k2, int split, const mifft::Pai
 int mifft_fusedp(int f64, int x, int y, int z, const mifft::FusedPairArgs* f, unsigned grid, hipStream_t s, int query, int* r0,
                  unsigned* tiles0, unsigned* tiles1);
 int mifft_nd2t(int f64, int x, int y, int z, const mifft::TileArgs* a, const mifft::TiledGeom* g, hipStream_t s, int query);
+int mifft_nd2t_split(int f64, int x, int y, int z, const mifft::TileArgs* a, const mifft::TiledGeom* g, hipStream_t s, int query);
 int mifft_mixed_supported_impl(int f64, int n);
 int mifft_mixed_launch(int f64, int n, long long rows, long long stride_in, long long stride_out, long long inner, const void* in,
                        void* out, const void* tw, int flags, double scale, hipStream_t s);

@@ -964,34 +964,46 @@ int mifft_nd_tiled_supported(int32_t precision, int32_t x, int32_t y, int32_t z)
     return mifft_nd2t(precision == MIFFT_F64, x, y, z, nullptr, nullptr, nullptr, 1) == 0 ? 0 : MIFFT_E_UNSUPPORTED;
 }
 
-int mifft_launch_nd_tiled(const mifft_pass* p, const mifft_tiling* t, const void* in, void* out, mifft_stream_t stream) {
+static int launch_nd_tiled(const mifft_pass* p, const mifft_tiling* t, const void* in0, const void* in1, void* out0, void* out1, bool split,
+                           mifft_stream_t stream) {
     if (!p || !t) return set_err(MIFFT_E_INVALID, "nd_tiled: null argument");
     if (p->kind != MIFFT_PASS_ND) return set_err(MIFFT_E_INVALID, "nd_tiled: not an ND pass");
     if (p->precision != MIFFT_F32 && p->precision != MIFFT_F64) return set_err(MIFFT_E_INVALID, "bad precision %d", p->precision);
-    if (p->layout != MIFFT_INTERLEAVED) return set_err(MIFFT_E_UNSUPPORTED, "nd_tiled: interleaved data only");
+    if (p->layout != (split ? MIFFT_SPLIT : MIFFT_INTERLEAVED))
+        return set_err(split ? MIFFT_E_INVALID : MIFFT_E_UNSUPPORTED, split ? "nd_tiled_split: the pass must say MIFFT_SPLIT" : "nd_tiled: interleaved data only (split planes: mifft_launch_nd_tiled_split)");
     if (mifft_nd_tiled_supported(p->precision, p->L, (int32_t)p->M, (int32_t)p->S) != 0)
         return set_err(MIFFT_E_UNSUPPORTED, "nd_tiled: no kernel for tiles of %d x %lld x %lld", p->L, (long long)p->M, (long long)p->S);
     if (t->cx < 1 || t->cy < 1 || t->cz < 1 || t->pitch_y < (int64_t)p->L * t->cx || t->pitch_z < t->pitch_y * p->M * t->cy ||
         t->parent_elems < t->pitch_z * p->S * t->cz || (t->pitch_y & 1) || (t->pitch_z & 1) || (t->parent_elems & 1))
         return set_err(MIFFT_E_INVALID, "nd_tiled: inconsistent tiling");
-    if (!in || !out) return set_err(MIFFT_E_INVALID, "null data buffer");
-    if (((uintptr_t)in | (uintptr_t)out) & 15) return set_err(MIFFT_E_INVALID, "data buffers must be 16-byte aligned");
+    if (!in0 || !out0 || (split && (!in1 || !out1))) return set_err(MIFFT_E_INVALID, "null data buffer");
+    if (((uintptr_t)in0 | (uintptr_t)out0 | (uintptr_t)in1 | (uintptr_t)out1) & 15) return set_err(MIFFT_E_INVALID, "data buffers must be 16-byte aligned");
     if ((p->L > 1 && !p->tw_L) || (p->M > 1 && !p->tw_lo) || (p->S > 1 && !p->tw_hi)) return set_err(MIFFT_E_INVALID, "ND pass: twiddle table missing");
     if (p->outer < 0) return set_err(MIFFT_E_INVALID, "negative outer count");
     if (p->outer == 0) return 0;
     mifft::TileArgs a;
     memset(&a, 0, sizeof(a));
-    a.in0 = in; a.out0 = out;
+    a.in0 = in0; a.in1 = in1; a.out0 = out0; a.out1 = out1;
+    a.split = a.split_out = split ? 1 : 0;
     a.tw_L = p->tw_L; a.tw_lo = p->tw_lo; a.tw_hi = p->tw_hi;
     a.inverse = p->inverse ? 1 : 0;
     a.scale = p->scale;
     mifft::TiledGeom g;
     g.pitch_y = t->pitch_y; g.pitch_z = t->pitch_z; g.parent = t->parent_elems; g.tiles = p->outer;
     g.cx = t->cx; g.cy = t->cy; g.cz = t->cz;
-    const int rc = mifft_nd2t(p->precision == MIFFT_F64, p->L, (int)p->M, (int)p->S, &a, &g, (hipStream_t)stream, 0);
+    const int rc = (split ? mifft_nd2t_split : mifft_nd2t)(p->precision == MIFFT_F64, p->L, (int)p->M, (int)p->S, &a, &g, (hipStream_t)stream, 0);
     if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
     if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
     return 0;
+}
+
+int mifft_launch_nd_tiled(const mifft_pass* p, const mifft_tiling* t, const void* in, void* out, mifft_stream_t stream) {
+    return launch_nd_tiled(p, t, in, nullptr, out, nullptr, false, stream);
+}
+
+int mifft_launch_nd_tiled_split(const mifft_pass* p, const mifft_tiling* t, const void* in_re, const void* in_im, void* out_re, void* out_im,
+                                mifft_stream_t stream) {
+    return launch_nd_tiled(p, t, in_re, in_im, out_re, out_im, true, stream);
 }
 
 int mifft_aux_copy(const mifft_copy* c, const void* src0, const void* src1, void* dst0, void* dst1, mifft_stream_t stream) {

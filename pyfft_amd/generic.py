@@ -142,7 +142,7 @@ class GenericFFTPlan(object):
         self._tiled = False
         self._tiled_tables = None
         tx, ty, tz = self._xyz
-        if all_pow2 and not self._split and parent_shape is not None and (tx > 1) + (ty > 1) + (tz > 1) >= 2 and not D.no_tiled_kernel() and \
+        if all_pow2 and parent_shape is not None and (tx > 1) + (ty > 1) + (tz > 1) >= 2 and not D.no_tiled_kernel() and \
                 N.lib.mifft_nd_shape_supported(self._precision, tx, ty, tz, N.VARIANT_INTERLEAVED_ONLY) == 0 and \
                 N.lib.mifft_nd_tiled_supported(self._precision, tx, ty, tz) == 0:
             self._tiled = True
@@ -337,7 +337,7 @@ class GenericFFTPlan(object):
         ctx.createQueue(ins + outs)
         ctx.order_scratch()
         if self._tiled:
-            return self._execute_tiled(wait_for_finish, bool(inverse), batch, ptr(ins[0]), ptr(outs[0]))
+            return self._execute_tiled(wait_for_finish, bool(inverse), batch, [ptr(b) for b in ins], [ptr(b) for b in outs])
         if self._direct_nd1:
             inv = bool(inverse)
             factor = self._scale if not inv else 1.0 / ((self._size if self._normalize else 1.0) * self._scale)
@@ -471,7 +471,7 @@ class GenericFFTPlan(object):
         px, py, pz = self._parent
         cx, cy, cz = self._counts
         d = N.MifftPass()
-        d.kind, d.precision, d.layout, d.inverse = N.PASS_ND, self._precision, N.INTERLEAVED, 1 if inverse else 0
+        d.kind, d.precision, d.layout, d.inverse = N.PASS_ND, self._precision, (N.SPLIT if self._split else N.INTERLEAVED), 1 if inverse else 0
         d.L, d.M, d.S = tx, ty, tz
         d.outer = batch * self._ntiles
         d.outer_stride_in = d.outer_stride_out = self._size
@@ -480,7 +480,11 @@ class GenericFFTPlan(object):
         t = N.MifftTiling()
         t.pitch_y, t.pitch_z, t.parent_elems = px, px * py, px * py * pz
         t.cx, t.cy, t.cz = cx, cy, cz
-        N.check(N.lib.mifft_launch_nd_tiled(ctypes.byref(d), ctypes.byref(t), src, dst, ctx.stream_handle()), "mifft_launch_nd_tiled")
+        if self._split:   # re / im planes of the parent, same launch (round 4)
+            N.check(N.lib.mifft_launch_nd_tiled_split(ctypes.byref(d), ctypes.byref(t), src[0], src[1], dst[0], dst[1], ctx.stream_handle()),
+                    "mifft_launch_nd_tiled_split")
+        else:
+            N.check(N.lib.mifft_launch_nd_tiled(ctypes.byref(d), ctypes.byref(t), src[0], dst[0], ctx.stream_handle()), "mifft_launch_nd_tiled")
         return self._epilogue(wait_for_finish)
 
     def _inner_plans(self):

@@ -444,3 +444,54 @@ def test_wide_tiles_fp32_mid_sizes(ctx, monkeypatch, n, batch):
         assert numpy.abs(ref - g).max() <= 1e-5 * numpy.abs(ref).max()
     back = _execute(ctx, (n,), numpy.complex64, batch, got, inverse=True, expect="fused2")
     assert oracle.difference(data, back, batch) < 1.1e-6
+
+
+# ---- tiled batches on split-complex parents in one launch (csrc/fft_nd2t.hpp, SPLIT; the reference's TODO.txt:6-7) -------
+@pytest.mark.parametrize("dtype", [numpy.float32, numpy.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape,parent", [((8, 8), (24, 40)), ((16, 16), (48, 80)), ((32, 32), (96, 64)), ((64, 64), (192, 128)),
+                                          ((128, 128), (256, 384)), ((16, 32), (32, 96)), ((32, 64), (96, 64)), ((64, 128), (128, 384)),
+                                          ((8, 8, 8), (16, 24, 8)), ((16, 16, 16), (32, 16, 48)), ((8, 16, 16), (8, 48, 32)),
+                                          ((8, 32, 32), (24, 32, 64)), ((32, 32, 32), (64, 32, 96))], ids=str)
+def test_tiled_batch_split_planes_single_launch(ctx, shape, parent, dtype, monkeypatch):
+    """The tiles of split-complex parent arrays (re / im planes) transformed where they lie, ONE launch and no work array: the bits
+    of the interleaved one-launch form on the same numbers, numpy tile by tile with the reference's thresholds, the input planes
+    untouched, in place, the inverse, and the gather / dense plan / scatter form of the same plan."""
+    from test_round2_gpu import _numpy_tiles
+    if shape == (32, 32, 32) and numpy.dtype(dtype) == numpy.float64:
+        shape, parent = (16, 32, 32), (32, 32, 96)
+    batch = 3
+    rd = numpy.dtype(dtype)
+    cd = numpy.dtype(numpy.complex64 if rd == numpy.float32 else numpy.complex128)
+    eps, mx = (1e-11, 1e-10) if rd == numpy.float64 else (1.1e-6, 1e-5)
+    full = (batch * parent[0],) + tuple(parent[1:])
+    rng = numpy.random.default_rng(177 + sum(parent))
+    re, im = rng.standard_normal(full).astype(rd), rng.standard_normal(full).astype(rd)
+    x = (re + 1j * im).astype(cd)
+    ref = _numpy_tiles(x, batch, shape, parent)
+    plan = ctx.getPlan(shape, dtype=dtype, parent_shape=parent)
+    assert plan._tiled and plan._work is None and plan._inner_plans() == []
+    a_re, a_im, b_re, b_im = ctx.toGpu(re), ctx.toGpu(im), ctx.allocate(full, rd), ctx.allocate(full, rd)
+    plan.execute(a_re, a_im, b_re, b_im, batch=batch)
+    got = b_re.get() + 1j * b_im.get()
+    assert numpy.array_equal(a_re.get(), re) and numpy.array_equal(a_im.get(), im), "out-of-place execute modified its input"
+    assert numpy.abs(got - ref).sum() / numpy.abs(ref).sum() < eps
+    assert numpy.abs(got - ref).max() <= mx * numpy.abs(ref).max()
+    # the interleaved one-launch form: same butterflies, same table factors
+    iplan = ctx.getPlan(shape, dtype=cd, parent_shape=parent)
+    assert iplan._tiled
+    c, d = ctx.toGpu(x), ctx.allocate(full, cd)
+    iplan.execute(c, d, batch=batch)
+    assert numpy.array_equal(d.get(), got.astype(cd))
+    plan.execute(a_re, a_im, batch=batch)                      # in place
+    assert numpy.array_equal(a_re.get(), b_re.get()) and numpy.array_equal(a_im.get(), b_im.get())
+    plan.execute(a_re, a_im, inverse=True, batch=batch)
+    back = a_re.get() + 1j * a_im.get()
+    assert numpy.abs(back - x).sum() / numpy.abs(x).sum() < 2 * eps
+    assert plan._work is None
+    monkeypatch.setenv("PYFFT_AMD_NO_TILED", "1")
+    plan3 = ctx.getPlan(shape, dtype=dtype, parent_shape=parent)
+    assert not plan3._tiled
+    e_re, e_im = ctx.allocate(full, rd), ctx.allocate(full, rd)
+    plan3.execute(ctx.toGpu(re), ctx.toGpu(im), e_re, e_im, batch=batch)
+    three = e_re.get() + 1j * e_im.get()
+    assert numpy.abs(three - got).sum() / numpy.abs(got).sum() < eps

@@ -94,6 +94,13 @@ if __name__ == "__main__":
             cases += [((128, 128, 128), c64, gib * 64), ((128, 128, 128), c128, gib * 32), ((512, 1024), c64, gib * 256), ((1024, 512), c64, gib * 256),
                       ((1024, 2048), c64, gib * 64), ((2048, 1024), c64, gib * 64), ((2048, 512), c64, gib * 128), ((512, 2048), c64, gib * 128),
                       ((1 << 21,), c128, gib * 32), ((1 << 22,), c128, gib * 16), ((1 << 20,), c128, gib * 64)]
+    elif len(sys.argv) > 1 and sys.argv[1] == "tail":                # shapes that still run two or three launches per cache-sized chunk (round 4 survey)
+        cases = [((256, 256), c64, 4096), ((256, 256), c128, 2048), ((512, 256), c64, 2048), ((64, 64, 64), c64, 1024), ((64, 64, 64), c128, 512),
+                 ((128, 128, 64), c64, 256), ((64, 128, 128), c64, 256), ((256, 128, 128), c64, 64), ((128, 128, 64), c128, 128),
+                 ((256, 256, 128), c64, 32), ((256, 256, 256), c64, 16), ((1 << 15,), c128, 4096), ((256, 4096), c64, 256), ((4096, 256), c64, 256),
+                 ((4096, 4096), c64, 16), ((1 << 20,), f32, 256), ((1 << 18,), f32, 1024), ((1024, 1024), f32, 256), ((128, 128, 128), f32, 128),
+                 ((1 << 20,), f64, 128), ((32, 32, 2048), c64, 128), ((2048, 32, 32), c64, 128), ((1 << 23,), c64, 32), ((1 << 24,), c64, 16),
+                 ((512, 512, 512), c64, 2), ((2048, 2048), c128, 32)]
     elif len(sys.argv) > 1 and sys.argv[1] == "1d":
         cases = [((1 << k,), c64, max(64, (1 << 31) >> (k + 3))) for k in (13, 14, 15, 16, 17, 18, 19, 20, 21, 22)]
     else:
