@@ -45,6 +45,9 @@ CONFIGS = {
     # tools/pmc_traffic.py and the round-4 evidence of the persistent two-pair kernel
     "cube": ((128, 128, 128), "complex64", 64, 1006),
     "cubed": ((128, 128, 128), "complex128", 32, 1007),
+    # configs 2 and 3 in the reference's OTHER layout (dtype float32: re / im planes), 4 GiB per side
+    "c2s": ((1 << 20,), "float32", 512, 1008),
+    "c3s": ((1024, 1024), "float32", 512, 1009),
 }
 
 

@@ -298,11 +298,12 @@ int mifft_launch_fused2(const mifft_pass *p0, const mifft_pass *p1, const void *
  * The same launch with one work list PER XCD (strategy `fusedx`, csrc/fft_fused2.hpp): XCD x owns the transforms x, x + 8, ... and
  * the ring slots [x * ring_slots, (x + 1) * ring_slots), so the ring holds 8 * ring_slots transforms.  A work-group whose own
  * list is exhausted drains the other XCDs' lists, so the result does not depend on where the work-groups land (the
- * intermediate is written write-through, like the global form's).  Interleaved fp32 1-D pairs with p0->L >= p1->L in
- * {256, 512, 1024}.
+ * intermediate is written write-through, like the global form's).  fp32 1-D pairs with p0->L >= p1->L in {256, 512, 1024};
+ * in1 / out1 = the imaginary planes of split-complex user buffers (NULL for interleaved data; the ring is always interleaved).
  */
-int mifft_launch_fused2x(const mifft_pass *p0, const mifft_pass *p1, const void *in0, void *out0, void *ring0, int32_t ring_slots,
-                         int32_t lag, const mifft_fused_sync *sync, int32_t grid, mifft_stream_t stream);
+int mifft_launch_fused2x(const mifft_pass *p0, const mifft_pass *p1, const void *in0, const void *in1, void *out0, void *out1,
+                         void *ring0, int32_t ring_slots, int32_t lag, const mifft_fused_sync *sync, int32_t grid,
+                         mifft_stream_t stream);
 
 /*
  * Persistent form of a 3-D plan made of two PASS PAIRS (mifft_pair_split > 0): passes[0..3] = ROW x | COL y (R0) | COL y (R1) |
@@ -310,9 +311,14 @@ int mifft_launch_fused2x(const mifft_pass *p0, const mifft_pass *p1, const void 
  * (COL y R1, COL z) tiles as second-pass items; the buffer between the two pairs is a ring of `ring_slots` whole transforms
  * (interleaved) that stays in the last-level cache.  Exists for the cubes whose transform is a fraction of that cache:
  *   mifft_fused_pair_supported   0 if (precision, x, y, z) has such a kernel for interleaved data, else MIFFT_E_UNSUPPORTED
+ *   mifft_fused_pair_split       the factor R0 of the y axis that kernel is built for (y = R0 * R1), 0 if there is none.  For the
+ *                                128^3 cubes it equals mifft_pair_split; the other shapes (64- and 128-point axes) have NO plain
+ *                                pair launches -- their chain is a plane pass + a strided z pass -- and the caller builds the
+ *                                four-pass list for this launch alone
  * Reference shape of the work: pyfft/plan.py:160-167 (one chain per axis), published row doc/source/index.rst:373 (128^3).
  */
 int mifft_fused_pair_supported(int32_t precision, int32_t x, int32_t y, int32_t z);
+int mifft_fused_pair_split(int32_t precision, int32_t x, int32_t y, int32_t z);
 int mifft_launch_fused_pair(const mifft_pass *passes, const void *in0, void *out0, void *ring0, int32_t ring_slots, int32_t lag,
                             const mifft_fused_sync *sync, int32_t grid, mifft_stream_t stream);
 

@@ -58,6 +58,11 @@ def no_fusedx():
     return bool(os.environ.get("PYFFT_AMD_NO_FUSEDX"))
 
 
+def no_fusedp_alt():
+    """PYFFT_AMD_NO_FUSEDP_ALT=1: no persistent two-pair launch for shapes whose chain is a plane pass + a z pass (A/B, tests)"""
+    return bool(os.environ.get("PYFFT_AMD_NO_FUSEDP_ALT"))
+
+
 def no_tiled_kernel():
     """PYFFT_AMD_NO_TILED=1: tiled-batch plans gather / transform / scatter even where a one-launch tile kernel exists (A/B, tests)"""
     return bool(os.environ.get("PYFFT_AMD_NO_TILED"))

@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
 // drains another XCD's list (work stealing) produces and consumes across XCDs, and only write-through stores + the consumer's
 // acquire are coherent between two L2s.  (Round 3's plain-store variant -- the intermediate in the owning XCD's L2 -- measured
 // 0-2 points more and was placement-dependent: removed.)
-template <typename T, int A0, int A1>
+template <typename T, int A0, int A1, bool SPLIT = false>
 __global__ void __launch_bounds__(256, 2) fft_fused2x_kernel(const FusedArgs f) {
     constexpr int E0 = Col2Lds<A0, true, sizeof(cplx<T>)>::ELEMS, E1 = Col2Lds<A1, false, sizeof(cplx<T>)>::ELEMS;
     __shared__ __attribute__((aligned(16))) cplx<T> lds[E0 > E1 ? E0 : E1];
@@ -343,12 +343,12 @@ __global__ void __launch_bounds__(256, 2) fft_fused2x_kernel(const FusedArgs f) 
     constexpr unsigned per0 = A0 > A1 ? 1u : (unsigned)(A1 / A0);
     constexpr unsigned per1 = A1 > A0 ? 1u : (unsigned)(A0 / A1);
     auto t0 = [&](unsigned t, unsigned slot, unsigned tile, auto hook) {
-        col2_tile<T, A0, true, true, false, true, true, false, false>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);
+        col2_tile<T, A0, true, true, SPLIT, true, !SPLIT, false, false>(f.p0, (long long)t, (long long)slot, (long long)tile * 16, lds, hook);
     };
     auto t1 = [&](unsigned slot, unsigned t, unsigned tile, auto hook) {
-        col2_tile<T, A1, false, false, false, false, false, true, false>(f.p1, (long long)slot, (long long)t, (long long)tile * 16, lds, hook);
+        col2_tile<T, A1, false, false, false, false, false, !SPLIT, SPLIT>(f.p1, (long long)slot, (long long)t, (long long)tile * 16, lds, hook);
     };
-    fused_loop<per0, per1, true, decltype(t0)&, decltype(t1)&, 1>(f.c, &s_item, t0, t1);
+    fused_loop<per0, per1, !SPLIT, decltype(t0)&, decltype(t1)&, 1>(f.c, &s_item, t0, t1);
 }
 
 // The 1-D kernel on the 32-column tiles of fft_col2w.hpp (round 4): fp32 interleaved, L0 >= L1 in {256, 512} (N = 2^16 ... 2^18);

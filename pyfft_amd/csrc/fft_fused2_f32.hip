@@ -49,11 +49,12 @@ extern "C" int mifft_fused2_f32_launch(int L0, int L1, const mifft::FusedArgs* f
     return -2;
 }
 
-// XCD-local work lists (strategy `fusedx`): interleaved fp32, L0 >= L1 in {256, 512, 1024}
-extern "C" int mifft_fused2x_f32_launch(int L0, int L1, const mifft::FusedArgs* f, unsigned grid, hipStream_t s) {
+// XCD-local work lists (strategy `fusedx`): fp32, L0 >= L1 in {256, 512, 1024}; split planes (user side) too
+extern "C" int mifft_fused2x_f32_launch(int L0, int L1, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s) {
 #define XL(A0, A1)                                                                                                  \
     if (L0 == 256 * A0 && L1 == 256 * A1) {                                                                         \
-        hipLaunchKernelGGL((mifft::fft_fused2x_kernel<float, A0, A1>), dim3(grid), dim3(256), 0, s, *f);            \
+        if (split) hipLaunchKernelGGL((mifft::fft_fused2x_kernel<float, A0, A1, true>), dim3(grid), dim3(256), 0, s, *f); \
+        else hipLaunchKernelGGL((mifft::fft_fused2x_kernel<float, A0, A1, false>), dim3(grid), dim3(256), 0, s, *f);      \
         return (int)hipGetLastError();                                                                              \
     }
     XL(1, 1)

@@ -27,7 +27,7 @@ extern "C" int mifft_fused2d_rect_f32_launch(int ny, int nx, const mifft::FusedA
     return MIFFT_E_UNSUPPORTED;
 }
 
-// 2-D shapes with a 512-point axis on 32-column tiles for that axis' pass (fft_fused2dw_kernel); *tiles0 / *tiles1 per transform
+// 2-D shapes with a 256- or 512-point axis on 32-column tiles for that axis' pass (fft_fused2dw_kernel); *tiles0 / *tiles1 per transform
 extern "C" int mifft_fused2dw_f32(int ny, int nx, const mifft::FusedArgs* f, unsigned grid, hipStream_t s, int query, unsigned* tiles0,
                                   unsigned* tiles1) {
 #define WIDE2D(NY, NX)                                                                                                   \
@@ -41,6 +41,12 @@ extern "C" int mifft_fused2dw_f32(int ny, int nx, const mifft::FusedArgs* f, uns
     WIDE2D(512, 512)
     WIDE2D(512, 1024)
     WIDE2D(1024, 512)
+    // a 256-point axis (round 4, second batch): 64 KiB tiles of 32 columns, as in the 1-D kernel for N = 2^16
+    WIDE2D(256, 256)
+    WIDE2D(256, 512)
+    WIDE2D(512, 256)
+    WIDE2D(256, 1024)
+    WIDE2D(1024, 256)
 #undef WIDE2D
     return MIFFT_E_UNSUPPORTED;
 }

@@ -29,10 +29,16 @@ extern "C" int mifft_fused3_f64_launch(int L0, int L1, const mifft::FusedArgs* f
 // 2-D (ny, nx) in {512, 1024}^2: 1024 x 1024 on the 512-thread tiles (fft_fused3d_kernel, split planes too); round 4: (512, 512) on the
 // 256-thread two-phase tiles (fft_fused2d_kernel<double>), (512, 1024) / (1024, 512) on the 512-thread tiles (axis length 512 * A)
 extern "C" int mifft_fused3d_f64_launch(int ny, int nx, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s) {
-    if (!split && ny == 512 && nx == 512) {
-        hipLaunchKernelGGL((mifft::fft_fused2d_kernel<double, 2, 2, false, true>), dim3(grid), dim3(256), 0, s, *f);
-        return (int)hipGetLastError();
+#define SMALL2D(NY, NX)                                                                                                            \
+    if (!split && ny == NY && nx == NX) {                                                                                          \
+        hipLaunchKernelGGL((mifft::fft_fused2d_kernel<double, NY / 256, NX / 256, false, true>), dim3(grid), dim3(256), 0, s, *f); \
+        return (int)hipGetLastError();                                                                                             \
     }
+    SMALL2D(512, 512)
+    SMALL2D(256, 256)      // (a 256-point axis: round 4, second batch)
+    SMALL2D(256, 512)
+    SMALL2D(512, 256)
+#undef SMALL2D
     if (!split && ny == 512 && nx == 1024) {
         hipLaunchKernelGGL((mifft::fft_fused3d_kernel<double, 1, 2, false, true>), dim3(grid), dim3(512), 0, s, *f);
         return (int)hipGetLastError();

@@ -49,5 +49,5 @@ extern "C" int mifft_fusedp(int f64, int x, int y, int z, const FusedPairArgs* f
     CASE(float, 0, 128, 128, 128, 32, 4, 16, XY128fn, YZ128fn, 3)
 #undef CASE
 #undef RL
-    return -2;
+    return variant == 0 ? mifft_fusedp_more(f64, x, y, z, f, grid, s, query, r0, tiles0, tiles1) : -2;   // fft_fusedp2.hip
 }

@@ -27,7 +27,7 @@ int mifft_nd2_f64_launch(int x, int y, int z, const mifft::TileArgs* a, hipStrea
 int mifft_fused2_f32_launch(int L0, int L1, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
 int mifft_fused2dw_f32(int ny, int nx, const mifft::FusedArgs* f, unsigned grid, hipStream_t s, int query, unsigned* tiles0, unsigned* tiles1);
 int mifft_fused2w_f32_launch(int L0, int L1, const mifft::FusedArgs* f, unsigned grid, hipStream_t s);
-int mifft_fused2x_f32_launch(int L0, int L1, const mifft::FusedArgs* f, unsigned grid, hipStream_t s);
+int mifft_fused2x_f32_launch(int L0, int L1, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
 int mifft_fused2d_f32_launch(int ny, int nx, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
 int mifft_fused3d_f64_launch(int ny, int nx, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s);
 int mifft_fusedx_f64(int L0, int L1, const mifft::FusedArgs* f, unsigned grid, hipStream_t s, int query, unsigned* tiles0, unsigned* tiles1);
@@ -41,6 +41,8 @@ int mifft_pair_f64(int kind, int k0, int k1, int k2, int split, const mifft::Pai
 int mifft_pair_f32(int kind, int k0, int k1, int k2, int split, const mifft::PairArgs* a, hipStream_t s, int query, int* width);
 int mifft_fusedp(int f64, int x, int y, int z, const mifft::FusedPairArgs* f, unsigned grid, hipStream_t s, int query, int* r0,
                  unsigned* tiles0, unsigned* tiles1);
+int mifft_fusedp_more(int f64, int x, int y, int z, const mifft::FusedPairArgs* f, unsigned grid, hipStream_t s, int query, int* r0,
+                      unsigned* tiles0, unsigned* tiles1);
 int mifft_nd2t(int f64, int x, int y, int z, const mifft::TileArgs* a, const mifft::TiledGeom* g, hipStream_t s, int query);
 int mifft_nd2t_split(int f64, int x, int y, int z, const mifft::TileArgs* a, const mifft::TiledGeom* g, hipStream_t s, int query);
 int mifft_mixed_supported_impl(int f64, int n);

@@ -691,11 +691,15 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     if (twod) {
         auto side = [](int L) { return L == 512 || L == 1024 || L == 2048; };
         auto side64 = [](int L) { return L == 512 || L == 1024; };
-        const bool okL = f64 ? (side64(p0->L) && side64(p1->L) && ((p0->L == 1024 && p1->L == 1024) || p0->layout != MIFFT_SPLIT))
-                             : (side(p0->L) && side(p1->L) && (p0->L == p1->L || p0->layout != MIFFT_SPLIT));
+        // a 256-point axis (interleaved): fp32 on the 32-column tiles next to a side <= 1024, fp64 next to a side <= 512
+        const bool small = p0->layout != MIFFT_SPLIT && (p0->L == 256 || p1->L == 256) &&
+                           (f64 ? (p0->L <= 512 && p1->L <= 512 && p0->L >= 256 && p1->L >= 256)
+                                : (g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 && mifft_fused2dw_f32(p1->L, p0->L, nullptr, 0, nullptr, 1, nullptr, nullptr) == 0));
+        const bool okL = small || (f64 ? (side64(p0->L) && side64(p1->L) && ((p0->L == 1024 && p1->L == 1024) || p0->layout != MIFFT_SPLIT))
+                             : (side(p0->L) && side(p1->L) && (p0->L == p1->L || p0->layout != MIFFT_SPLIT)));
         if (p1->kind != MIFFT_PASS_COL || !okL || p1->S != p0->L || p1->M != 1 ||
             p0->outer != p1->outer * p1->L || p0->layout != p1->layout || p0->inverse != p1->inverse)
-            return set_err(MIFFT_E_UNSUPPORTED, "fused2: the 2-D form takes (ny, nx) in {512, 1024, 2048}^2 (fp32; split planes: squares) / {512, 1024}^2 (fp64; split planes: 1024 x 1024)");
+            return set_err(MIFFT_E_UNSUPPORTED, "fused2: the 2-D form takes (ny, nx) in {512, 1024, 2048}^2 (fp32; split planes: squares; interleaved: also a 256-point side next to one <= 1024) / {256, 512, 1024}^2 (fp64; split planes: 1024 x 1024; 256 only next to <= 512)");
     } else {
     if (p0->kind != MIFFT_PASS_COL || p1->kind != MIFFT_PASS_COL || p0->S != 1 || p0->M != p1->L || p1->M != 1 ||
         p1->S != p0->L || p0->outer != p1->outer || p0->layout != p1->layout || p0->inverse != p1->inverse)
@@ -766,30 +770,34 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     return 0;
 }
 
-int mifft_launch_fused2x(const mifft_pass* p0, const mifft_pass* p1, const void* in0, void* out0, void* ring0, int32_t ring_slots,
-                         int32_t lag, const mifft_fused_sync* sync, int32_t grid, mifft_stream_t stream) {
+int mifft_launch_fused2x(const mifft_pass* p0, const mifft_pass* p1, const void* in0, const void* in1, void* out0, void* out1, void* ring0,
+                         int32_t ring_slots, int32_t lag, const mifft_fused_sync* sync, int32_t grid, mifft_stream_t stream) {
     int rc = validate(p0);
     if (rc) return rc;
     rc = validate(p1);
     if (rc) return rc;
-    if (p0->precision != MIFFT_F32 || p1->precision != MIFFT_F32 || p0->layout != MIFFT_INTERLEAVED || p1->layout != MIFFT_INTERLEAVED)
-        return set_err(MIFFT_E_UNSUPPORTED, "fused2x: interleaved fp32 only");
+    if (p0->precision != MIFFT_F32 || p1->precision != MIFFT_F32 || p0->layout != p1->layout)
+        return set_err(MIFFT_E_UNSUPPORTED, "fused2x: fp32 only, one layout on both sides");
+    const bool split = p0->layout == MIFFT_SPLIT;
     if (p0->kind != MIFFT_PASS_COL || p1->kind != MIFFT_PASS_COL || p0->S != 1 || p0->M != p1->L || p1->M != 1 ||
         p1->S != p0->L || p0->outer != p1->outer || p0->inverse != p1->inverse)
         return set_err(MIFFT_E_INVALID, "fused2x: passes are not the two passes of one long contiguous axis");
-    if (!in0 || !out0 || !ring0) return set_err(MIFFT_E_INVALID, "fused2x: null buffer");
+    if (!in0 || !out0 || !ring0 || (split && (!in1 || !out1))) return set_err(MIFFT_E_INVALID, "fused2x: null buffer");
     if (ring_slots < 2 || lag < 1 || lag >= ring_slots || grid < 1) return set_err(MIFFT_E_INVALID, "fused2x: need 1 <= lag < ring_slots, grid >= 1");
-    if (((uintptr_t)in0 | (uintptr_t)out0 | (uintptr_t)ring0) & 15) return set_err(MIFFT_E_INVALID, "data buffers must be 16-byte aligned");
+    if (((uintptr_t)in0 | (uintptr_t)out0 | (uintptr_t)ring0 | (uintptr_t)in1 | (uintptr_t)out1) & 15)
+        return set_err(MIFFT_E_INVALID, "data buffers must be 16-byte aligned");
     if (p1->outer == 0) return 0;
     const int64_t n = (int64_t)p0->L * p1->L;
     mifft::FusedArgs f;
-    fill_args(p0, in0, nullptr, ring0, nullptr, &f.p0);
-    fill_args(p1, ring0, nullptr, out0, nullptr, &f.p1);
+    fill_args(p0, in0, in1, ring0, nullptr, &f.p0);
+    fill_args(p1, ring0, nullptr, out0, out1, &f.p1);
     f.p0.ostride_out = n;
     f.p1.ostride_in = n;
+    f.p0.split_out = 0;      // the ring is interleaved for both layouts
+    f.p1.split = 0;
     rc = fill_ctl(&f.c, sync, p1->outer, lag, ring_slots, (unsigned)(p0->M / 16), (unsigned)(p1->S / 16), (hipStream_t)stream, "fused2x");
     if (rc) return rc;
-    rc = mifft_fused2x_f32_launch(p0->L, p1->L, &f, (unsigned)grid, (hipStream_t)stream);
+    rc = mifft_fused2x_f32_launch(p0->L, p1->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream);
     if (rc == MIFFT_E_UNSUPPORTED) return set_err(rc, "fused2x: no kernel for %d x %d", p0->L, p1->L);
     if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
     return 0;
@@ -798,6 +806,13 @@ int mifft_launch_fused2x(const mifft_pass* p0, const mifft_pass* p1, const void*
 int mifft_fused_pair_supported(int32_t precision, int32_t x, int32_t y, int32_t z) {
     if (precision != MIFFT_F32 && precision != MIFFT_F64) return MIFFT_E_UNSUPPORTED;
     return mifft_fusedp(precision == MIFFT_F64, x, y, z, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr) == 0 ? 0 : MIFFT_E_UNSUPPORTED;
+}
+
+int mifft_fused_pair_split(int32_t precision, int32_t x, int32_t y, int32_t z) {
+    if (precision != MIFFT_F32 && precision != MIFFT_F64) return 0;
+    int r0 = 0;
+    if (mifft_fusedp(precision == MIFFT_F64, x, y, z, nullptr, 0, nullptr, 1, &r0, nullptr, nullptr) != 0) return 0;
+    return r0;
 }
 
 int mifft_launch_fused_pair(const mifft_pass* passes, const void* in0, void* out0, void* ring0, int32_t ring_slots, int32_t lag,

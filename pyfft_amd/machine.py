@@ -72,8 +72,10 @@ class Machine(object):
         ring = 2 * lag
         if ring > slots or fill_cache:
             # fill_cache: transforms of many small tiles (the 128^3 cubes: 512 tiles of 32-64 KiB) want the whole ring whatever
-            # the tile count says -- fp64 128^3: lag 2 / ring 4 0.366, 4 / 7 0.388 (profiles/r04_b_cube_sweep.log)
-            ring = min(slots, 14)
+            # the tile count says -- fp64 128^3: lag 2 / ring 4 0.366, 4 / 7 0.388 (profiles/r04_b_cube_sweep.log); the smaller
+            # 3-D shapes up to 56 slots: 64^3 fp32 14 slots 0.246, 28 0.395, 56 0.418, 112 0.414; (64, 128, 128) 14 0.366, 28 0.417
+            # (profiles/r04_z_pair_small_axes_rings.log)
+            ring = min(slots, 56 if fill_cache else 14)
             lag = max(1, 4 * ring // 7)
         return lag, ring, grid
 

@@ -168,13 +168,26 @@ class FFTPlan(object):
                 self._slab_passes = k
 
         self._tables = {}      # key -> device allocation
-        self._table_ptrs = []  # per pass: (tw_L, tw_lo, tw_hi, shift)
-        for k in self._kernels:
+        self._table_ptrs = self._pass_tables(self._kernels)   # per pass: (tw_L, tw_lo, tw_hi, shift)
+        # 3-D shapes whose chain is a plane pass + a strided z pass but that have a persistent two-pair kernel (64- and 128-point axes,
+        # csrc/fft_fusedp2.hip): the four-pass list with the y axis factored R0 x R1 exists for that launch alone
+        self._pair_alt = None
+        self._pair_alt_tables = None
+        if not self._paired and not p.split and min(int(p.x), int(p.y), int(p.z)) > 1 and not D.no_fusedp_alt():
+            r0 = N.lib.mifft_fused_pair_split(p.precision, int(p.x), int(p.y), int(p.z))
+            if r0 > 0:
+                self._pair_alt = P.pair_chain(int(p.x), int(p.y), int(p.z), r0)
+                self._pair_alt_tables = self._pass_tables(self._pair_alt)
+
+    def _pass_tables(self, kernels):
+        p = self._params
+        ptrs = []
+        for k in kernels:
             if k.kind == N.PASS_ND:
                 # one w(len)^k table per axis (x, y, z) in the tw_L / tw_lo / tw_hi slots
                 tabs = [self._device_table(("L", n), lambda L=n: _twiddle_table(L, L, 1, p.complex_dtype)) if n > 1 else None
                         for n in (k.L, k.M, k.S)]
-                self._table_ptrs.append((tabs[0], tabs[1], tabs[2], 0))
+                ptrs.append((tabs[0], tabs[1], tabs[2], 0))
                 continue
             twL = self._device_table(("L", k.L), lambda L=k.L: _twiddle_table(L, L, 1, p.complex_dtype))
             if k.M > 1:
@@ -184,9 +197,10 @@ class FFTPlan(object):
                                         lambda n=n, s=shift: _twiddle_table(n, 1 << s, 1, p.complex_dtype))
                 hi = self._device_table(("hi", n, shift),
                                         lambda n=n, s=shift: _twiddle_table(n, n >> s, 1 << s, p.complex_dtype))
-                self._table_ptrs.append((twL, lo, hi, shift))
+                ptrs.append((twL, lo, hi, shift))
             else:
-                self._table_ptrs.append((twL, None, None, 0))
+                ptrs.append((twL, None, None, 0))
+        return ptrs
 
     def _device_table(self, key, make):
         if key not in self._tables:
@@ -205,19 +219,20 @@ class FFTPlan(object):
         coeff = (self._params.size if self._normalize else 1.0) * self._scale
         return 1.0 / coeff
 
-    def _descriptors(self, batch, is_inplace, inverse):
+    def _descriptors(self, batch, is_inplace, inverse, alt=False):
         """Pass descriptor array for (batch, schedule, direction); cached like the reference's
-        kernel.prepare(batch) (kernel.py:85-93)."""
-        key = (batch, is_inplace, inverse)
+        kernel.prepare(batch) (kernel.py:85-93).  alt: the four-pass list of the persistent two-pair launch (_pair_alt)."""
+        key = (batch, is_inplace, inverse, alt)
         d = self._desc_cache.get(key)
         if d is not None:
             return d
         p = self._params
         mach = self._context.machine
-        _, sched = P.buffer_schedule(self._kernels, is_inplace, self._via_temp)
-        arr = (N.MifftPass * max(1, len(self._kernels)))()
-        last = len(self._kernels) - 1
-        for i, (k, (src, dst), (twL, lo, hi, shift)) in enumerate(zip(self._kernels, sched, self._table_ptrs)):
+        kernels, tables = (self._pair_alt, self._pair_alt_tables) if alt else (self._kernels, self._table_ptrs)
+        _, sched = P.buffer_schedule(kernels, is_inplace, self._via_temp and not alt)
+        arr = (N.MifftPass * max(1, len(kernels)))()
+        last = len(kernels) - 1
+        for i, (k, (src, dst), (twL, lo, hi, shift)) in enumerate(zip(kernels, sched, tables)):
             d = arr[i]
             d.kind = k.kind
             d.precision = p.precision
@@ -248,7 +263,7 @@ class FFTPlan(object):
             # multi-pass plans: the first pass reads the input once, nobody re-reads what the last pass writes.  Only
             # while a transform's intermediate can stay in the 256 MiB Infinity Cache (256^3 fp64: 256 MiB per transform,
             # measured 1 % slower with the hints)
-            if last >= 1 and (p.size * p.complex_nbytes <= mach.stream_hint_item_bytes or self._slab_passes or self._paired) and not D.no_stream_hints():
+            if last >= 1 and (p.size * p.complex_nbytes <= mach.stream_hint_item_bytes or self._slab_passes or self._paired or alt) and not D.no_stream_hints():
                 if i == 0:
                     d.flags |= N.FLAG_STREAM_SRC
                 if i == last:
@@ -290,7 +305,10 @@ class FFTPlan(object):
         k = self._kernels
         nx, ny = int(p.x), int(p.y)
         sides = (512, 1024) if p.precision == N.F64 else (512, 1024, 2048)
-        if nx not in sides or ny not in sides or int(p.z) != 1 or len(k) != 2:
+        # a 256-point axis (interleaved; second batch of round 4): fp32 on the 32-column tiles next to a side <= 1024, fp64 next to <= 512
+        small = not p.split and 256 in (nx, ny) and min(nx, ny) == 256 and max(nx, ny) <= (512 if p.precision == N.F64 else 1024) and \
+            (p.precision == N.F64 or N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1)
+        if (not small and (nx not in sides or ny not in sides)) or int(p.z) != 1 or len(k) != 2:
             return False
         if p.split and (nx != ny or D.forced_strategy() != "fused" or (p.precision == N.F64 and nx != 1024)):
             return False      # (split planes: 29 % against 35 % for the pipelined chunks -- squares, on request only)
@@ -330,14 +348,14 @@ class FFTPlan(object):
         """Per-XCD work lists: interleaved fp32 1-D, both passes on the 256-thread tiles, a device with 8 XCDs."""
         p = self._params
         k = self._kernels
-        return (self._fused2_eligible() and not self._fused2d_eligible() and not p.split and p.precision == N.F32
+        return (self._fused2_eligible() and not self._fused2d_eligible() and p.precision == N.F32
                 and k[0].L <= 1024 and k[0].L >= k[1].L and self._context.machine.xcd_cooperative)
 
     def _fusedp_eligible(self):
         """3-D plans made of two pass pairs whose transform is a fraction of the last-level cache (128^3)."""
         p = self._params
-        return (self._paired and len(self._kernels) == 4 and not p.split
-                and N.lib.mifft_fused_pair_supported(p.precision, int(p.x), int(p.y), int(p.z)) == 0)
+        return self._pair_alt is not None or (self._paired and len(self._kernels) == 4 and not p.split
+                                              and N.lib.mifft_fused_pair_supported(p.precision, int(p.x), int(p.y), int(p.z)) == 0)
 
     def _xcd2_eligible(self):
         k = self._kernels
@@ -349,11 +367,12 @@ class FFTPlan(object):
         """First-pass tiles per transform of the plan's persistent form (what the lag is counted in)."""
         k = self._kernels
         if self._fusedp_eligible():
-            return int(self._params.z) * int(k[1].M)             # planes x R1
+            r1 = int((self._pair_alt or k)[1].M)
+            return int(self._params.z) * r1                      # planes x R1
         if self._fused2d_eligible():
-            if self._params.precision == N.F32 and not self._params.split and k[1].L == 512 and k[0].L <= 1024 and \
+            if self._params.precision == N.F32 and not self._params.split and k[1].L <= 512 and k[0].L <= 1024 and \
                     N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1:
-                return k[0].L // 32                              # a 512-point y axis: its pass runs on 32-column tiles
+                return k[0].L // 32                              # a 256- / 512-point y axis: its pass runs on 32-column tiles
             return k[0].L // 16                                  # nx / 16 column tiles of the y pass
         if self._params.precision == N.F64 and k[0].L == 2048:
             return k[0].M // 8                                   # 8-column tiles (csrc/fft_fusedx_f64.hip)
@@ -400,10 +419,23 @@ class FFTPlan(object):
             lag, ring = self.FUSEDX_LAG_RING
             if batch >= 8 * 2 * ring and 8 * ring * item_bytes <= mach.ring_bytes:
                 return ("fused2x", lag, ring, 2 * mach.compute_units)
+        # split-complex fp32 (re / im planes): a 16-column tile touches HALF of every 128-byte line of a plane; on the global list the
+        # sibling tile runs on another XCD and every input line crosses the fabric twice (PMC 2.48 x the algorithmic bytes), on an
+        # XCD's own list the siblings share one L2: 2^16 0.294 (pipelined chunks) -> 0.378, 2^17 0.285 -> 0.358, 2^18 0.355 (global
+        # list) -> 0.39; from 2^19 up the eight rings are too short (0.318-0.338 against 0.328; 2^20 0.28 against 0.33)
+        # (profiles/r04_w_split_per_xcd_lists.log)
+        if forced == "auto" and p.split and self._fusedx_eligible() and not D.no_fusedx():
+            ring = min(self.FUSEDX_LAG_RING[1], (mach.ring_bytes * 4 // 7) // (8 * item_bytes))
+            if ring >= 6 and batch >= 8 * 2 * ring:
+                return ("fused2x", ring // 2, ring, 2 * mach.compute_units)
         if forced in ("auto", "fused") and self._fusedp_eligible():
             geo = mach.fused_geometry(item_bytes, self._fused_tiles0(), D.fused_grid_per_cu(2), fill_cache=True)
             if geo is not None:
                 lag, ring, grid = geo
+                # a batch that cannot fill the ring twice: half the pipeline, down to the 14 slots of the cubes
+                while forced == "auto" and batch < 2 * ring and ring >= 28:
+                    ring //= 2
+                    lag = max(1, 4 * ring // 7)
                 lag, ring = D.fused_ring(lag, ring)
                 if batch >= 2 * ring:
                     return ("fusedp", lag, ring, grid)
@@ -419,6 +451,8 @@ class FFTPlan(object):
             # (profiles/r04_o_fp32_wide_tiles.log)
             wide32 = p.precision == N.F32 and not p.split and not self._fused2d_eligible() and self._kernels[0].L <= 512 and \
                 self._kernels[1].L <= 512 and N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1
+            # (the 2-D shapes with a 256-point axis run on the same 32-column tiles)
+            wide32 = wide32 or (p.precision == N.F32 and not p.split and self._fused2d_eligible() and min(int(p.x), int(p.y)) == 256)
             big = item_bytes >= ((1 << 20) if p.precision == N.F64 else ((1 << 19) if wide32 else (2 << 20)))
             # (fp64 2^22: 64 MiB per transform, three ring slots are all the cache holds)
             geo = mach.fused_geometry(item_bytes, self._fused_tiles0(), D.fused_grid_per_cu(1 if huge else 2),   # (four per CU for L <= 512: no gain)
@@ -525,10 +559,14 @@ class FFTPlan(object):
                 if strat[0] == "fused2x":
                     _, lag, ring, grid = strat
                     d0, d1 = descs[0], descs[1]
-                    N.check(N.lib.mifft_launch_fused2x(ctypes.byref(d0), ctypes.byref(d1), bufs0[d0.src], bufs0[d1.dst], bufs0[2], ring, lag,
-                                                       ctypes.byref(sync), grid, stream), "mifft_launch_fused2x")
+                    in1 = bufs1[d0.src] if bufs1 is not None else None
+                    out1 = bufs1[d1.dst] if bufs1 is not None else None
+                    N.check(N.lib.mifft_launch_fused2x(ctypes.byref(d0), ctypes.byref(d1), bufs0[d0.src], in1, bufs0[d1.dst], out1, bufs0[2],
+                                                       ring, lag, ctypes.byref(sync), grid, stream), "mifft_launch_fused2x")
                 elif strat[0] == "fusedp":
                     _, lag, ring, grid = strat
+                    if self._pair_alt is not None:       # the four-pass list of this launch alone (the chain is plane pass + z pass)
+                        descs = self._descriptors(batch, is_inplace, bool(inverse), alt=True)
                     N.check(N.lib.mifft_launch_fused_pair(descs, bufs0[descs[0].src], bufs0[descs[3].dst], bufs0[2], ring, lag,
                                                           ctypes.byref(sync), grid, stream), "mifft_launch_fused_pair")
                 else:

@@ -499,7 +499,10 @@ def test_planner_constants_come_from_the_device():
     assert _strategy_on(full, (1 << 21,), c64, 512)[1] == ("fused2", 8, 14, 512)              # 16 MiB transforms: the cache caps the ring
     assert _strategy_on(full, (1 << 17,), c64, 8192)[1] == ("fused2", 112, 224, 512)          # 2^16 / 2^17: 8 tiles of 32 columns per pass
     assert _strategy_on(full, (1 << 16,), c64, 16384)[1] == ("fused2", 112, 224, 512)
-    assert _strategy_on(full, (1 << 17,), numpy.float32, 8192)[1][0] == "pipelined"           # (split planes: no 32-column tiles)
+    assert _strategy_on(full, (1 << 17,), numpy.float32, 8192)[1] == ("fused2x", 8, 16, 512)  # split planes: sibling tiles share an XCD's L2
+    assert _strategy_on(full, (1 << 18,), numpy.float32, 4096)[1] == ("fused2x", 4, 8, 512)
+    assert _strategy_on(full, (256, 256), c64, 4096)[1] == ("fused2", 112, 224, 512)          # a 256-point axis on the 2-D persistent kernel
+    assert _strategy_on(full, (512, 256), c128, 1024)[1][0] == "fused2"
     assert _strategy_on(full, (1 << 22,), numpy.complex128, 64)[1][0] == "pipelined"          # fp64 2^22: a ring of three 64 MiB slots loses
     assert _strategy_on(full, (1 << 21,), numpy.complex128, 128)[1] == ("fused2", 4, 7, 256)
     assert _strategy_on(full, (1 << 22,), numpy.float64, 64)[1][0] == "pipelined"             # (split planes: no kernel)
@@ -559,8 +562,8 @@ def test_round4_entry_points_reject_bad_arguments_without_touching_the_gpu():
     assert N.lib.mifft_launch_fused2(byref(p0), byref(p1), 16, None, 32, None, 64, None, 28, 14, None, 512, None) == N.E_INVALID
     assert N.lib.mifft_launch_fused2(byref(p0), byref(p1), 16, None, 32, None, 64, None, 14, 14, byref(ok), 512, None) == N.E_INVALID   # lag == ring
     assert N.lib.mifft_launch_fused2(byref(p0), byref(p1), 16, None, 32, None, 64, None, 28, 0, byref(ok), 512, None) == N.E_INVALID    # sequential list: ring == outer
-    assert N.lib.mifft_launch_fused2x(byref(p0), byref(p1), 16, 32, 64, 8, 4, None, 512, None) == N.E_INVALID
-    assert N.lib.mifft_launch_fused2x(byref(p0), byref(p1), 16, 32, 64, 8, 4, byref(N.MifftFusedSync(4096, 4096, None)), 512, None) == N.E_INVALID
+    assert N.lib.mifft_launch_fused2x(byref(p0), byref(p1), 16, None, 32, None, 64, 8, 4, None, 512, None) == N.E_INVALID
+    assert N.lib.mifft_launch_fused2x(byref(p0), byref(p1), 16, None, 32, None, 64, 8, 4, byref(N.MifftFusedSync(4096, 4096, None)), 512, None) == N.E_INVALID
     # the persistent pass-pair form exists for the 128^3 cubes, interleaved
     assert N.lib.mifft_fused_pair_supported(N.F32, 128, 128, 128) == 0 and N.lib.mifft_fused_pair_supported(N.F64, 128, 128, 128) == 0
     assert N.lib.mifft_fused_pair_supported(N.F32, 256, 256, 256) == N.E_UNSUPPORTED

@@ -215,7 +215,8 @@ def test_generic_plans_build_only_what_they_run(ctx):
     assert tiled._tiled and tiled._inner_plans() == [] and tiled._tiled_tables[0] and tiled._tiled_tables[2] is None
     nd = ctx.getPlan((60, 16), dtype=numpy.complex64, any_size=True)
     assert nd._direct_nd is not None and nd._inner_plans() == [] and nd._rowplans == {}
-    work = ctx.getPlan((16, 16), parent_shape=(64, 64), dtype=numpy.float32)            # split planes: gather / N-D plan / scatter
+    assert ctx.getPlan((16, 16), parent_shape=(64, 64), dtype=numpy.float32)._tiled     # (split planes: one launch too, second batch of round 4)
+    work = ctx.getPlan((16, 4), parent_shape=(64, 64), dtype=numpy.complex64)           # a tile shape without a one-launch kernel: gather / N-D plan / scatter
     assert not work._tiled and len(work._inner_plans()) == 1
     blue = ctx.getPlan((4099, 4), dtype=numpy.complex64, any_size=True)                 # a long prime axis: padded power-of-two rows
     assert len(blue._inner_plans()) >= 1
@@ -495,3 +496,119 @@ def test_tiled_batch_split_planes_single_launch(ctx, shape, parent, dtype, monke
     plan3.execute(ctx.toGpu(re), ctx.toGpu(im), e_re, e_im, batch=batch)
     three = e_re.get() + 1j * e_im.get()
     assert numpy.abs(three - got).sum() / numpy.abs(got).sum() < eps
+
+
+# ---- 2-D shapes with a 256-point axis on the persistent kernels (second batch of round 4) ---------------------------------------
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
+@pytest.mark.parametrize("shape,batch", [((256, 256), 530), ((256, 512), 270), ((512, 256), 265), ((256, 1024), 140), ((1024, 256), 133)], ids=str)
+def test_fused_2d_256_sides(ctx, monkeypatch, shape, batch, dtype):
+    """(ny, nx) with a 256-point axis beyond the chain threshold, interleaved: fp32 next to a side <= 1024 on the 32-column tiles
+    (fft_fused2dw_kernel), fp64 next to a side <= 512 on the 256-thread two-phase tiles -- one persistent launch of two transposing
+    passes instead of ROW + strided COL per cache-sized chunk (pyfft/plan.py:135-171).  numpy with the reference's thresholds on
+    sampled transforms, input untouched, in place == out of place, inverse, and the chain's result to rounding."""
+    ny, nx = shape
+    cd = numpy.dtype(dtype)
+    f64 = cd == numpy.complex128
+    if f64 and max(shape) > 512:
+        assert ctx.getPlan(shape, dtype=dtype).strategy(batch)[0] in ("pipelined", "chain")
+        return
+    if f64:
+        batch = batch // 2 + 1
+    eps, mx = (1e-11, 1e-10) if f64 else (1.1e-6, 1e-5)
+    data = oracle.get_test_data(shape, cd, batch, 1300 + ny // 256 + nx // 64)
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    got = _execute(ctx, shape, cd, batch, data, expect="fused2")
+    assert numpy.array_equal(_execute(ctx, shape, cd, batch, data, inplace=True, expect="fused2"), got)
+    for item in (0, 1, batch // 2, batch - 1):
+        sl = slice(item * ny, (item + 1) * ny)
+        ref = numpy.fft.fft2(data[sl].astype(numpy.complex128))
+        assert numpy.abs(ref - got[sl]).sum() / numpy.abs(ref).sum() < eps
+        assert numpy.abs(ref - got[sl]).max() <= mx * numpy.abs(ref).max()
+    back = _execute(ctx, shape, cd, batch, got, inverse=True, expect="fused2")
+    assert oracle.difference(data, back, batch) < eps
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
+    want = _execute(ctx, shape, cd, batch, data, expect="chain")
+    assert oracle.difference(want, got, batch) < (1e-14 if f64 else 5e-7)
+
+
+# ---- split-complex fp32 on the persistent 1-D kernel: sibling tiles per item ------------------------------------------------------
+def _execute_split(ctx, shape, rdtype, batch, re, im, inplace=False, inverse=False, expect=None):
+    plan = ctx.getPlan(shape, dtype=rdtype)
+    if expect is not None:
+        assert plan.strategy(batch)[0] == expect, plan.strategy(batch)
+    a_re, a_im = ctx.toGpu(re), ctx.toGpu(im)
+    if inplace:
+        plan.execute(a_re, a_im, batch=batch, inverse=inverse)
+        return a_re.get(), a_im.get()
+    b_re, b_im = ctx.allocate(re.shape, re.dtype), ctx.allocate(im.shape, im.dtype)
+    plan.execute(a_re, a_im, b_re, b_im, batch=batch, inverse=inverse)
+    assert numpy.array_equal(a_re.get(), re) and numpy.array_equal(a_im.get(), im), "an out-of-place execute touched its input"
+    return b_re.get(), b_im.get()
+
+
+@pytest.mark.parametrize("n,batch,expect", [(1 << 16, 1100, "fused2x"), (1 << 17, 515, "fused2x"), (1 << 18, 259, "fused2x"),
+                                            (1 << 19, 130, "fused2"), (1 << 20, 70, "fused2")], ids=str)
+def test_split_planes_on_per_xcd_lists(ctx, monkeypatch, n, batch, expect):
+    """float32 planes (the reference's split layout, pyfft/plan.py:10-63 dtype rule) on the persistent 1-D kernels: 2^16 ... 2^18 by
+    the plan's own choice on the per-XCD work lists (the two 16-column tiles that share every 128-byte line of a plane then share an
+    L2), 2^19 / 2^20 on the global list.  The bits of the chain (same
+    tiles, same order of operations), in place == out of place, numpy with the reference's thresholds on sampled transforms, the
+    inverse round trip, batches that are no multiple of 8 (lists of unequal length)."""
+    rng = numpy.random.default_rng(1400 + n % 97)
+    re = rng.standard_normal(n * batch).astype(numpy.float32)
+    im = rng.standard_normal(n * batch).astype(numpy.float32)
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
+    want = _execute_split(ctx, (n,), numpy.float32, batch, re, im, expect="chain")
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    got = _execute_split(ctx, (n,), numpy.float32, batch, re, im, expect=expect)
+    assert numpy.array_equal(want[0], got[0]) and numpy.array_equal(want[1], got[1])
+    inp = _execute_split(ctx, (n,), numpy.float32, batch, re, im, inplace=True, expect=expect)
+    assert numpy.array_equal(inp[0], got[0]) and numpy.array_equal(inp[1], got[1])
+    for item in (0, batch // 2, batch - 1):
+        sl = slice(item * n, (item + 1) * n)
+        ref = numpy.fft.fft(re[sl].astype(numpy.float64) + 1j * im[sl].astype(numpy.float64))
+        g = got[0][sl] + 1j * got[1][sl]
+        assert numpy.abs(ref - g).sum() / numpy.abs(ref).sum() < 1.1e-6
+        assert numpy.abs(ref - g).max() <= 1e-5 * numpy.abs(ref).max()
+    back = _execute_split(ctx, (n,), numpy.float32, batch, got[0], got[1], inverse=True, expect=expect)
+    x = re + 1j * im
+    assert numpy.abs((back[0] + 1j * back[1]) - x).sum() / numpy.abs(x).sum() < 1.1e-6
+
+
+# ---- persistent two-pair kernel for 3-D shapes with 64- and 128-point axes (csrc/fft_fusedp2.hip) --------------------------------
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
+@pytest.mark.parametrize("shape,batch", [((64, 64, 64), 141), ((64, 128, 128), 59), ((128, 128, 64), 57), ((64, 128, 64), 115), ((128, 64, 128), 61),
+                                         ((64, 64, 128), 117), ((128, 64, 64), 113)], ids=str)
+def test_fused_pair_small_axes(ctx, monkeypatch, shape, batch, dtype):
+    """3-D shapes whose chain is one plane pass + one strided z pass (pyfft/plan.py:160-167: one chain per axis) and that have a
+    persistent two-pair kernel: beyond the chain threshold the plan factors the y axis R0 x R1 FOR THAT LAUNCH ALONE (four passes as
+    two tile kinds, the buffer between them a ring in the last-level cache).  The reference's thresholds against numpy on sampled
+    transforms, input untouched, in place == out of place, inverse round trip, the chain's result to rounding (another operation
+    order), and the A/B switch that keeps such shapes on their chain."""
+    cd = numpy.dtype(dtype)
+    f64 = cd == numpy.complex128
+    if f64:
+        batch = batch // 2 + 1
+    nz, ny, nx = shape
+    n = nz * ny * nx
+    eps, mx = (1e-11, 1e-10) if f64 else (1.1e-6, 1e-5)
+    plan = ctx.getPlan(shape, dtype=cd)
+    assert plan._pair_alt is not None and len(plan._kernels) == 2 and not plan._paired
+    assert plan.strategy(2)[0] == "chain"
+    data = oracle.get_test_data(shape, cd, batch, 1500 + nz + nx // 64)
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    got = _execute(ctx, shape, cd, batch, data, expect="fusedp")
+    assert numpy.array_equal(_execute(ctx, shape, cd, batch, data, inplace=True, expect="fusedp"), got)
+    for item in (0, 1, batch // 2, batch - 1):
+        ref = numpy.fft.fftn(data.reshape((batch,) + shape)[item].astype(numpy.complex128)).reshape(-1)
+        g = got.reshape(batch, n)[item]
+        assert numpy.abs(ref - g).sum() / numpy.abs(ref).sum() < eps
+        assert numpy.abs(ref - g).max() <= mx * numpy.abs(ref).max()
+    back = _execute(ctx, shape, cd, batch, got, inverse=True, expect="fusedp")
+    assert oracle.difference(data, back, batch) < eps
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
+    want = _execute(ctx, shape, cd, batch, data, expect="chain")
+    assert oracle.difference(want, got, batch) < (1e-14 if f64 else 5e-7)
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    monkeypatch.setenv("PYFFT_AMD_NO_FUSEDP_ALT", "1")
+    assert ctx.getPlan(shape, dtype=cd).strategy(batch)[0] == "pipelined"

@@ -57,16 +57,25 @@ def fill(buf, blk):
 
 def sweep(shape, dtype, gib, variants, reps=5, iters=10):
     dt = numpy.dtype(dtype)
+    split = dt.kind == "f"               # float32 / float64: two scalar planes per side (GIB counts both)
+    cbytes = dt.itemsize * (2 if split else 1)
     size = int(numpy.prod(shape))
-    batch = max(1, int(gib * (1 << 30)) // (size * dt.itemsize))
+    batch = max(1, int(gib * (1 << 30)) // (size * cbytes))
     rng = numpy.random.default_rng(7)
     nblk = min(batch, 8)
-    blk = (rng.standard_normal((nblk, size)) + 1j * rng.standard_normal((nblk, size))).astype(dt)
-    a = DeviceArray((size * batch,), dt)
-    b = DeviceArray((size * batch,), dt)
-    fill(a, blk)
+    cblk = rng.standard_normal((nblk, size)) + 1j * rng.standard_normal((nblk, size))
+    if split:
+        ins = [DeviceArray((size * batch,), dt), DeviceArray((size * batch,), dt)]
+        outs = [DeviceArray((size * batch,), dt), DeviceArray((size * batch,), dt)]
+        fill(ins[0], cblk.real.astype(dt)); fill(ins[1], cblk.imag.astype(dt))
+        blk = (cblk.real.astype(dt) + 1j * cblk.imag.astype(dt))
+    else:
+        blk = cblk.astype(dt)
+        ins, outs = [DeviceArray((size * batch,), dt)], [DeviceArray((size * batch,), dt)]
+        fill(ins[0], blk)
+    bufs = ins + outs
     refs = {}
-    out = numpy.empty(size, dt)
+    parts = [numpy.empty(size, dt) for _ in outs]
     for v in variants:
         for k in KEYS:
             os.environ.pop(k, None)
@@ -75,11 +84,14 @@ def sweep(shape, dtype, gib, variants, reps=5, iters=10):
         N.lib.mifft_debug_set(N.DEBUG_NARROW_TILES, int(os.environ.get("MIFFT_NARROW_TILES", "0")))
         try:
             plan = Plan(shape if len(shape) > 1 else shape[0], dtype=dt, wait_for_finish=True)
-            N.check(N.lib.mifft_memset(b.ptr, 0, b.nbytes, None))
-            plan.execute(a, b, batch=batch)
+            for b in outs:
+                N.check(N.lib.mifft_memset(b.ptr, 0, b.nbytes, None))
+            plan.execute(*bufs, batch=batch)
             worst = 0.0
             for item in sorted(set((0, 1, nblk - 1, batch // 2, batch - 2, batch - 1)) & set(range(batch))):
-                N.check(N.lib.mifft_memcpy_d2h(out.ctypes.data, b.ptr + item * size * dt.itemsize, size * dt.itemsize, None))
+                for part, b in zip(parts, outs):
+                    N.check(N.lib.mifft_memcpy_d2h(part.ctypes.data, b.ptr + item * size * dt.itemsize, size * dt.itemsize, None))
+                out = parts[0] + 1j * parts[1] if split else parts[0]
                 j = item % nblk
                 if j not in refs:
                     refs[j] = numpy.fft.fftn(blk[j].reshape(shape).astype(numpy.complex128)).reshape(-1)
@@ -89,12 +101,12 @@ def sweep(shape, dtype, gib, variants, reps=5, iters=10):
             for _ in range(reps):
                 e0 = Event().record(st)
                 for _ in range(iters):
-                    plan.execute(a, b, batch=batch, wait_for_finish=False)
+                    plan.execute(*bufs, batch=batch, wait_for_finish=False)
                 e1 = Event().record(st)
                 e1.synchronize()
                 best = min(best, e1.time_since(e0) / iters)
             plan.finish()
-            frac = 2.0 * size * batch * dt.itemsize / (best * 1e-3) / 8e12
+            frac = 2.0 * size * batch * cbytes / (best * 1e-3) / 8e12
             print("%-16s %-10s x %-6d %-28s %-40s %9.3f ms  %.3f  err %.1e" % (
                 "x".join(str(s) for s in shape), dt.name, batch, v, str(plan.strategy(batch)[:5]), best, frac, worst), flush=True)
             plan.close()
