@@ -310,17 +310,20 @@ int mifft_launch_fused2x(const mifft_pass *p0, const mifft_pass *p1, const void 
  * COL z as the chain holds them.  Work list as in mifft_launch_fused2 with the (ROW x, COL y R0) tiles as first-pass items and the
  * (COL y R1, COL z) tiles as second-pass items; the buffer between the two pairs is a ring of `ring_slots` whole transforms
  * (interleaved) that stays in the last-level cache.  Exists for the cubes whose transform is a fraction of that cache:
- *   mifft_fused_pair_supported   0 if (precision, x, y, z) has such a kernel for interleaved data, else MIFFT_E_UNSUPPORTED
+ *   mifft_fused_pair_supported   0 if (precision, layout, x, y, z) has such a kernel, else MIFFT_E_UNSUPPORTED.  Split-complex user
+ *                                buffers (in1 / out1 = the imaginary planes, layout MIFFT_SPLIT in the descriptors, the ring
+ *                                interleaved: MIFFT_FLAG_DST_INTERLEAVED on passes[1], MIFFT_FLAG_SRC_INTERLEAVED on passes[2]):
+ *                                the same shapes
  *   mifft_fused_pair_split       the factor R0 of the y axis that kernel is built for (y = R0 * R1), 0 if there is none.  For the
  *                                128^3 cubes it equals mifft_pair_split; the other shapes (64- and 128-point axes) have NO plain
  *                                pair launches -- their chain is a plane pass + a strided z pass -- and the caller builds the
  *                                four-pass list for this launch alone
  * Reference shape of the work: pyfft/plan.py:160-167 (one chain per axis), published row doc/source/index.rst:373 (128^3).
  */
-int mifft_fused_pair_supported(int32_t precision, int32_t x, int32_t y, int32_t z);
-int mifft_fused_pair_split(int32_t precision, int32_t x, int32_t y, int32_t z);
-int mifft_launch_fused_pair(const mifft_pass *passes, const void *in0, void *out0, void *ring0, int32_t ring_slots, int32_t lag,
-                            const mifft_fused_sync *sync, int32_t grid, mifft_stream_t stream);
+int mifft_fused_pair_supported(int32_t precision, int32_t layout, int32_t x, int32_t y, int32_t z);
+int mifft_fused_pair_split(int32_t precision, int32_t layout, int32_t x, int32_t y, int32_t z);
+int mifft_launch_fused_pair(const mifft_pass *passes, const void *in0, const void *in1, void *out0, void *out1, void *ring0,
+                            int32_t ring_slots, int32_t lag, const mifft_fused_sync *sync, int32_t grid, mifft_stream_t stream);
 
 /*
  * XCD-cooperative form of the same two-pass axis for N = 1024 * 1024, fp32 (csrc/fft_xcd2.hpp): ONE persistent launch of

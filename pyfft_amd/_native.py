@@ -177,9 +177,9 @@ PROTOTYPES = {
                                                       ctypes.c_int64, _vp, _vpp, _i32, _vpp]),
     "mifft_launch_fused2": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _sync_p, _i32, _vp]),
     "mifft_launch_fused2x": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _sync_p, _i32, _vp]),
-    "mifft_fused_pair_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
-    "mifft_fused_pair_split": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
-    "mifft_launch_fused_pair": (ctypes.c_int, [_pass_p, _vp, _vp, _vp, _i32, _i32, _sync_p, _i32, _vp]),
+    "mifft_fused_pair_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32]),
+    "mifft_fused_pair_split": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32]),
+    "mifft_launch_fused_pair": (ctypes.c_int, [_pass_p, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _sync_p, _i32, _vp]),
     "mifft_launch_xcd2": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "mifft_nd_tiled_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32]),
     "mifft_launch_nd_tiled": (ctypes.c_int, [_pass_p, ctypes.POINTER(MifftTiling), _vp, _vp, _vp]),

@@ -6,8 +6,9 @@
 using namespace mifft;
 
 // *tiles0 / *tiles1 = tiles per transform of the two pairs; query != 0: nothing is launched
-extern "C" int mifft_fusedp(int f64, int x, int y, int z, const FusedPairArgs* f, unsigned grid, hipStream_t s, int query, int* r0,
+extern "C" int mifft_fusedp(int f64, int split, int x, int y, int z, const FusedPairArgs* f, unsigned grid, hipStream_t s, int query, int* r0,
                             unsigned* tiles0, unsigned* tiles1) {
+    if (split) return mifft_fusedp_more(f64, split, x, y, z, f, grid, s, query, r0, tiles0, tiles1);   // split planes: fft_fusedp2.hip
 #define RL(...) RadixList<__VA_ARGS__>
     // development switch (A/B, MIFFT_PAIR): 3 = the first form of this kernel (narrow fp64 tiles, the (16, 2) y list in fp32)
     const int variant = mifft_debug_get(MIFFT_DEBUG_PAIR) == 3 ? 3 : 0;
@@ -49,5 +50,5 @@ extern "C" int mifft_fusedp(int f64, int x, int y, int z, const FusedPairArgs* f
     CASE(float, 0, 128, 128, 128, 32, 4, 16, XY128fn, YZ128fn, 3)
 #undef CASE
 #undef RL
-    return variant == 0 ? mifft_fusedp_more(f64, x, y, z, f, grid, s, query, r0, tiles0, tiles1) : -2;   // fft_fusedp2.hip
+    return variant == 0 ? mifft_fusedp_more(f64, 0, x, y, z, f, grid, s, query, r0, tiles0, tiles1) : -2;   // fft_fusedp2.hip
 }

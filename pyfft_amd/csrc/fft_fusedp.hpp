@@ -16,8 +16,8 @@
 namespace mifft {
 
 struct FusedPairArgs {
-    PairArgs a0;       // XY pair: in0 = user input, out0 = ring
-    PairArgs a1;       // YZ pair: in0 = ring, out0 = user output
+    PairArgs a0;       // XY pair: in0 (+ in1: split-complex planes) = user input, out0 = ring (always interleaved)
+    PairArgs a1;       // YZ pair: in0 = ring, out0 (+ out1) = user output
     FusedCtl c;
     long long n;       // elements per transform (= ring slot pitch)
 };
@@ -30,7 +30,7 @@ struct FusedPairArgs {
 template <typename T, typename C0, typename C1, unsigned PER0, unsigned PER1>
 __global__ void __launch_bounds__(C1::NT, C1::NT >= 512 ? 4 : 2) fft_fusedp_kernel(const FusedPairArgs f) {
     static_assert(C1::NT % C0::NT == 0, "the XY tile kind runs on a whole fraction of the work-group");
-    static_assert(C0::HALF == C1::HALF && !C0::SPLIT_IN && !C1::SPLIT_OUT, "interleaved tiles with the same exchange form");
+    static_assert(C0::HALF == C1::HALF && C0::SPLIT_IN == C1::SPLIT_OUT, "the same exchange form; split planes on both user sides or on neither");
     constexpr int SUB0 = C1::NT / C0::NT;
     constexpr int LDS0 = C0::P + C0::P / 16, LDS1 = C1::P + C1::P / 16;
     constexpr int LDSN = SUB0 * LDS0 > LDS1 ? SUB0 * LDS0 : LDS1;

@@ -9,8 +9,12 @@
 
 using namespace mifft;
 
-extern "C" int mifft_fusedp_more(int f64, int x, int y, int z, const FusedPairArgs* f, unsigned grid, hipStream_t s, int query, int* r0,
+extern "C" int mifft_fusedp_split(int f64, int x, int y, int z, const FusedPairArgs* f, unsigned grid, hipStream_t s, int query, int* r0,
+                                  unsigned* tiles0, unsigned* tiles1);   // fft_fusedp3.hip
+
+extern "C" int mifft_fusedp_more(int f64, int split, int x, int y, int z, const FusedPairArgs* f, unsigned grid, hipStream_t s, int query, int* r0,
                                  unsigned* tiles0, unsigned* tiles1) {
+    if (split) return mifft_fusedp_split(f64, x, y, z, f, grid, s, query, r0, tiles0, tiles1);
 #define RL(...) RadixList<__VA_ARGS__>
 #define CASE(T, F64, NX, NY, NZ, R0, R1, W, XY, YZ)                                               \
     if (f64 == F64 && x == NX && y == NY && z == NZ) {                                            \

@@ -39,9 +39,9 @@ int mifft_wave_launch(int f64, int N, const mifft::WaveArgs* a, int max_blocks, 
 int mifft_wave_16x16_launch(const mifft::WaveArgs* a, int max_blocks, hipStream_t s);
 int mifft_pair_f64(int kind, int k0, int k1, int k2, int split, const mifft::PairArgs* a, hipStream_t s, int query, int* width);
 int mifft_pair_f32(int kind, int k0, int k1, int k2, int split, const mifft::PairArgs* a, hipStream_t s, int query, int* width);
-int mifft_fusedp(int f64, int x, int y, int z, const mifft::FusedPairArgs* f, unsigned grid, hipStream_t s, int query, int* r0,
+int mifft_fusedp(int f64, int split, int x, int y, int z, const mifft::FusedPairArgs* f, unsigned grid, hipStream_t s, int query, int* r0,
                  unsigned* tiles0, unsigned* tiles1);
-int mifft_fusedp_more(int f64, int x, int y, int z, const mifft::FusedPairArgs* f, unsigned grid, hipStream_t s, int query, int* r0,
+int mifft_fusedp_more(int f64, int split, int x, int y, int z, const mifft::FusedPairArgs* f, unsigned grid, hipStream_t s, int query, int* r0,
                       unsigned* tiles0, unsigned* tiles1);
 int mifft_nd2t(int f64, int x, int y, int z, const mifft::TileArgs* a, const mifft::TiledGeom* g, hipStream_t s, int query);
 int mifft_nd2t_split(int f64, int x, int y, int z, const mifft::TileArgs* a, const mifft::TiledGeom* g, hipStream_t s, int query);

@@ -803,20 +803,20 @@ int mifft_launch_fused2x(const mifft_pass* p0, const mifft_pass* p1, const void*
     return 0;
 }
 
-int mifft_fused_pair_supported(int32_t precision, int32_t x, int32_t y, int32_t z) {
-    if (precision != MIFFT_F32 && precision != MIFFT_F64) return MIFFT_E_UNSUPPORTED;
-    return mifft_fusedp(precision == MIFFT_F64, x, y, z, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr) == 0 ? 0 : MIFFT_E_UNSUPPORTED;
+int mifft_fused_pair_supported(int32_t precision, int32_t layout, int32_t x, int32_t y, int32_t z) {
+    if ((precision != MIFFT_F32 && precision != MIFFT_F64) || (layout != MIFFT_INTERLEAVED && layout != MIFFT_SPLIT)) return MIFFT_E_UNSUPPORTED;
+    return mifft_fusedp(precision == MIFFT_F64, layout == MIFFT_SPLIT, x, y, z, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr) == 0 ? 0 : MIFFT_E_UNSUPPORTED;
 }
 
-int mifft_fused_pair_split(int32_t precision, int32_t x, int32_t y, int32_t z) {
-    if (precision != MIFFT_F32 && precision != MIFFT_F64) return 0;
+int mifft_fused_pair_split(int32_t precision, int32_t layout, int32_t x, int32_t y, int32_t z) {
+    if ((precision != MIFFT_F32 && precision != MIFFT_F64) || (layout != MIFFT_INTERLEAVED && layout != MIFFT_SPLIT)) return 0;
     int r0 = 0;
-    if (mifft_fusedp(precision == MIFFT_F64, x, y, z, nullptr, 0, nullptr, 1, &r0, nullptr, nullptr) != 0) return 0;
+    if (mifft_fusedp(precision == MIFFT_F64, layout == MIFFT_SPLIT, x, y, z, nullptr, 0, nullptr, 1, &r0, nullptr, nullptr) != 0) return 0;
     return r0;
 }
 
-int mifft_launch_fused_pair(const mifft_pass* passes, const void* in0, void* out0, void* ring0, int32_t ring_slots, int32_t lag,
-                            const mifft_fused_sync* sync, int32_t grid, mifft_stream_t stream) {
+int mifft_launch_fused_pair(const mifft_pass* passes, const void* in0, const void* in1, void* out0, void* out1, void* ring0, int32_t ring_slots,
+                            int32_t lag, const mifft_fused_sync* sync, int32_t grid, mifft_stream_t stream) {
     if (!passes) return set_err(MIFFT_E_INVALID, "fused pair: null pass list");
     for (int i = 0; i < 4; ++i) {
         const int rc = validate(&passes[i]);
@@ -824,18 +824,20 @@ int mifft_launch_fused_pair(const mifft_pass* passes, const void* in0, void* out
     }
     const mifft_pass *px = &passes[0], *py0 = &passes[1], *py1 = &passes[2], *pz = &passes[3];
     int kxy, kyz, keyxy[3], keyyz[3], sxy, syz;
-    if (classify_pair(px, py0, &kxy, keyxy, &sxy) != 0 || classify_pair(py1, pz, &kyz, keyyz, &syz) != 0 || kxy != 0 || kyz != 1 || sxy || syz ||
-        px->layout != MIFFT_INTERLEAVED || py1->S != (int64_t)px->L * py0->L || py1->L != py0->M || pz->outer != py0->outer / pz->L ||
-        py1->inverse != px->inverse)
-        return set_err(MIFFT_E_INVALID, "fused pair: not the (ROW x, COL y R0) + (COL y R1, COL z) pairs of one dense interleaved 3-D batch");
+    // split-complex plans: the XY pair reads the two planes, the YZ pair writes them, the ring between them is interleaved
+    const bool split = px->layout == MIFFT_SPLIT;
+    if (classify_pair(px, py0, &kxy, keyxy, &sxy) != 0 || classify_pair(py1, pz, &kyz, keyyz, &syz) != 0 || kxy != 0 || kyz != 1 ||
+        sxy != (split ? 1 : 0) || syz != (split ? 1 : 0) || pz->layout != px->layout ||
+        py1->S != (int64_t)px->L * py0->L || py1->L != py0->M || pz->outer != py0->outer / pz->L || py1->inverse != px->inverse)
+        return set_err(MIFFT_E_INVALID, "fused pair: not the (ROW x, COL y R0) + (COL y R1, COL z) pairs of one dense 3-D batch with an interleaved buffer between them");
     const int nx = px->L, ny = py0->L * (int)py0->M, nz = pz->L;
     const bool f64 = px->precision == MIFFT_F64;
     int r0 = 0;
     unsigned tiles0 = 0, tiles1 = 0;
-    if (mifft_fusedp(f64, nx, ny, nz, nullptr, 0, nullptr, 1, &r0, &tiles0, &tiles1) != 0 || r0 != py0->L)
-        return set_err(MIFFT_E_UNSUPPORTED, "fused pair: no kernel for %d x %d x %d with y = %d x %lld", nz, ny, nx, py0->L, (long long)py0->M);
-    if (!in0 || !out0 || !ring0) return set_err(MIFFT_E_INVALID, "fused pair: null buffer");
-    if (((uintptr_t)in0 | (uintptr_t)out0 | (uintptr_t)ring0) & 15) return set_err(MIFFT_E_INVALID, "data buffers must be 16-byte aligned");
+    if (mifft_fusedp(f64, split ? 1 : 0, nx, ny, nz, nullptr, 0, nullptr, 1, &r0, &tiles0, &tiles1) != 0 || r0 != py0->L)
+        return set_err(MIFFT_E_UNSUPPORTED, "fused pair: no kernel for %d x %d x %d with y = %d x %lld%s", nz, ny, nx, py0->L, (long long)py0->M, split ? " (split planes)" : "");
+    if (!in0 || !out0 || !ring0 || (split && (!in1 || !out1))) return set_err(MIFFT_E_INVALID, "fused pair: null buffer");
+    if (((uintptr_t)in0 | (uintptr_t)out0 | (uintptr_t)ring0 | (uintptr_t)in1 | (uintptr_t)out1) & 15) return set_err(MIFFT_E_INVALID, "data buffers must be 16-byte aligned");
     if (ring0 == in0 || ring0 == out0) return set_err(MIFFT_E_INVALID, "fused pair: the ring must be a buffer of its own");
     if (grid < 1) return set_err(MIFFT_E_INVALID, "fused pair: grid >= 1");
     const long long batch = pz->outer;
@@ -846,6 +848,7 @@ int mifft_launch_fused_pair(const mifft_pass* passes, const void* in0, void* out
     memset(&f, 0, sizeof(f));
     f.n = (long long)nx * ny * nz;
     f.a0.in0 = in0;
+    f.a0.in1 = split ? in1 : nullptr;
     f.a0.out0 = ring0;
     f.a0.tw[0] = px->tw_L;     // w(nx)
     f.a0.tw[1] = py0->tw_L;    // w(R0)
@@ -856,6 +859,7 @@ int mifft_launch_fused_pair(const mifft_pass* passes, const void* in0, void* out
     f.a0.scale = px->scale * py0->scale;
     f.a1.in0 = ring0;
     f.a1.out0 = out0;
+    f.a1.out1 = split ? out1 : nullptr;
     f.a1.tw[1] = py1->tw_L;    // w(R1)
     f.a1.tw[2] = pz->tw_L;     // w(nz)
     f.a1.inverse = f.a0.inverse;
@@ -863,7 +867,7 @@ int mifft_launch_fused_pair(const mifft_pass* passes, const void* in0, void* out
     int rc = fill_ctl(&f.c, sync, batch, lag, ring_slots, tiles0, tiles1, (hipStream_t)stream, "fused pair");
     if (rc) return rc;
     if (lag == 0) grid = resident_grid(grid, 2);
-    rc = mifft_fusedp(f64, nx, ny, nz, &f, (unsigned)grid, (hipStream_t)stream, 0, nullptr, nullptr, nullptr);
+    rc = mifft_fusedp(f64, split ? 1 : 0, nx, ny, nz, &f, (unsigned)grid, (hipStream_t)stream, 0, nullptr, nullptr, nullptr);
     if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
     return 0;
 }

@@ -173,8 +173,8 @@ class FFTPlan(object):
         # csrc/fft_fusedp2.hip): the four-pass list with the y axis factored R0 x R1 exists for that launch alone
         self._pair_alt = None
         self._pair_alt_tables = None
-        if not self._paired and not p.split and min(int(p.x), int(p.y), int(p.z)) > 1 and not D.no_fusedp_alt():
-            r0 = N.lib.mifft_fused_pair_split(p.precision, int(p.x), int(p.y), int(p.z))
+        if not self._paired and min(int(p.x), int(p.y), int(p.z)) > 1 and not D.no_fusedp_alt():
+            r0 = N.lib.mifft_fused_pair_split(p.precision, p.layout, int(p.x), int(p.y), int(p.z))
             if r0 > 0:
                 self._pair_alt = P.pair_chain(int(p.x), int(p.y), int(p.z), r0)
                 self._pair_alt_tables = self._pass_tables(self._pair_alt)
@@ -355,7 +355,7 @@ class FFTPlan(object):
         """3-D plans made of two pass pairs whose transform is a fraction of the last-level cache (128^3)."""
         p = self._params
         return self._pair_alt is not None or (self._paired and len(self._kernels) == 4 and not p.split
-                                              and N.lib.mifft_fused_pair_supported(p.precision, int(p.x), int(p.y), int(p.z)) == 0)
+                                              and N.lib.mifft_fused_pair_supported(p.precision, p.layout, int(p.x), int(p.y), int(p.z)) == 0)
 
     def _xcd2_eligible(self):
         k = self._kernels
@@ -567,7 +567,9 @@ class FFTPlan(object):
                     _, lag, ring, grid = strat
                     if self._pair_alt is not None:       # the four-pass list of this launch alone (the chain is plane pass + z pass)
                         descs = self._descriptors(batch, is_inplace, bool(inverse), alt=True)
-                    N.check(N.lib.mifft_launch_fused_pair(descs, bufs0[descs[0].src], bufs0[descs[3].dst], bufs0[2], ring, lag,
+                    in1 = bufs1[descs[0].src] if bufs1 is not None else None
+                    out1 = bufs1[descs[3].dst] if bufs1 is not None else None
+                    N.check(N.lib.mifft_launch_fused_pair(descs, bufs0[descs[0].src], in1, bufs0[descs[3].dst], out1, bufs0[2], ring, lag,
                                                           ctypes.byref(sync), grid, stream), "mifft_launch_fused_pair")
                 else:
                     _, lag, ring, grid = strat

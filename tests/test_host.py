@@ -564,10 +564,19 @@ def test_round4_entry_points_reject_bad_arguments_without_touching_the_gpu():
     assert N.lib.mifft_launch_fused2(byref(p0), byref(p1), 16, None, 32, None, 64, None, 28, 0, byref(ok), 512, None) == N.E_INVALID    # sequential list: ring == outer
     assert N.lib.mifft_launch_fused2x(byref(p0), byref(p1), 16, None, 32, None, 64, 8, 4, None, 512, None) == N.E_INVALID
     assert N.lib.mifft_launch_fused2x(byref(p0), byref(p1), 16, None, 32, None, 64, 8, 4, byref(N.MifftFusedSync(4096, 4096, None)), 512, None) == N.E_INVALID
-    # the persistent pass-pair form exists for the 128^3 cubes, interleaved
-    assert N.lib.mifft_fused_pair_supported(N.F32, 128, 128, 128) == 0 and N.lib.mifft_fused_pair_supported(N.F64, 128, 128, 128) == 0
-    assert N.lib.mifft_fused_pair_supported(N.F32, 256, 256, 256) == N.E_UNSUPPORTED
-    assert N.lib.mifft_fused_pair_supported(7, 128, 128, 128) == N.E_UNSUPPORTED
+    # the persistent pass-pair form exists for the shapes with every axis in {64, 128}, both precisions, both layouts
+    I, S = N.INTERLEAVED, N.SPLIT
+    assert N.lib.mifft_fused_pair_supported(N.F32, I, 128, 128, 128) == 0 and N.lib.mifft_fused_pair_supported(N.F64, I, 128, 128, 128) == 0
+    assert N.lib.mifft_fused_pair_supported(N.F32, I, 256, 256, 256) == N.E_UNSUPPORTED
+    assert N.lib.mifft_fused_pair_supported(7, I, 128, 128, 128) == N.E_UNSUPPORTED and N.lib.mifft_fused_pair_supported(N.F32, 5, 128, 128, 128) == N.E_UNSUPPORTED
+    for x in (64, 128):
+        for y in (64, 128):
+            for z in (64, 128):
+                want = {64: 16, 128: 32}[y]
+                assert N.lib.mifft_fused_pair_split(N.F32, I, x, y, z) == want and N.lib.mifft_fused_pair_split(N.F64, I, x, y, z) == want
+                assert N.lib.mifft_fused_pair_split(N.F64, S, x, y, z) == want
+                assert N.lib.mifft_fused_pair_split(N.F32, S, x, y, z) == want
+    assert N.lib.mifft_fused_pair_split(N.F32, I, 64, 32, 64) == 0
     from pyfft_amd import passes as P
     chain = P.build_chain(128, 128, 128, N.F32, interleaved=True)
     assert [k.pair_with_next for k in chain] == [True, False, True, False]
@@ -576,11 +585,11 @@ def test_round4_entry_points_reject_bad_arguments_without_touching_the_gpu():
         d.kind, d.precision, d.layout, d.L, d.M, d.S = k.kind, N.F32, N.INTERLEAVED, k.L, k.M, k.S
         d.outer, d.outer_stride_in, d.outer_stride_out, d.scale = k.outer_per_batch * 20, k.outer_stride, k.outer_stride, 1.0
         d.tw_L, d.tw_lo, d.tw_hi, d.tw_shift = 16, 16, 16, 4
-    assert N.lib.mifft_launch_fused_pair(descs, 16, 32, 32, 4, 2, byref(ok), 512, None) == N.E_INVALID and "ring" in N.last_error()
-    assert N.lib.mifft_launch_fused_pair(descs, 16, 32, 64, 4, 4, byref(ok), 512, None) == N.E_INVALID
-    assert N.lib.mifft_launch_fused_pair(descs, 16, 32, 64, 4, 2, None, 512, None) == N.E_INVALID
+    assert N.lib.mifft_launch_fused_pair(descs, 16, None, 32, None, 32, 4, 2, byref(ok), 512, None) == N.E_INVALID and "ring" in N.last_error()
+    assert N.lib.mifft_launch_fused_pair(descs, 16, None, 32, None, 64, 4, 4, byref(ok), 512, None) == N.E_INVALID
+    assert N.lib.mifft_launch_fused_pair(descs, 16, None, 32, None, 64, 4, 2, None, 512, None) == N.E_INVALID
     descs[1].L, descs[1].M = 64, 2                      # not the split the library's kernels use
-    assert N.lib.mifft_launch_fused_pair(descs, 16, 32, 64, 4, 2, byref(ok), 512, None) in (N.E_INVALID, N.E_UNSUPPORTED)
+    assert N.lib.mifft_launch_fused_pair(descs, 16, None, 32, None, 64, 4, 2, byref(ok), 512, None) in (N.E_INVALID, N.E_UNSUPPORTED)
     # device properties carry the memory-system fields the planner reads
     assert {"llc_bytes", "num_xcc"} <= {f[0] for f in N.MifftDeviceProps._fields_}
 

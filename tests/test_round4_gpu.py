@@ -612,3 +612,39 @@ def test_fused_pair_small_axes(ctx, monkeypatch, shape, batch, dtype):
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
     monkeypatch.setenv("PYFFT_AMD_NO_FUSEDP_ALT", "1")
     assert ctx.getPlan(shape, dtype=cd).strategy(batch)[0] == "pipelined"
+
+
+@pytest.mark.parametrize("shape,rdtype,batch", [((64, 64, 64), numpy.float32, 141), ((64, 128, 128), numpy.float32, 59), ((64, 128, 64), numpy.float32, 115),
+                                                ((64, 64, 128), numpy.float32, 117), ((64, 64, 64), numpy.float64, 71), ((128, 128, 128), numpy.float64, 15),
+                                                ((128, 128, 64), numpy.float64, 30), ((128, 64, 128), numpy.float64, 31), ((128, 64, 64), numpy.float64, 57),
+                                                ((64, 128, 128), numpy.float64, 29), ((128, 128, 128), numpy.float32, 29), ((128, 64, 64), numpy.float32, 113)], ids=str)
+def test_fused_pair_split_planes(ctx, monkeypatch, shape, rdtype, batch):
+    """Split-complex user buffers (the reference's float32 / float64 dtypes, pyfft/plan.py:10-63) on the persistent two-pair kernel:
+    the XY tiles read the re / im planes, the YZ tiles write them, the ring between them is interleaved.  Every shape of
+    {64, 128}^3 in both precisions.  numpy with the reference's thresholds
+    on sampled transforms, planes untouched, in place == out of place, inverse round trip, the chain's result to rounding."""
+    rd = numpy.dtype(rdtype)
+    f64 = rd == numpy.float64
+    eps, mx = (1e-11, 1e-10) if f64 else (1.1e-6, 1e-5)
+    n = shape[0] * shape[1] * shape[2]
+    rng = numpy.random.default_rng(1600 + sum(shape))
+    re = rng.standard_normal(n * batch).astype(rd)
+    im = rng.standard_normal(n * batch).astype(rd)
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    assert ctx.getPlan(shape, dtype=rd)._pair_alt is not None
+    got = _execute_split(ctx, shape, rd, batch, re, im, expect="fusedp")
+    inp = _execute_split(ctx, shape, rd, batch, re, im, inplace=True, expect="fusedp")
+    assert numpy.array_equal(inp[0], got[0]) and numpy.array_equal(inp[1], got[1])
+    for item in (0, 1, batch // 2, batch - 1):
+        sl = slice(item * n, (item + 1) * n)
+        ref = numpy.fft.fftn((re[sl].astype(numpy.float64) + 1j * im[sl].astype(numpy.float64)).reshape(shape)).reshape(-1)
+        g = got[0][sl] + 1j * got[1][sl]
+        assert numpy.abs(ref - g).sum() / numpy.abs(ref).sum() < eps
+        assert numpy.abs(ref - g).max() <= mx * numpy.abs(ref).max()
+    back = _execute_split(ctx, shape, rd, batch, got[0], got[1], inverse=True, expect="fusedp")
+    x = re + 1j * im
+    assert numpy.abs((back[0] + 1j * back[1]) - x).sum() / numpy.abs(x).sum() < eps
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
+    want = _execute_split(ctx, shape, rd, batch, re, im, expect="chain")
+    d = numpy.abs((want[0] - got[0]) + 1j * (want[1] - got[1])).sum() / numpy.abs(want[0] + 1j * want[1]).sum()
+    assert d < (1e-14 if f64 else 5e-7)
