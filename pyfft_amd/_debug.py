@@ -58,6 +58,11 @@ def no_fusedx():
     return bool(os.environ.get("PYFFT_AMD_NO_FUSEDX"))
 
 
+def split_fusedx():
+    """PYFFT_AMD_SPLIT_FUSEDX=1: split-complex fp32 N = 2^16 ... 2^18 on the per-XCD work lists (the default at 2^18 only; A/B)"""
+    return bool(os.environ.get("PYFFT_AMD_SPLIT_FUSEDX"))
+
+
 def no_fusedp_alt():
     """PYFFT_AMD_NO_FUSEDP_ALT=1: no persistent two-pair launch for shapes whose chain is a plane pass + a z pass (A/B, tests)"""
     return bool(os.environ.get("PYFFT_AMD_NO_FUSEDP_ALT"))

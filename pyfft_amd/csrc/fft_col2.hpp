@@ -88,7 +88,7 @@ struct TileNoHook {
 template <typename T, int A, bool TR, bool TW, bool SPLIT, bool WT = false, bool NTIN = false, bool NTOUT = false,
           bool SPLIT_OUT = SPLIT, typename LdsPtr = cplx<T>*, typename Hook = TileNoHook>
 __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_in, const long long o_out,
-                                          const long long rem0, LdsPtr lds, Hook hook = Hook()) {
+                                          const long long rem0, LdsPtr lds, Hook hook = Hook(), const int tid_in = -1) {
     constexpr int L = A * 256;
     constexpr int PPT = A * 16;
     constexpr int PITCH = Col2Lds<A, TR, sizeof(cplx<T>)>::PITCH;
@@ -96,7 +96,8 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
     constexpr bool kDoubleBuf = Col2Lds<A, TR, sizeof(cplx<T>)>::DOUBLE;
     constexpr bool kHalf = Col2Lds<A, TR, sizeof(cplx<T>)>::HALF;
 
-    int tid = threadIdx.x;
+    // tid_in: the thread's index within the tile when a bigger work-group runs several tiles side by side (fft_fused2s_kernel)
+    int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x;
     asm volatile("" : "+v"(tid));  // same reason as below, for the per-thread (VGPR) address pieces
     const int c = tid & 15, b0 = tid >> 4;
     // The shift amounts are laundered through an empty asm so that, when this body sits inside the persistent

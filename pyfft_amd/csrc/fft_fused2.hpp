@@ -331,6 +331,38 @@ __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
         });
 }
 
+// Split-complex fp32 with the SIBLING tiles side by side (second batch of round 4).  A 16-column tile touches 64 bytes per row of
+// each plane -- half of a 128-byte line; on the global list the tile that owns the other half runs on whatever XCD drew its ticket
+// and every input line crosses the fabric twice (PMC 2.48 x the algorithmic bytes, profiles/r04v_pmc_traffic_split.log).  Here a
+// work-group is 512 threads = two 256-thread tiles in lock step (same code, same barriers), each on its own half of the LDS array,
+// and an item is the sibling pair: both halves of every line are requested by the same CU at the same time.  One work-group per CU
+// (the two tiles take the registers of two ordinary work-groups).  TWOD: the 2-D data flow (two transposing passes, no twiddle).
+template <int A0, int A1, bool TWOD>
+__global__ void __launch_bounds__(512, 2) fft_fused2s_kernel(const FusedArgs f) {
+    constexpr int E0 = Col2Lds<A0, true, sizeof(cplx<float>)>::ELEMS, E1 = Col2Lds<A1, TWOD, sizeof(cplx<float>)>::ELEMS;
+    constexpr int E = E0 > E1 ? E0 : E1;
+    __shared__ __attribute__((aligned(16))) cplx<float> lds[2 * E];
+    __shared__ unsigned s_item;
+    constexpr unsigned per0 = A0 > A1 ? 1u : (unsigned)(A1 / A0);
+    constexpr unsigned per1 = A1 > A0 ? 1u : (unsigned)(A0 / A1);
+    fused_loop<per0, per1, false>(
+        f.c, &s_item,
+        [&](unsigned t, unsigned slot, unsigned item, auto hook) {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const int sub = __builtin_amdgcn_readfirstlane(tid >> 8);      // (wave-uniform: the tile's base addresses stay in SGPRs)
+            col2_tile<float, A0, true, !TWOD, true, true, false, false, false>(f.p0, (long long)t, (long long)slot, ((long long)item * 2 + sub) * 16,
+                                                                              lds + sub * E, hook, tid & 255);
+        },
+        [&](unsigned slot, unsigned t, unsigned item, auto hook) {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const int sub = __builtin_amdgcn_readfirstlane(tid >> 8);
+            col2_tile<float, A1, TWOD, false, false, false, false, false, true>(f.p1, (long long)slot, (long long)t, ((long long)item * 2 + sub) * 16,
+                                                                               lds + sub * E, hook, tid & 255);
+        });
+}
+
 // XCD-local lists (see fused_xcc_id above).  The intermediate is written WRITE-THROUGH, as in the global form: a work-group that
 // drains another XCD's list (work stealing) produces and consumes across XCDs, and only write-through stores + the consumer's
 // acquire are coherent between two L2s.  (Round 3's plain-store variant -- the intermediate in the owning XCD's L2 -- measured

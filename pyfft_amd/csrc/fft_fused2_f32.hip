@@ -11,7 +11,11 @@ template <int A0, int A1> int launch(const mifft::FusedArgs* f, int split, unsig
     const bool wt = mifft_debug_get(MIFFT_DEBUG_STORE) == 2;   // A/B: write-through stores of the output
     // (round 4: every interleaved size streams non-temporally, not only 1024 x 1024 -- the XCD-local development kernel always
     // did, which was part of its lead at 2^19; the plain and write-through forms stay as A/B instances of 1024 x 1024)
-    if (split)
+    // split planes: the sibling 16-column tiles side by side in a 512-thread work-group (fft_fused2s_kernel); MIFFT_NARROW_TILES=1: the
+    // round-2 form, one tile per 256-thread work-group (A/B)
+    if (split && mifft_debug_get(MIFFT_DEBUG_NARROW_TILES) != 1)
+        hipLaunchKernelGGL((mifft::fft_fused2s_kernel<A0, A1, false>), dim3(grid), dim3(512), 0, s, *f);
+    else if (split)
         hipLaunchKernelGGL((mifft::fft_fused2_kernel<float, A0, A1, true, 0>), dim3(grid), dim3(256), 0, s, *f);
     else if (nt && wt && A0 == 4 && A1 == 4)
         hipLaunchKernelGGL((mifft::fft_fused2_kernel<float, A0, A1, false, 2>), dim3(grid), dim3(256), 0, s, *f);
@@ -72,8 +76,10 @@ extern "C" int mifft_fused2d_rect_f32_launch(int ny, int nx, const mifft::FusedA
 extern "C" int mifft_fused2d_f32_launch(int ny, int nx, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s) {
     if (ny != nx) return split ? MIFFT_E_UNSUPPORTED : mifft_fused2d_rect_f32_launch(ny, nx, f, grid, s);
     const int L = nx;
+    const bool sib = split && mifft_debug_get(MIFFT_DEBUG_NARROW_TILES) != 1;   // split planes: sibling tiles side by side
     if (L == 512) {
-        if (split) hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 2, 2, true, false>), dim3(grid), dim3(256), 0, s, *f);
+        if (sib) hipLaunchKernelGGL((mifft::fft_fused2s_kernel<2, 2, true>), dim3(grid), dim3(512), 0, s, *f);
+        else if (split) hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 2, 2, true, false>), dim3(grid), dim3(256), 0, s, *f);
         else hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 2, 2, false, true>), dim3(grid), dim3(256), 0, s, *f);
         return (int)hipGetLastError();
     }
@@ -83,7 +89,8 @@ extern "C" int mifft_fused2d_f32_launch(int ny, int nx, const mifft::FusedArgs* 
         return (int)hipGetLastError();
     }
     if (L != 1024) return MIFFT_E_UNSUPPORTED;
-    if (split) hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 4, 4, true, false>), dim3(grid), dim3(256), 0, s, *f);
+    if (sib) hipLaunchKernelGGL((mifft::fft_fused2s_kernel<4, 4, true>), dim3(grid), dim3(512), 0, s, *f);
+    else if (split) hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 4, 4, true, false>), dim3(grid), dim3(256), 0, s, *f);
     else hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 4, 4, false, true>), dim3(grid), dim3(256), 0, s, *f);
     return (int)hipGetLastError();
 }

@@ -751,12 +751,19 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
         if (!mixed32) tiles0 /= 2;
         tiles1 /= 2;
     }
+    // split-complex fp32 on the 256-thread tiles (1-D: L0, L1 <= 1024; 2-D: the 512 and 1024 squares): an item is the two sibling
+    // 16-column tiles side by side in one 512-thread work-group (fft_fused2s_kernel)
+    const bool siblings = !f64 && split && !narrow && p0->L <= 1024 && p1->L <= 1024;
+    if (siblings) {
+        tiles0 /= 2;
+        tiles1 /= 2;
+    }
     // 2-D fp32 interleaved with a 512-point axis: that axis' pass on 32-column tiles (p1->L = ny, p0->L = nx)
     const bool wide2d = twod && !f64 && !split && !narrow && mifft_fused2dw_f32(p1->L, p0->L, nullptr, 0, nullptr, 1, &tiles0, &tiles1) == 0;
     rc = fill_ctl(&f.c, sync, p1->outer, lag, ring_slots, tiles0, tiles1, (hipStream_t)stream, "fused2");
     if (rc) return rc;
     if (lag == 0) {
-        const bool wide = (f64 && (p0->L > 512 || p1->L > 512)) || p0->L == 2048 || p1->L == 2048;       // 512- / 1024-thread tiles: one work-group per CU
+        const bool wide = (f64 && (p0->L > 512 || p1->L > 512)) || p0->L == 2048 || p1->L == 2048 || siblings;       // 512- / 1024-thread tiles: one work-group per CU
         grid = resident_grid(grid, wide ? 1 : 2);
     }
     rc = wide2d ? mifft_fused2dw_f32(p1->L, p0->L, &f, (unsigned)grid, (hipStream_t)stream, 0, nullptr, nullptr) :

@@ -324,7 +324,16 @@ class FFTPlan(object):
         k = self._kernels
         if self._params.precision == N.F64:
             return not (k[0].L <= 512 and k[1].L <= 512)     # (fp64 2^16 ... 2^18 and the (512, 512) square: 256-thread tiles)
+        if self._split_siblings():
+            return max(k[0].L, k[1].L) > 512                 # two sibling tiles side by side on 512 threads: L = 1024 fills a CU
         return k[1].L == 2048 or (self._fused2d_eligible() and k[0].L == 2048)
+
+    def _split_siblings(self):
+        """Split-complex fp32 on the 256-thread tiles: the persistent kernel runs the two 16-column tiles that share every 128-byte
+        line of a plane side by side in one 512-thread work-group (csrc/fft_fused2.hpp fft_fused2s_kernel)."""
+        k = self._kernels
+        return (self._params.precision == N.F32 and self._params.split and len(k) == 2 and k[0].L <= 1024 and k[1].L <= 1024
+                and N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1)
 
     def _fused2_eligible(self):
         p = self._params
@@ -369,6 +378,8 @@ class FFTPlan(object):
         if self._fusedp_eligible():
             r1 = int((self._pair_alt or k)[1].M)
             return int(self._params.z) * r1                      # planes x R1
+        if self._split_siblings():
+            return (k[0].L if self._fused2d_eligible() else k[0].M) // 32   # sibling pairs of 16-column tiles
         if self._fused2d_eligible():
             if self._params.precision == N.F32 and not self._params.split and k[1].L <= 512 and k[0].L <= 1024 and \
                     N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1:
@@ -420,11 +431,13 @@ class FFTPlan(object):
             if batch >= 8 * 2 * ring and 8 * ring * item_bytes <= mach.ring_bytes:
                 return ("fused2x", lag, ring, 2 * mach.compute_units)
         # split-complex fp32 (re / im planes): a 16-column tile touches HALF of every 128-byte line of a plane; on the global list the
-        # sibling tile runs on another XCD and every input line crosses the fabric twice (PMC 2.48 x the algorithmic bytes), on an
-        # XCD's own list the siblings share one L2: 2^16 0.294 (pipelined chunks) -> 0.378, 2^17 0.285 -> 0.358, 2^18 0.355 (global
-        # list) -> 0.39; from 2^19 up the eight rings are too short (0.318-0.338 against 0.328; 2^20 0.28 against 0.33)
-        # (profiles/r04_w_split_per_xcd_lists.log)
-        if forced == "auto" and p.split and self._fusedx_eligible() and not D.no_fusedx():
+        # sibling tile ran on another XCD and every input line crossed the fabric twice (PMC 2.48 x the algorithmic bytes).  Two
+        # answers (second batch of round 4): the siblings side by side in one 512-thread work-group (fft_fused2s_kernel: the default
+        # form of the global list, below), or one work list per XCD, where the siblings share an L2.  Same process, 2 GiB
+        # (profiles/r04_ac_split_siblings.log): 2^16 side by side 0.423 / per XCD 0.358 (pipelined chunks 0.27), 2^17 0.352 / 0.330,
+        # 2^18 0.337 / 0.357, 2^19 0.330 / 0.338 with rings too short to last, 2^20 0.331 / 0.28 -- so the lists only at 2^18
+        if forced == "auto" and p.split and self._fusedx_eligible() and not D.no_fusedx() and \
+                (self._kernels[0].L * self._kernels[1].L == (1 << 18) or D.split_fusedx()):
             ring = min(self.FUSEDX_LAG_RING[1], (mach.ring_bytes * 4 // 7) // (8 * item_bytes))
             if ring >= 6 and batch >= 8 * 2 * ring:
                 return ("fused2x", ring // 2, ring, 2 * mach.compute_units)
@@ -453,12 +466,20 @@ class FFTPlan(object):
                 self._kernels[1].L <= 512 and N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1
             # (the 2-D shapes with a 256-point axis run on the same 32-column tiles)
             wide32 = wide32 or (p.precision == N.F32 and not p.split and self._fused2d_eligible() and min(int(p.x), int(p.y)) == 256)
+            # (split planes with the sibling tiles side by side: 2^16 0.27 on the pipelined chunks, 0.42 here)
+            wide32 = wide32 or (self._split_siblings() and not self._fused2d_eligible())
             big = item_bytes >= ((1 << 20) if p.precision == N.F64 else ((1 << 19) if wide32 else (2 << 20)))
             # (fp64 2^22: 64 MiB per transform, three ring slots are all the cache holds)
             geo = mach.fused_geometry(item_bytes, self._fused_tiles0(), D.fused_grid_per_cu(1 if huge else 2),   # (four per CU for L <= 512: no gain)
                                       min_slots=3 if (p.precision == N.F64 and self._kernels[0].L == 2048) else None)
             if geo is not None:
                 lag, ring, grid = geo
+                if self._split_siblings() and not huge:
+                    # two 512-thread work-groups per CU, items of two tiles: the ring that measured best is HALF the cache ring in bytes
+                    # whatever the tile count (2 GiB: 2^16 224 slots 0.421 / 112 0.392 / 56 0.279, 2^17 224 0.359 / 112 0.374 / 56 0.276,
+                    # 2^18 112 0.308 / 56 0.339; profiles/r04_ac_split_siblings.log)
+                    ring = max(self._context.machine.MIN_RING_SLOTS, (mach.ring_bytes // 2) // item_bytes)
+                    lag = max(1, ring // 2)
                 if huge:
                     lag, ring = D.fused3_lag_ring(lag, ring)
                 lag, ring = D.fused_ring(lag, ring)

@@ -546,12 +546,13 @@ def _execute_split(ctx, shape, rdtype, batch, re, im, inplace=False, inverse=Fal
     return b_re.get(), b_im.get()
 
 
-@pytest.mark.parametrize("n,batch,expect", [(1 << 16, 1100, "fused2x"), (1 << 17, 515, "fused2x"), (1 << 18, 259, "fused2x"),
+@pytest.mark.parametrize("n,batch,expect", [(1 << 16, 1100, "fused2"), (1 << 17, 515, "fused2"), (1 << 18, 259, "fused2x"),
                                             (1 << 19, 130, "fused2"), (1 << 20, 70, "fused2")], ids=str)
 def test_split_planes_on_per_xcd_lists(ctx, monkeypatch, n, batch, expect):
-    """float32 planes (the reference's split layout, pyfft/plan.py:10-63 dtype rule) on the persistent 1-D kernels: 2^16 ... 2^18 by
-    the plan's own choice on the per-XCD work lists (the two 16-column tiles that share every 128-byte line of a plane then share an
-    L2), 2^19 / 2^20 on the global list.  The bits of the chain (same
+    """float32 planes (the reference's split layout, pyfft/plan.py:10-63 dtype rule) on the persistent 1-D kernels by the plan's own
+    choice: the two 16-column tiles that share every 128-byte line of a plane run side by side in one 512-thread work-group
+    (2^16, 2^17, 2^19, 2^20: fft_fused2s_kernel on the global list) or share an XCD's L2 (2^18: the per-XCD lists); with
+    PYFFT_AMD_SPLIT_FUSEDX the lists also below 2^18.  The bits of the chain (same
     tiles, same order of operations), in place == out of place, numpy with the reference's thresholds on sampled transforms, the
     inverse round trip, batches that are no multiple of 8 (lists of unequal length)."""
     rng = numpy.random.default_rng(1400 + n % 97)
@@ -573,6 +574,10 @@ def test_split_planes_on_per_xcd_lists(ctx, monkeypatch, n, batch, expect):
     back = _execute_split(ctx, (n,), numpy.float32, batch, got[0], got[1], inverse=True, expect=expect)
     x = re + 1j * im
     assert numpy.abs((back[0] + 1j * back[1]) - x).sum() / numpy.abs(x).sum() < 1.1e-6
+    if n < (1 << 18):
+        monkeypatch.setenv("PYFFT_AMD_SPLIT_FUSEDX", "1")
+        lists = _execute_split(ctx, (n,), numpy.float32, batch, re, im, expect="fused2x")
+        assert numpy.array_equal(lists[0], got[0]) and numpy.array_equal(lists[1], got[1])
 
 
 # ---- persistent two-pair kernel for 3-D shapes with 64- and 128-point axes (csrc/fft_fusedp2.hip) --------------------------------
