@@ -63,6 +63,11 @@ def split_fusedx():
     return bool(os.environ.get("PYFFT_AMD_SPLIT_FUSEDX"))
 
 
+def no_split_rowfirst():
+    """PYFFT_AMD_NO_SPLIT_ROWFIRST=1: split-complex fp32 2-D plans keep the round-3 rule (pipelined chunks; two transposing passes on request)"""
+    return bool(os.environ.get("PYFFT_AMD_NO_SPLIT_ROWFIRST"))
+
+
 def no_fusedp_alt():
     """PYFFT_AMD_NO_FUSEDP_ALT=1: no persistent two-pair launch for shapes whose chain is a plane pass + a z pass (A/B, tests)"""
     return bool(os.environ.get("PYFFT_AMD_NO_FUSEDP_ALT"))

@@ -695,7 +695,10 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
         const bool small = p0->layout != MIFFT_SPLIT && (p0->L == 256 || p1->L == 256) &&
                            (f64 ? (p0->L <= 512 && p1->L <= 512 && p0->L >= 256 && p1->L >= 256)
                                 : (g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 && mifft_fused2dw_f32(p1->L, p0->L, nullptr, 0, nullptr, 1, nullptr, nullptr) == 0));
-        const bool okL = small || (f64 ? (side64(p0->L) && side64(p1->L) && ((p0->L == 1024 && p1->L == 1024) || p0->layout != MIFFT_SPLIT))
+        // split-complex fp32: the row-first kernel (fft_fused2r.hpp), (ny, nx) in {256, 512, 1024}^2
+        const bool rowfirst_ok = !f64 && p0->layout == MIFFT_SPLIT && g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 &&
+                                 mifft_fused2r_f32(p1->L, p0->L, nullptr, 0, nullptr, 1) == 0;
+        const bool okL = small || rowfirst_ok || (f64 ? (side64(p0->L) && side64(p1->L) && ((p0->L == 1024 && p1->L == 1024) || p0->layout != MIFFT_SPLIT))
                              : (side(p0->L) && side(p1->L) && (p0->L == p1->L || p0->layout != MIFFT_SPLIT)));
         if (p1->kind != MIFFT_PASS_COL || !okL || p1->S != p0->L || p1->M != 1 ||
             p0->outer != p1->outer * p1->L || p0->layout != p1->layout || p0->inverse != p1->inverse)
@@ -728,7 +731,15 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     fill_args(p1, ring0, nullptr, out0, out1, &f.p1);
     f.p0.ostride_out = n;  // ring slot pitch
     f.p1.ostride_in = n;
-    if (twod) {
+    // split-complex fp32 2-D: the chain's own order -- ROW x from the planes, COL y to the planes -- on the persistent list
+    const bool rowfirst = twod && !f64 && p0->layout == MIFFT_SPLIT && g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 &&
+                          mifft_fused2r_f32(p1->L, p0->L, nullptr, 0, nullptr, 1) == 0;
+    if (rowfirst) {
+        f.p0.nt = 4;                // the ring is written through (the consumers acquire it, fft_fused2.hpp)
+        f.p0.scale = p0->scale;
+        f.p1.logMS = f.p1.logS = ilog2(p0->L);   // M = 1, S = nx
+        f.p1.has_tw = 0;
+    } else if (twod) {
         // pass 0 = the y axis as a transposing column pass over in[y][x] (ny rows of M = nx columns, S = 1) -> ring[x][ky], with the
         // COL pass's table w(ny); pass 1 = the x axis as the same pass over ring[x][ky] (nx rows of ny columns) -> out[ky][kx],
         // with the ROW pass's table w(nx)
@@ -741,6 +752,10 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     // tiles per transform: 2-D: nx / 16 column tiles in pass 0, ny / 16 in pass 1; 1-D: L1 / 16 and L0 / 16 (fp64 2048-point
     // passes: the tile widths of fft_fusedx_f64.hip)
     unsigned tiles0 = twod ? (unsigned)(p0->L / 16) : (unsigned)(p0->M / 16), tiles1 = twod ? (unsigned)(p1->L / 16) : (unsigned)(p1->S / 16);
+    if (rowfirst) {                 // groups of 16 rows, then tiles of 16 columns
+        tiles0 = (unsigned)(p1->L / 16);
+        tiles1 = (unsigned)(p0->L / 16);
+    }
     if (wide64 && mifft_fusedx_f64(p0->L, p1->L, nullptr, 0, nullptr, 1, &tiles0, &tiles1) != 0)
         return set_err(MIFFT_E_UNSUPPORTED, "fused2: no kernel for %d x %d", p0->L, p1->L);
     // fp32 interleaved 2^16 ... 2^18: 32-column tiles (fft_col2w.hpp) -- half as many tiles per pass
@@ -753,7 +768,7 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     }
     // split-complex fp32 on the 256-thread tiles (1-D: L0, L1 <= 1024; 2-D: the 512 and 1024 squares): an item is the two sibling
     // 16-column tiles side by side in one 512-thread work-group (fft_fused2s_kernel)
-    const bool siblings = !f64 && split && !narrow && p0->L <= 1024 && p1->L <= 1024;
+    const bool siblings = !f64 && split && !narrow && !rowfirst && p0->L <= 1024 && p1->L <= 1024;
     if (siblings) {
         tiles0 /= 2;
         tiles1 /= 2;
@@ -766,7 +781,8 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
         const bool wide = (f64 && (p0->L > 512 || p1->L > 512)) || p0->L == 2048 || p1->L == 2048 || siblings;       // 512- / 1024-thread tiles: one work-group per CU
         grid = resident_grid(grid, wide ? 1 : 2);
     }
-    rc = wide2d ? mifft_fused2dw_f32(p1->L, p0->L, &f, (unsigned)grid, (hipStream_t)stream, 0, nullptr, nullptr) :
+    rc = rowfirst ? mifft_fused2r_f32(p1->L, p0->L, &f, (unsigned)grid, (hipStream_t)stream, 0) :
+         wide2d ? mifft_fused2dw_f32(p1->L, p0->L, &f, (unsigned)grid, (hipStream_t)stream, 0, nullptr, nullptr) :
          wide32 ? mifft_fused2w_f32_launch(p0->L, p1->L, &f, (unsigned)grid, (hipStream_t)stream) :
          wide64 ? mifft_fusedx_f64(p0->L, p1->L, &f, (unsigned)grid, (hipStream_t)stream, 0, nullptr, nullptr) : twod ? (f64 ? mifft_fused3d_f64_launch(p1->L, p0->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream)
                      : mifft_fused2d_f32_launch(p1->L, p0->L, &f, split ? 1 : 0, (unsigned)grid, (hipStream_t)stream))

@@ -304,6 +304,14 @@ class FFTPlan(object):
         p = self._params
         k = self._kernels
         nx, ny = int(p.x), int(p.y)
+        if p.split and p.precision == N.F32 and nx in (256, 512, 1024) and ny in (256, 512, 1024) and int(p.z) == 1 and len(k) == 2 and \
+                N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1 and not D.no_split_rowfirst() and \
+                ((ny, nx) not in ((256, 256), (256, 1024)) or D.forced_strategy() == "fused"):
+            # split-complex fp32: the row-first persistent kernel (csrc/fft_fused2r.hpp), second batch of round 4: 1024^2 0.359 (pipelined
+            # chunks) -> 0.398, 512^2 0.364 -> 0.425, (1024, 512) 0.374 -> 0.425, (512, 1024) 0.347 -> 0.389, (1024, 256) 0.376 -> 0.399,
+            # (256, 512) 0.365 -> 0.397, (512, 256) 0.345 -> 0.386; (256, 256) 0.330 against 0.380 and (256, 1024) 0.363 against 0.369 stay
+            # on the chunks (on request only)
+            return (k[0].kind == N.PASS_ROW and k[0].L == nx and k[1].kind == N.PASS_COL and k[1].L == ny and k[1].M == 1 and k[1].S == nx)
         sides = (512, 1024) if p.precision == N.F64 else (512, 1024, 2048)
         # a 256-point axis (interleaved; second batch of round 4): fp32 on the 32-column tiles next to a side <= 1024, fp64 next to <= 512
         small = not p.split and 256 in (nx, ny) and min(nx, ny) == 256 and max(nx, ny) <= (512 if p.precision == N.F64 else 1024) and \
@@ -311,7 +319,7 @@ class FFTPlan(object):
         if (not small and (nx not in sides or ny not in sides)) or int(p.z) != 1 or len(k) != 2:
             return False
         if p.split and (nx != ny or D.forced_strategy() != "fused" or (p.precision == N.F64 and nx != 1024)):
-            return False      # (split planes: 29 % against 35 % for the pipelined chunks -- squares, on request only)
+            return False      # (split planes, two transposing passes: 29 % against 35 % for the pipelined chunks -- squares, on request only)
         if (ny, nx) == (512, 2048) and D.forced_strategy() != "fused":
             # 512-point columns on the 512-thread tiles (16 points per thread, 64 KiB tiles, one work-group per CU): 0.355 against
             # 0.392 for the pipelined chunks -- the one rectangle that loses (profiles/r04_c_rect_sweep.log); on request only
@@ -333,7 +341,13 @@ class FFTPlan(object):
         line of a plane side by side in one 512-thread work-group (csrc/fft_fused2.hpp fft_fused2s_kernel)."""
         k = self._kernels
         return (self._params.precision == N.F32 and self._params.split and len(k) == 2 and k[0].L <= 1024 and k[1].L <= 1024
-                and N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1)
+                and N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1 and not self._split_rowfirst())
+
+    def _split_rowfirst(self):
+        """Split-complex fp32 2-D plans on the row-first persistent kernel (ROW x from the planes, COL y to the planes)."""
+        p = self._params
+        return (p.precision == N.F32 and p.split and int(p.y) > 1 and int(p.z) == 1 and self._fused2d_eligible()
+                and int(p.x) <= 1024 and int(p.y) <= 1024 and N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1 and not D.no_split_rowfirst())
 
     def _fused2_eligible(self):
         p = self._params
@@ -378,6 +392,8 @@ class FFTPlan(object):
         if self._fusedp_eligible():
             r1 = int((self._pair_alt or k)[1].M)
             return int(self._params.z) * r1                      # planes x R1
+        if self._split_rowfirst():
+            return int(self._params.y) // 16                     # groups of 16 rows
         if self._split_siblings():
             return (k[0].L if self._fused2d_eligible() else k[0].M) // 32   # sibling pairs of 16-column tiles
         if self._fused2d_eligible():
@@ -467,17 +483,18 @@ class FFTPlan(object):
             # (the 2-D shapes with a 256-point axis run on the same 32-column tiles)
             wide32 = wide32 or (p.precision == N.F32 and not p.split and self._fused2d_eligible() and min(int(p.x), int(p.y)) == 256)
             # (split planes with the sibling tiles side by side: 2^16 0.27 on the pipelined chunks, 0.42 here)
-            wide32 = wide32 or (self._split_siblings() and not self._fused2d_eligible())
+            wide32 = wide32 or (self._split_siblings() and not self._fused2d_eligible()) or self._split_rowfirst()
             big = item_bytes >= ((1 << 20) if p.precision == N.F64 else ((1 << 19) if wide32 else (2 << 20)))
             # (fp64 2^22: 64 MiB per transform, three ring slots are all the cache holds)
             geo = mach.fused_geometry(item_bytes, self._fused_tiles0(), D.fused_grid_per_cu(1 if huge else 2),   # (four per CU for L <= 512: no gain)
                                       min_slots=3 if (p.precision == N.F64 and self._kernels[0].L == 2048) else None)
             if geo is not None:
                 lag, ring, grid = geo
-                if self._split_siblings() and not huge:
+                if (self._split_siblings() and not huge) or self._split_rowfirst():
                     # two 512-thread work-groups per CU, items of two tiles: the ring that measured best is HALF the cache ring in bytes
                     # whatever the tile count (2 GiB: 2^16 224 slots 0.421 / 112 0.392 / 56 0.279, 2^17 224 0.359 / 112 0.374 / 56 0.276,
-                    # 2^18 112 0.308 / 56 0.339; profiles/r04_ac_split_siblings.log)
+                    # 2^18 112 0.308 / 56 0.339; profiles/r04_ac_split_siblings.log); the same for the row-first 2-D kernel: 1024^2 14 slots
+                    # 0.398 / 28 0.348, 512^2 56 0.425 / 112 0.360, (1024, 512) 28 0.425 / 56 0.354 (profiles/r04_ag_split_2d_row_first.log)
                     ring = max(self._context.machine.MIN_RING_SLOTS, (mach.ring_bytes // 2) // item_bytes)
                     lag = max(1, ring // 2)
                 if huge:

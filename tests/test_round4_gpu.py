@@ -653,3 +653,37 @@ def test_fused_pair_split_planes(ctx, monkeypatch, shape, rdtype, batch):
     want = _execute_split(ctx, shape, rd, batch, re, im, expect="chain")
     d = numpy.abs((want[0] - got[0]) + 1j * (want[1] - got[1])).sum() / numpy.abs(want[0] + 1j * want[1]).sum()
     assert d < (1e-14 if f64 else 5e-7)
+
+
+# ---- split-complex fp32 2-D plans on the row-first persistent kernel (csrc/fft_fused2r.hpp) ------------------------------------------
+@pytest.mark.parametrize("shape,batch", [((1024, 1024), 37), ((512, 512), 140), ((256, 256), 530), ((512, 1024), 70), ((1024, 512), 67), ((256, 1024), 135),
+                                         ((1024, 256), 131), ((256, 512), 261), ((512, 256), 259)], ids=str)   # ((256, 256), (256, 1024): on request only)
+def test_fused_2d_split_row_first(ctx, monkeypatch, shape, batch):
+    """float32 planes, 2-D, beyond the chain threshold: ROW x from the planes and COL y to the planes on the persistent work list (the
+    chain's own order, pyfft/plan.py:135-171, instead of two transposing passes whose 16-column tiles read half lines of the planes).
+    numpy with the reference's thresholds on sampled transforms, planes untouched, in place == out of place, inverse round trip, the
+    chain's result to rounding, and the A/B switch back to the pipelined chunks."""
+    ny, nx = shape
+    n = ny * nx
+    rng = numpy.random.default_rng(1700 + ny // 256 + nx // 64)
+    re = rng.standard_normal(n * batch).astype(numpy.float32)
+    im = rng.standard_normal(n * batch).astype(numpy.float32)
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto" if shape not in ((256, 256), (256, 1024)) else "fused")
+    got = _execute_split(ctx, shape, numpy.float32, batch, re, im, expect="fused2")
+    inp = _execute_split(ctx, shape, numpy.float32, batch, re, im, inplace=True, expect="fused2")
+    assert numpy.array_equal(inp[0], got[0]) and numpy.array_equal(inp[1], got[1])
+    for item in (0, 1, batch // 2, batch - 1):
+        sl = slice(item * n, (item + 1) * n)
+        ref = numpy.fft.fft2((re[sl].astype(numpy.float64) + 1j * im[sl].astype(numpy.float64)).reshape(shape)).reshape(-1)
+        g = got[0][sl] + 1j * got[1][sl]
+        assert numpy.abs(ref - g).sum() / numpy.abs(ref).sum() < 1.1e-6
+        assert numpy.abs(ref - g).max() <= 1e-5 * numpy.abs(ref).max()
+    back = _execute_split(ctx, shape, numpy.float32, batch, got[0], got[1], inverse=True, expect="fused2")
+    x = re + 1j * im
+    assert numpy.abs((back[0] + 1j * back[1]) - x).sum() / numpy.abs(x).sum() < 1.1e-6
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
+    want = _execute_split(ctx, shape, numpy.float32, batch, re, im, expect="chain")
+    assert numpy.abs((want[0] - got[0]) + 1j * (want[1] - got[1])).sum() / numpy.abs(want[0] + 1j * want[1]).sum() < 5e-7
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    monkeypatch.setenv("PYFFT_AMD_NO_SPLIT_ROWFIRST", "1")
+    assert ctx.getPlan(shape, dtype=numpy.float32).strategy(batch)[0] == "pipelined"

@@ -13,16 +13,16 @@ cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 
 # 1. kernel stats + PMC traffic of the same command, per configuration (writes profiles/traffic_<c>.json and
 #    profiles/<tag>_<c>_kernel_stats.csv)
-timeout 2400 python3 tools/pmc_traffic.py --tag $TAG c2 c3 c4 c4s c5 cube cubed > $OUT/pmc_traffic.log 2>&1
+timeout 2400 python3 tools/pmc_traffic.py --tag $TAG c2 c3 c4 c4s c5 cube cubed c2s > $OUT/pmc_traffic.log 2>&1
 cp $OUT/pmc_traffic.log $P/${TAG}_pmc_traffic.log
 cp profiles/traffic_*.json profiles/${TAG}_*_kernel_stats.csv $P/ 2>/dev/null
 
 # 2. the bench lines (after the traffic files exist, so that every line carries roofline.traffic): default line (c2) and every other BASELINE configuration
 timeout 600 python3 bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
-for c in c1 c3 c4 c4s c5 cube cubed; do
+for c in c1 c3 c4 c4s c5 cube cubed c2s c3s; do
     timeout 600 python3 bench.py --config $c --steps 10 --warmup 2 > $OUT/bench_$c.json 2> $OUT/bench_$c.err
 done
-for c in c1 c2 c3 c4 c4s c5 cube cubed; do cp $OUT/bench_$c.json $P/${TAG}_bench_$c.json; done
+for c in c1 c2 c3 c4 c4s c5 cube cubed c2s c3s; do cp $OUT/bench_$c.json $P/${TAG}_bench_$c.json; done
 
 # 3. the reference's published shapes (test/test_performance.py method), the vendor yardstick (cuda/test.cu counterpart) and its
 #    value cross-check
@@ -41,6 +41,8 @@ timeout 900 python3 tools/quick_bench.py 1d1g >> $OUT/long_1d.log 2>&1
 timeout 900 python3 tools/quick_bench.py 1d8g >> $OUT/long_1d.log 2>&1
 cp $OUT/long_1d.log $P/${TAG}_long_1d_sizes.log
 timeout 900 python3 tools/quick_bench.py r4 > $OUT/r4_shapes.log 2>&1; cp $OUT/r4_shapes.log $P/${TAG}_cubes_rectangles_fp64.log
+# (second batch of round 4: 2-D shapes with a 256-point axis, {64, 128}^3, split-complex layouts -- 2 GiB per side)
+timeout 900 python3 tools/quick_bench.py r4b 2>&1 | sed 's/passes=\[.*\]//' > $OUT/r4b_shapes.log; cp $OUT/r4b_shapes.log $P/${TAG}_second_batch_shapes.log
 timeout 600 python3 tools/mixed_probe.py > $OUT/mixed.log 2>&1; cp $OUT/mixed.log $P/${TAG}_mixed_radix.log
 timeout 300 python3 tools/small_batch_probe.py sp > $OUT/small_batch.log 2>&1
 timeout 300 python3 tools/small_batch_probe.py dp >> $OUT/small_batch.log 2>&1

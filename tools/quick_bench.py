@@ -94,6 +94,15 @@ if __name__ == "__main__":
             cases += [((128, 128, 128), c64, gib * 64), ((128, 128, 128), c128, gib * 32), ((512, 1024), c64, gib * 256), ((1024, 512), c64, gib * 256),
                       ((1024, 2048), c64, gib * 64), ((2048, 1024), c64, gib * 64), ((2048, 512), c64, gib * 128), ((512, 2048), c64, gib * 128),
                       ((1 << 21,), c128, gib * 32), ((1 << 22,), c128, gib * 16), ((1 << 20,), c128, gib * 64)]
+    elif len(sys.argv) > 1 and sys.argv[1] == "r4b":                 # second batch of round 4, 2 GiB per side
+        def nb(shape, dt):
+            d = numpy.dtype(dt)
+            return (2 << 30) // (int(numpy.prod(shape)) * d.itemsize * (2 if d.kind == "f" else 1))
+        shapes = [((256, 256), c64), ((256, 512), c64), ((512, 256), c64), ((256, 1024), c64), ((1024, 256), c64), ((256, 256), c128), ((512, 256), c128)] + \
+            [((a, b, c), dt) for dt in (c64, c128) for a in (64, 128) for b in (64, 128) for c in (64, 128)] + \
+            [((64, 64, 64), f32), ((64, 128, 128), f32), ((128, 128, 128), f32), ((64, 64, 64), f64), ((128, 128, 128), f64), ((128, 128, 64), f64)] + \
+            [((1 << k,), f32) for k in (16, 17, 18, 19, 20)] + [((1 << 20,), f64), ((1024, 1024), f32)]
+        cases = [(s, d, nb(s, d)) for s, d in shapes]
     elif len(sys.argv) > 1 and sys.argv[1] == "tail":                # shapes that still run two or three launches per cache-sized chunk (round 4 survey)
         cases = [((256, 256), c64, 4096), ((256, 256), c128, 2048), ((512, 256), c64, 2048), ((64, 64, 64), c64, 1024), ((64, 64, 64), c128, 512),
                  ((128, 128, 64), c64, 256), ((64, 128, 128), c64, 256), ((256, 128, 128), c64, 64), ((128, 128, 64), c128, 128),
