@@ -133,8 +133,13 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
             static_for<PPT>([&](auto kk) {
                 constexpr int k = kk, ia = k >> 4, b1 = k & 15;
                 const long long off = ((long long)(b1 * 16 * A + ia * 16) << logMS) * (long long)sizeof(T);
-                v[k].x = *reinterpret_cast<const T*>(sre + off + vb);
-                v[k].y = *reinterpret_cast<const T*>(sim + off + vb);
+                if constexpr (NTIN) {
+                    v[k].x = __builtin_nontemporal_load(reinterpret_cast<const T*>(sre + off + vb));
+                    v[k].y = __builtin_nontemporal_load(reinterpret_cast<const T*>(sim + off + vb));
+                } else {
+                    v[k].x = *reinterpret_cast<const T*>(sre + off + vb);
+                    v[k].y = *reinterpret_cast<const T*>(sim + off + vb);
+                }
             });
         }
     }
@@ -318,8 +323,13 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
             } else {
                 char* pr = reinterpret_cast<char*>(reinterpret_cast<T*>(a.out0) + gu);
                 char* pi = reinterpret_cast<char*>(reinterpret_cast<T*>(a.out1) + gu);
-                *reinterpret_cast<T*>(pr + ovoff * (unsigned)sizeof(T)) = r.x;
-                *reinterpret_cast<T*>(pi + ovoff * (unsigned)sizeof(T)) = r.y;
+                if constexpr (NTOUT) {
+                    __builtin_nontemporal_store(r.x, reinterpret_cast<T*>(pr + ovoff * (unsigned)sizeof(T)));
+                    __builtin_nontemporal_store(r.y, reinterpret_cast<T*>(pi + ovoff * (unsigned)sizeof(T)));
+                } else {
+                    *reinterpret_cast<T*>(pr + ovoff * (unsigned)sizeof(T)) = r.x;
+                    *reinterpret_cast<T*>(pi + ovoff * (unsigned)sizeof(T)) = r.y;
+                }
             }
         });
     });
@@ -338,11 +348,11 @@ __global__ void __launch_bounds__(256, 2) fft_col2_kernel(const TileArgs a) {
     // (MIFFT_FLAG_WRITE_THROUGH, small launches: write-through stores whatever the other hints say)
     if constexpr (TR && !SPLIT) {
         if (a.nt & 4) col2_tile<T, A, TR, TW, SPLIT, true, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
-        else if (a.nt & 1) col2_tile<T, A, TR, TW, SPLIT, false, true, false, SPLIT_OUT>(a, o, o, rem0, lds);
+        else if (a.nt & 1) col2_tile<T, A, TR, TW, SPLIT, false, !SPLIT, false, SPLIT_OUT>(a, o, o, rem0, lds);   // (planes: plain loads, as measured in rounds 1-3)
         else col2_tile<T, A, TR, TW, SPLIT, false, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
     } else if constexpr (!TR && !SPLIT_OUT) {
         if (a.nt & 4) col2_tile<T, A, TR, TW, SPLIT, true, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
-        else if (a.nt & 2) col2_tile<T, A, TR, TW, SPLIT, false, false, true, SPLIT_OUT>(a, o, o, rem0, lds);
+        else if (a.nt & 2) col2_tile<T, A, TR, TW, SPLIT, false, false, !SPLIT_OUT, SPLIT_OUT>(a, o, o, rem0, lds);
         else col2_tile<T, A, TR, TW, SPLIT, false, false, false, SPLIT_OUT>(a, o, o, rem0, lds);
     } else {
         col2_tile<T, A, TR, TW, SPLIT, false, false, false, SPLIT_OUT>(a, o, o, rem0, lds);

@@ -13,8 +13,15 @@ template <int A0, int A1> int launch(const mifft::FusedArgs* f, int split, unsig
     // did, which was part of its lead at 2^19; the plain and write-through forms stay as A/B instances of 1024 x 1024)
     // split planes: the sibling 16-column tiles side by side in a 512-thread work-group (fft_fused2s_kernel); MIFFT_NARROW_TILES=1: the
     // round-2 form, one tile per 256-thread work-group (A/B)
-    if (split && mifft_debug_get(MIFFT_DEBUG_NARROW_TILES) != 1)
+    if (split && mifft_debug_get(MIFFT_DEBUG_NARROW_TILES) != 1) {
+        if constexpr (A0 >= A1) {      // (the shapes plans build; A/B: non-temporal accesses to the planes, MIFFT_STORE = 1)
+            if (mifft_debug_get(MIFFT_DEBUG_STORE) == 1) {
+                hipLaunchKernelGGL((mifft::fft_fused2s_kernel<A0, A1, false, true>), dim3(grid), dim3(512), 0, s, *f);
+                return (int)hipGetLastError();
+            }
+        }
         hipLaunchKernelGGL((mifft::fft_fused2s_kernel<A0, A1, false>), dim3(grid), dim3(512), 0, s, *f);
+    }
     else if (split)
         hipLaunchKernelGGL((mifft::fft_fused2_kernel<float, A0, A1, true, 0>), dim3(grid), dim3(256), 0, s, *f);
     else if (nt && wt && A0 == 4 && A1 == 4)
