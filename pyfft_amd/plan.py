@@ -306,10 +306,10 @@ class FFTPlan(object):
         nx, ny = int(p.x), int(p.y)
         if p.split and p.precision == N.F32 and nx in (256, 512, 1024) and ny in (256, 512, 1024) and int(p.z) == 1 and len(k) == 2 and \
                 N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1 and not D.no_split_rowfirst() and \
-                ((ny, nx) not in ((256, 256), (256, 1024)) or D.forced_strategy() == "fused"):
+                ((ny, nx) != (256, 256) or D.forced_strategy() == "fused"):
             # split-complex fp32: the row-first persistent kernel (csrc/fft_fused2r.hpp), second batch of round 4: 1024^2 0.359 (pipelined
-            # chunks) -> 0.398, 512^2 0.364 -> 0.425, (1024, 512) 0.374 -> 0.425, (512, 1024) 0.347 -> 0.389, (1024, 256) 0.376 -> 0.399,
-            # (256, 512) 0.365 -> 0.397, (512, 256) 0.345 -> 0.386; (256, 256) 0.330 against 0.380 and (256, 1024) 0.363 against 0.369 stay
+            # chunks) -> 0.425, 512^2 0.364 -> 0.425, (1024, 512) 0.374 -> 0.425, (512, 1024) 0.347 -> 0.422, (1024, 256) 0.376 -> 0.405,
+            # (256, 1024) 0.355 -> 0.408, (256, 512) 0.365 -> 0.398, (512, 256) 0.345 -> 0.389; (256, 256) 0.328 against 0.362-0.380 stays
             # on the chunks (on request only)
             return (k[0].kind == N.PASS_ROW and k[0].L == nx and k[1].kind == N.PASS_COL and k[1].L == ny and k[1].M == 1 and k[1].S == nx)
         sides = (512, 1024) if p.precision == N.F64 else (512, 1024, 2048)
@@ -490,11 +490,12 @@ class FFTPlan(object):
                                       min_slots=3 if (p.precision == N.F64 and self._kernels[0].L == 2048) else None)
             if geo is not None:
                 lag, ring, grid = geo
-                if (self._split_siblings() and not huge) or self._split_rowfirst():
+                if self._split_siblings() and not huge:
                     # two 512-thread work-groups per CU, items of two tiles: the ring that measured best is HALF the cache ring in bytes
                     # whatever the tile count (2 GiB: 2^16 224 slots 0.421 / 112 0.392 / 56 0.279, 2^17 224 0.359 / 112 0.374 / 56 0.276,
-                    # 2^18 112 0.308 / 56 0.339; profiles/r04_ac_split_siblings.log); the same for the row-first 2-D kernel: 1024^2 14 slots
-                    # 0.398 / 28 0.348, 512^2 56 0.425 / 112 0.360, (1024, 512) 28 0.425 / 56 0.354 (profiles/r04_ag_split_2d_row_first.log)
+                    # 2^18 112 0.308 / 56 0.339; profiles/r04_ac_split_siblings.log).  (The row-first 2-D kernel touches the planes with
+                    # non-temporal loads AND stores and keeps the tile-count rule: 1024^2 28 slots 0.425 / 14 slots 0.397; while its stores
+                    # were plain the half ring won, 0.398 against 0.348: profiles/r04_ag_split_2d_row_first.log, r04_aj_split_nt_ab.log)
                     ring = max(self._context.machine.MIN_RING_SLOTS, (mach.ring_bytes // 2) // item_bytes)
                     lag = max(1, ring // 2)
                 if huge:

@@ -14,7 +14,7 @@ from pyfft_amd.hip import Plan, DeviceArray, Event
 from pyfft_amd import _native as N
 
 KEYS = ("PYFFT_AMD_STRATEGY", "PYFFT_AMD_FUSED_RING", "PYFFT_AMD_FUSEDX", "PYFFT_AMD_FUSED3", "PYFFT_AMD_FUSED_WGS", "PYFFT_AMD_PIPE_MB",
-        "PYFFT_AMD_FUSED_MEMSET", "PYFFT_AMD_NO_FUSEDX", "PYFFT_AMD_SMALL_FUSED", "MIFFT_PAIR", "MIFFT_NARROW_TILES", "PYFFT_AMD_SPLIT_FUSEDX", "PYFFT_AMD_NO_SPLIT_ROWFIRST")
+        "PYFFT_AMD_FUSED_MEMSET", "PYFFT_AMD_NO_FUSEDX", "PYFFT_AMD_SMALL_FUSED", "MIFFT_PAIR", "MIFFT_NARROW_TILES", "PYFFT_AMD_SPLIT_FUSEDX", "PYFFT_AMD_NO_SPLIT_ROWFIRST", "MIFFT_STORE")
 
 
 def variant_env(v):
@@ -82,6 +82,7 @@ def sweep(shape, dtype, gib, variants, reps=5, iters=10):
         os.environ.update(variant_env(v))
         N.lib.mifft_debug_set(N.DEBUG_PAIR, int(os.environ.get("MIFFT_PAIR", "0")))     # (library switches: read at import otherwise)
         N.lib.mifft_debug_set(N.DEBUG_NARROW_TILES, int(os.environ.get("MIFFT_NARROW_TILES", "0")))
+        N.lib.mifft_debug_set(N.DEBUG_STORE, int(os.environ.get("MIFFT_STORE", "0")))
         try:
             plan = Plan(shape if len(shape) > 1 else shape[0], dtype=dt, wait_for_finish=True)
             for b in outs:
