@@ -119,8 +119,13 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
             static_for<PPT>([&](auto kk) {
                 constexpr int k = kk, ia = k >> 4, b1 = k & 15;
                 const long long off = ((long long)(2 * (b1 * 16 * A + ia * 16)) << logMS) * (long long)sizeof(T);
-                v[k].x = *reinterpret_cast<const T*>(sre + off + vb);
-                v[k].y = *reinterpret_cast<const T*>(sim + off + vb);
+                if constexpr (NTIN) {
+                    v[k].x = __builtin_nontemporal_load(reinterpret_cast<const T*>(sre + off + vb));
+                    v[k].y = __builtin_nontemporal_load(reinterpret_cast<const T*>(sim + off + vb));
+                } else {
+                    v[k].x = *reinterpret_cast<const T*>(sre + off + vb);
+                    v[k].y = *reinterpret_cast<const T*>(sim + off + vb);
+                }
             });
         }
     }
@@ -270,8 +275,13 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
             } else {
                 char* pr = reinterpret_cast<char*>(reinterpret_cast<T*>(a.out0) + gu);
                 char* pi = reinterpret_cast<char*>(reinterpret_cast<T*>(a.out1) + gu);
-                *reinterpret_cast<T*>(pr + ovoff * (unsigned)sizeof(T)) = r.x;
-                *reinterpret_cast<T*>(pi + ovoff * (unsigned)sizeof(T)) = r.y;
+                if constexpr (NTOUT) {
+                    __builtin_nontemporal_store(r.x, reinterpret_cast<T*>(pr + ovoff * (unsigned)sizeof(T)));
+                    __builtin_nontemporal_store(r.y, reinterpret_cast<T*>(pi + ovoff * (unsigned)sizeof(T)));
+                } else {
+                    *reinterpret_cast<T*>(pr + ovoff * (unsigned)sizeof(T)) = r.x;
+                    *reinterpret_cast<T*>(pi + ovoff * (unsigned)sizeof(T)) = r.y;
+                }
             }
         });
     });

@@ -710,8 +710,8 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     auto ok_len = [](int L) { return L == 256 || L == 512 || L == 1024; };
     const bool big = p0->L == 2048 && (p1->L == 2048 || p1->L == 1024);   // 512-thread tiles (fft_col3.hpp)
     const bool wide64 = f64 && p0->L == 2048 && (p1->L == 2048 || p1->L == 1024) && p0->layout == MIFFT_INTERLEAVED;   // fft_fusedx_f64.hip
-    const bool small64 = f64 && p0->layout == MIFFT_INTERLEAVED && (p0->L == 256 || p0->L == 512) && (p1->L == 256 || p1->L == 512) && p0->L >= p1->L;
-    const bool mid64 = f64 && p0->L == 1024 && (p1->L == 1024 || (p1->L == 512 && p0->layout == MIFFT_INTERLEAVED));
+    const bool small64 = f64 && (p0->L == 256 || p0->L == 512) && (p1->L == 256 || p1->L == 512) && p0->L >= p1->L;
+    const bool mid64 = f64 && p0->L == 1024 && (p1->L == 1024 || p1->L == 512);
     if (f64 ? (!wide64 && !small64 && !mid64) : (!big && (!ok_len(p0->L) || !ok_len(p1->L)))) return set_err(MIFFT_E_UNSUPPORTED, "fused2: no kernel for %d x %d", p0->L, p1->L);
     }
     const bool wide64 = !twod && f64 && p0->L == 2048;

@@ -318,8 +318,10 @@ class FFTPlan(object):
             (p.precision == N.F64 or N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1)
         if (not small and (nx not in sides or ny not in sides)) or int(p.z) != 1 or len(k) != 2:
             return False
-        if p.split and (nx != ny or D.forced_strategy() != "fused" or (p.precision == N.F64 and nx != 1024)):
-            return False      # (split planes, two transposing passes: 29 % against 35 % for the pipelined chunks -- squares, on request only)
+        if p.split and p.precision == N.F64 and (ny, nx) == (1024, 1024):
+            pass              # fp64 planes (16 columns = a whole line): 0.346 (pipelined chunks) -> 0.423 once the tiles stream the planes non-temporally
+        elif p.split and (nx != ny or D.forced_strategy() != "fused" or (p.precision == N.F64 and nx != 1024)):
+            return False      # (fp32 planes, two transposing passes: 29 % against 35 % for the pipelined chunks -- squares, on request only)
         if (ny, nx) == (512, 2048) and D.forced_strategy() != "fused":
             # 512-point columns on the 512-thread tiles (16 points per thread, 64 KiB tiles, one work-group per CU): 0.355 against
             # 0.392 for the pipelined chunks -- the one rectangle that loses (profiles/r04_c_rect_sweep.log); on request only
@@ -362,9 +364,10 @@ class FFTPlan(object):
             # kernel runs 2048 x 2048 -- 64 MiB per transform, a ring of three -- BELOW the pipelined chunks (0.243 - 0.259 against
             # 0.269, profiles/r04_e_fp64_long_fused.log): on request only
             # round 4 also: 2^16 ... 2^18 (L0 >= L1 in {256, 512}) on the 256-thread tiles, interleaved
-            return (k[0].L == 1024 and k[1].L == 1024) or (k[0].L == 1024 and k[1].L == 512 and not p.split) or \
+            # (second batch: 2^16 ... 2^19 also for split planes -- an fp64 plane's 16 columns are whole lines, streamed non-temporally)
+            return (k[0].L == 1024 and k[1].L == 1024) or (k[0].L == 1024 and k[1].L == 512) or \
                 (k[0].L == 2048 and not p.split and (k[1].L == 1024 or (k[1].L == 2048 and D.forced_strategy() == "fused"))) or \
-                (not p.split and k[0].L in (256, 512) and k[1].L in (256, 512) and k[0].L >= k[1].L)
+                (k[0].L in (256, 512) and k[1].L in (256, 512) and k[0].L >= k[1].L)
         return (k[0].L in (256, 512, 1024) and k[1].L in (256, 512, 1024)) or (k[0].L == 2048 and k[1].L in (1024, 2048))
 
     def _fusedx_eligible(self):

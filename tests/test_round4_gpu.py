@@ -687,3 +687,32 @@ def test_fused_2d_split_row_first(ctx, monkeypatch, shape, batch):
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
     monkeypatch.setenv("PYFFT_AMD_NO_SPLIT_ROWFIRST", "1")
     assert ctx.getPlan(shape, dtype=numpy.float32).strategy(batch)[0] == "pipelined"
+
+
+# ---- split-complex fp64 (float64 planes) on the persistent kernels, planes streamed non-temporally -----------------------------------
+@pytest.mark.parametrize("shape,batch", [((1 << 16,), 270), ((1 << 17,), 131), ((1 << 18,), 67), ((1 << 19,), 35), ((1 << 20,), 29), ((1024, 1024), 30)], ids=str)
+def test_fused_split_planes_fp64(ctx, monkeypatch, shape, batch):
+    """float64 planes beyond the chain threshold: 1-D 2^16 ... 2^20 and the published 1024 x 1024 on the persistent kernels (16 columns
+    of an fp64 plane are a whole 128-byte line; the tiles stream the planes with non-temporal loads and stores, second batch of
+    round 4).  numpy with the reference's fp64 thresholds on sampled transforms, planes untouched, in place == out of place, inverse
+    round trip, and the chain's result to rounding."""
+    n = int(numpy.prod(shape))
+    rng = numpy.random.default_rng(1800 + n % 89 + len(shape))
+    re = rng.standard_normal(n * batch)
+    im = rng.standard_normal(n * batch)
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
+    got = _execute_split(ctx, shape, numpy.float64, batch, re, im, expect="fused2")
+    inp = _execute_split(ctx, shape, numpy.float64, batch, re, im, inplace=True, expect="fused2")
+    assert numpy.array_equal(inp[0], got[0]) and numpy.array_equal(inp[1], got[1])
+    for item in (0, batch // 2, batch - 1):
+        sl = slice(item * n, (item + 1) * n)
+        ref = numpy.fft.fftn((re[sl] + 1j * im[sl]).reshape(shape)).reshape(-1)
+        g = got[0][sl] + 1j * got[1][sl]
+        assert numpy.abs(ref - g).sum() / numpy.abs(ref).sum() < 1e-11
+        assert numpy.abs(ref - g).max() <= 1e-10 * numpy.abs(ref).max()
+    back = _execute_split(ctx, shape, numpy.float64, batch, got[0], got[1], inverse=True, expect="fused2")
+    x = re + 1j * im
+    assert numpy.abs((back[0] + 1j * back[1]) - x).sum() / numpy.abs(x).sum() < 1e-11
+    monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
+    want = _execute_split(ctx, shape, numpy.float64, batch, re, im, expect="chain")
+    assert numpy.abs((want[0] - got[0]) + 1j * (want[1] - got[1])).sum() / numpy.abs(want[0] + 1j * want[1]).sum() < 1e-14
