@@ -59,7 +59,7 @@ def no_fusedx():
 
 
 def split_fusedx():
-    """PYFFT_AMD_SPLIT_FUSEDX=1: split-complex fp32 N = 2^16 ... 2^18 on the per-XCD work lists (the default at 2^18 only; A/B)"""
+    """PYFFT_AMD_SPLIT_FUSEDX=1: split-complex fp32 N = 2^16 ... 2^18 on the per-XCD work lists (A/B; the default is the sibling-tile kernel on the global list)"""
     return bool(os.environ.get("PYFFT_AMD_SPLIT_FUSEDX"))
 
 

@@ -85,8 +85,12 @@ struct TileNoHook {
     __device__ __forceinline__ void operator()() const {}
 };
 
+// WIDE (second batch of round 4; 512-thread work-groups): TWO adjacent 16-column tiles interleaved at LANE level -- thread index p
+//     = (b0, c32) with c32 < 32 the column within the 32-column double tile at rem0 (a multiple of 32), so that one wave instruction
+//     touches 32 adjacent columns: whole 128-byte lines of an fp32 plane.  Each half (sub = c32 >> 4) runs the ordinary tile on its
+//     own LDS slab (lds + sub * ELEMS); the arithmetic and the exchange layout per half are unchanged.
 template <typename T, int A, bool TR, bool TW, bool SPLIT, bool WT = false, bool NTIN = false, bool NTOUT = false,
-          bool SPLIT_OUT = SPLIT, typename LdsPtr = cplx<T>*, typename Hook = TileNoHook>
+          bool SPLIT_OUT = SPLIT, bool WIDE = false, typename LdsPtr = cplx<T>*, typename Hook = TileNoHook>
 __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_in, const long long o_out,
                                           const long long rem0, LdsPtr lds, Hook hook = Hook(), const int tid_in = -1) {
     constexpr int L = A * 256;
@@ -99,7 +103,10 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
     // tid_in: the thread's index within the tile when a bigger work-group runs several tiles side by side (fft_fused2s_kernel)
     int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x;
     asm volatile("" : "+v"(tid));  // same reason as below, for the per-thread (VGPR) address pieces
-    const int c = tid & 15, b0 = tid >> 4;
+    // WIDE: cg = the thread's column within the double tile (global addressing), c = within its half (LDS indices)
+    const int cg = WIDE ? (tid & 31) : (tid & 15), b0 = WIDE ? (tid >> 5) : (tid >> 4);
+    const int c = cg & 15;
+    if constexpr (WIDE) lds = lds + (cg >> 4) * Col2Lds<A, TR, sizeof(cplx<T>)>::ELEMS;
     // The shift amounts are laundered through an empty asm so that, when this body sits inside the persistent
     // loop of the fused kernel, the ~130 wave-uniform row offsets derived from them are recomputed per tile
     // (2 SALU ops each) instead of being hoisted out of the loop and spilled (measured: 453 SGPR spills).
@@ -114,7 +121,7 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
     cplx<T> v[PPT];
     {
         const long long ubase = o_in * a.ostride_in + rem0;  // uniform, elements
-        const unsigned voff = (((unsigned)b0 << logMS) + (unsigned)c);
+        const unsigned voff = (((unsigned)b0 << logMS) + (unsigned)cg);
         if constexpr (!SPLIT) {
             const char* src = reinterpret_cast<const char*>(reinterpret_cast<const cplx<T>*>(a.in0) + ubase);
             const unsigned vb = voff * (unsigned)sizeof(cplx<T>);
@@ -212,14 +219,16 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
     // ---- exchange + stage 3, one qa slab per round
     // phase-2 thread roles: non-TR (u = tid>>4, c2 = tid&15): lanes along the columns (128-byte row segments)
     //                       TR     (u = tid&15, c2 = tid>>4): lanes along q (the write is contiguous in q)
-    const int u = TR ? (tid & 15) : (tid >> 4);
-    const int c2 = TR ? (tid >> 4) : (tid & 15);
+    // (WIDE: the same roles within the thread's half; c2g = its column within the double tile)
+    const int u = TR ? c : b0;
+    const int c2 = TR ? b0 : c;
+    const int c2g = WIDE ? ((cg & 16) + c2) : c2;
     // output addressing, again uniform base + 32-bit per-thread offset.  The tile's 16 columns start at rem0
     // (a multiple of 16): l0/jp0 are uniform, (dl, djp) is the per-thread part (dl > 0 only when S < 16).
     const long long l0 = rem0 >> logS;
     const long long jp0 = rem0 & ((1ll << logS) - 1);
-    const unsigned dl = (unsigned)(((rem0 + c2) >> logS) - l0);
-    const unsigned djp = (unsigned)(((rem0 + c2) & ((1ll << logS) - 1)) - jp0);
+    const unsigned dl = (unsigned)(((rem0 + c2g) >> logS) - l0);
+    const unsigned djp = (unsigned)(((rem0 + c2g) & ((1ll << logS) - 1)) - jp0);
     const unsigned l = (unsigned)l0 + dl;  // row index of this thread's column in the inter-pass twiddle
     const T sx = (T)a.scale;
     const T sy = a.inverse ? -sx : sx;
@@ -234,7 +243,7 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
     // non-TR: out[o][l][q][jp] -> uniform o*ostride + ((l0*L + qconst) << logS) + jp0 ; thread ((dl*L + u) << logS) + djp
     // TR (S == 1): out[o][l][q] -> uniform o*ostride + rem0*L + qconst ; thread c2*L + u
     const long long oubase = TR ? (a.ostride_out * o_out + rem0 * L) : (a.ostride_out * o_out + ((l0 * L) << logS) + jp0);
-    const unsigned ovoff = TR ? ((unsigned)c2 * L + (unsigned)u) : ((((unsigned)dl * L + (unsigned)u) << logS) + djp);
+    const unsigned ovoff = TR ? ((unsigned)c2g * L + (unsigned)u) : ((((unsigned)dl * L + (unsigned)u) << logS) + djp);
 
     static_for<A>([&](auto rr) {
         constexpr int qa = rr;

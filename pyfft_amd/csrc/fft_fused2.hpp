@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(256, 2) fft_fused2_kernel(const FusedArgs f) {
 // work-group is 512 threads = two 256-thread tiles in lock step (same code, same barriers), each on its own half of the LDS array,
 // and an item is the sibling pair: both halves of every line are requested by the same CU at the same time.  One work-group per CU
 // (the two tiles take the registers of two ordinary work-groups).  TWOD: the 2-D data flow (two transposing passes, no twiddle).
-template <int A0, int A1, bool TWOD, bool NT = false>
+template <int A0, int A1, bool TWOD, bool NT = false, bool SPLIT = true>
 __global__ void __launch_bounds__(512, 2) fft_fused2s_kernel(const FusedArgs f) {
     constexpr int E0 = Col2Lds<A0, true, sizeof(cplx<float>)>::ELEMS, E1 = Col2Lds<A1, TWOD, sizeof(cplx<float>)>::ELEMS;
     constexpr int E = E0 > E1 ? E0 : E1;
@@ -350,16 +350,12 @@ __global__ void __launch_bounds__(512, 2) fft_fused2s_kernel(const FusedArgs f) 
         [&](unsigned t, unsigned slot, unsigned item, auto hook) {
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
-            const int sub = __builtin_amdgcn_readfirstlane(tid >> 8);      // (wave-uniform: the tile's base addresses stay in SGPRs)
-            col2_tile<float, A0, true, !TWOD, true, true, NT, false, false>(f.p0, (long long)t, (long long)slot, ((long long)item * 2 + sub) * 16,
-                                                                           lds + sub * E, hook, tid & 255);
+            col2_tile<float, A0, true, !TWOD, SPLIT, true, NT, false, false, true>(f.p0, (long long)t, (long long)slot, (long long)item * 32, lds, hook, tid);
         },
         [&](unsigned slot, unsigned t, unsigned item, auto hook) {
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
-            const int sub = __builtin_amdgcn_readfirstlane(tid >> 8);
-            col2_tile<float, A1, TWOD, false, false, false, false, NT, true>(f.p1, (long long)slot, (long long)t, ((long long)item * 2 + sub) * 16,
-                                                                            lds + sub * E, hook, tid & 255);
+            col2_tile<float, A1, TWOD, false, false, false, false, NT, SPLIT, true>(f.p1, (long long)slot, (long long)t, (long long)item * 32, lds, hook, tid);
         });
 }
 

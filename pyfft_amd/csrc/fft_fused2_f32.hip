@@ -14,16 +14,19 @@ template <int A0, int A1> int launch(const mifft::FusedArgs* f, int split, unsig
     // split planes: the sibling 16-column tiles side by side in a 512-thread work-group (fft_fused2s_kernel); MIFFT_NARROW_TILES=1: the
     // round-2 form, one tile per 256-thread work-group (A/B)
     if (split && mifft_debug_get(MIFFT_DEBUG_NARROW_TILES) != 1) {
-        if constexpr (A0 >= A1) {      // (the shapes plans build; A/B: non-temporal accesses to the planes, MIFFT_STORE = 1)
-            if (mifft_debug_get(MIFFT_DEBUG_STORE) == 1) {
-                hipLaunchKernelGGL((mifft::fft_fused2s_kernel<A0, A1, false, true>), dim3(grid), dim3(512), 0, s, *f);
+        // the planes streamed non-temporally, like interleaved data (whole lines per wave instruction: 2^20 0.366 -> 0.420); A/B:
+        // MIFFT_STORE = 3 plain accesses
+        if constexpr (A0 >= A1) {      // (the shapes plans build)
+            if (mifft_debug_get(MIFFT_DEBUG_STORE) == 3) {
+                hipLaunchKernelGGL((mifft::fft_fused2s_kernel<A0, A1, false, false>), dim3(grid), dim3(512), 0, s, *f);
                 return (int)hipGetLastError();
             }
         }
-        hipLaunchKernelGGL((mifft::fft_fused2s_kernel<A0, A1, false>), dim3(grid), dim3(512), 0, s, *f);
+        hipLaunchKernelGGL((mifft::fft_fused2s_kernel<A0, A1, false, true>), dim3(grid), dim3(512), 0, s, *f);
     }
     else if (split)
         hipLaunchKernelGGL((mifft::fft_fused2_kernel<float, A0, A1, true, 0>), dim3(grid), dim3(256), 0, s, *f);
+
     else if (nt && wt && A0 == 4 && A1 == 4)
         hipLaunchKernelGGL((mifft::fft_fused2_kernel<float, A0, A1, false, 2>), dim3(grid), dim3(256), 0, s, *f);
     else if (!nt && A0 == 4 && A1 == 4)

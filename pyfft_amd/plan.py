@@ -455,8 +455,9 @@ class FFTPlan(object):
         # form of the global list, below), or one work list per XCD, where the siblings share an L2.  Same process, 2 GiB
         # (profiles/r04_ac_split_siblings.log): 2^16 side by side 0.423 / per XCD 0.358 (pipelined chunks 0.27), 2^17 0.352 / 0.330,
         # 2^18 0.337 / 0.357, 2^19 0.330 / 0.338 with rings too short to last, 2^20 0.331 / 0.28 -- so the lists only at 2^18
-        if forced == "auto" and p.split and self._fusedx_eligible() and not D.no_fusedx() and \
-                (self._kernels[0].L * self._kernels[1].L == (1 << 18) or D.split_fusedx()):
+        # (final form of the side-by-side kernel, the two tiles interleaved at lane level: 2^18 0.430-0.440 against 0.377 for the lists, which
+        # remain on request: PYFFT_AMD_SPLIT_FUSEDX)
+        if forced == "auto" and p.split and self._fusedx_eligible() and not D.no_fusedx() and D.split_fusedx():
             ring = min(self.FUSEDX_LAG_RING[1], (mach.ring_bytes * 4 // 7) // (8 * item_bytes))
             if ring >= 6 and batch >= 8 * 2 * ring:
                 return ("fused2x", ring // 2, ring, 2 * mach.compute_units)
@@ -493,14 +494,11 @@ class FFTPlan(object):
                                       min_slots=3 if (p.precision == N.F64 and self._kernels[0].L == 2048) else None)
             if geo is not None:
                 lag, ring, grid = geo
-                if self._split_siblings() and not huge:
-                    # two 512-thread work-groups per CU, items of two tiles: the ring that measured best is HALF the cache ring in bytes
-                    # whatever the tile count (2 GiB: 2^16 224 slots 0.421 / 112 0.392 / 56 0.279, 2^17 224 0.359 / 112 0.374 / 56 0.276,
-                    # 2^18 112 0.308 / 56 0.339; profiles/r04_ac_split_siblings.log).  (The row-first 2-D kernel touches the planes with
-                    # non-temporal loads AND stores and keeps the tile-count rule: 1024^2 28 slots 0.425 / 14 slots 0.397; while its stores
-                    # were plain the half ring won, 0.398 against 0.348: profiles/r04_ag_split_2d_row_first.log, r04_aj_split_nt_ab.log)
-                    ring = max(self._context.machine.MIN_RING_SLOTS, (mach.ring_bytes // 2) // item_bytes)
-                    lag = max(1, ring // 2)
+                # (split planes.  While the sibling-tile kernel touched the planes with plain accesses, half the cache ring measured best
+                # -- 2^16 224 slots 0.421 / 112 0.392, 2^18 112 0.308 / 56 0.339 -- and the row-first 2-D kernel likewise, 1024^2 0.398
+                # against 0.348; with the planes streamed non-temporally the cache belongs to the ring again and the tile-count rule
+                # holds: 2^18 56 / 112 0.452 against 28 / 56 0.438, 1024^2 14 / 28 0.425 against 7 / 14 0.397.
+                # profiles/r04_ac_split_siblings.log, r04_ag_split_2d_row_first.log, r04_aj_split_nt_ab.log, r04_an_split_lane_interleaved.log)
                 if huge:
                     lag, ring = D.fused3_lag_ring(lag, ring)
                 lag, ring = D.fused_ring(lag, ring)

@@ -499,10 +499,10 @@ def test_planner_constants_come_from_the_device():
     assert _strategy_on(full, (1 << 21,), c64, 512)[1] == ("fused2", 8, 14, 512)              # 16 MiB transforms: the cache caps the ring
     assert _strategy_on(full, (1 << 17,), c64, 8192)[1] == ("fused2", 112, 224, 512)          # 2^16 / 2^17: 8 tiles of 32 columns per pass
     assert _strategy_on(full, (1 << 16,), c64, 16384)[1] == ("fused2", 112, 224, 512)
-    assert _strategy_on(full, (1 << 17,), numpy.float32, 8192)[1] == ("fused2", 56, 112, 512)  # split planes: sibling tiles side by side, 512-thread work-groups
+    assert _strategy_on(full, (1 << 17,), numpy.float32, 8192)[1] == ("fused2", 112, 224, 512)  # split planes: sibling tiles interleaved at lane level, 512-thread work-groups
     assert _strategy_on(full, (1 << 16,), numpy.float32, 8192)[1] == ("fused2", 112, 224, 512)
     assert _strategy_on(full, (1 << 20,), numpy.float32, 512)[1] == ("fused2", 14, 28, 256)    # (L = 1024: one such work-group per CU)
-    assert _strategy_on(full, (1 << 18,), numpy.float32, 4096)[1] == ("fused2x", 4, 8, 512)   # (2^18: the per-XCD lists, where siblings share an L2)
+    assert _strategy_on(full, (1 << 18,), numpy.float32, 4096)[1] == ("fused2", 56, 112, 512)
     assert _strategy_on(full, (256, 256), c64, 4096)[1] == ("fused2", 112, 224, 512)          # a 256-point axis on the 2-D persistent kernel
     assert _strategy_on(full, (512, 256), c128, 1024)[1][0] == "fused2"
     assert _strategy_on(full, (1 << 22,), numpy.complex128, 64)[1][0] == "pipelined"          # fp64 2^22: a ring of three 64 MiB slots loses

@@ -259,9 +259,9 @@ def test_fused_2d_rectangles(ctx, monkeypatch, shape, batch):
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
     want = _execute(ctx, shape, numpy.complex64, batch, data, expect="chain")
     assert oracle.difference(want, got, batch) < 5e-7
-    # split planes keep the pipelined chunks (rectangles have no split form of the fused kernel)
+    # split planes: the row-first kernel where both sides are <= 1024 (test_fused_2d_split_row_first), else the pipelined chunks
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
-    assert ctx.getPlan(shape, dtype=numpy.float32).strategy(batch)[0] in ("pipelined", "chain")
+    assert ctx.getPlan(shape, dtype=numpy.float32).strategy(batch)[0] == ("fused2" if max(shape) <= 1024 else "pipelined")
 
 
 # ---- f4 tails: smooth N-D shapes in one launch, Bluestein rows up to 5000 points in one launch ----------------------------------
@@ -546,13 +546,13 @@ def _execute_split(ctx, shape, rdtype, batch, re, im, inplace=False, inverse=Fal
     return b_re.get(), b_im.get()
 
 
-@pytest.mark.parametrize("n,batch,expect", [(1 << 16, 1100, "fused2"), (1 << 17, 515, "fused2"), (1 << 18, 259, "fused2x"),
+@pytest.mark.parametrize("n,batch,expect", [(1 << 16, 1100, "fused2"), (1 << 17, 515, "fused2"), (1 << 18, 259, "fused2"),
                                             (1 << 19, 130, "fused2"), (1 << 20, 70, "fused2")], ids=str)
 def test_split_planes_on_per_xcd_lists(ctx, monkeypatch, n, batch, expect):
     """float32 planes (the reference's split layout, pyfft/plan.py:10-63 dtype rule) on the persistent 1-D kernels by the plan's own
-    choice: the two 16-column tiles that share every 128-byte line of a plane run side by side in one 512-thread work-group
-    (2^16, 2^17, 2^19, 2^20: fft_fused2s_kernel on the global list) or share an XCD's L2 (2^18: the per-XCD lists); with
-    PYFFT_AMD_SPLIT_FUSEDX the lists also below 2^18.  The bits of the chain (same
+    choice: the two 16-column tiles that share every 128-byte line of a plane run in one 512-thread work-group, interleaved at lane
+    level (fft_fused2s_kernel on the global list); with PYFFT_AMD_SPLIT_FUSEDX the per-XCD lists, where siblings share an L2 (2^16
+    ... 2^18).  The bits of the chain (same
     tiles, same order of operations), in place == out of place, numpy with the reference's thresholds on sampled transforms, the
     inverse round trip, batches that are no multiple of 8 (lists of unequal length)."""
     rng = numpy.random.default_rng(1400 + n % 97)
@@ -574,7 +574,7 @@ def test_split_planes_on_per_xcd_lists(ctx, monkeypatch, n, batch, expect):
     back = _execute_split(ctx, (n,), numpy.float32, batch, got[0], got[1], inverse=True, expect=expect)
     x = re + 1j * im
     assert numpy.abs((back[0] + 1j * back[1]) - x).sum() / numpy.abs(x).sum() < 1.1e-6
-    if n < (1 << 18):
+    if n <= (1 << 18):
         monkeypatch.setenv("PYFFT_AMD_SPLIT_FUSEDX", "1")
         lists = _execute_split(ctx, (n,), numpy.float32, batch, re, im, expect="fused2x")
         assert numpy.array_equal(lists[0], got[0]) and numpy.array_equal(lists[1], got[1])
