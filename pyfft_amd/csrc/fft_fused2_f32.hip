@@ -88,7 +88,7 @@ extern "C" int mifft_fused2d_f32_launch(int ny, int nx, const mifft::FusedArgs* 
     const int L = nx;
     const bool sib = split && mifft_debug_get(MIFFT_DEBUG_NARROW_TILES) != 1;   // split planes: sibling tiles side by side
     if (L == 512) {
-        if (sib) hipLaunchKernelGGL((mifft::fft_fused2s_kernel<2, 2, true>), dim3(grid), dim3(512), 0, s, *f);
+        if (sib) hipLaunchKernelGGL((mifft::fft_fused2s_kernel<2, 2, true, true>), dim3(grid), dim3(512), 0, s, *f);
         else if (split) hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 2, 2, true, false>), dim3(grid), dim3(256), 0, s, *f);
         else hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 2, 2, false, true>), dim3(grid), dim3(256), 0, s, *f);
         return (int)hipGetLastError();
@@ -99,7 +99,7 @@ extern "C" int mifft_fused2d_f32_launch(int ny, int nx, const mifft::FusedArgs* 
         return (int)hipGetLastError();
     }
     if (L != 1024) return MIFFT_E_UNSUPPORTED;
-    if (sib) hipLaunchKernelGGL((mifft::fft_fused2s_kernel<4, 4, true>), dim3(grid), dim3(512), 0, s, *f);
+    if (sib) hipLaunchKernelGGL((mifft::fft_fused2s_kernel<4, 4, true, true>), dim3(grid), dim3(512), 0, s, *f);
     else if (split) hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 4, 4, true, false>), dim3(grid), dim3(256), 0, s, *f);
     else hipLaunchKernelGGL((mifft::fft_fused2d_kernel<float, 4, 4, false, true>), dim3(grid), dim3(256), 0, s, *f);
     return (int)hipGetLastError();
