@@ -702,7 +702,7 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
                              : (side(p0->L) && side(p1->L) && (p0->L == p1->L || p0->layout != MIFFT_SPLIT)));
         if (p1->kind != MIFFT_PASS_COL || !okL || p1->S != p0->L || p1->M != 1 ||
             p0->outer != p1->outer * p1->L || p0->layout != p1->layout || p0->inverse != p1->inverse)
-            return set_err(MIFFT_E_UNSUPPORTED, "fused2: the 2-D form takes (ny, nx) in {512, 1024, 2048}^2 (fp32; split planes: squares; interleaved: also a 256-point side next to one <= 1024) / {256, 512, 1024}^2 (fp64; split planes: 1024 x 1024; 256 only next to <= 512)");
+            return set_err(MIFFT_E_UNSUPPORTED, "fused2: the 2-D form takes (ny, nx) in {512, 1024, 2048}^2 (fp32; interleaved: also a 256-point side next to one <= 1024; split planes: {256, 512, 1024}^2 and the 2048 square) / {256, 512, 1024}^2 (fp64; split planes: 1024 x 1024; 256 only next to <= 512)");
     } else {
     if (p0->kind != MIFFT_PASS_COL || p1->kind != MIFFT_PASS_COL || p0->S != 1 || p0->M != p1->L || p1->M != 1 ||
         p1->S != p0->L || p0->outer != p1->outer || p0->layout != p1->layout || p0->inverse != p1->inverse)
