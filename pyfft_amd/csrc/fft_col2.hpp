@@ -368,4 +368,26 @@ __global__ void __launch_bounds__(256, 2) fft_col2_kernel(const TileArgs a) {
     }
 }
 
+// Split-complex fp32 planes as PLAIN launches (second batch of round 4): a 512-thread work-group runs the two sibling 16-column tiles
+// interleaved at lane level (col2_tile WIDE), so that a wave instruction touches whole 128-byte lines of a plane -- the 16-column
+// tile reads / writes half lines, and below the chain threshold split plans ran 15-25 % behind interleaved ones
+// (profiles/r04_aq_split_chain_mode.log).  One tile = 32 adjacent columns; the hints as fft_col2_kernel.
+template <int A, bool TR, bool TW, bool SPLIT, bool SPLIT_OUT>
+__global__ void __launch_bounds__(512, 2) fft_col2x_kernel(const TileArgs a) {
+    using T = float;
+    __shared__ __attribute__((aligned(16))) cplx<T> lds[2 * Col2Lds<A, TR, sizeof(cplx<T>)>::ELEMS];
+    const long long col0 = (long long)blockIdx.x * 32;
+    const long long o = col0 >> a.logMS;
+    const long long rem0 = col0 & ((1ll << a.logMS) - 1);
+    const int tid = threadIdx.x;
+    if constexpr (TR) {
+        if (a.nt & 4) col2_tile<T, A, TR, TW, SPLIT, true, false, false, SPLIT_OUT, true>(a, o, o, rem0, lds, TileNoHook(), tid);
+        else if (a.nt & 1) col2_tile<T, A, TR, TW, SPLIT, false, true, false, SPLIT_OUT, true>(a, o, o, rem0, lds, TileNoHook(), tid);
+        else col2_tile<T, A, TR, TW, SPLIT, false, false, false, SPLIT_OUT, true>(a, o, o, rem0, lds, TileNoHook(), tid);
+    } else {
+        if (a.nt & 2) col2_tile<T, A, TR, TW, SPLIT, false, false, true, SPLIT_OUT, true>(a, o, o, rem0, lds, TileNoHook(), tid);
+        else col2_tile<T, A, TR, TW, SPLIT, false, false, false, SPLIT_OUT, true>(a, o, o, rem0, lds, TileNoHook(), tid);
+    }
+}
+
 }  // namespace mifft

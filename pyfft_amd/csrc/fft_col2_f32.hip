@@ -58,7 +58,11 @@ bool wide_ok(int L, int tr, const mifft::TileArgs* a) {
 }
 }  // namespace
 
+extern "C" int mifft_col2x_f32_eligible(int L, int tr, const mifft::TileArgs* a);   // fft_col2x_f32.hip
+extern "C" int mifft_col2x_f32_launch(int L, int tr, const mifft::TileArgs* a, hipStream_t s);
+
 extern "C" int mifft_col2_f32_launch(int L, int tr, const mifft::TileArgs* a, hipStream_t s) {
+    if (mifft_col2x_f32_eligible(L, tr, a)) return mifft_col2x_f32_launch(L, tr, a, s);   // split planes: whole lines per wave instruction
     if (wide_ok(L, tr, a)) return L == 512 ? launch_w<2>(tr, a, s) : launch_w<1>(tr, a, s);
     switch (L) {
         case 1024: return launch<4>(tr, a, s);
