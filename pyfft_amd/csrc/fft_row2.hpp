@@ -47,10 +47,12 @@ __device__ __forceinline__ int row2_pad(int i) { return i + (i >> 4); }
 // TPR = threads per row; `tid` below is the thread's index within its row, `lds` the row's own LDS slab.
 // HALF: the exchange between two stages moves the real parts, then the imaginary parts, through an LDS slab of L scalars
 // instead of L complex numbers: twice the barriers, half the LDS, so twice the work-groups per CU for the longest rows.
-template <typename T, int L, int TPR, int Ns, bool FIRST, bool HALF, typename RL> struct Row2Stages;
+// LAY (second batch of round 4): bit 0 = the input is two scalar planes (inb / inb1 = the row's first real / imaginary scalar), bit 1 =
+// the output likewise (outb / outb1); 0 = interleaved complex numbers on both sides.
+template <typename T, int L, int TPR, int Ns, bool FIRST, bool HALF, typename RL, int LAY = 0> struct Row2Stages;
 
-template <typename T, int L, int TPR, int Ns, bool FIRST, bool HALF, int R, int... Rest>
-struct Row2Stages<T, L, TPR, Ns, FIRST, HALF, RadixList<R, Rest...>> {
+template <typename T, int L, int TPR, int Ns, bool FIRST, bool HALF, int R, int... Rest, int LAY>
+struct Row2Stages<T, L, TPR, Ns, FIRST, HALF, RadixList<R, Rest...>, LAY> {
     static constexpr int NT = TPR;
     static constexpr int PPT = L / NT;
     static constexpr int NB = PPT / R;
@@ -110,6 +112,24 @@ struct Row2Stages<T, L, TPR, Ns, FIRST, HALF, RadixList<R, Rest...>> {
         });
     }
 
+    // the same operands from two scalar planes (voff = the thread's byte offset within a plane)
+    template <int I0, int CNT, bool NTL>
+    static __device__ __forceinline__ void load_regs_split(cplx<T>* v, const char* inre, const char* inim, unsigned voff) {
+        static_assert(FIRST, "first-stage addressing");
+        static_for<CNT>([&](auto ii) {
+            constexpr int i = I0 + ii, b = i / R, k = i % R;
+            const T* pr = reinterpret_cast<const T*>(inre + (size_t)(b * NT + k * LR) * sizeof(T) + voff);
+            const T* pi = reinterpret_cast<const T*>(inim + (size_t)(b * NT + k * LR) * sizeof(T) + voff);
+            if constexpr (NTL) {
+                v[i].x = __builtin_nontemporal_load(pr);
+                v[i].y = __builtin_nontemporal_load(pi);
+            } else {
+                v[i].x = *pr;
+                v[i].y = *pi;
+            }
+        });
+    }
+
     // PRELOADED: v already holds the row (persistent form: loaded behind the previous row's stores).
     // FirstStage / (next_inb, next_valid): persistent form only -- the LAST stage issues the NEXT row's first-stage loads into
     // the registers of every butterfly right behind that butterfly's stores, so that they fly under the remaining
@@ -117,7 +137,7 @@ struct Row2Stages<T, L, TPR, Ns, FIRST, HALF, RadixList<R, Rest...>> {
     template <bool PRELOADED = false, typename FirstStage = void>
     static __device__ __forceinline__ void run(LdsT* lds, cplx<T>* v, const TileArgs& a, int tid, const char* inb,
                                                char* outb, unsigned voff, bool valid, const char* next_inb = nullptr,
-                                               bool next_valid = false) {
+                                               bool next_valid = false, const char* inb1 = nullptr, char* outb1 = nullptr) {
         const cplx<T>* twL = reinterpret_cast<const cplx<T>*>(a.tw_L);
         if constexpr (FIRST) {
             if constexpr (!PRELOADED) {
@@ -125,8 +145,13 @@ struct Row2Stages<T, L, TPR, Ns, FIRST, HALF, RadixList<R, Rest...>> {
                 static_for<PPT>([&](auto i) { v[i].x = 0; v[i].y = 0; });
                 if (valid) {
                     // MIFFT_FLAG_STREAM_SRC: the input is read once (first pass of a multi-pass plan)
-                    if (a.nt & 1) load_regs<0, PPT, true>(v, inb, voff);
-                    else load_regs<0, PPT, false>(v, inb, voff);
+                    if constexpr (LAY & 1) {     // planes: voff counts complex numbers' bytes, a plane's scalar is half as wide
+                        if (a.nt & 1) load_regs_split<0, PPT, true>(v, inb, inb1, voff / 2);
+                        else load_regs_split<0, PPT, false>(v, inb, inb1, voff / 2);
+                    } else {
+                        if (a.nt & 1) load_regs<0, PPT, true>(v, inb, voff);
+                        else load_regs<0, PPT, false>(v, inb, voff);
+                    }
                 }
             }
             if (a.inverse) static_for<PPT>([&](auto i) { v[i].y = -v[i].y; });
@@ -176,18 +201,33 @@ struct Row2Stages<T, L, TPR, Ns, FIRST, HALF, RadixList<R, Rest...>> {
                             cplx<T> p = v[b * R + k];
                             p.x *= sx;
                             p.y *= sy;
+                            if constexpr (LAY & 2) {
+                                T* qr = reinterpret_cast<T*>(outb + (size_t)(b * NT + k * Ns) * sizeof(T) + voff / 2);
+                                T* qi = reinterpret_cast<T*>(outb1 + (size_t)(b * NT + k * Ns) * sizeof(T) + voff / 2);
+                                if constexpr (NTS == 2) {          // write-through: agent-scope stores of the two scalars
+                                    __hip_atomic_store(qr, p.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    __hip_atomic_store(qi, p.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                } else if constexpr (NTS == 1) {
+                                    __builtin_nontemporal_store(p.x, qr);
+                                    __builtin_nontemporal_store(p.y, qi);
+                                } else {
+                                    *qr = p.x;
+                                    *qi = p.y;
+                                }
+                            } else {
                             char* kb = outb + (size_t)(b * NT + k * Ns) * sizeof(cplx<T>);
                             cplx<T>* q = reinterpret_cast<cplx<T>*>(kb + voff);
                             if constexpr (NTS == 2) store_wt_ptr<T>(kb + voff, p);   // (the row base may differ across the wave)
                             else if constexpr (NTS == 1) __builtin_nontemporal_store(p, q);
                             else *q = p;
+                            }
                         });
                     });
                 };
                 if (a.nt & 4) stores(IC<2>{}); else if (a.nt & 2) stores(IC<1>{}); else stores(IC<0>{});
             }
         } else {
-            using Next = Row2Stages<T, L, TPR, Ns * R, false, HALF, RadixList<Rest...>>;
+            using Next = Row2Stages<T, L, TPR, Ns * R, false, HALF, RadixList<Rest...>, LAY>;
             if constexpr (!FIRST) __syncthreads();  // everybody has fetched its operands of this stage
             if constexpr (!HALF) {
                 spill<0>(lds, v, tid);
@@ -209,13 +249,13 @@ struct Row2Stages<T, L, TPR, Ns, FIRST, HALF, RadixList<R, Rest...>> {
                 __syncthreads();
                 Next::template fetch<2>(lds, v, fresh());
             }
-            Next::template run<PRELOADED, FirstStage>(lds, v, a, tid, inb, outb, voff, valid, next_inb, next_valid);
+            Next::template run<PRELOADED, FirstStage>(lds, v, a, tid, inb, outb, voff, valid, next_inb, next_valid, inb1, outb1);
         }
     }
 };
 
 // OCC: waves per SIMD the register allocation must leave room for (1 = whatever the kernel needs)
-template <typename T, int L, int W, int NT, bool HALF, int OCC, typename RL>
+template <typename T, int L, int W, int NT, bool HALF, int OCC, typename RL, int LAY = 0>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) fft_row2_kernel(const TileArgs a) {
     constexpr int TPR = NT / W;
     constexpr int PPT = L / TPR;
@@ -226,16 +266,23 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) 
     const int c = W == 1 ? 0 : threadIdx.x / TPR, u = W == 1 ? threadIdx.x : threadIdx.x % TPR;
     const long long row = (long long)blockIdx.x * W + c;
     const bool valid = row < a.total;
-    const char* inb = reinterpret_cast<const char*>(reinterpret_cast<const cplx<T>*>(a.in0) + row * a.ostride_in);
-    char* outb = reinterpret_cast<char*>(reinterpret_cast<cplx<T>*>(a.out0) + row * a.ostride_out);
+    // (planes: the row's first real / imaginary scalar; the thread's offset below counts complex numbers' bytes and is halved at the access)
+    const char* inb = (LAY & 1) ? reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.in0) + row * a.ostride_in)
+                                : reinterpret_cast<const char*>(reinterpret_cast<const cplx<T>*>(a.in0) + row * a.ostride_in);
+    const char* inb1 = (LAY & 1) ? reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.in1) + row * a.ostride_in) : nullptr;
+    char* outb = (LAY & 2) ? reinterpret_cast<char*>(reinterpret_cast<T*>(a.out0) + row * a.ostride_out)
+                           : reinterpret_cast<char*>(reinterpret_cast<cplx<T>*>(a.out0) + row * a.ostride_out);
+    char* outb1 = (LAY & 2) ? reinterpret_cast<char*>(reinterpret_cast<T*>(a.out1) + row * a.ostride_out) : nullptr;
     unsigned voff = (unsigned)u * (unsigned)sizeof(cplx<T>);
     if constexpr (W > 1) {  // the row differs across the wave: fold the thread's offset into its own 64-bit base
-        inb += voff;
-        outb += voff;
+        inb += (LAY & 1) ? voff / 2 : voff;
+        if constexpr (LAY & 1) inb1 += voff / 2;
+        outb += (LAY & 2) ? voff / 2 : voff;
+        if constexpr (LAY & 2) outb1 += voff / 2;
         voff = 0;
     }
     cplx<T> v[PPT];
-    Row2Stages<T, L, TPR, 1, true, HALF, RL>::run(lds + c * LP, v, a, u, inb, outb, voff, valid);
+    Row2Stages<T, L, TPR, 1, true, HALF, RL, LAY>::run(lds + c * LP, v, a, u, inb, outb, voff, valid, nullptr, false, inb1, outb1);
 }
 
 // Persistent form for the rows that fill a CU (W == 1, one work-group per CU or two): the work-group walks rows
@@ -288,14 +335,24 @@ static inline int launch_row2p(const TileArgs* a, hipStream_t s, int blocks_per_
     return (int)hipGetLastError();
 }
 
-template <typename T, int L, int W, int NT, typename RL, bool HALF = false, int OCC = 1>
+template <typename T, int L, int W, int NT, typename RL, bool HALF = false, int OCC = 1, int LAY = 0>
 static inline int launch_row2(const TileArgs* a, hipStream_t s, int query_only) {
     if (query_only) return 0;
     const long long tiles = (a->total + W - 1) / W;
     if (tiles <= 0) return 0;
     if (tiles > 2147483647ll) return -1;
-    hipLaunchKernelGGL((fft_row2_kernel<T, L, W, NT, HALF, OCC, RL>), dim3((unsigned)tiles), dim3(NT), 0, s, *a);
+    hipLaunchKernelGGL((fft_row2_kernel<T, L, W, NT, HALF, OCC, RL, LAY>), dim3((unsigned)tiles), dim3(NT), 0, s, *a);
     return (int)hipGetLastError();
+}
+
+// the same configuration for the layout of the pass at hand: interleaved, planes -> planes (a split-complex single-pass plan), planes
+// -> interleaved (the first pass of a split-complex multi-pass plan, whose temp buffer is interleaved)
+template <typename T, int L, int W, int NT, typename RL, bool HALF = false, int OCC = 1>
+static inline int launch_row2_lay(const TileArgs* a, hipStream_t s, int query_only) {
+    if (query_only || (!a->split && !a->split_out)) return launch_row2<T, L, W, NT, RL, HALF, OCC, 0>(a, s, query_only);
+    if (a->split && a->split_out) return launch_row2<T, L, W, NT, RL, HALF, OCC, 3>(a, s, 0);
+    if (a->split) return launch_row2<T, L, W, NT, RL, HALF, OCC, 1>(a, s, 0);
+    return -2;      // (interleaved -> planes: no plan has a contiguous-axis pass last but one; the LDS-staged kernel takes it)
 }
 
 }  // namespace mifft
