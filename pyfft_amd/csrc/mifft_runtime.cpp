@@ -207,6 +207,29 @@ int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0,
         if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
         return 0;
     }
+    // split-complex planes on both sides (a single-pass N-D plan): the fixed-shape stage chain exists for planes in its TILED form
+    // (fft_nd2t.hpp, second batch of round 4) -- a dense batch is the tiling with one tile per "parent".  (128, 128) planes at 1 GiB:
+    // 0.471 on the run-time-shaped kernel below -> 0.653 (interleaved fixed-shape kernel 0.700), (64, 64) 0.535 -> 0.597, fp64 16^3
+    // 0.510 -> 0.584; shapes whose x rows are shorter than 128 bytes per plane stay below -- fp32 (16, 16) 0.717 against 0.460, 16^3 0.674
+    // against 0.475: their tiles move scalars over short runs (profiles/r04_at_rows_split.log)
+    if (p->layout == MIFFT_SPLIT && !(p->flags & (MIFFT_FLAG_SRC_INTERLEAVED | MIFFT_FLAG_DST_INTERLEAVED)) && !no_nd2 && in1 && out1 &&
+        g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 && p->L * (f64nd ? 8 : 4) >= 128 &&
+        mifft_nd2t_split(f64nd, (int)p->L, (int)p->M, (int)p->S, nullptr, nullptr, nullptr, 1) == 0) {
+        mifft::TileArgs t;
+        memset(&t, 0, sizeof(t));
+        t.in0 = in0; t.in1 = in1; t.out0 = out0; t.out1 = out1;
+        t.split = t.split_out = 1;
+        t.tw_L = p->tw_L; t.tw_lo = p->tw_lo; t.tw_hi = p->tw_hi;
+        t.inverse = p->inverse ? 1 : 0;
+        t.scale = p->scale;
+        mifft::TiledGeom g;
+        g.pitch_y = p->L; g.pitch_z = (long long)p->L * p->M; g.parent = (long long)p->L * p->M * p->S; g.tiles = p->outer;
+        g.cx = g.cy = g.cz = 1;
+        const int rc = mifft_nd2t_split(f64nd, (int)p->L, (int)p->M, (int)p->S, &t, &g, s, 0);
+        if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
+        if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
+        return 0;
+    }
     mifft::NdArgs a;
     memset(&a, 0, sizeof(a));
     a.in0 = in0; a.in1 = in1; a.out0 = out0; a.out1 = out1;
