@@ -21,6 +21,7 @@ E_NODEVICE = -3
 F32, F64 = 0, 1
 INTERLEAVED, SPLIT = 0, 1
 VARIANT_INTERLEAVED_ONLY = 2
+VARIANT_SPLIT_ONLY = 3
 PASS_COL, PASS_ROW, PASS_ND = 0, 1, 2
 FLAG_SRC_INTERLEAVED, FLAG_DST_INTERLEAVED = 1, 2
 FLAG_STREAM_SRC, FLAG_STREAM_DST = 4, 8

@@ -70,7 +70,9 @@ int validate(const mifft_pass* p) {
         if (!is_pow2(p->M) || !is_pow2(p->S)) return set_err(MIFFT_E_INVALID, "ND pass: y and z must be powers of two");
         const long long n = (long long)p->L * p->M * p->S;
         const bool both_interleaved = p->layout != MIFFT_SPLIT || ((p->flags & MIFFT_FLAG_SRC_INTERLEAVED) && (p->flags & MIFFT_FLAG_DST_INTERLEAVED));
-        if (n < 4 || mifft_nd_shape_supported(p->precision, p->L, (int32_t)p->M, (int32_t)p->S, both_interleaved ? MIFFT_VARIANT_INTERLEAVED_ONLY : 0) != 0)
+        const bool both_split = p->layout == MIFFT_SPLIT && !(p->flags & (MIFFT_FLAG_SRC_INTERLEAVED | MIFFT_FLAG_DST_INTERLEAVED));
+        if (n < 4 || mifft_nd_shape_supported(p->precision, p->L, (int32_t)p->M, (int32_t)p->S,
+                                              both_interleaved ? MIFFT_VARIANT_INTERLEAVED_ONLY : both_split ? MIFFT_VARIANT_SPLIT_ONLY : 0) != 0)
             return set_err(MIFFT_E_UNSUPPORTED, "ND pass: no kernel for %d x %lld x %lld (%lld points)", p->L, (long long)p->M, (long long)p->S, n);
         if ((p->L > 1 && !p->tw_L) || (p->M > 1 && !p->tw_lo) || (p->S > 1 && !p->tw_hi)) return set_err(MIFFT_E_INVALID, "ND pass: twiddle table missing");
         return 0;
@@ -539,6 +541,11 @@ int mifft_nd_shape_supported(int32_t precision, int32_t x, int32_t y, int32_t z,
     if (x < 1 || y < 1 || z < 1 || (x & (x - 1)) || (y & (y - 1)) || (z & (z - 1))) return MIFFT_E_UNSUPPORTED;
     const long long n = (long long)x * y * z;
     if (n <= mifft_nd_max_points(precision == MIFFT_F64)) return 0;
+    if (variant == MIFFT_VARIANT_SPLIT_ONLY)      // planes on both sides: the tiled fixed-shape kernel with one tile per parent (launch_nd)
+        // (x rows of >= 256 bytes per plane: fp64 (128, 128) 0.374 as two passes -> 0.568, (16, 32, 32) 0.338 -> 0.499; fp32 32^3, 128-byte
+        // rows, measured 0.285 against 0.307 for its two passes and keeps them -- profiles/r04_at_rows_split.log)
+        return (g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 && g_debug[MIFFT_DEBUG_NO_ND2] == 0 && x * (precision == MIFFT_F64 ? 8 : 4) >= 256 &&
+                mifft_nd2t_split(precision == MIFFT_F64, x, y, z, nullptr, nullptr, nullptr, 1) == 0) ? 0 : MIFFT_E_UNSUPPORTED;
     if (variant != MIFFT_VARIANT_INTERLEAVED_ONLY) return MIFFT_E_UNSUPPORTED;
     const int rc = precision == MIFFT_F64 ? mifft_nd2_f64_supported(x, y, z) : mifft_nd2_f32_supported(x, y, z);
     return rc == 0 ? 0 : MIFFT_E_UNSUPPORTED;

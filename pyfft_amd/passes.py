@@ -146,7 +146,10 @@ def build_chain(x, y, z, precision, interleaved=False):
 
     # small 2-D / 3-D transforms: every axis inside LDS, one launch, one HBM round trip (csrc/fft_nd.hpp, fft_nd2.hpp)
     ndims = (x > 1) + (y > 1) + (z > 1)
-    if ndims >= 2 and x * y * z >= 4 and nd_ok(x, y, z):
+    # (split-complex plans: a few shapes beyond the run-time-shaped kernel's tile exist for planes on both sides of ONE launch -- the tiled
+    # fixed-shape kernel with one tile per parent, second batch of round 4: (32, 32, 32) fp32 0.31 as two passes)
+    if ndims >= 2 and x * y * z >= 4 and (nd_ok(x, y, z) or (not interleaved and
+                                                             N.lib.mifft_nd_shape_supported(precision, x, y, z, N.VARIANT_SPLIT_ONLY) == 0)):
         return [PassSpec(N.PASS_ND, X_DIRECTION, x * y * z, x, y, z, 1, x * y * z, True)]
     # 3-D shapes the library has pass-pair kernels for: two launches of two passes each -- (ROW x, COL y R0) on R0 rows of a plane
     # and (COL y R1, COL z) on 128-byte column segments (csrc/fft_pair.hpp).  256^3: the plane fits no tile, so this replaces one
