@@ -48,6 +48,17 @@ def test_supported_lengths():
             L *= 2
         assert N.lib.mifft_pass_supported(N.PASS_ROW, prec, 3, 0) == N.E_UNSUPPORTED
         assert N.lib.mifft_pass_supported(N.PASS_COL, prec, 1 << 20, 0) == N.E_UNSUPPORTED
+    # the longest rows exist for planes too (second batch of round 4), so a split-complex 1-D plan of that length is one pass
+    assert P.row_max(N.F32) == P.row_max(N.F32, interleaved=True) == 32768 and P.row_max(N.F64) == P.row_max(N.F64, interleaved=True) == 16384
+    assert [k.kind for k in P.build_chain(32768, 1, 1, N.F32, interleaved=False)] == [N.PASS_ROW]
+    # single-launch N-D shapes beyond the run-time-shaped kernel's tile: interleaved only, or (a few, with long x rows) planes on both sides
+    big = N.lib.mifft_nd_max_points_for(N.F64)
+    assert 128 * 128 > big and N.lib.mifft_nd_shape_supported(N.F64, 128, 128, 1, 0) == N.E_UNSUPPORTED
+    assert N.lib.mifft_nd_shape_supported(N.F64, 128, 128, 1, N.VARIANT_INTERLEAVED_ONLY) == 0
+    assert N.lib.mifft_nd_shape_supported(N.F64, 128, 128, 1, N.VARIANT_SPLIT_ONLY) == 0
+    assert N.lib.mifft_nd_shape_supported(N.F32, 32, 32, 32, N.VARIANT_SPLIT_ONLY) == N.E_UNSUPPORTED      # (128-byte rows: two passes measured faster)
+    assert [k.kind for k in P.build_chain(128, 128, 1, N.F64, interleaved=False)] == [N.PASS_ND]
+    assert len(P.build_chain(32, 32, 32, N.F32, interleaved=False)) == 2
 
 
 def test_launch_rejects_bad_descriptors_without_touching_the_gpu():
