@@ -36,6 +36,7 @@ struct NdArgs {
     int split_out;  // output layout
     int inverse;
     int edge_out;   // last stage writes its results straight to HBM (interleaved output only)
+    int wt;         // write-through stores of the result (MIFFT_FLAG_WRITE_THROUGH: small launches; the store phase, either layout)
     double scale;
 };
 
@@ -178,8 +179,8 @@ __global__ void __launch_bounds__(NT) fft_nd_kernel(const NdArgs a) {
     }
     if (a.edge_out) return;
 
-    auto store_phase = [&](auto vv) {
-        constexpr int V = vv;
+    auto store_phase = [&](auto vv, auto ntc) {
+        constexpr int V = vv, NTS = ntc;
         static_for<PPT / V>([&](auto ii) {
             constexpr int it = ii;
             const int e = (it * NT + tid) * V;
@@ -190,10 +191,14 @@ __global__ void __launch_bounds__(NT) fft_nd_kernel(const NdArgs a) {
                 p[k].x *= sx;
                 p[k].y *= sy;
             });
-            if (g0 + e < a.total) store_vec<T, V>(io, g0 + e, p);
+            if (g0 + e < a.total) store_vec<T, V, NTS>(io, g0 + e, p);
         });
     };
-    if (a.split_out) store_phase(IC<4>{}); else store_phase(IC<2>{});
+    if (a.wt) {
+        if (a.split_out) store_phase(IC<4>{}, IC<2>{}); else store_phase(IC<2>{}, IC<2>{});
+    } else {
+        if (a.split_out) store_phase(IC<4>{}, IC<0>{}); else store_phase(IC<2>{}, IC<0>{});
+    }
 }
 
 }  // namespace mifft

@@ -10,11 +10,14 @@ using namespace mifft;
 #define MIFFT_ND2T_SPLIT false
 #define MIFFT_ND2T_NAME mifft_nd2t
 #endif
+#ifndef MIFFT_ND2T_SPLIT_OUT
+#define MIFFT_ND2T_SPLIT_OUT MIFFT_ND2T_SPLIT
+#endif
 
 extern "C" int MIFFT_ND2T_NAME(int f64, int x, int y, int z, const TileArgs* a, const TiledGeom* g, hipStream_t s, int query) {
 #define SHAPE(T, F, X, Y, Z)                                         \
     if (f64 == F && x == X && y == Y && z == Z)                      \
-        return query ? 0 : launch_nd2t_auto<T, X, Y, Z, MIFFT_ND2T_SPLIT>(a, g, s);
+        return query ? 0 : launch_nd2t_auto<T, X, Y, Z, MIFFT_ND2T_SPLIT, MIFFT_ND2T_SPLIT_OUT>(a, g, s);
 #define BOTH(X, Y, Z) SHAPE(float, 0, X, Y, Z) SHAPE(double, 1, X, Y, Z)
     BOTH(8, 8, 1) BOTH(16, 16, 1) BOTH(32, 32, 1) BOTH(64, 64, 1) BOTH(128, 128, 1)
     BOTH(32, 16, 1) BOTH(64, 32, 1) BOTH(128, 64, 1)

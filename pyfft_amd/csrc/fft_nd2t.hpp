@@ -34,7 +34,10 @@ template <int LX, int LY, int LZ> struct Nd2tAddr {
     }
 };
 
-template <typename T, int LX, int LY, int LZ, int P, int NT, bool HALF, int OCC, bool EDGE_IN, typename RLX, typename RLY, typename RLZ, bool SPLIT = false>
+// SPLIT: planes on the input side; SPLIT_OUT: on the output side (default: both alike; planes in / interleaved out = the plane pass of a
+// split-complex multi-pass plan, whose temp buffer is interleaved)
+template <typename T, int LX, int LY, int LZ, int P, int NT, bool HALF, int OCC, bool EDGE_IN, typename RLX, typename RLY, typename RLZ, bool SPLIT = false,
+          bool SPLIT_OUT = SPLIT>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) fft_nd2t_kernel(const TileArgs a, const TiledGeom g) {
     constexpr int PPT = P / NT;
     static_assert(PPT * NT == P && P % (LX * LY * LZ) == 0 && PPT % 2 == 0, "bad tile");
@@ -130,7 +133,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) 
                     cplx<T> p = vv[b * St::R + k];
                     p.x *= sx;
                     p.y *= sy;
-                    if constexpr (SPLIT) {
+                    if constexpr (SPLIT_OUT) {
                         out_re[off + k * step] = p.x;
                         out_im[off + k * step] = p.y;
                     } else {
@@ -144,13 +147,14 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) 
 }
 
 // launch with the tile configuration Nd2Auto derives for the dense kernel of the same shape
-template <typename T, int X, int Y, int Z, bool SPLIT = false> static inline int launch_nd2t_auto(const TileArgs* a, const TiledGeom* g, hipStream_t s) {
+template <typename T, int X, int Y, int Z, bool SPLIT = false, bool SPLIT_OUT = SPLIT>
+static inline int launch_nd2t_auto(const TileArgs* a, const TiledGeom* g, hipStream_t s) {
     using C = Nd2Auto<T, X, Y, Z>;
     const long long per_wg = C::P / (X * Y * Z);
     const long long wgs = (g->tiles + per_wg - 1) / per_wg;
     if (wgs <= 0) return 0;
     if (wgs > 2147483647ll) return -1;
-    hipLaunchKernelGGL((fft_nd2t_kernel<T, X, Y, Z, C::P, C::NT, C::HALF, C::OCC, C::EDGE_IN, typename C::RLX, typename C::RLY, typename C::RLZ, SPLIT>),
+    hipLaunchKernelGGL((fft_nd2t_kernel<T, X, Y, Z, C::P, C::NT, C::HALF, C::OCC, C::EDGE_IN, typename C::RLX, typename C::RLY, typename C::RLZ, SPLIT, SPLIT_OUT>),
                        dim3((unsigned)wgs), dim3(C::NT), 0, s, *a, *g);
     return (int)hipGetLastError();
 }

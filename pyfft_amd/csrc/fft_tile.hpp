@@ -105,8 +105,13 @@ template <typename T, int V, int NT = 0> __device__ __forceinline__ void store_v
         V4 re, im;
         re.x = p[0].x; im.x = p[0].y; re.y = p[1].x; im.y = p[1].y;
         re.z = p[2].x; im.z = p[2].y; re.w = p[3].x; im.w = p[3].y;
-        *reinterpret_cast<V4*>(reinterpret_cast<T*>(a.out0) + g) = re;
-        *reinterpret_cast<V4*>(reinterpret_cast<T*>(a.out1) + g) = im;
+        if constexpr (NT == 2) {      // write-through (small launches)
+            store_vec_wt(reinterpret_cast<V4*>(reinterpret_cast<T*>(a.out0) + g), re);
+            store_vec_wt(reinterpret_cast<V4*>(reinterpret_cast<T*>(a.out1) + g), im);
+        } else {
+            *reinterpret_cast<V4*>(reinterpret_cast<T*>(a.out0) + g) = re;
+            *reinterpret_cast<V4*>(reinterpret_cast<T*>(a.out1) + g) = im;
+        }
     }
 }
 

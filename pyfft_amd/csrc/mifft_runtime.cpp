@@ -214,20 +214,23 @@ int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0,
     // 0.471 on the run-time-shaped kernel below -> 0.653 (interleaved fixed-shape kernel 0.700), (64, 64) 0.535 -> 0.597, fp64 16^3
     // 0.510 -> 0.584; shapes whose x rows are shorter than 128 bytes per plane stay below -- fp32 (16, 16) 0.717 against 0.460, 16^3 0.674
     // against 0.475: their tiles move scalars over short runs (profiles/r04_at_rows_split.log)
-    if (p->layout == MIFFT_SPLIT && !(p->flags & (MIFFT_FLAG_SRC_INTERLEAVED | MIFFT_FLAG_DST_INTERLEAVED)) && !no_nd2 && in1 && out1 &&
+    // (planes in, interleaved out -- the plane pass of a split-complex multi-pass plan -- likewise: fft_nd2t_split_in.hip)
+    const bool planes_in_only = p->layout == MIFFT_SPLIT && !(p->flags & MIFFT_FLAG_SRC_INTERLEAVED) && (p->flags & MIFFT_FLAG_DST_INTERLEAVED);
+    if (p->layout == MIFFT_SPLIT && !(p->flags & MIFFT_FLAG_SRC_INTERLEAVED) && !no_nd2 && in1 && (out1 || planes_in_only) &&
         g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 && p->L * (f64nd ? 8 : 4) >= 128 &&
         mifft_nd2t_split(f64nd, (int)p->L, (int)p->M, (int)p->S, nullptr, nullptr, nullptr, 1) == 0) {
         mifft::TileArgs t;
         memset(&t, 0, sizeof(t));
-        t.in0 = in0; t.in1 = in1; t.out0 = out0; t.out1 = out1;
-        t.split = t.split_out = 1;
+        t.in0 = in0; t.in1 = in1; t.out0 = out0; t.out1 = planes_in_only ? nullptr : out1;
+        t.split = 1;
+        t.split_out = planes_in_only ? 0 : 1;
         t.tw_L = p->tw_L; t.tw_lo = p->tw_lo; t.tw_hi = p->tw_hi;
         t.inverse = p->inverse ? 1 : 0;
         t.scale = p->scale;
         mifft::TiledGeom g;
         g.pitch_y = p->L; g.pitch_z = (long long)p->L * p->M; g.parent = (long long)p->L * p->M * p->S; g.tiles = p->outer;
         g.cx = g.cy = g.cz = 1;
-        const int rc = mifft_nd2t_split(f64nd, (int)p->L, (int)p->M, (int)p->S, &t, &g, s, 0);
+        const int rc = (planes_in_only ? mifft_nd2t_split_in : mifft_nd2t_split)(f64nd, (int)p->L, (int)p->M, (int)p->S, &t, &g, s, 0);
         if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
         if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
         return 0;
@@ -267,6 +270,9 @@ int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0,
         const long long run_out = ((dims[axn] / a.st_radix[ns - 1]) << a.logS[axn]) * (f64 ? 16 : 8);
         a.edge_out = (!a.split_out && run_out >= 128) ? 1 : 0;
     }
+    // small launches: write-through stores of the result (the store phase -- planes always go through it; an interleaved result that
+    // leaves by the register edge keeps plain stores).  MIFFT_NARROW_TILES = 1: off (A/B)
+    a.wt = ((stream_policy(p->flags) & 4) && g_debug[MIFFT_DEBUG_NARROW_TILES] != 1) ? 1 : 0;
     const int rc = mifft_nd_launch(f64 ? 1 : 0, dims[0] * dims[1] * dims[2], &a, s);
     if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
     if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");

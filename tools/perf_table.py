@@ -16,7 +16,8 @@ PUBLISHED_C2050 = {  # shape -> (pyfft sp, cufft sp, pyfft dp, cufft dp) GFLOPS
 SHAPES = [(16,), (1024,), (8192,), (16, 16), (128, 128), (1024, 1024), (8, 8, 64), (16, 16, 16), (16, 16, 128),
           (32, 32, 128), (128, 128, 128)]
 
-def run(shape, double, buffer_mib):
+def run(shape, double, buffer_mib, split=False):
+    """split: the reference's other layout (dtype float32 / float64: re / im planes; the same bytes per side)"""
     dtype = numpy.complex128 if double else numpy.complex64
     size = int(numpy.prod(shape))
     batch = (buffer_mib << 20) // (size * numpy.dtype(dtype).itemsize)
@@ -24,16 +25,20 @@ def run(shape, double, buffer_mib):
         return None
     rng = numpy.random.default_rng(5)
     fdt = numpy.float64 if double else numpy.float32
-    data = (rng.standard_normal(size * batch).astype(fdt) + 1j * rng.standard_normal(size * batch).astype(fdt)).astype(dtype)
-    a = DeviceArray((size * batch,), dtype).set(data)
-    b = DeviceArray((size * batch,), dtype)
+    if split:
+        bufs = [DeviceArray((size * batch,), fdt).set(rng.standard_normal(size * batch).astype(fdt)) for _ in range(2)] + \
+            [DeviceArray((size * batch,), fdt) for _ in range(2)]
+        dtype = fdt
+    else:
+        data = (rng.standard_normal(size * batch).astype(fdt) + 1j * rng.standard_normal(size * batch).astype(fdt)).astype(dtype)
+        bufs = [DeviceArray((size * batch,), dtype).set(data), DeviceArray((size * batch,), dtype)]
     plan = Plan(shape if len(shape) > 1 else shape[0], dtype=dtype, wait_for_finish=True)
     gflop = 5.0e-9 * sum(numpy.log2(s) for s in shape) * size * batch
-    plan.execute(a, b, batch=batch)
+    plan.execute(*bufs, batch=batch)
     st = plan._context.getQueue()
     e0 = Event().record(st)
     for _ in range(10):
-        plan.execute(a, b, batch=batch, wait_for_finish=False)
+        plan.execute(*bufs, batch=batch, wait_for_finish=False)
     e1 = Event().record(st); e1.synchronize()
     t = e1.time_since(e0) / 1e3 / 10
     return batch, t, gflop / t
@@ -45,6 +50,14 @@ if __name__ == "__main__":
         for shape in ((1024,), (128, 128)):
             batch, t, gf = run(shape, False, 32)
             print(json.dumps({"shape": list(shape), "batch": batch, "seconds_per_execute": t, "gflops": gf}), flush=True)
+        sys.exit(0)
+    if "--split" in sys.argv:
+        # the same shapes in the reference's split-complex layout next to the interleaved one (second batch of round 4)
+        for buffer_mib in (32, 1024):
+            print("buffer %d MiB per side; GFLOPS interleaved / split planes, single and double precision" % buffer_mib)
+            for shape in SHAPES:
+                r = [run(shape, d, buffer_mib, sp)[2] for d in (False, True) for sp in (False, True)]
+                print("%-16s sp %9.1f / %9.1f (%.2f)   dp %9.1f / %9.1f (%.2f)" % (str(shape), r[0], r[1], r[1] / r[0], r[2], r[3], r[3] / r[2]), flush=True)
         sys.exit(0)
     for buffer_mib in (32, 1024):
         print("buffer %d MiB (the reference uses 32 MiB, test/helpers.py:7)" % buffer_mib)
