@@ -70,7 +70,8 @@ int validate(const mifft_pass* p) {
         if (!is_pow2(p->M) || !is_pow2(p->S)) return set_err(MIFFT_E_INVALID, "ND pass: y and z must be powers of two");
         const long long n = (long long)p->L * p->M * p->S;
         const bool both_interleaved = p->layout != MIFFT_SPLIT || ((p->flags & MIFFT_FLAG_SRC_INTERLEAVED) && (p->flags & MIFFT_FLAG_DST_INTERLEAVED));
-        const bool both_split = p->layout == MIFFT_SPLIT && !(p->flags & (MIFFT_FLAG_SRC_INTERLEAVED | MIFFT_FLAG_DST_INTERLEAVED));
+        // (planes on the input side at least: the tiled fixed-shape kernel takes planes -> planes and planes -> interleaved)
+        const bool both_split = p->layout == MIFFT_SPLIT && !(p->flags & MIFFT_FLAG_SRC_INTERLEAVED);
         if (n < 4 || mifft_nd_shape_supported(p->precision, p->L, (int32_t)p->M, (int32_t)p->S,
                                               both_interleaved ? MIFFT_VARIANT_INTERLEAVED_ONLY : both_split ? MIFFT_VARIANT_SPLIT_ONLY : 0) != 0)
             return set_err(MIFFT_E_UNSUPPORTED, "ND pass: no kernel for %d x %lld x %lld (%lld points)", p->L, (long long)p->M, (long long)p->S, n);

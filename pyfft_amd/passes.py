@@ -160,7 +160,8 @@ def build_chain(x, y, z, precision, interleaved=False):
             return pair_chain(x, y, z, r0)
     # 3-D shapes too big for one tile but with a small (y, x) plane: x and y together in LDS per plane (the planes
     # are just more batch items), then only z as a strided chain -- two HBM round trips instead of three
-    if ndims == 3 and nd_ok(x, y, 1):
+    # (split-complex plans: also the planes that exist for plane input only as the tiled fixed-shape kernel -- fp64 (128, 128))
+    if ndims == 3 and (nd_ok(x, y, 1) or (not interleaved and N.lib.mifft_nd_shape_supported(precision, x, y, 1, N.VARIANT_SPLIT_ONLY) == 0)):
         return [PassSpec(N.PASS_ND, X_DIRECTION, x * y, x, y, 1, z, x * y, True)] + \
             col_chain(Z_DIRECTION, z, x * y, 1, precision, interleaved)
     if x > 1:
