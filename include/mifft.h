@@ -160,7 +160,10 @@ const char *mifft_last_error(void);
 #define MIFFT_DEBUG_PAIR 6         /* pass pairs: 0 = default split, 1 = off, 2 = the alternative y split, 3 = the first tile forms of the persistent two-pair kernel (A/B measurements) */
 #define MIFFT_DEBUG_STORE 7        /* streamed output stores (A/B): 0 = default, 1 = non-temporal, 2 = write-through (sc1), 3 = plain */
 #define MIFFT_DEBUG_ROWS_ND 8      /* dense smooth rows: 0 = default, 1 = two-buffer row kernel only, 2 = single-buffer tile kernel wherever it fits (A/B) */
-#define MIFFT_DEBUG_NARROW_TILES 9 /* fp32 L = 256 / 512: 1 = 16-column tiles also in the persistent kernel (rounds 1-3), 2 = 32-column tiles also in plain launches (A/B) */
+#define MIFFT_DEBUG_NARROW_TILES 9 /* A/B of the round-4 tile forms: 1 = the rounds 1-3 forms -- fp32 L = 256 / 512 on 16-column tiles also in the persistent
+                                    * kernel, and for split-complex planes no lane-interleaved double tiles, no register-edged rows, no fixed-shape N-D
+                                    * route, no row-first 2-D kernel, no write-through in the run-time-shaped N-D kernel; 2 = 32-column tiles (and the
+                                    * double tile of a plane-writing L = 1024 pass) also in plain launches */
 #define MIFFT_DEBUG_KEYS 10
 int mifft_debug_set(int32_t key, int32_t value);
 int mifft_debug_get(int32_t key);
