@@ -12,6 +12,27 @@ from test_errors_gpu import run_protocol
 pytestmark = pytest.mark.gpu
 
 
+def _noise(rng, count, dtype):
+    """`count` N(0, 1) numbers: a seeded block of 2^22 + 17 draws, repeated (the period is no multiple of any transform size, so every
+    transform of a batch sees different numbers; drawing 300 MiB afresh for every case took most of the suite's time)."""
+    blk = rng.standard_normal(min(int(count), (1 << 22) + 17)).astype(dtype)
+    return numpy.resize(blk, int(count))
+
+
+def _test_data(shape, dtype, batch, seed):
+    """Interleaved test data of `batch` transforms (the layout of oracle.get_test_data: the first axis times batch) from tiled noise."""
+    rng = numpy.random.default_rng(seed)
+    dtype = numpy.dtype(dtype)
+    fdt = numpy.float32 if dtype == numpy.complex64 else numpy.float64
+    full = [int(v) for v in (shape if isinstance(shape, tuple) else (shape,))]
+    full[0] *= batch
+    count = int(numpy.prod(full))
+    out = numpy.empty(count, dtype)
+    out.real = _noise(rng, count, fdt)
+    out.imag = _noise(rng, count, fdt)
+    return out.reshape(full)
+
+
 def _execute(ctx, shape, dtype, batch, data, inplace=False, inverse=False, expect=None):
     plan = ctx.getPlan(shape, dtype=dtype)
     if expect is not None:
@@ -86,7 +107,7 @@ def test_per_xcd_lists(ctx, monkeypatch, n, batch):
     batch that is not a multiple of 8 leaves the lists uneven, work stealing drains them."""
     if not ctx.hip.Machine.from_props(ctx.hip.device_props()).xcd_cooperative:
         pytest.skip("needs 8 XCDs x 32 CUs")
-    data = oracle.get_test_data((n,), numpy.complex64, batch, 91)
+    data = _test_data((n,), numpy.complex64, batch, 91)
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
     want = _execute(ctx, (n,), numpy.complex64, batch, data, expect="chain")
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "fusedx")
@@ -108,7 +129,7 @@ def test_fused_ring_rule_2_19(ctx, monkeypatch):
     plan = ctx.getPlan((n,), dtype=numpy.complex64)
     if ctx.hip.Machine.from_props(ctx.hip.device_props()).llc_bytes == 256 << 20 and plan._context.compute_units == 256:
         assert plan.strategy(batch) == ("fused2", 28, 56, 512)
-    data = oracle.get_test_data((n,), numpy.complex64, batch, 92)
+    data = _test_data((n,), numpy.complex64, batch, 92)
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
     want = _execute(ctx, (n,), numpy.complex64, batch, data, expect="chain")
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
@@ -124,7 +145,7 @@ def test_sequential_single_launch_of_tiny_batches(ctx, monkeypatch, shape, dtype
     """The reference's own benchmark protocol runs 32 MiB buffers (test/test_performance.py:11,22-30): there the two passes of a
     transform are two dependent launches.  The sequential work list runs them in ONE persistent launch (lag 0: every first-pass
     tile, then every second-pass tile); it must give the chain's bits, in place and out of place, forward and inverse."""
-    data = oracle.get_test_data(shape, dtype, batch, 93)
+    data = _test_data(shape, dtype, batch, 93)
     monkeypatch.setenv("PYFFT_AMD_SMALL_FUSED", "0")
     want = _execute(ctx, shape, dtype, batch, data, expect="chain")
     monkeypatch.setenv("PYFFT_AMD_SMALL_FUSED", "1")
@@ -152,7 +173,7 @@ def test_alternating_counter_sets_and_memset_form_agree(ctx, monkeypatch):
     no memset node precedes a launch; the round-3 form (one set, zeroed by the call) is kept behind a switch.  Both give the same
     bits over many back-to-back executes, with a batch change in between (new sets) and alternating directions."""
     n = 1 << 20
-    data = oracle.get_test_data((n,), numpy.complex64, 70, 94)
+    data = _test_data((n,), numpy.complex64, 70, 94)
     outs = {}
     for memset in ("", "1"):
         if memset:
@@ -187,7 +208,7 @@ def test_plan_with_stream_and_context_index(ctx):
     home = cur.value
     N.check(N.lib.mifft_set_device(dev), "set")
     stream = hip.Stream()
-    data = oracle.get_test_data((8192,), numpy.complex64, 3, 95)
+    data = _test_data((8192,), numpy.complex64, 3, 95)
     a = ctx.toGpu(data)
     N.check(N.lib.mifft_set_device(home), "set")
     plan = ctx.getPlan((8192,), dtype=numpy.complex64, stream=stream, context=dev)
@@ -221,7 +242,7 @@ def test_generic_plans_build_only_what_they_run(ctx):
     blue = ctx.getPlan((4099, 4), dtype=numpy.complex64, any_size=True)                 # a long prime axis: padded power-of-two rows
     assert len(blue._inner_plans()) >= 1
     for plan, shape, batch in ((tiled, (64, 64), 2), (nd, (60, 16), 3)):
-        data = oracle.get_test_data(shape, numpy.complex64, batch, 96)
+        data = _test_data(shape, numpy.complex64, batch, 96)
         a = ctx.toGpu(data)
         plan.execute(a, batch=batch)
         got = a.get().reshape((batch,) + shape)
@@ -245,7 +266,7 @@ def test_fused_2d_rectangles(ctx, monkeypatch, shape, batch):
     thresholds against numpy on sampled transforms, input untouched, in place == out of place, inverse round trip, and the
     chain's result within fp32 rounding (another operation order: ROW + strided COL)."""
     ny, nx = shape
-    data = oracle.get_test_data(shape, numpy.complex64, batch, 1100 + ny // 512 + nx // 128)
+    data = _test_data(shape, numpy.complex64, batch, 1100 + ny // 512 + nx // 128)
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto" if shape != (512, 2048) else "fused")
     got = _execute(ctx, shape, numpy.complex64, batch, data, expect="fused2")
     assert numpy.array_equal(_execute(ctx, shape, numpy.complex64, batch, data, inplace=True, expect="fused2"), got)
@@ -371,7 +392,7 @@ def test_fused_mid_sizes_fp64(ctx, monkeypatch, n, batch, forced):
     (`fft_fused2_kernel<double>`; round 3: pipelined chunks): the chain's tile code, so the chain's bits; 2^19 = 1024 x 512 on the
     512-thread tiles (`fft_fused3_kernel<double, 2, 1>`); in place; numpy on sampled
     transforms with the reference's fp64 thresholds (test/test_errors.py:20-23); inverse round trip."""
-    data = oracle.get_test_data((n,), numpy.complex128, batch, 97)
+    data = _test_data((n,), numpy.complex128, batch, 97)
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
     want = _execute(ctx, (n,), numpy.complex128, batch, data, expect="chain")
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", forced)
@@ -399,7 +420,7 @@ def test_fused_2d_fp64_512_sides(ctx, monkeypatch, shape, batch):
     256-thread two-phase tiles, the rectangles on the 512-thread ones.  numpy with the reference's fp64 thresholds on sampled
     transforms, in place == out of place, inverse, and the chain's result to rounding (two transposing passes against ROW + COL)."""
     ny, nx = shape
-    data = oracle.get_test_data(shape, numpy.complex128, batch, 1200 + ny // 512 + nx // 256)
+    data = _test_data(shape, numpy.complex128, batch, 1200 + ny // 512 + nx // 256)
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
     monkeypatch.setenv("PYFFT_AMD_FUSED_RING", "8,16")
     got = _execute(ctx, shape, numpy.complex128, batch, data, expect="fused2")
@@ -423,7 +444,7 @@ def test_wide_tiles_fp32_mid_sizes(ctx, monkeypatch, n, batch):
     of the 16-column tiles, in place, numpy with the reference's thresholds, inverse round trip; a batch that fills the ring only
     once takes half the pipeline instead of falling back to the chunks."""
     N = ctx.hip.N
-    data = oracle.get_test_data((n,), numpy.complex64, batch, 98)
+    data = _test_data((n,), numpy.complex64, batch, 98)
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
     want = _execute(ctx, (n,), numpy.complex64, batch, data, expect="chain")
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
@@ -515,7 +536,7 @@ def test_fused_2d_256_sides(ctx, monkeypatch, shape, batch, dtype):
     if f64:
         batch = batch // 2 + 1
     eps, mx = (1e-11, 1e-10) if f64 else (1.1e-6, 1e-5)
-    data = oracle.get_test_data(shape, cd, batch, 1300 + ny // 256 + nx // 64)
+    data = _test_data(shape, cd, batch, 1300 + ny // 256 + nx // 64)
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
     got = _execute(ctx, shape, cd, batch, data, expect="fused2")
     assert numpy.array_equal(_execute(ctx, shape, cd, batch, data, inplace=True, expect="fused2"), got)
@@ -556,8 +577,8 @@ def test_split_planes_on_per_xcd_lists(ctx, monkeypatch, n, batch, expect):
     tiles, same order of operations), in place == out of place, numpy with the reference's thresholds on sampled transforms, the
     inverse round trip, batches that are no multiple of 8 (lists of unequal length)."""
     rng = numpy.random.default_rng(1400 + n % 97)
-    re = rng.standard_normal(n * batch).astype(numpy.float32)
-    im = rng.standard_normal(n * batch).astype(numpy.float32)
+    re = _noise(rng, n * batch, numpy.float32)
+    im = _noise(rng, n * batch, numpy.float32)
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
     want = _execute_split(ctx, (n,), numpy.float32, batch, re, im, expect="chain")
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
@@ -600,7 +621,7 @@ def test_fused_pair_small_axes(ctx, monkeypatch, shape, batch, dtype):
     plan = ctx.getPlan(shape, dtype=cd)
     assert plan._pair_alt is not None and len(plan._kernels) == 2 and not plan._paired
     assert plan.strategy(2)[0] == "chain"
-    data = oracle.get_test_data(shape, cd, batch, 1500 + nz + nx // 64)
+    data = _test_data(shape, cd, batch, 1500 + nz + nx // 64)
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
     got = _execute(ctx, shape, cd, batch, data, expect="fusedp")
     assert numpy.array_equal(_execute(ctx, shape, cd, batch, data, inplace=True, expect="fusedp"), got)
@@ -633,8 +654,8 @@ def test_fused_pair_split_planes(ctx, monkeypatch, shape, rdtype, batch):
     eps, mx = (1e-11, 1e-10) if f64 else (1.1e-6, 1e-5)
     n = shape[0] * shape[1] * shape[2]
     rng = numpy.random.default_rng(1600 + sum(shape))
-    re = rng.standard_normal(n * batch).astype(rd)
-    im = rng.standard_normal(n * batch).astype(rd)
+    re = _noise(rng, n * batch, rd)
+    im = _noise(rng, n * batch, rd)
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
     assert ctx.getPlan(shape, dtype=rd)._pair_alt is not None
     got = _execute_split(ctx, shape, rd, batch, re, im, expect="fusedp")
@@ -666,8 +687,8 @@ def test_fused_2d_split_row_first(ctx, monkeypatch, shape, batch):
     ny, nx = shape
     n = ny * nx
     rng = numpy.random.default_rng(1700 + ny // 256 + nx // 64)
-    re = rng.standard_normal(n * batch).astype(numpy.float32)
-    im = rng.standard_normal(n * batch).astype(numpy.float32)
+    re = _noise(rng, n * batch, numpy.float32)
+    im = _noise(rng, n * batch, numpy.float32)
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto" if shape != (256, 256) else "fused")
     got = _execute_split(ctx, shape, numpy.float32, batch, re, im, expect="fused2")
     inp = _execute_split(ctx, shape, numpy.float32, batch, re, im, inplace=True, expect="fused2")
@@ -698,8 +719,8 @@ def test_fused_split_planes_fp64(ctx, monkeypatch, shape, batch):
     round trip, and the chain's result to rounding."""
     n = int(numpy.prod(shape))
     rng = numpy.random.default_rng(1800 + n % 89 + len(shape))
-    re = rng.standard_normal(n * batch)
-    im = rng.standard_normal(n * batch)
+    re = _noise(rng, n * batch, numpy.float64)
+    im = _noise(rng, n * batch, numpy.float64)
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
     got = _execute_split(ctx, shape, numpy.float64, batch, re, im, expect="fused2")
     inp = _execute_split(ctx, shape, numpy.float64, batch, re, im, inplace=True, expect="fused2")
