@@ -350,7 +350,8 @@ __global__ void __launch_bounds__(NT) fft_tile_kernel(const TileArgs a) {
         });
     };
     if constexpr (kQuadShape) {
-        if (quad_out) store_phase(IC<4>{}, IC<0>{});
+        if (quad_out && (a.nt & 4)) store_phase(IC<4>{}, IC<2>{});   // (planes in small launches: write-through 16-byte stores, second batch of round 4)
+        else if (quad_out) store_phase(IC<4>{}, IC<0>{});
         else if (a.nt & 4) store_phase(IC<2>{}, IC<2>{});
         else if (a.nt & 2) store_phase(IC<2>{}, IC<1>{});
         else store_phase(IC<2>{}, IC<0>{});
