@@ -51,6 +51,9 @@ CONFIGS = {
 }
 
 
+C5_SHARE = 8192     # transforms per GPU of BASELINE.json configs[4] (65536 over 8 GPUs)
+
+
 def shard_batch(global_batch, rank, world):
     """Contiguous slice [start, start+count) of the batch axis owned by `rank`:
     independent transforms, no exchange."""
@@ -273,7 +276,13 @@ def cpu_baseline(shape, dtype, host_items, flop_per_xform, budget_s=24.0):
         value, used, impl, sample = pool_val, cores, "numpy.fft.fftn, process pool of %d workers" % cores, res["numpy_fft_pool_sample_xforms"]
     else:
         value, used, impl, sample = res["numpy_fft_1core_gflops"], 1, "numpy.fft.fftn (1 thread)", done
-    out = {"value": value, "unit": "GFLOPS", "cores": used, "kind": "reference",
+    # the strongest CPU figure of the run, whatever library it comes from (the reference's own path is `value`)
+    cands = [(res.get("numpy_fft_pool_gflops"), "numpy.fft.fftn, process pool of %d workers" % cores, cores),
+             (res.get("numpy_fft_1core_gflops"), "numpy.fft.fftn (1 thread)", 1),
+             (res.get("scipy_fft_allcores_gflops"), "scipy.fft.fftn(workers=%d)" % cores, cores)]
+    bv, bimpl, bcores = max((c for c in cands if c[0] is not None), key=lambda c: c[0])
+    best = {"value": bv, "unit": "GFLOPS", "impl": bimpl, "cores": bcores}
+    out = {"value": value, "unit": "GFLOPS", "cores": used, "kind": "reference", "best": best,
            "impl": impl + " -- the reference's own CPU path (test/test_errors.py:35)",
            "sample": "%d transforms drawn from %d items of the same %s %s data the GPU transforms (host copy), nominal 5*N*log2(N) flop" %
                      (sample, n, "x".join(map(str, shape)), dtype),
@@ -311,6 +320,16 @@ def global_item(shape, dtname, batch, seed, g):
     return host_c[g % blk]
 
 
+def library_digest():
+    """First 16 hex digits of the sha256 of the libmifft.so this process runs (what profiles/traffic_<c>.json records)."""
+    import hashlib
+    try:
+        with open(os.path.join(ROOT, "pyfft_amd", "libmifft.so"), "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def stats(xs):
     xs = sorted(xs)
     n = len(xs)
@@ -321,7 +340,7 @@ def stats(xs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default 10; config c5: the 32 chunks of the per-GPU share)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS.keys()))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (development only)")
@@ -329,6 +348,9 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="repeats of the out-of-place / in-place protocol blocks (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plain", action="store_true", help="only parity + warm-up + the K timed steps (no protocol repeats, per-pass timing or CPU baseline): profiler runs")
+    ap.add_argument("--chunk-only", action="store_true",
+                    help="config c5: time K executes of ONE resident 256-transform chunk (8 GiB in + 8 GiB out, out of place) instead of "
+                         "the stated per-GPU share of 8192 transforms (profiler runs, rounds 1-4 lines)")
     ap.add_argument("--selftest-dist", action="store_true", help="CPU/gloo self-test of the multi-process harness")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even at world size 1 (test)")
     ap.add_argument("--control", default="nccl", choices=["nccl", "gloo"],
@@ -344,6 +366,11 @@ def main():
     if args.plain:
         args.repeats = 0
         args.no_cpu_baseline = True
+    # config 5 as BASELINE.json states it: 65536 transforms of 2^22 points over 8 GPUs = 8192 per GPU = 256 GiB per GPU, run as a
+    # streaming loop over 256-transform chunks.  One step = one chunk; the default K is one sweep over the share.
+    share_mode = args.config == "c5" and not args.chunk_only and not args.batch
+    if args.steps <= 0:
+        args.steps = C5_SHARE // CONFIGS["c5"][2] if share_mode else 10
     if args.gpus > 1 and "RANK" not in os.environ:
         return self_launch(args, sys.argv[1:])       # never returns
     if args.selftest_dist:
@@ -364,14 +391,16 @@ def main():
     log2n = sum(int(round(numpy.log2(s))) for s in shape)
     flop_per_xform = 5.0 * size * log2n
     alg_bytes_per_xform = 2.0 * size * cdtype.itemsize          # read once + write once
-    gstart, _ = shard_batch(batch * world, rank, world)          # this rank's slice of the global batch
+    share = C5_SHARE if share_mode else batch                    # transforms this rank owns (share mode: `batch` is the chunk)
+    gstart, _ = shard_batch(share * world, rank, world)          # this rank's slice of the global batch
 
     # ---- synthetic data: one host block of <= 64 transforms (tiled across the batch on the device further down)
     blk, host_re, host_im, host_c = make_host_block(shape, dtname, batch, seed, gstart)
 
-    # ---- CPU baseline first: rank 0 at N = 1 only, before this process initialises the GPU (the pool forks)
+    # ---- CPU baseline first: rank 0 (at every world size: the other ranks wait in init_process_group), before this process
+    # initialises the GPU (the pool forks) -- numpy.fft on the box's host cores in the same run, as north_star words it
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(shape, dtname, host_c[:min(blk, 16)], flop_per_xform)
 
     torch = None
@@ -401,7 +430,23 @@ def main():
     props = device_props(device)
 
     nel = size * batch
-    if split:
+    resident = False
+    chunks = 1
+    if share_mode:
+        # the whole per-GPU share resident, transformed IN PLACE chunk by chunk (256 GiB of the 288 GB; out of place would need 512)
+        chunks = share // batch
+        try:
+            ins = [DeviceArray((size * share,), dtype)]
+            outs = ins
+            resident = True
+            fill_device(N, ins[0].ptr, ins[0].nbytes, host_c)
+        except RuntimeError as e:
+            # no room (a shared or smaller device): the streaming loop over ONE pair of reused chunk buffers, out of place
+            sys.stderr.write("bench.py: the %d-transform share does not fit (%s): reusing one resident chunk\n" % (share, str(e)[:120]))
+            ins = None
+    if share_mode and resident:
+        pass
+    elif split:
         ins = [DeviceArray((nel,), dtype), DeviceArray((nel,), dtype)]
         outs = ins if args.inplace else [DeviceArray((nel,), dtype), DeviceArray((nel,), dtype)]
         fill_device(N, ins[0].ptr, ins[0].nbytes, host_re)
@@ -427,8 +472,22 @@ def main():
             else:
                 plan.execute(ins[0], outs[0], batch=batch, inverse=inverse)
 
+    chunk_bytes = size * batch * cdtype.itemsize
+
+    def execute_chunk(c, inverse=False):
+        """share mode, resident: chunk c of the share (global transforms [gstart + c * batch, gstart + (c + 1) * batch)) in place"""
+        plan.execute(ins[0].ptr + c * chunk_bytes, batch=batch, inverse=inverse)
+
+    step_no = [0]
+
     def step():
-        execute(args.inplace)
+        if resident:
+            # one sweep over the share forward, the next one inverse, ...: the values stay those of the data set
+            i = step_no[0]
+            step_no[0] = i + 1
+            execute_chunk(i % chunks, inverse=bool((i // chunks) & 1))
+        else:
+            execute(args.inplace)
 
     def sync_all():
         if torch is not None and torch.cuda.is_available():
@@ -442,7 +501,42 @@ def main():
 
     # ---- parity gate (before timing, on the untouched input): sampled batch items vs numpy.fft
     parity = None
-    if not args.inplace:
+    if resident:
+        # every chunk of the share forward in place; first / middle / last transform of the first, a middle and the last chunk against
+        # numpy; then every chunk inverse in place (the data set is back, up to rounding) and the round trip of the same samples
+        isz = dtype.itemsize
+        eps, mx = 1.1e-6, 1e-5
+
+        def fetch(g):
+            got = numpy.empty(size, dtype)
+            N.check(N.lib.mifft_memcpy_d2h(got.ctypes.data, ins[0].ptr + g * size * isz, size * isz, None), "d2h")
+            return got.astype(numpy.complex128)
+
+        samples = sorted(set(c * batch + s for c in (0, chunks // 2, chunks - 1) for s in (0, batch // 2, batch - 1)))
+        for c in range(chunks):
+            execute_chunk(c)
+        plan.finish()
+        worst_diff, worst_max = 0.0, 0.0
+        for g in samples:
+            got = fetch(g)
+            ref = numpy.fft.fft(host_c[g % blk].astype(numpy.complex128))
+            worst_diff = max(worst_diff, float(numpy.abs(ref - got).sum() / numpy.abs(ref).sum()))
+            worst_max = max(worst_max, float(numpy.abs(ref - got).max() / numpy.abs(ref).max()))
+            if args.dump_dir and g in (0, share - 1):
+                numpy.save(os.path.join(args.dump_dir, "xform_%d.npy" % (gstart + g)), got)
+        for c in range(chunks):
+            execute_chunk(c, inverse=True)
+        plan.finish()
+        worst_rt = 0.0
+        for g in samples:
+            want = host_c[g % blk].astype(numpy.complex128)
+            worst_rt = max(worst_rt, float(numpy.abs(want - fetch(g)).sum() / numpy.abs(want).sum()))
+        parity = {"samples": len(samples), "sampled_transforms": samples, "difference": worst_diff, "max_rel": worst_max,
+                  "round_trip_difference": worst_rt, "tol_difference": eps, "tol_max_rel": mx,
+                  "ok": bool(worst_diff < eps and worst_max <= mx and worst_rt < eps)}
+        if not parity["ok"]:
+            raise SystemExit("PARITY FAILURE: %r" % (parity,))
+    elif not args.inplace:
         step()
         plan.finish()
         # >= 8 sampled batch items including the first and the last one (all of them when the batch is smaller)
@@ -474,8 +568,12 @@ def main():
             raise SystemExit("PARITY FAILURE: %r" % (parity,))
 
     # ---- warm-up, then EXACTLY K timed steps bracketed by barrier + device sync on both sides
-    for _ in range(args.warmup):
-        step()
+    for w in range(args.warmup):
+        if resident:
+            execute_chunk(w % chunks)
+            execute_chunk(w % chunks, inverse=True)
+        else:
+            step()
     sync_all()
     barrier()
     sync_all()
@@ -499,7 +597,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # every rank's slice of the global batch and its own parity verdict (checked against the GLOBAL dataset)
-        mine = torch.tensor([float(gstart), float(batch), 1.0 if (parity is None or parity["ok"]) else 0.0,
+        mine = torch.tensor([float(gstart), float(share), 1.0 if (parity is None or parity["ok"]) else 0.0,
                              parity["difference"] if parity else 0.0, float(device)], dtype=torch.float64, device=ctl_dev)
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
@@ -510,8 +608,28 @@ def main():
     # block of back-to-back executes between two HIP events (test/test_performance.py:22-30 times 10 executes once;
     # cuda/test.cu:37-64 times both forms).  In place alternates forward / inverse so that the values stay bounded.
     protocol = None
-    if args.repeats > 0 and world == 1 and not args.inplace:
-        per = max(2, min(args.steps, 10))
+    if resident and args.repeats > 0:
+        # the same share as ONE in-place execute (batch = 8192: element offsets beyond 2^35), forward then inverse, HIP events
+        protocol = {"one_execute_of_the_share": {"batch": share, "repeats": min(args.repeats, 3)}}
+        ms = []
+        for _ in range(min(args.repeats, 3)):
+            for inv in (False, True):
+                e0, e1 = Event(), Event()
+                e0.record(stream)
+                plan.execute(ins[0], batch=share, inverse=inv)
+                e1.record(stream)
+                e1.synchronize()
+                ms.append(e1.time_since(e0))
+        plan.finish()
+        st = stats(ms)
+        protocol["one_execute_of_the_share"].update({
+            "ms_per_execute": st, "strategy": plan.strategy(share)[0],
+            "frac_median": alg_bytes_per_xform * share / (st["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "transforms_per_s_median": share / (st["median"] * 1e-3)})
+    elif args.repeats > 0 and world == 1 and not args.inplace:
+        # blocks of >= 20 ms of back-to-back executes (a burst of a few short launches behind a synchronisation measures the clock
+        # ramp and the fill / drain of the first launch: 3-4 points at 1 GiB per side)
+        per = max(2, min(args.steps, 10), int(0.020 / max(1e-6, elapsed / args.steps)) + 1)
         per += per & 1
         protocol = {"executes_per_repeat": per, "repeats": args.repeats}
         for name, inpl in (("out_of_place", False), ("in_place", True)):
@@ -588,23 +706,37 @@ def main():
 
     # HBM traffic of one step from the PMC counters: profiles/traffic_<config>.json, regenerated by tools/pmc_traffic.py
     # (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very command; the file names its source run)
+    # (config 5: the file is measured on the --chunk-only form, the same kernel on the same 256-transform chunk)
     traffic = None
+    traffic_source = None
     tf = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.config)
     if os.path.exists(tf) and not args.batch and not args.inplace:   # measured on the default workload only
         try:
             tj = json.load(open(tf))
             if tj.get("strategy", strategy[0]) == strategy[0]:
                 traffic = tj.get("hbm_bytes_per_step")
+                lib_now = library_digest()
+                traffic_source = {"file": "profiles/traffic_%s.json" % args.config, "commit": tj.get("commit"),
+                                  "libmifft_sha256_16": tj.get("libmifft_sha256_16"),
+                                  "measured_on_the_running_library": (tj.get("libmifft_sha256_16") == lib_now) if tj.get("libmifft_sha256_16") else None,
+                                  "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --config %s --plain` "
+                                            "(tools/pmc_traffic.py), not collected in this run" % args.config}
         except Exception:
             traffic = None
 
     c5_note = None
     if args.config == "c5" and not args.batch:
-        # BASELINE.json configs[4]: 65536 transforms of 2^22 points over 8 GPUs = 8192 per GPU = 256 GiB per side, run as a streaming
-        # loop over resident chunks: one step of this line is ONE 256-transform chunk (8 GiB in + 8 GiB out)
-        c5_note = {"chunk_transforms": batch, "chunks_per_gpu_for_stated_config": 8192 // batch,
-                   "ms_per_gpu_for_stated_config": ms_per_step * (8192 // batch),
-                   "stated_config": "1-D c2c fp32 N=2^22 batch=65536 sharded across 8 GPUs (8192 per GPU)"}
+        # BASELINE.json configs[4]: 65536 transforms of 2^22 points over 8 GPUs = 8192 per GPU = 256 GiB per GPU, run as a streaming
+        # loop over 256-transform chunks: one step of this line is ONE chunk
+        c5_note = {"chunk_transforms": batch, "chunks_per_gpu_for_stated_config": C5_SHARE // batch,
+                   "ms_per_gpu_for_stated_config": ms_per_step * (C5_SHARE // batch),
+                   "transforms_per_s_per_gpu": batch / (ms_per_step * 1e-3),
+                   "stated_config": "1-D c2c fp32 N=2^22 batch=65536 sharded across 8 GPUs (8192 per GPU)",
+                   "form": ("the rank's whole share of %d transforms (256 GiB) resident in HBM, transformed in place chunk by chunk: step i = "
+                            "chunk i %% %d, sweeps alternate forward / inverse" % (share, chunks)) if resident else
+                           ("ONE resident chunk, out of place, executed K times (--chunk-only)" if not share_mode else
+                            "the share did not fit this device: ONE pair of reused chunk buffers, out of place, executed K times"),
+                   "share_resident": bool(resident)}
     result = {
         "metric": "batched_c2c_fft_gflops_5NlogN_1d_n2^20" if args.config == "c2" else "batched_c2c_fft_gflops_5NlogN_" + args.config,
         "value": gflops,
@@ -618,10 +750,10 @@ def main():
         "vs_baseline": None,
         "dtype": "f32" if cdtype == numpy.complex64 else "f64",
         "data": "synthetic",
-        "config": {"workload": "%s: %s c2c %s, batch %d per GPU, %s, %s" % (
-            args.config, "x".join(map(str, shape)), dtname, batch,
-            "split re/im planes" if split else "interleaved", "in place" if args.inplace else "out of place"),
-            "global_batch": batch * world, "first_transform_of_rank0": gstart,
+        "config": {"workload": "%s: %s c2c %s, batch %s per GPU, %s, %s" % (
+            args.config, "x".join(map(str, shape)), dtname, ("%d in chunks of %d" % (share, batch)) if share_mode else str(batch),
+            "split re/im planes" if split else "interleaved", "in place" if (args.inplace or resident) else "out of place"),
+            "global_batch": share * world, "first_transform_of_rank0": gstart,
             "parallelism": "batch-sharded x%d, no collective%s" % (world, " (control plane: %s)" % args.control if dist is not None else ""),
             "ranks": rank_report,
             "passes": [repr(p) for p in plan.pass_list()], "strategy": strategy[0]},
@@ -629,7 +761,7 @@ def main():
         "algorithmic_GBps": alg_gbs,
         "hbm_fraction_of_8TBps": alg_gbs / world / HBM_PEAK_GBS,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "%s: %s" % (strategy[0], launches),
                      "algorithmic_bytes_per_step": alg_bytes_per_xform * batch,
                      "chain_ms_hip_events": chain_ms, "pass_ms_hip_events": pass_ms},

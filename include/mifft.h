@@ -25,7 +25,7 @@
  *     records a thread-local message readable with mifft_last_error();
  *   - all device buffers (user data, temp, twiddle tables) are owned by the caller and only borrowed for
  *     the duration of the enqueued work; the library keeps no per-plan or per-call state (process-wide are only the
- *     development switches of mifft_debug_set and a cached compute-unit count);
+ *     DEFAULTS of the development switches, mifft_debug_set_default; mifft_debug_set itself is per thread);
  *   - launches are asynchronous on the caller's stream; nothing here synchronises except the *_sync calls.
  */
 #ifndef MIFFT_H
@@ -42,7 +42,7 @@ extern "C" {
  * call; streams are blocking streams; mifft_stream_wait_event
  * 3: the persistent launches take a mifft_fused_sync: two alternating counter sets, error word anywhere the device can write;
  * mifft_device_props carries the last-level cache size and the XCD count; mifft_launch_fused_pair */
-#define MIFFT_ABI_VERSION 3
+#define MIFFT_ABI_VERSION 4
 
 /* negative library error codes (positive values are hipError_t) */
 #define MIFFT_E_INVALID      (-1)  /* malformed descriptor / argument              */
@@ -164,9 +164,22 @@ const char *mifft_last_error(void);
                                     * kernel, and for split-complex planes no lane-interleaved double tiles, no register-edged rows, no fixed-shape N-D
                                     * route, no row-first 2-D kernel, no write-through in the run-time-shaped N-D kernel; 2 = 32-column tiles (and the
                                     * double tile of a plane-writing L = 1024 pass) also in plain launches */
-#define MIFFT_DEBUG_KEYS 10
+#define MIFFT_DEBUG_NO_ROWFIRST 10 /* split-complex fp32 2-D persistent launches: 1 = two transposing passes on sibling tiles instead of the row-first kernel (A/B) */
+#define MIFFT_DEBUG_KEYS 11
+/* mifft_debug_set changes a switch for the CALLING THREAD only (a thread that never set a key sees the process default), so a
+ * measurement that flips a switch in one thread cannot change the kernels another thread's plan gets; mifft_debug_set_default sets
+ * the process default (what the environment variables of pyfft_amd/_debug.py do once, when the library is loaded).  A switch must
+ * not change between the support queries a plan is built from and that plan's launches: the launch then fails with
+ * MIFFT_E_UNSUPPORTED instead of running another kernel. */
 int mifft_debug_set(int32_t key, int32_t value);
+int mifft_debug_set_default(int32_t key, int32_t value);
 int mifft_debug_get(int32_t key);
+/* Optional parts of the library.  The default build leaves out the measured-and-not-adopted strategies (`make DEV=1` builds them):
+ * their launchers then return MIFFT_E_UNSUPPORTED and mifft_has_feature says so beforehand. */
+#define MIFFT_FEATURE_XCD2 0            /* mifft_launch_xcd2: XCD-resident single-crossing form of 1024 x 1024 (0.32-0.34 against 0.44) */
+#define MIFFT_FEATURE_FUSED2X 1         /* mifft_launch_fused2x: one work list per XCD */
+#define MIFFT_FEATURE_SEQUENTIAL_LIST 2 /* lag == 0 in the persistent launchers: both passes of a tiny batch in one launch */
+int mifft_has_feature(int32_t feature); /* 1 = built in, 0 = not */
 
 /* ---- runtime shim (replaces cuda.py Context: allocate / stream lifecycle / device limits) ---------- */
 int mifft_device_count(int *count);
@@ -189,6 +202,22 @@ int mifft_stream_create(mifft_stream_t *stream);
 int mifft_stream_destroy(mifft_stream_t stream);
 int mifft_stream_sync(mifft_stream_t stream);
 int mifft_device_sync(void);
+/*
+ * Stream capture / hipGraph replay of the calls a plan enqueues (HIP graphs are how a launch-bound inner loop is replayed on this
+ * part; the reference's execute is an asynchronous enqueue on the caller's stream, pyfft/plan.py:250-259, and a torch-ROCm caller
+ * may capture that stream).  Every launcher of this library may be called on a capturing stream; the persistent launches then
+ * REQUIRE the single-set form of their mifft_fused_sync argument -- counters_next == NULL --, see there.
+ *   mifft_stream_is_capturing   *capturing = 1 while `stream` records into a graph
+ *   mifft_stream_begin_capture  start recording the work enqueued on `stream` (relaxed mode; not the default stream)
+ *   mifft_stream_end_capture    stop recording and instantiate: *graph is an executable graph (hipGraphExec_t)
+ *   mifft_graph_launch          replay it on `stream`; mifft_graph_destroy frees it
+ */
+typedef void *mifft_graph_t; /* hipGraphExec_t */
+int mifft_stream_is_capturing(mifft_stream_t stream, int32_t *capturing);
+int mifft_stream_begin_capture(mifft_stream_t stream);
+int mifft_stream_end_capture(mifft_stream_t stream, mifft_graph_t *graph);
+int mifft_graph_launch(mifft_graph_t graph, mifft_stream_t stream);
+int mifft_graph_destroy(mifft_graph_t graph);
 int mifft_event_create(mifft_event_t *event);
 int mifft_event_destroy(mifft_event_t event);
 int mifft_event_record(mifft_event_t event, mifft_stream_t stream);
@@ -279,13 +308,16 @@ int mifft_launch_chain_pipelined(const mifft_pass *passes, int32_t npasses, void
 /*
  * Synchronisation state of one persistent launch (all caller-owned device-accessible memory):
  *   counters       MIFFT_FUSED2_COUNTER_BYTES(outer) bytes.  With counters_next == NULL the call zeroes them on `stream` in front
- *                  of the launch (a memset node: ~5 us, what a 32 MiB execute cannot afford).
+ *                  of the launch (a memset node: ~5 us, what a 32 MiB execute cannot afford).  The ONLY form allowed on a
+ *                  capturing stream (a replayed graph runs on the same set every time): MIFFT_E_INVALID otherwise.
  *   counters_next  a second buffer of the same size: the caller guarantees that `counters` is ALL ZERO when the launch starts, and
  *                  THIS launch zeroes `counters_next` -- a plan that alternates between two sets (set A zeroes B, B zeroes A) after
  *                  one initial mifft_memset of both never pays the memset again.
  *   error_word     a uint32 the kernel sets (system-scope store) when a bounded dependency wait times out = results INVALID; any
  *                  address the device can write: pinned host memory from mifft_host_alloc (device-accessible under the same
- *                  pointer; the host then reads it without a copy), or NULL = word [1] of `counters`.  Never cleared by the library.
+ *                  pointer; the host then reads it without a copy), or NULL = word [1] of `counters` -- in the single-set form only:
+ *                  with counters_next the next launch zeroes that word, so the two-set form REQUIRES an error word of its own
+ *                  (MIFFT_E_INVALID otherwise).  A word of the caller's is never cleared by the library.
  */
 typedef struct mifft_fused_sync {
     void *counters;
@@ -294,7 +326,11 @@ typedef struct mifft_fused_sync {
 } mifft_fused_sync;
 /* lag == 0 selects the SEQUENTIAL work list for tiny batches (ring_slots == outer): every first-pass tile of every transform,
  * then every second-pass tile -- two dependent launches folded into one, without the launch gap and the end-of-kernel
- * write-back between them (the reference's own 32 MiB benchmark protocol, test/test_performance.py:11,22-30). */
+ * write-back between them (the reference's own 32 MiB benchmark protocol, test/test_performance.py:11,22-30).  Development form
+ * (MIFFT_FEATURE_SEQUENTIAL_LIST; measured slower than two launches): the list is dealt out statically, which is deadlock-free
+ * only while EVERY work-group of the launch is resident -- the launcher caps the grid by the kernel's occupancy on this device,
+ * but it cannot see other streams, processes or CU masks, so the device must be the caller's alone; otherwise the bounded waits
+ * time out (~4 s per item), the error word is set and the output is invalid. */
 int mifft_launch_fused2(const mifft_pass *p0, const mifft_pass *p1, const void *in0, const void *in1, void *out0,
                         void *out1, void *ring0, void *ring1, int32_t ring_slots, int32_t lag, const mifft_fused_sync *sync,
                         int32_t grid, mifft_stream_t stream);
@@ -344,6 +380,8 @@ int mifft_launch_fused_pair(const mifft_pass *passes, const void *in0, const voi
  *            the control words, 32 time stamps (100 MHz) per work-group for the per-XCD transform index (flags >> 8)
  *            bits 4..6 (development): elimination variant 1..5 of csrc/fft_xcd2.hpp -- same launch with a part of the work
  *            removed; the results are WRONG by construction (profiles/r03_xcd2_elimination.log)
+ *            bits 8..23 the traced transform index; bits 24..30 (development, round 5): the XCDs with an odd id start that many
+ *            microseconds late (anti-phase HBM bursts, profiles/r05_xcd2_antiphase.log); results unchanged
  * Requires a device with 8 XCDs x 32 CUs (MI355X); MIFFT_E_UNSUPPORTED otherwise or for other lengths.
  */
 #define MIFFT_XCD2_SCRATCH_BYTES (8u * 64u * 16u * 256u * 8u)

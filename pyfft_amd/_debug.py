@@ -64,8 +64,13 @@ def split_fusedx():
 
 
 def no_split_rowfirst():
-    """PYFFT_AMD_NO_SPLIT_ROWFIRST=1: split-complex fp32 2-D plans keep the round-3 rule (pipelined chunks; two transposing passes on request)"""
-    return bool(os.environ.get("PYFFT_AMD_NO_SPLIT_ROWFIRST"))
+    """PYFFT_AMD_NO_SPLIT_ROWFIRST=1: split-complex fp32 2-D plans keep the round-3 rule (pipelined chunks; two transposing passes on
+    request).  The launcher picks the kernel too, so the calling thread's native switch follows the variable whenever the planner asks."""
+    from . import _native
+    off = bool(os.environ.get("PYFFT_AMD_NO_SPLIT_ROWFIRST"))
+    if bool(_native.lib.mifft_debug_get(_native.DEBUG_NO_ROWFIRST)) != off:
+        _native.lib.mifft_debug_set(_native.DEBUG_NO_ROWFIRST, 1 if off else 0)
+    return off
 
 
 def no_fusedp_alt():
@@ -110,17 +115,18 @@ def xcd2_flags(default):
 
 
 def apply_native_switches(native):
-    """Environment -> libmifft's development switches (mifft_debug_set); called once when the library is loaded."""
+    """Environment -> the process defaults of libmifft's development switches (mifft_debug_set_default); called once when the library
+    is loaded.  (mifft_debug_set itself changes a switch for the calling thread only: tests and tools use that.)"""
     for env, key in (("MIFFT_NO_ND2", native.DEBUG_NO_ND2), ("MIFFT_FUSED_NO_NT", native.DEBUG_FUSED_NO_NT),
                      ("MIFFT_NO_WAVE", native.DEBUG_NO_WAVE), ("MIFFT_FORCE_WAVE", native.DEBUG_FORCE_WAVE),
                      ("MIFFT_PERSIST", native.DEBUG_PERSIST)):
         if os.environ.get(env):
-            native.lib.mifft_debug_set(key, 1)
+            native.lib.mifft_debug_set_default(key, 1)
     if os.environ.get("MIFFT_STORE"):       # streamed output stores: 1 = non-temporal, 2 = write-through, 3 = plain
-        native.lib.mifft_debug_set(native.DEBUG_STORE, int(os.environ["MIFFT_STORE"]))
+        native.lib.mifft_debug_set_default(native.DEBUG_STORE, int(os.environ["MIFFT_STORE"]))
     if os.environ.get("MIFFT_ROWS_ND"):     # dense smooth rows: 1 = two-buffer row kernel only, 2 = single-buffer tile kernel wherever it fits
-        native.lib.mifft_debug_set(native.DEBUG_ROWS_ND, int(os.environ["MIFFT_ROWS_ND"]))
+        native.lib.mifft_debug_set_default(native.DEBUG_ROWS_ND, int(os.environ["MIFFT_ROWS_ND"]))
     if os.environ.get("MIFFT_NARROW_TILES"):   # fp32 2^16 ... 2^18 persistent: 16-column tiles (A/B)
-        native.lib.mifft_debug_set(native.DEBUG_NARROW_TILES, int(os.environ["MIFFT_NARROW_TILES"]))
+        native.lib.mifft_debug_set_default(native.DEBUG_NARROW_TILES, int(os.environ["MIFFT_NARROW_TILES"]))
     if os.environ.get("MIFFT_PAIR"):        # pass pairs: 1 = off, 2 = the alternative y split
-        native.lib.mifft_debug_set(native.DEBUG_PAIR, int(os.environ["MIFFT_PAIR"]))
+        native.lib.mifft_debug_set_default(native.DEBUG_PAIR, int(os.environ["MIFFT_PAIR"]))

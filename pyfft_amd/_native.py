@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmifft.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 E_INVALID = -1
 E_UNSUPPORTED = -2
@@ -41,6 +41,8 @@ XCD2_PREFETCH = 1
 DEBUG_NO_ND2, DEBUG_FUSED_NO_NT, DEBUG_NO_WAVE, DEBUG_FORCE_WAVE, DEBUG_PERSIST, DEBUG_ALT_ROWS, DEBUG_PAIR, DEBUG_STORE = 0, 1, 2, 3, 4, 5, 6, 7
 DEBUG_ROWS_ND = 8
 DEBUG_NARROW_TILES = 9
+DEBUG_NO_ROWFIRST = 10
+FEATURE_XCD2, FEATURE_FUSED2X, FEATURE_SEQUENTIAL_LIST = 0, 1, 2     # mifft_has_feature: parts only `make DEV=1` builds
 XCD2_TRACE = 2
 XCD2_TRACE_BYTES = 512 * 32 * 8
 
@@ -141,7 +143,9 @@ PROTOTYPES = {
     "mifft_abi_version": (ctypes.c_int, []),
     "mifft_last_error": (ctypes.c_char_p, []),
     "mifft_debug_set": (ctypes.c_int, [_i32, _i32]),
+    "mifft_debug_set_default": (ctypes.c_int, [_i32, _i32]),
     "mifft_debug_get": (ctypes.c_int, [_i32]),
+    "mifft_has_feature": (ctypes.c_int, [_i32]),
     "mifft_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     "mifft_set_device": (ctypes.c_int, [ctypes.c_int]),
     "mifft_get_device": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
@@ -159,6 +163,11 @@ PROTOTYPES = {
     "mifft_stream_destroy": (ctypes.c_int, [_vp]),
     "mifft_stream_sync": (ctypes.c_int, [_vp]),
     "mifft_device_sync": (ctypes.c_int, []),
+    "mifft_stream_is_capturing": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int32)]),
+    "mifft_stream_begin_capture": (ctypes.c_int, [_vp]),
+    "mifft_stream_end_capture": (ctypes.c_int, [_vp, _vpp]),
+    "mifft_graph_launch": (ctypes.c_int, [_vp, _vp]),
+    "mifft_graph_destroy": (ctypes.c_int, [_vp]),
     "mifft_event_create": (ctypes.c_int, [_vpp]),
     "mifft_event_destroy": (ctypes.c_int, [_vp]),
     "mifft_event_record": (ctypes.c_int, [_vp, _vp]),

@@ -64,7 +64,12 @@ extern "C" int mifft_fused2_f32_launch(int L0, int L1, const mifft::FusedArgs* f
 }
 
 // XCD-local work lists (strategy `fusedx`): fp32, L0 >= L1 in {256, 512, 1024}; split planes (user side) too
+// (a development strategy: instantiated by `make DEV=1` only, mifft_has_feature(MIFFT_FEATURE_FUSED2X))
 extern "C" int mifft_fused2x_f32_launch(int L0, int L1, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s) {
+#ifndef MIFFT_DEV_BUILD
+    (void)L0; (void)L1; (void)f; (void)split; (void)grid; (void)s;
+    return -2;
+#else
 #define XL(A0, A1)                                                                                                  \
     if (L0 == 256 * A0 && L1 == 256 * A1) {                                                                         \
         if (split) hipLaunchKernelGGL((mifft::fft_fused2x_kernel<float, A0, A1, true>), dim3(grid), dim3(256), 0, s, *f); \
@@ -78,6 +83,7 @@ extern "C" int mifft_fused2x_f32_launch(int L0, int L1, const mifft::FusedArgs* 
     XL(4, 4)
 #undef XL
     return -2;
+#endif
 }
 
 // 2-D squares: 512 and 1024 on the 256-thread tiles (fft_fused2d_kernel), 2048 on the 512-thread ones (fft_fused3d_kernel);

@@ -462,12 +462,12 @@ extern "C" int mifft_bluestein_launch(int f64, int n, int m, long long rows, lon
         static thread_local int granted[2][16] = {{0}};
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
-        if (dev >= 0 && dev < 16 && !granted[f64][dev]) {
+        if (dev < 0 || dev >= 16 || !granted[f64][dev]) {     // (devices beyond the table: asked for at every launch)
             const void* fn = f64 ? reinterpret_cast<const void*>(&fft_bluestein_kernel<double, 1024, 1>)
                                  : reinterpret_cast<const void*>(&fft_bluestein_kernel<float, 1024, 1>);
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
-            granted[f64][dev] = 1;
+            if (dev >= 0 && dev < 16) granted[f64][dev] = 1;
         }
         if (f64) hipLaunchKernelGGL((fft_bluestein_kernel<double, 1024, 1>), dim3((unsigned)blocks), dim3(1024), lds_bytes, s, a);
         else hipLaunchKernelGGL((fft_bluestein_kernel<float, 1024, 1>), dim3((unsigned)blocks), dim3(1024), lds_bytes, s, a);

@@ -179,11 +179,11 @@ template <typename T, int NT> int launch_nd_kernel(const MixedNdArgs& a, unsigne
     static thread_local int granted[16] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
-    if (dev >= 0 && dev < 16 && !granted[dev]) {
+    if (dev < 0 || dev >= 16 || !granted[dev]) {     // (devices beyond the table: asked for at every launch)
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fft_mixed_nd_kernel<T, NT>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        granted[dev] = 1;
+        if (dev >= 0 && dev < 16) granted[dev] = 1;
     }
     hipLaunchKernelGGL((fft_mixed_nd_kernel<T, NT>), dim3(blocks), dim3(NT), lds_bytes, s, a);
     return (int)hipGetLastError();

@@ -39,6 +39,8 @@ struct Xcd2Args {
     unsigned long long* trace;   // development: 32 time stamps (100 MHz) per work-group for transform index trace_iter, or null
     unsigned trace_iter;
     unsigned pace;               // development: throttle the HBM burst of the last stage
+    unsigned phase_us;           // development (round 5): XCDs with an odd HW_REG_XCC_ID start this many microseconds late, so that about
+                                 // half of the XCDs are in their HBM burst while the other half exchange (profiles/r05_xcd2_antiphase.log)
 };
 constexpr unsigned kXcd2FS = 32u;   // words between two flags: one 128-byte line per flag (packed, the 64 flags of an XCD shared two lines
                                     // that all its work-groups poll)
@@ -420,6 +422,10 @@ __global__ void __launch_bounds__(256, 2) fft_xcd2_kernel(const Xcd2Args f) {
     __syncthreads();
     const unsigned r = __builtin_amdgcn_readfirstlane(s_w[0]);   // (an LDS read is not provably uniform: without this every address is a VGPR pair)
     if (s_w[1] == 0u || r >= 64u) return;
+    if (f.phase_us != 0u && (x & 1u)) {   // anti-phase start of the odd XCDs (100 MHz wall clock)
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (unsigned long long)f.phase_us * 100ull) __builtin_amdgcn_s_sleep(32);
+    }
     switch (r & 3u) {
         case 0: xcd2_body<T, 0, SPLIT, NT, PREFETCH, MODE>(f, x, r, lds, s_w + 2); break;
         case 1: xcd2_body<T, 1, SPLIT, NT, PREFETCH, MODE>(f, x, r, lds, s_w + 2); break;

@@ -4,6 +4,7 @@
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -15,9 +16,18 @@
 namespace {
 
 thread_local char g_err[512] = "";
-// the library's only process-wide state: the development switches (mifft_debug_set; all zero in production) and the
-// compute-unit count cached by wave_max_blocks()
-int g_debug[MIFFT_DEBUG_KEYS] = {0};
+// the library's only process-wide state: the DEFAULTS of the development switches (all zero in production) and a per-device
+// compute-unit count.  The switches: a process default (mifft_debug_set_default) under a per-thread override (mifft_debug_set) -- a switch flipped
+// by one thread never changes what another thread's plan launches
+std::atomic<int> g_debug_default[MIFFT_DEBUG_KEYS];
+thread_local int t_debug_value[MIFFT_DEBUG_KEYS];
+thread_local unsigned t_debug_mask = 0;
+struct DebugSwitches {
+    int operator[](int key) const {
+        return ((t_debug_mask >> key) & 1u) ? t_debug_value[key] : g_debug_default[key].load(std::memory_order_relaxed);
+    }
+};
+const DebugSwitches g_debug;
 
 int set_err(int code, const char* fmt, ...) {
     va_list ap;
@@ -149,21 +159,24 @@ int nd_radices(int L, int maxr, int* out) {
     return n;
 }
 
-// grid cap of the grid-stride wave kernels: 8 work-groups of 4 waves per CU
-int wave_max_blocks() {
-    static int blocks = 0;
-    if (!blocks) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        blocks = cus * 8;
-    }
-    return blocks;
+// compute units of the CURRENT device (cached per device index: a process may drive several different devices)
+int current_cus() {
+    static std::atomic<int> cached[64];
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev >= 0 && dev < 64 && (cus = cached[dev].load(std::memory_order_relaxed)) > 0) return cus;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return 256;
+    if (dev >= 0 && dev < 64) cached[dev].store(cus, std::memory_order_relaxed);
+    return cus;
 }
+
+// grid cap of the grid-stride wave kernels: 8 work-groups of 4 waves per CU
+int wave_max_blocks() { return current_cus() * 8; }
 
 // The statically dealt sequential work list (lag == 0) is deadlock-free only while every work-group of the launch is resident:
 // the grid is capped at `per_cu` work-groups per compute unit (what the kernel's registers and LDS allow), whatever the caller asked for
 int resident_grid(int grid, int per_cu) {
-    const int cus = wave_max_blocks() / 8;
+    const int cus = current_cus();
     const int cap = per_cu * (cus > 0 ? cus : 1);
     return grid > cap ? cap : grid;
 }
@@ -386,6 +399,12 @@ void probe_memory_system(const hipDeviceProp_t& hp, int64_t* llc_bytes, int32_t*
     }
     *llc_bytes = probe.found ? (int64_t)probe.cache[2] : 0;
     *num_xcc = (probe.found && probe.xcc >= 1) ? (int32_t)probe.xcc : 0;
+    // a partition (CPX / DPX / QPX: an agent of 1, 2 or 4 of the 8 XCDs) may still report the whole part's Infinity Cache; the other
+    // partitions stream through it too, so the planner gets this agent's FAIR SHARE (not verified on partitioned hardware: the sizes
+    // derived from it are only ever too small, never too large)
+    if (probe.found && probe.xcc >= 1 && probe.xcc < 8 && hp.multiProcessorCount < 228 && *llc_bytes >= (int64_t)(256ll << 20) &&
+        (strncmp(hp.gcnArchName, "gfx94", 5) == 0 || strncmp(hp.gcnArchName, "gfx95", 5) == 0))
+        *llc_bytes = *llc_bytes * (int64_t)probe.xcc / 8;
     if (*llc_bytes == 0 && (strncmp(hp.gcnArchName, "gfx94", 5) == 0 || strncmp(hp.gcnArchName, "gfx95", 5) == 0)) {
         // no answer from HSA on a CDNA3/4 part: the documented 256 MiB per 8 XCDs, scaled to the partition this device is
         *llc_bytes = (int64_t)(256ll << 20) * (hp.multiProcessorCount >= 228 ? 8 : (hp.multiProcessorCount + 37) / 38) / 8;
@@ -410,6 +429,17 @@ int fill_ctl(mifft::FusedCtl* c, const mifft_fused_sync* sync, long long outer, 
     if ((uintptr_t)sync->error_word & 3) return set_err(MIFFT_E_INVALID, "%s: misaligned error word", who);
     if (sync->counters_next == sync->counters) return set_err(MIFFT_E_INVALID, "%s: counters_next must be a second buffer", who);
     if (outer > 0x3fffffff) return set_err(MIFFT_E_INVALID, "%s: batch too large", who);
+    if (sync->counters_next) {
+        // the launch zeroes words 0 and 1 of EVERY line of counters_next -- word 1 of line 0 is the default error word of the launch
+        // that ran on that set, so a time-out report would vanish with the next launch
+        if (!sync->error_word) return set_err(MIFFT_E_INVALID, "%s: alternating counter sets need an error word of their own", who);
+        // a CAPTURED launch replays on the same set every time, while the two-set form relies on the host alternating the sets per
+        // launch: the second replay would start on non-zero counters.  Captured launches take the single-set form, whose memset
+        // becomes a node of the graph in front of the kernel
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &st) == hipSuccess && st == hipStreamCaptureStatusActive)
+            return set_err(MIFFT_E_INVALID, "%s: a launch on a capturing stream must use the single-set form (counters_next = NULL)", who);
+    }
     c->counters = (unsigned*)sync->counters;
     c->counters_next = (unsigned*)sync->counters_next;
     c->err = sync->error_word ? (unsigned*)sync->error_word : (unsigned*)sync->counters + 1;
@@ -431,8 +461,22 @@ extern "C" {
 int mifft_abi_version(void) { return MIFFT_ABI_VERSION; }
 int mifft_debug_set(int32_t key, int32_t value) {
     if (key < 0 || key >= MIFFT_DEBUG_KEYS) return set_err(MIFFT_E_INVALID, "bad debug key %d", key);
-    g_debug[key] = value;
+    t_debug_value[key] = value;
+    t_debug_mask |= 1u << key;
     return 0;
+}
+int mifft_debug_set_default(int32_t key, int32_t value) {
+    if (key < 0 || key >= MIFFT_DEBUG_KEYS) return set_err(MIFFT_E_INVALID, "bad debug key %d", key);
+    g_debug_default[key].store(value, std::memory_order_relaxed);
+    return 0;
+}
+int mifft_has_feature(int32_t feature) {
+#ifdef MIFFT_DEV_BUILD
+    return (feature == MIFFT_FEATURE_XCD2 || feature == MIFFT_FEATURE_FUSED2X || feature == MIFFT_FEATURE_SEQUENTIAL_LIST) ? 1 : 0;
+#else
+    (void)feature;
+    return 0;
+#endif
 }
 int mifft_debug_get(int32_t key) { return (key >= 0 && key < MIFFT_DEBUG_KEYS) ? g_debug[key] : 0; }
 const char* mifft_last_error(void) { return g_err; }
@@ -523,6 +567,38 @@ int mifft_stream_wait_event(mifft_stream_t stream, mifft_event_t event) {
 }
 int mifft_stream_destroy(mifft_stream_t stream) { return hip_check(hipStreamDestroy((hipStream_t)stream), "hipStreamDestroy"); }
 int mifft_stream_sync(mifft_stream_t stream) { return hip_check(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize"); }
+int mifft_stream_is_capturing(mifft_stream_t stream, int32_t* capturing) {
+    if (!capturing) return set_err(MIFFT_E_INVALID, "null argument");
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    const int rc = hip_check(hipStreamIsCapturing((hipStream_t)stream, &st), "hipStreamIsCapturing");
+    if (rc) return rc;
+    *capturing = st == hipStreamCaptureStatusActive ? 1 : 0;
+    return 0;
+}
+int mifft_stream_begin_capture(mifft_stream_t stream) {
+    if (!stream) return set_err(MIFFT_E_INVALID, "the default stream cannot be captured");
+    return hip_check(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed), "hipStreamBeginCapture");
+}
+int mifft_stream_end_capture(mifft_stream_t stream, mifft_graph_t* graph) {
+    if (!graph) return set_err(MIFFT_E_INVALID, "null argument");
+    hipGraph_t g = nullptr;
+    int rc = hip_check(hipStreamEndCapture((hipStream_t)stream, &g), "hipStreamEndCapture");
+    if (rc) return rc;
+    hipGraphExec_t ge = nullptr;
+    rc = hip_check(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0), "hipGraphInstantiate");
+    (void)hipGraphDestroy(g);
+    if (rc) return rc;
+    *graph = (mifft_graph_t)ge;
+    return 0;
+}
+int mifft_graph_launch(mifft_graph_t graph, mifft_stream_t stream) {
+    if (!graph) return set_err(MIFFT_E_INVALID, "null graph");
+    return hip_check(hipGraphLaunch((hipGraphExec_t)graph, (hipStream_t)stream), "hipGraphLaunch");
+}
+int mifft_graph_destroy(mifft_graph_t graph) {
+    if (!graph) return 0;
+    return hip_check(hipGraphExecDestroy((hipGraphExec_t)graph), "hipGraphExecDestroy");
+}
 int mifft_device_sync(void) { return hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize"); }
 int mifft_event_create(mifft_event_t* event) {
     if (!event) return set_err(MIFFT_E_INVALID, "null argument");
@@ -733,7 +809,7 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
                            (f64 ? (p0->L <= 512 && p1->L <= 512 && p0->L >= 256 && p1->L >= 256)
                                 : (g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 && mifft_fused2dw_f32(p1->L, p0->L, nullptr, 0, nullptr, 1, nullptr, nullptr) == 0));
         // split-complex fp32: the row-first kernel (fft_fused2r.hpp), (ny, nx) in {256, 512, 1024}^2
-        const bool rowfirst_ok = !f64 && p0->layout == MIFFT_SPLIT && g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 &&
+        const bool rowfirst_ok = !f64 && p0->layout == MIFFT_SPLIT && g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 && !g_debug[MIFFT_DEBUG_NO_ROWFIRST] &&
                                  mifft_fused2r_f32(p1->L, p0->L, nullptr, 0, nullptr, 1) == 0;
         const bool okL = small || rowfirst_ok || (f64 ? (side64(p0->L) && side64(p1->L) && ((p0->L == 1024 && p1->L == 1024) || p0->layout != MIFFT_SPLIT))
                              : (side(p0->L) && side(p1->L) && (p0->L == p1->L || p0->layout != MIFFT_SPLIT)));
@@ -757,6 +833,8 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     (void)ring1;  // the ring is always interleaved
     if (grid < 1) return set_err(MIFFT_E_INVALID, "fused2: grid >= 1");
     // lag == 0: the sequential list of a tiny batch, one ring slot per transform
+    if (lag == 0 && !mifft_has_feature(MIFFT_FEATURE_SEQUENTIAL_LIST))
+        return set_err(MIFFT_E_UNSUPPORTED, "fused2: the sequential list (lag == 0) is a development form, not in this build (make DEV=1)");
     if (lag == 0 ? ring_slots != p1->outer && p1->outer > 0 : (ring_slots < 2 || lag < 1 || lag >= ring_slots))
         return set_err(MIFFT_E_INVALID, "fused2: need 1 <= lag < ring_slots, or lag == 0 with ring_slots == outer");
     if (((uintptr_t)in0 | (uintptr_t)out0 | (uintptr_t)ring0 | (uintptr_t)in1 | (uintptr_t)out1) & 15)
@@ -769,7 +847,7 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
     f.p0.ostride_out = n;  // ring slot pitch
     f.p1.ostride_in = n;
     // split-complex fp32 2-D: the chain's own order -- ROW x from the planes, COL y to the planes -- on the persistent list
-    const bool rowfirst = twod && !f64 && p0->layout == MIFFT_SPLIT && g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 &&
+    const bool rowfirst = twod && !f64 && p0->layout == MIFFT_SPLIT && g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 && !g_debug[MIFFT_DEBUG_NO_ROWFIRST] &&
                           mifft_fused2r_f32(p1->L, p0->L, nullptr, 0, nullptr, 1) == 0;
     if (rowfirst) {
         f.p0.nt = 4;                // the ring is written through (the consumers acquire it, fft_fused2.hpp)
@@ -832,6 +910,8 @@ int mifft_launch_fused2(const mifft_pass* p0, const mifft_pass* p1, const void* 
 
 int mifft_launch_fused2x(const mifft_pass* p0, const mifft_pass* p1, const void* in0, const void* in1, void* out0, void* out1, void* ring0,
                          int32_t ring_slots, int32_t lag, const mifft_fused_sync* sync, int32_t grid, mifft_stream_t stream) {
+    if (!mifft_has_feature(MIFFT_FEATURE_FUSED2X))
+        return set_err(MIFFT_E_UNSUPPORTED, "fused2x: a development strategy, not in this build of the library (make DEV=1; mifft_has_feature)");
     int rc = validate(p0);
     if (rc) return rc;
     rc = validate(p1);
@@ -901,6 +981,8 @@ int mifft_launch_fused_pair(const mifft_pass* passes, const void* in0, const voi
     if (ring0 == in0 || ring0 == out0) return set_err(MIFFT_E_INVALID, "fused pair: the ring must be a buffer of its own");
     if (grid < 1) return set_err(MIFFT_E_INVALID, "fused pair: grid >= 1");
     const long long batch = pz->outer;
+    if (lag == 0 && !mifft_has_feature(MIFFT_FEATURE_SEQUENTIAL_LIST))
+        return set_err(MIFFT_E_UNSUPPORTED, "fused pair: the sequential list (lag == 0) is a development form, not in this build (make DEV=1)");
     if (lag == 0 ? ring_slots != batch && batch > 0 : (ring_slots < 2 || lag < 1 || lag >= ring_slots))
         return set_err(MIFFT_E_INVALID, "fused pair: need 1 <= lag < ring_slots, or lag == 0 with ring_slots == outer");
     if (batch == 0) return 0;
@@ -934,6 +1016,10 @@ int mifft_launch_fused_pair(const mifft_pass* passes, const void* in0, const voi
 
 int mifft_launch_xcd2(const mifft_pass* p0, const mifft_pass* p1, const void* in0, const void* in1, void* out0, void* out1,
                       void* scratch, void* control, int32_t flags, mifft_stream_t stream) {
+#ifndef MIFFT_DEV_BUILD
+    (void)p0; (void)p1; (void)in0; (void)in1; (void)out0; (void)out1; (void)scratch; (void)control; (void)flags; (void)stream;
+    return set_err(MIFFT_E_UNSUPPORTED, "xcd2: a development strategy, not in this build of the library (make DEV=1; mifft_has_feature)");
+#else
     int rc = validate(p0);
     if (rc) return rc;
     rc = validate(p1);
@@ -970,12 +1056,14 @@ int mifft_launch_xcd2(const mifft_pass* p0, const mifft_pass* p1, const void* in
     f.trace = (flags & MIFFT_XCD2_TRACE) ? (unsigned long long*)((char*)control + MIFFT_XCD2_CONTROL_BYTES) : nullptr;
     f.trace_iter = (unsigned)((flags >> 8) & 0xffff);   // (flags bits 4..6: elimination mode, development)
     f.pace = (flags & 4) ? 1u : 0u;
+    f.phase_us = (unsigned)((flags >> 24) & 0x7f);       // (flags bits 24..30: start offset of the odd XCDs in microseconds, development)
     rc = hip_check(hipMemsetAsync(control, 0, MIFFT_XCD2_CONTROL_BYTES, (hipStream_t)stream), "hipMemsetAsync");
     if (rc) return rc;
     rc = mifft_xcd2_f32_launch(&f, split ? 1 : 0, (flags & MIFFT_XCD2_PREFETCH) ? 1 : 0, (flags >> 4) & 7, 2u * (unsigned)cus, (hipStream_t)stream);
     if (rc == MIFFT_E_UNSUPPORTED) return set_err(rc, "xcd2: elimination modes exist for the interleaved prefetching form only");
     if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
     return 0;
+#endif
 }
 
 int mifft_launch_chain_pipelined(const mifft_pass* passes, int32_t npasses, void* const bufs0[3], void* const bufs1[3],

@@ -180,6 +180,51 @@ class Event(object):
             pass
 
 
+class Graph(object):
+    """Stream capture and hipGraph replay of what plans enqueue (include/mifft.h: mifft_stream_begin_capture ...):
+
+        plan = Plan(shape, stream=s)            # wait_for_finish defaults to False with a stream
+        plan.execute(a, b, batch=n)             # once, eagerly: scratch, tables and strategy exist before the capture
+        with Graph(s) as g:
+            plan.execute(a, b, batch=n)         # recorded, not run
+        g.launch(); g.launch(); s.synchronize()
+
+    A captured execute of a persistent strategy runs on a counter set of its own with the memset as a node of the graph, so replays
+    and eager executes of the same plan may alternate on one stream.  A torch.cuda.graph() capture around execute() works the
+    same way (the plan follows torch's current stream)."""
+
+    def __init__(self, stream):
+        self.stream = stream
+        self.handle = None
+
+    def __enter__(self):
+        N.check(N.lib.mifft_stream_begin_capture(_stream_handle(self.stream)), "mifft_stream_begin_capture")
+        return self
+
+    def __exit__(self, etype, evalue, tb):
+        h = ctypes.c_void_p()
+        rc = N.lib.mifft_stream_end_capture(_stream_handle(self.stream), ctypes.byref(h))
+        if etype is None:
+            N.check(rc, "mifft_stream_end_capture")
+            self.handle = h.value
+        elif rc == 0 and h.value:
+            N.lib.mifft_graph_destroy(h.value)
+        return False
+
+    def launch(self, stream=None):
+        if not self.handle:
+            raise RuntimeError("pyfft_amd: nothing was captured")
+        N.check(N.lib.mifft_graph_launch(self.handle, _stream_handle(self.stream if stream is None else stream)), "mifft_graph_launch")
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                N.lib.mifft_graph_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 class ErrorMailbox(object):
     """Pinned host words that receive a persistent kernel's error word behind every launch (FFTPlan.check / finish):
     an asynchronous 4-byte copy plus an event on the launch's stream, inspected by the host without synchronising."""
@@ -370,6 +415,12 @@ class Context(object):
     def stream_handle(self):
         return _stream_handle(self._call_stream)
 
+    def capturing(self):
+        """The stream of the coming execute() is recording into a graph (hipStreamIsCapturing)."""
+        c = ctypes.c_int32()
+        N.check(N.lib.mifft_stream_is_capturing(self.stream_handle(), ctypes.byref(c)), "mifft_stream_is_capturing")
+        return bool(c.value)
+
     @property
     def device(self):
         return self._device
@@ -396,6 +447,10 @@ class Context(object):
         (cuda.py:94-107,129), where that order is implicit."""
         h = self.stream_handle()
         last = self._last_stream_handle
+        if last is not None and last[0] != h and self.capturing():
+            # a capturing stream cannot wait for work outside its graph (and enqueues nothing now): the caller orders the replays
+            # behind the plan's earlier work, as with any captured graph
+            return
         if last is not None and last[0] != h:
             if self._order_event is None:
                 self._order_event = Event()

@@ -293,236 +293,136 @@ class FFTPlan(object):
     #   xcd2       1024 x 1024 fp32: one persistent launch, each transform stays on one XCD between its two HBM
     #              crossings (mifft_launch_xcd2); development only
     # Every size below comes from the device (pyfft_amd/machine.py: fractions of the last-level cache, multiples of the CU count).
-    PIPELINE_STREAMS = 2
-    XCD2_MIN_BATCH = 64                # 8 transforms per XCD: below that the pipelined chunks win
-    SMALL_FUSED_LAG_DIV = 0            # small-batch fused form: off (see _select_strategy)
-    FUSEDX_LAG_RING = (8, 16)          # per XCD (profiles/r04_a_fused_sweep.log: 4 / 8 loses 3-6 points at 2^16 / 2^17)
+    # ---- which persistent launch, if any: the plan's SHAPE CLASS matched against the rules of the tuning table -----------------
+    def _shape_class(self):
+        """What the rules of pyfft_amd/tuning_gfx950.json are keyed on: "1d" = the two strided passes of one long contiguous axis
+        (L0 x L1), "2d" = ROW x + strided COL y of a (ny, nx) plan, "3d" = a plan the library has a persistent two-pair kernel for."""
+        p = self._params
+        k = self._kernels
+        cls = {"precision": "f64" if p.precision == N.F64 else "f32", "layout": "split" if p.split else "interleaved"}
+        if self._pair_alt is not None or (self._paired and len(k) == 4 and not p.split and
+                                          N.lib.mifft_fused_pair_supported(p.precision, p.layout, int(p.x), int(p.y), int(p.z)) == 0):
+            cls.update(kind="3d", planes=int(p.z) * int((self._pair_alt or k)[1].M))          # first-pass items: planes x R1
+        elif len(k) == 2 and int(p.z) == 1 and k[0].kind == N.PASS_ROW and k[0].L == int(p.x) and k[1].kind == N.PASS_COL and \
+                k[1].L == int(p.y) and k[1].M == 1 and k[1].S == int(p.x):
+            cls.update(kind="2d", ny=int(p.y), nx=int(p.x), M=0)
+        elif len(k) == 2 and int(p.y) == 1 and int(p.z) == 1 and k[0].kind == N.PASS_COL and k[1].kind == N.PASS_COL and k[0].S == 1 and \
+                k[0].M == k[1].L and k[1].M == 1 and self._temp_buffer_needed:
+            cls.update(kind="1d", L0=int(k[0].L), L1=int(k[1].L), M=int(k[0].M))
+        else:
+            return None
+        return cls
+
+    def _persistent_rule(self):
+        """The tuning rule of this plan's persistent launch (None: it has none) under the development switches in force."""
+        narrow = N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) == 1
+        return self._context.machine.tuning.match(self._shape_class(), narrow, not D.no_split_rowfirst())
 
     def _fused2d_eligible(self):
-        """2-D (ny, nx) in {512, 1024, 2048}^2 (fp32; BASELINE config 3 is the 1024 square) and the published double-precision
-        1024 x 1024: ROW + strided COL, run by the fused kernel as two transposing passes.  Round 4: rectangles (interleaved)."""
+        rule = self._persistent_rule()
+        return rule is not None and rule["kind"] == "2d"
+
+    def _persistent_strategy(self, batch, forced):
+        """(strategy, lag, ring, grid) of the rule's persistent launch for this batch, or None: the rule is on request only, the
+        transform is below its admission size, the cache holds no ring, or the batch cannot fill the ring twice."""
+        rule = self._persistent_rule()
+        if rule is None or forced not in ("auto", "fused") or (rule.get("on_request") and forced != "fused"):
+            return None
         p = self._params
-        k = self._kernels
-        nx, ny = int(p.x), int(p.y)
-        if p.split and p.precision == N.F32 and nx in (256, 512, 1024) and ny in (256, 512, 1024) and int(p.z) == 1 and len(k) == 2 and \
-                N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1 and not D.no_split_rowfirst() and \
-                ((ny, nx) != (256, 256) or D.forced_strategy() == "fused"):
-            # split-complex fp32: the row-first persistent kernel (csrc/fft_fused2r.hpp), second batch of round 4: 1024^2 0.359 (pipelined
-            # chunks) -> 0.425, 512^2 0.364 -> 0.425, (1024, 512) 0.374 -> 0.425, (512, 1024) 0.347 -> 0.422, (1024, 256) 0.376 -> 0.405,
-            # (256, 1024) 0.355 -> 0.408, (256, 512) 0.365 -> 0.398, (512, 256) 0.345 -> 0.389; (256, 256) 0.328 against 0.362-0.380 stays
-            # on the chunks (on request only)
-            return (k[0].kind == N.PASS_ROW and k[0].L == nx and k[1].kind == N.PASS_COL and k[1].L == ny and k[1].M == 1 and k[1].S == nx)
-        sides = (512, 1024) if p.precision == N.F64 else (512, 1024, 2048)
-        # a 256-point axis (interleaved; second batch of round 4): fp32 on the 32-column tiles next to a side <= 1024, fp64 next to <= 512
-        small = not p.split and 256 in (nx, ny) and min(nx, ny) == 256 and max(nx, ny) <= (512 if p.precision == N.F64 else 1024) and \
-            (p.precision == N.F64 or N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1)
-        if (not small and (nx not in sides or ny not in sides)) or int(p.z) != 1 or len(k) != 2:
-            return False
-        if p.split and p.precision == N.F64 and (ny, nx) == (1024, 1024):
-            pass              # fp64 planes (16 columns = a whole line): 0.346 (pipelined chunks) -> 0.423 once the tiles stream the planes non-temporally
-        elif p.split and (nx != ny or D.forced_strategy() != "fused" or (p.precision == N.F64 and nx != 1024)):
-            return False      # (fp32 planes, two transposing passes: 29 % against 35 % for the pipelined chunks -- squares, on request only)
-        if (ny, nx) == (512, 2048) and D.forced_strategy() != "fused":
-            # 512-point columns on the 512-thread tiles (16 points per thread, 64 KiB tiles, one work-group per CU): 0.355 against
-            # 0.392 for the pipelined chunks -- the one rectangle that loses (profiles/r04_c_rect_sweep.log); on request only
-            return False
-        return (k[0].kind == N.PASS_ROW and k[0].L == nx and k[1].kind == N.PASS_COL and k[1].L == ny
-                and k[1].M == 1 and k[1].S == nx)
+        mach = self._context.machine
+        rr = mach.tuning.ring_rule
+        cls = self._shape_class()
+        item_bytes = p.size * p.complex_nbytes
+        name = rule["strategy"]
+        tiles0 = max(1, int(cls[rule["extent0"]]) // int(rule["cols0"]))
+        per_cu = D.fused_grid_per_cu(int(rule["per_cu"]))
+        geo = mach.fused_geometry(item_bytes, tiles0, per_cu, fill_cache=rule.get("ring") == "cache", min_slots=rule.get("min_slots"))
+        if geo is None:
+            return None
+        lag, ring, grid = geo
+        if name == "fused2":
+            if int(rule["per_cu"]) == 1:
+                lag, ring = D.fused3_lag_ring(lag, ring)
+            lag, ring = D.fused_ring(lag, ring)
+        # a batch that cannot fill the ring twice: halve the pipeline (2^18 x 160: 28 / 56 instead of 56 / 112) rather than fall back
+        # to the chunks -- down to the 14 slots of the biggest transforms
+        hn, hd = rr["halved_lag"][name]
+        while forced == "auto" and batch < 2 * ring and ring >= rr["halve_while_ring_at_least"]:
+            ring //= 2
+            lag = max(1, hn * ring // hd)
+        if name == "fusedp":
+            lag, ring = D.fused_ring(lag, ring)
+        elif forced == "fused" and batch < 2 * ring and batch >= 8:      # on request: a shorter pipeline for a small batch
+            lag = batch // 4
+            ring = 2 * lag
+        big = item_bytes >= int(rule.get("min_item_bytes", 0)) or forced == "fused"
+        return (name, lag, ring, grid) if (batch >= 2 * ring and big) else None
 
-    def _fused_wide_tiles(self):
-        """The plan's persistent kernel runs on the 512-thread tiles (one work-group per CU): fp64, or a 2048-point pass."""
-        k = self._kernels
-        if self._params.precision == N.F64:
-            return not (k[0].L <= 512 and k[1].L <= 512)     # (fp64 2^16 ... 2^18 and the (512, 512) square: 256-thread tiles)
-        if self._split_siblings():
-            return max(k[0].L, k[1].L) > 512                 # two sibling tiles side by side on 512 threads: L = 1024 fills a CU
-        return k[1].L == 2048 or (self._fused2d_eligible() and k[0].L == 2048)
-
-    def _split_siblings(self):
-        """Split-complex fp32 on the 256-thread tiles: the persistent kernel runs the two 16-column tiles that share every 128-byte
-        line of a plane side by side in one 512-thread work-group (csrc/fft_fused2.hpp fft_fused2s_kernel)."""
-        k = self._kernels
-        return (self._params.precision == N.F32 and self._params.split and len(k) == 2 and k[0].L <= 1024 and k[1].L <= 1024
-                and N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1 and not self._split_rowfirst())
-
-    def _split_rowfirst(self):
-        """Split-complex fp32 2-D plans on the row-first persistent kernel (ROW x from the planes, COL y to the planes)."""
+    def _development_strategy(self, batch, forced, tiny):
+        """The measured-and-not-adopted forms, on request (PYFFT_AMD_* switches; `make DEV=1` builds of the library): the sequential
+        list of a tiny batch, the per-XCD work lists, the XCD-resident single-crossing kernel.  DESIGN.md section 5."""
         p = self._params
-        return (p.precision == N.F32 and p.split and int(p.y) > 1 and int(p.z) == 1 and self._fused2d_eligible()
-                and int(p.x) <= 1024 and int(p.y) <= 1024 and N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1 and not D.no_split_rowfirst())
-
-    def _fused2_eligible(self):
-        p = self._params
+        mach = self._context.machine
+        dev = mach.tuning.development
+        rule = self._persistent_rule()
+        item_bytes = p.size * p.complex_nbytes
+        if tiny:
+            if D.small_fused(int(dev["small_fused_lag_div"])) and N.lib.mifft_has_feature(N.FEATURE_SEQUENTIAL_LIST) == 1 and \
+                    not p.split and rule is not None and not rule.get("on_request"):
+                # statically dealt list: every work-group must be resident (1 or 2 per CU by the kernels' resources)
+                return (rule["strategy"], 0, batch, int(rule["per_cu"]) * mach.compute_units)
+            return None
+        one_d = rule is not None and rule["kind"] == "1d" and p.precision == N.F32
         k = self._kernels
-        if self._fused2d_eligible():
-            return True
-        if not (len(k) == 2 and int(p.y) == 1 and int(p.z) == 1 and k[0].kind == N.PASS_COL and k[1].kind == N.PASS_COL
-                and k[0].S == 1 and k[0].M == k[1].L and k[1].M == 1):
-            return False
-        if p.precision == N.F64:
-            # 1024 x 1024 on the 512-thread tiles; round 4: 2048 x 1024 on the stage-chain tiles (interleaved): 0.285 -> 0.330.  The same
-            # kernel runs 2048 x 2048 -- 64 MiB per transform, a ring of three -- BELOW the pipelined chunks (0.243 - 0.259 against
-            # 0.269, profiles/r04_e_fp64_long_fused.log): on request only
-            # round 4 also: 2^16 ... 2^18 (L0 >= L1 in {256, 512}) on the 256-thread tiles, interleaved
-            # (second batch: 2^16 ... 2^19 also for split planes -- an fp64 plane's 16 columns are whole lines, streamed non-temporally)
-            return (k[0].L == 1024 and k[1].L == 1024) or (k[0].L == 1024 and k[1].L == 512) or \
-                (k[0].L == 2048 and not p.split and (k[1].L == 1024 or (k[1].L == 2048 and D.forced_strategy() == "fused"))) or \
-                (k[0].L in (256, 512) and k[1].L in (256, 512) and k[0].L >= k[1].L)
-        return (k[0].L in (256, 512, 1024) and k[1].L in (256, 512, 1024)) or (k[0].L == 2048 and k[1].L in (1024, 2048))
-
-    def _fusedx_eligible(self):
-        """Per-XCD work lists: interleaved fp32 1-D, both passes on the 256-thread tiles, a device with 8 XCDs."""
-        p = self._params
-        k = self._kernels
-        return (self._fused2_eligible() and not self._fused2d_eligible() and p.precision == N.F32
-                and k[0].L <= 1024 and k[0].L >= k[1].L and self._context.machine.xcd_cooperative)
-
-    def _fusedp_eligible(self):
-        """3-D plans made of two pass pairs whose transform is a fraction of the last-level cache (128^3)."""
-        p = self._params
-        return self._pair_alt is not None or (self._paired and len(self._kernels) == 4 and not p.split
-                                              and N.lib.mifft_fused_pair_supported(p.precision, p.layout, int(p.x), int(p.y), int(p.z)) == 0)
-
-    def _xcd2_eligible(self):
-        k = self._kernels
-        return (self._fused2_eligible() and not self._fused2d_eligible() and self._params.precision == N.F32
-                and k[0].L == 1024 and k[1].L == 1024 and self._context.machine.xcd_cooperative
-                and not self._xcd2_disabled)
-
-    def _fused_tiles0(self):
-        """First-pass tiles per transform of the plan's persistent form (what the lag is counted in)."""
-        k = self._kernels
-        if self._fusedp_eligible():
-            r1 = int((self._pair_alt or k)[1].M)
-            return int(self._params.z) * r1                      # planes x R1
-        if self._split_rowfirst():
-            return int(self._params.y) // 16                     # groups of 16 rows
-        if self._split_siblings():
-            return (k[0].L if self._fused2d_eligible() else k[0].M) // 32   # sibling pairs of 16-column tiles
-        if self._fused2d_eligible():
-            if self._params.precision == N.F32 and not self._params.split and k[1].L <= 512 and k[0].L <= 1024 and \
-                    N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1:
-                return k[0].L // 32                              # a 256- / 512-point y axis: its pass runs on 32-column tiles
-            return k[0].L // 16                                  # nx / 16 column tiles of the y pass
-        if self._params.precision == N.F64 and k[0].L == 2048:
-            return k[0].M // 8                                   # 8-column tiles (csrc/fft_fusedx_f64.hip)
-        if self._params.precision == N.F32 and not self._params.split and k[0].L <= 512 and k[1].L <= 512 and \
-                N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1:
-            return k[0].M // 32                                  # 32-column tiles (csrc/fft_col2w.hpp)
-        return k[0].M // 16
+        xcd_ok = one_d and k[0].L <= 1024 and k[0].L >= k[1].L and mach.xcd_cooperative
+        lists_ok = xcd_ok and N.lib.mifft_has_feature(N.FEATURE_FUSED2X) == 1
+        if forced == "fusedx" and lists_ok and batch >= 64:
+            lag, ring = D.fusedx()[:2]            # explicit lag / ring slots per XCD
+            return ("fused2x", lag, ring, 2 * mach.compute_units)
+        if forced == "xcd" and xcd_ok and k[0].L == 1024 and k[1].L == 1024 and not self._xcd2_disabled and \
+                N.lib.mifft_has_feature(N.FEATURE_XCD2) == 1 and batch >= int(dev["xcd2_min_batch"]):
+            return ("xcd2", D.xcd2_flags(N.XCD2_PREFETCH))
+        if forced == "auto" and lists_ok and not D.no_fusedx():
+            lag, ring = dev["fusedx_lag_ring"]
+            # 2^17 on the 16-column tiles (MIFFT_NARROW_TILES=1): + 2 points over the pipelined chunks (profiles/r04_d_list_sweep.log)
+            if k[0].L * k[1].L == (1 << 17) and N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) == 1 and \
+                    batch >= 8 * 2 * ring and 8 * ring * item_bytes <= mach.ring_bytes:
+                return ("fused2x", lag, ring, 2 * mach.compute_units)
+            # split-complex planes with PYFFT_AMD_SPLIT_FUSEDX: sibling tiles share an XCD's L2 (profiles/r04_ac_split_siblings.log)
+            if p.split and D.split_fusedx():
+                ring = min(ring, (mach.ring_bytes * 4 // 7) // (8 * item_bytes))
+                if ring >= 6 and batch >= 8 * 2 * ring:
+                    return ("fused2x", ring // 2, ring, 2 * mach.compute_units)
+        return None
 
     def _select_strategy(self, batch):
+        """How the batch is cut and overlapped.  Every measured constant comes from the tuning table
+        (pyfft_amd/tuning_gfx950.json) and every size from the device (pyfft_amd/machine.py)."""
         forced = D.forced_strategy()
         p = self._params
         mach = self._context.machine
         item_bytes = p.size * p.complex_nbytes
         target = D.pipeline_chunk_bytes(mach.pipeline_chunk_bytes)
-        nstreams = D.pipeline_streams(self.PIPELINE_STREAMS)
-        chunk = max(1, target // item_bytes)
-        strat = ("chain",)
-        # up to the cache size per side one launch per pass over the whole batch is the fastest form: the side-stream fork / join of
-        # the pipelined chunks and the fill / drain of the persistent kernels only pay beyond it (profiles/r03_d_pipeline_threshold.log:
-        # (1024, 1024) x 32 chain 0.348 / pipelined 0.317, 2^18 x 128 chain 0.374 / fused 0.329, 2^16 x 512 0.387 / 0.343,
-        # 128^3 x 16 0.346 / 0.299; at twice the size the order flips)
-        small = forced == "auto" and batch * item_bytes <= mach.chain_max_bytes
-        if small or target < 1:
-            # tiny batches of a shape with a persistent kernel: both passes in ONE launch on the sequential work list (every
-            # first-pass tile, then every second-pass tile; one ring slot per transform) -- PYFFT_AMD_SMALL_FUSED, see DESIGN.md
-            if small and D.small_fused(self.SMALL_FUSED_LAG_DIV) and batch >= 1 and not p.split and \
-                    (self._fused2_eligible() or self._fusedp_eligible()):
-                huge = not self._fusedp_eligible() and self._fused_wide_tiles()
-                # statically dealt list: every work-group must be resident (1 or 2 per CU by the kernels' resources)
-                grid = (1 if huge else 2) * mach.compute_units
-                return ("fusedp" if self._fusedp_eligible() else "fused2", 0, batch, grid)
+        # up to the cache size per side one launch per pass over the whole batch is the fastest form: the fork / join of the chunks and
+        # the fill / drain of the persistent kernels only pay beyond it (profiles/r03_d_pipeline_threshold.log)
+        tiny = forced == "auto" and batch * item_bytes <= mach.chain_max_bytes
+        small = tiny or target < 1
+        strat = self._development_strategy(batch, forced, tiny) if (tiny or not small) else None
+        if strat is None and not small:
+            strat = self._persistent_strategy(batch, forced)
+        if strat is not None:
             return strat
-        if forced == "fusedx" and self._fusedx_eligible() and batch >= 64:
-            lag, ring = D.fusedx()[:2]            # development: explicit lag / ring slots per XCD
-            return ("fused2x", lag, ring, 2 * mach.compute_units)
-        if forced == "xcd" and self._xcd2_eligible() and batch >= self.XCD2_MIN_BATCH:   # not the default: DESIGN.md section 4
-            return ("xcd2", D.xcd2_flags(N.XCD2_PREFETCH))
-        # per-XCD lists where they win: 2^17 = 512 x 256 (+ 2 points over the pipelined chunks at 0.5 / 2 / 8 GiB; 2^16 is within
-        # +- 0.5 of them, 2^18 and up within +- 0.5 of the global list: profiles/r04_d_list_sweep.log)
-        # (superseded within round 4 by the 32-column tiles of the global list, 0.410 -> 0.462: the lists remain for the 16-column
-        # tiles, MIFFT_NARROW_TILES=1, and on request)
-        if forced == "auto" and self._fusedx_eligible() and self._kernels[0].L * self._kernels[1].L == (1 << 17) and not D.no_fusedx() \
-                and N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) == 1:
-            lag, ring = self.FUSEDX_LAG_RING
-            if batch >= 8 * 2 * ring and 8 * ring * item_bytes <= mach.ring_bytes:
-                return ("fused2x", lag, ring, 2 * mach.compute_units)
-        # split-complex fp32 (re / im planes): a 16-column tile touches HALF of every 128-byte line of a plane; on the global list the
-        # sibling tile ran on another XCD and every input line crossed the fabric twice (PMC 2.48 x the algorithmic bytes).  Two
-        # answers (second batch of round 4): the siblings side by side in one 512-thread work-group (fft_fused2s_kernel: the default
-        # form of the global list, below), or one work list per XCD, where the siblings share an L2.  Same process, 2 GiB
-        # (profiles/r04_ac_split_siblings.log): 2^16 side by side 0.423 / per XCD 0.358 (pipelined chunks 0.27), 2^17 0.352 / 0.330,
-        # 2^18 0.337 / 0.357, 2^19 0.330 / 0.338 with rings too short to last, 2^20 0.331 / 0.28 -- so the lists only at 2^18
-        # (final form of the side-by-side kernel, the two tiles interleaved at lane level: 2^18 0.430-0.440 against 0.377 for the lists, which
-        # remain on request: PYFFT_AMD_SPLIT_FUSEDX)
-        if forced == "auto" and p.split and self._fusedx_eligible() and not D.no_fusedx() and D.split_fusedx():
-            ring = min(self.FUSEDX_LAG_RING[1], (mach.ring_bytes * 4 // 7) // (8 * item_bytes))
-            if ring >= 6 and batch >= 8 * 2 * ring:
-                return ("fused2x", ring // 2, ring, 2 * mach.compute_units)
-        if forced in ("auto", "fused") and self._fusedp_eligible():
-            geo = mach.fused_geometry(item_bytes, self._fused_tiles0(), D.fused_grid_per_cu(2), fill_cache=True)
-            if geo is not None:
-                lag, ring, grid = geo
-                # a batch that cannot fill the ring twice: half the pipeline, down to the 14 slots of the cubes
-                while forced == "auto" and batch < 2 * ring and ring >= 28:
-                    ring //= 2
-                    lag = max(1, 4 * ring // 7)
-                lag, ring = D.fused_ring(lag, ring)
-                if batch >= 2 * ring:
-                    return ("fusedp", lag, ring, grid)
-        if (self._temp_buffer_needed or self._fused2d_eligible()) and forced in ("auto", "fused") and self._fused2_eligible():
-            huge = self._fused_wide_tiles()   # 512-thread tiles: one work-group per CU
-            # measured on MI355X (end of round 2, counters on their own lines): the persistent kernel beats the stream-pipelined
-            # chunks from N = 2^18 up (2^18: 42.0 vs 39.5 %, 2^19: 37.2 vs 36.2 %; 2^17: 39.1 vs 39.5, 2^16: 33 vs 40)
-            # fp32 from 2^18 (2 MiB) up -- below, the pipelined chunks or the per-XCD lists win; fp64 from 2^16 (1 MiB) up: its 16-column
-            # tiles are 256-byte segments, 2^16 0.422 -> 0.474, 2^17 0.406 -> 0.465, 2^18 0.405 -> 0.470
-            # (profiles/r04_l_anchored_twiddles_fp64_mid.log)
-            # fp32 2^16 ... 2^18 on the 32-column tiles (round 4, csrc/fft_col2w.hpp: 16-byte lanes, 256-byte segments): 2^16 0.403
-            # (pipelined) -> 0.469, 2^17 0.410 (per-XCD lists) -> 0.462, 2^18 0.420 (16-column tiles) -> 0.448
-            # (profiles/r04_o_fp32_wide_tiles.log)
-            wide32 = p.precision == N.F32 and not p.split and not self._fused2d_eligible() and self._kernels[0].L <= 512 and \
-                self._kernels[1].L <= 512 and N.lib.mifft_debug_get(N.DEBUG_NARROW_TILES) != 1
-            # (the 2-D shapes with a 256-point axis run on the same 32-column tiles)
-            wide32 = wide32 or (p.precision == N.F32 and not p.split and self._fused2d_eligible() and min(int(p.x), int(p.y)) == 256)
-            # (split planes with the sibling tiles side by side: 2^16 0.27 on the pipelined chunks, 0.42 here)
-            wide32 = wide32 or (self._split_siblings() and not self._fused2d_eligible()) or self._split_rowfirst()
-            big = item_bytes >= ((1 << 20) if p.precision == N.F64 else ((1 << 19) if wide32 else (2 << 20)))
-            # (fp64 2^22: 64 MiB per transform, three ring slots are all the cache holds)
-            geo = mach.fused_geometry(item_bytes, self._fused_tiles0(), D.fused_grid_per_cu(1 if huge else 2),   # (four per CU for L <= 512: no gain)
-                                      min_slots=3 if (p.precision == N.F64 and self._kernels[0].L == 2048) else None)
-            if geo is not None:
-                lag, ring, grid = geo
-                # (split planes.  While the sibling-tile kernel touched the planes with plain accesses, half the cache ring measured best
-                # -- 2^16 224 slots 0.421 / 112 0.392, 2^18 112 0.308 / 56 0.339 -- and the row-first 2-D kernel likewise, 1024^2 0.398
-                # against 0.348; with the planes streamed non-temporally the cache belongs to the ring again and the tile-count rule
-                # holds: 2^18 56 / 112 0.452 against 28 / 56 0.438, 1024^2 14 / 28 0.425 against 7 / 14 0.397.
-                # profiles/r04_ac_split_siblings.log, r04_ag_split_2d_row_first.log, r04_aj_split_nt_ab.log, r04_an_split_lane_interleaved.log)
-                if huge:
-                    lag, ring = D.fused3_lag_ring(lag, ring)
-                lag, ring = D.fused_ring(lag, ring)
-                # a batch that cannot fill the ring twice: halve the pipeline (2^18 x 160: 28 / 56 instead of 56 / 112) rather than fall
-                # back to the chunks -- down to the 14 slots of the biggest transforms
-                while forced == "auto" and batch < 2 * ring and ring >= 28:
-                    ring //= 2
-                    lag = max(1, ring // 2)
-                if forced == "fused" and batch < 2 * ring and batch >= 8:   # on request: a shorter pipeline for a small batch
-                    lag = batch // 4
-                    ring = 2 * lag
-                if batch >= 2 * ring and (big or forced == "fused"):
-                    return ("fused2", lag, ring, grid)
-        # any multi-pass plan gains from cache-sized chunks (the second pass re-reads what the first just wrote),
-        # whether or not it needs a temp buffer
-        if len(self._kernels) >= 2 and forced in ("auto", "pipelined") and batch >= 4 * chunk:
+        # any multi-pass plan gains from cache-sized chunks (the second pass re-reads what the first just wrote)
+        chunk = max(1, target // item_bytes) if target >= 1 else 1
+        pipe = mach.tuning.pipelined
+        if not small and len(self._kernels) >= 2 and forced in ("auto", "pipelined") and batch >= pipe["min_chunks"] * chunk:
             nslab = 0
             if self._slab_passes and not D.no_slabs():
                 plane_bytes = int(p.x) * int(p.y) * p.complex_nbytes
-                slab_target = D.slab_bytes(mach.slab_bytes // 2 if p.split else mach.slab_bytes)   # split planes measured best at half
-                planes = min(int(p.z), max(1, slab_target // plane_bytes))
-                nslab = int(p.z) // planes
-            return ("pipelined", chunk, nstreams, nslab)
-        return strat
+                slab_target = D.slab_bytes(mach.slab_bytes // (pipe["split_slab_divisor"] if p.split else 1))   # split planes measured best at half
+                nslab = int(p.z) // min(int(p.z), max(1, slab_target // plane_bytes))
+            return ("pipelined", chunk, D.pipeline_streams(pipe["streams"]), nslab)
+        return ("chain",)
 
     PERSISTENT = ("fused2", "fused2x", "fusedp")
 
@@ -550,9 +450,10 @@ class FFTPlan(object):
         if self._strategy[0] in self.PERSISTENT:
             # ring slots: `ring` of them; the per-XCD lists hold `ring` slots for each of the 8 XCDs
             items = self._strategy[2] * (8 if self._strategy[0] == "fused2x" else 1)
-            # two counter sets: every launch runs on one and zeroes the other (mifft_fused_sync), so no memset precedes a launch
+            # two counter sets: every launch runs on one and zeroes the other (mifft_fused_sync), so no memset precedes a launch;
+            # a third one for launches captured into a graph (_fused_sync)
             self._counter_bytes = N.fused2_counter_bytes(batch)
-            self._counters = ctx.allocate_raw(2 * self._counter_bytes)
+            self._counters = ctx.allocate_raw(3 * self._counter_bytes)
             self._counters_clean = False
             if self._errword is None:
                 from .hip import ErrorWord
@@ -567,9 +468,13 @@ class FFTPlan(object):
 
     def _fused_sync(self, stream):
         """mifft_fused_sync of the coming persistent launch: the counter set it runs on (zero: the previous launch cleared it, or
-        the memset below), the set it clears for the next launch, the pinned error word."""
+        the memset below), the set it clears for the next launch, the pinned error word.  A launch that is being CAPTURED into a
+        graph replays on the same set every time, so it takes the third set in the single-set form -- the library zeroes it with a
+        memset node in front of the kernel -- and leaves the alternation of the eager launches alone."""
         base = self._context.pointer_of(self._counters)
         nb = self._counter_bytes
+        if self._context.capturing():
+            return N.MifftFusedSync(base + 2 * nb, None, self._errword.ptr)
         if D.fused_memset():            # development A/B: one counter set, zeroed by a memset in front of every launch
             return N.MifftFusedSync(base, None, self._errword.ptr)
         if not self._counters_clean:
@@ -586,6 +491,8 @@ class FFTPlan(object):
         stream = ctx.stream_handle()
         strat = self._strategy
         if strat[0] == "xcd2":
+            if ctx.capturing():
+                raise RuntimeError("pyfft_amd: the development strategy xcd2 cannot be captured into a graph")
             d0, d1 = descs[0], descs[1]
             in1 = bufs1[d0.src] if bufs1 is not None else None
             out1 = bufs1[d1.dst] if bufs1 is not None else None
@@ -716,6 +623,10 @@ class FFTPlan(object):
         if self._mailbox is not None or self._errword is not None:
             self.check()
         if self._last_batch_size != batch:
+            ctx.createQueue(args)
+            if ctx.capturing():
+                # scratch, counters and side streams are allocated here, which a capturing stream cannot record
+                raise RuntimeError("pyfft_amd: execute() on a capturing stream needs one eager execute() of the same batch first")
             self._prepare(batch)
         # small transforms are launch-bound (a 32 MiB execute is ~12 us of device time): the pointer triples of the last
         # call are kept, so that repeated executes on the same buffers skip rebuilding them

@@ -565,7 +565,7 @@ def test_round4_entry_points_reject_bad_arguments_without_touching_the_gpu():
         return p
 
     p0, p1 = col(1024, 1024, 1, 64, 1 << 20), col(1024, 1, 1024, 64, 1 << 20)
-    ok = N.MifftFusedSync(4096, 8192, None)
+    ok = N.MifftFusedSync(4096, 8192, 12288)
     byref = ctypes.byref
     # null / misaligned / aliased counter sets, bad lag / ring combinations
     for sync, what in ((N.MifftFusedSync(None, None, None), "null counters"), (N.MifftFusedSync(4096 + 64, None, None), "256-byte"),
@@ -574,9 +574,21 @@ def test_round4_entry_points_reject_bad_arguments_without_touching_the_gpu():
         assert what in N.last_error(), N.last_error()
     assert N.lib.mifft_launch_fused2(byref(p0), byref(p1), 16, None, 32, None, 64, None, 28, 14, None, 512, None) == N.E_INVALID
     assert N.lib.mifft_launch_fused2(byref(p0), byref(p1), 16, None, 32, None, 64, None, 14, 14, byref(ok), 512, None) == N.E_INVALID   # lag == ring
-    assert N.lib.mifft_launch_fused2(byref(p0), byref(p1), 16, None, 32, None, 64, None, 28, 0, byref(ok), 512, None) == N.E_INVALID    # sequential list: ring == outer
-    assert N.lib.mifft_launch_fused2x(byref(p0), byref(p1), 16, None, 32, None, 64, 8, 4, None, 512, None) == N.E_INVALID
-    assert N.lib.mifft_launch_fused2x(byref(p0), byref(p1), 16, None, 32, None, 64, 8, 4, byref(N.MifftFusedSync(4096, 4096, None)), 512, None) == N.E_INVALID
+    # two alternating counter sets need an error word of their own (the next launch zeroes the default one, word 1 of line 0)
+    assert N.lib.mifft_launch_fused2(byref(p0), byref(p1), 16, None, 32, None, 64, None, 28, 14, byref(N.MifftFusedSync(4096, 8192, None)), 512, None) == N.E_INVALID
+    assert "error word of their own" in N.last_error(), N.last_error()
+    # the development forms (sequential list, per-XCD lists, XCD-resident kernel) exist in `make DEV=1` builds only; the default
+    # build says so loudly and mifft_has_feature tells beforehand
+    dev = [N.lib.mifft_has_feature(f) for f in (N.FEATURE_XCD2, N.FEATURE_FUSED2X, N.FEATURE_SEQUENTIAL_LIST)]
+    assert dev in ([0, 0, 0], [1, 1, 1]) and N.lib.mifft_has_feature(99) == 0
+    seq = N.lib.mifft_launch_fused2(byref(p0), byref(p1), 16, None, 32, None, 64, None, 28, 0, byref(ok), 512, None)    # sequential list: ring == outer
+    assert seq == (N.E_INVALID if dev[2] else N.E_UNSUPPORTED)
+    for sync in (None, byref(N.MifftFusedSync(4096, 4096, None))):
+        rc = N.lib.mifft_launch_fused2x(byref(p0), byref(p1), 16, None, 32, None, 64, 8, 4, sync, 512, None)
+        assert rc == (N.E_INVALID if dev[1] else N.E_UNSUPPORTED)
+    if not dev[0]:
+        assert N.lib.mifft_launch_xcd2(byref(p0), byref(p1), 16, None, 32, None, 256, 256, 1, None) == N.E_UNSUPPORTED
+        assert "DEV=1" in N.last_error()
     # the persistent pass-pair form exists for the shapes with every axis in {64, 128}, both precisions, both layouts
     I, S = N.INTERLEAVED, N.SPLIT
     assert N.lib.mifft_fused_pair_supported(N.F32, I, 128, 128, 128) == 0 and N.lib.mifft_fused_pair_supported(N.F64, I, 128, 128, 128) == 0
@@ -622,3 +634,123 @@ def test_pyfft_import_name():
         pass
     else:
         raise AssertionError("pyfft.cuda must not exist")
+
+
+def test_round5_debug_switches_are_per_thread_over_a_process_default():
+    """mifft_debug_set changes a development switch for the calling thread only; a thread that never set the key sees the process
+    default (mifft_debug_set_default) -- a measurement in one thread cannot change the kernels of another thread's plan."""
+    import threading
+    from pyfft_amd import _native as N
+    key = N.DEBUG_ALT_ROWS
+    assert N.lib.mifft_debug_get(key) == 0
+    seen = []
+
+    def other(tag):
+        seen.append((tag, N.lib.mifft_debug_get(key)))
+
+    def run(tag):
+        t = threading.Thread(target=other, args=(tag,))
+        t.start()
+        t.join()
+
+    try:
+        assert N.lib.mifft_debug_set(key, 2) == 0
+        run("after the main thread's set")
+        assert N.lib.mifft_debug_get(key) == 2
+        assert N.lib.mifft_debug_set_default(key, 3) == 0
+        run("after the default changed")
+        assert N.lib.mifft_debug_get(key) == 2            # the thread's own value wins
+    finally:
+        N.lib.mifft_debug_set_default(key, 0)
+        N.lib.mifft_debug_set(key, 0)
+    assert seen == [("after the main thread's set", 0), ("after the default changed", 3)]
+    assert N.lib.mifft_debug_set(N.DEBUG_NO_ROWFIRST + 1, 1) == N.E_INVALID and N.lib.mifft_debug_set_default(-1, 1) == N.E_INVALID
+
+
+def test_round5_capture_entry_points_reject_bad_arguments_without_touching_the_gpu():
+    """Stream capture / graph replay shims (include/mifft.h): argument errors are negative library codes, never a crash."""
+    import ctypes
+    from pyfft_amd import _native as N
+    assert N.lib.mifft_stream_is_capturing(None, None) == N.E_INVALID
+    assert N.lib.mifft_stream_begin_capture(None) == N.E_INVALID and "default stream" in N.last_error()
+    assert N.lib.mifft_stream_end_capture(None, None) == N.E_INVALID
+    assert N.lib.mifft_graph_launch(None, None) == N.E_INVALID
+    assert N.lib.mifft_graph_destroy(None) == 0
+    assert N.ABI_VERSION == 4 and N.lib.mifft_abi_version() == 4
+
+
+def test_round5_no_split_rowfirst_follows_the_environment_into_the_library(monkeypatch):
+    """PYFFT_AMD_NO_SPLIT_ROWFIRST decides the planner's tile count AND the launcher's kernel: the planner's query forwards it to
+    the calling thread's native switch (the two used to disagree)."""
+    from pyfft_amd import _debug as D
+    from pyfft_amd import _native as N
+    monkeypatch.delenv("PYFFT_AMD_NO_SPLIT_ROWFIRST", raising=False)
+    assert D.no_split_rowfirst() is False and N.lib.mifft_debug_get(N.DEBUG_NO_ROWFIRST) == 0
+    monkeypatch.setenv("PYFFT_AMD_NO_SPLIT_ROWFIRST", "1")
+    assert D.no_split_rowfirst() is True and N.lib.mifft_debug_get(N.DEBUG_NO_ROWFIRST) == 1
+    monkeypatch.delenv("PYFFT_AMD_NO_SPLIT_ROWFIRST")
+    assert D.no_split_rowfirst() is False and N.lib.mifft_debug_get(N.DEBUG_NO_ROWFIRST) == 0
+
+
+def test_strategy_snapshot_of_the_table_driven_planner():
+    """FFTPlan._select_strategy is a lookup in pyfft_amd/tuning_gfx950.json since round 5.  It must answer what the round-4 planner
+    (nested literals) answered for every shape of profiles/r04_long_1d_sizes.log / r04_second_batch_shapes.log / r04_t_tail_survey.log
+    at seven buffer sizes on three devices, and on the full part under the development switches the choice depends on: tests/golden/strategy_snapshot.json.gz, written by make_strategy_snapshot.py BEFORE the move."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_strategy_snapshot as snap
+    import gzip
+    from pyfft_amd import _native as N
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "strategy_snapshot.json.gz"), "rt") as f:
+        want = json.load(f)
+    got = snap.snapshot()
+    assert len(got) == len(want) > 30000
+    # (the per-XCD work lists are part of `make DEV=1` builds only: 18 rows of the 16-column A/B mode)
+    lists = N.lib.mifft_has_feature(N.FEATURE_FUSED2X) == 1
+    bad = [(w, g) for w, g in zip(want, got) if w != json.loads(json.dumps(g)) and (lists or w[5][0] != "fused2x")]
+    assert not bad, bad[:10]
+    assert not lists or sum(1 for g in got if g[5][0] == "fused2x") == 18
+    assert set(r[5][0] for r in want) == {"chain", "pipelined", "fused2", "fusedp", "fused2x"}
+
+
+def test_planner_follows_a_doctored_tuning_table():
+    """The planner holds no measured literal of its own: a table with other fractions / rules (what tools/fused_sweep.py --emit
+    writes after a sweep on another part) changes the strategies accordingly, and a broken table is refused when it is loaded."""
+    import copy
+    import numpy
+    from pyfft_amd import tuning
+    from pyfft_amd.machine import Machine
+    from pyfft_amd.plan import FFTPlan
+    base = tuning.default()
+    assert base.source.endswith("tuning_gfx950.json") and len(base.rules) >= 20 and all("evidence" in r for r in base.rules)
+    c64 = numpy.complex64
+
+    def on(table, shape, dtype, batch):
+        mach = Machine(256, 8, 4 << 20, 256 << 20, tuning=tuning.Tuning(table, "doctored"))
+        return FFTPlan(_FakeContext(mach), shape, dtype=dtype)._select_strategy(batch)
+
+    assert on(base.table, (1 << 20,), c64, 4096) == ("fused2", 14, 28, 512)
+    t = copy.deepcopy(base.table)
+    t["cache_fractions"]["ring"] = [1, 2]                       # half the cache for the ring: 16 slots of 8 MiB -> the cap rule (14 slots)
+    t["cache_fractions"]["chain_max"] = [1, 8]                  # chain only up to 32 MiB per side
+    t["cache_fractions"]["pipeline_chunk"] = [1, 16]            # 16 MiB chunks
+    assert on(t, (1 << 20,), c64, 4096) == ("fused2", 8, 14, 512)
+    assert on(t, (1 << 20,), c64, 8) == ("pipelined", 2, 2, 0) and on(base.table, (1 << 20,), c64, 8) == ("chain",)
+    t = copy.deepcopy(base.table)
+    for r in t["rules"]:
+        if r["kind"] == "1d" and r.get("precision") == "f32" and 1024 in r.get("L0", []) and r["cols0"] == 16:
+            r["on_request"] = True                              # "the persistent form lost on this part"
+    assert on(t, (1 << 20,), c64, 4096)[0] == "pipelined" and on(t, (1 << 18,), c64, 4096)[0] == "fused2"
+    t = copy.deepcopy(base.table)
+    t["ring_rule"]["lag_waves"] = [7, 2]                        # producers 3.5 waves ahead
+    assert on(base.table, (1 << 19,), c64, 2048) == ("fused2", 28, 56, 512)
+    assert on(t, (1 << 19,), c64, 2048) == ("fused2", 8, 14, 512)      # the tile rule would ask for 56 / 112, the cache holds 56: the capped ring
+    t = copy.deepcopy(base.table)
+    del t["rules"][0]["cols0"]
+    try:
+        tuning.Tuning(t, "broken")
+    except ValueError as e:
+        assert "cols0" in str(e)
+    else:
+        raise AssertionError("a rule without cols0 was accepted")

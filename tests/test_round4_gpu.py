@@ -105,6 +105,9 @@ def test_per_xcd_lists(ctx, monkeypatch, n, batch):
     """The fused kernel with one work list per XCD (mifft_launch_fused2x; pyfft/kernel.py:259-283 chain semantics), on request
     (within round 4 the 32-column tiles of the global list overtook it at 2^17): the bits of the chain, in place == out of place; a
     batch that is not a multiple of 8 leaves the lists uneven, work stealing drains them."""
+    from pyfft_amd import _native as N
+    if N.lib.mifft_has_feature(N.FEATURE_FUSED2X) != 1:
+        pytest.skip("development strategy: not in the default build of libmifft.so (make DEV=1)")
     if not ctx.hip.Machine.from_props(ctx.hip.device_props()).xcd_cooperative:
         pytest.skip("needs 8 XCDs x 32 CUs")
     data = _test_data((n,), numpy.complex64, batch, 91)
@@ -144,7 +147,11 @@ def test_fused_ring_rule_2_19(ctx, monkeypatch):
 def test_sequential_single_launch_of_tiny_batches(ctx, monkeypatch, shape, dtype, batch):
     """The reference's own benchmark protocol runs 32 MiB buffers (test/test_performance.py:11,22-30): there the two passes of a
     transform are two dependent launches.  The sequential work list runs them in ONE persistent launch (lag 0: every first-pass
-    tile, then every second-pass tile); it must give the chain's bits, in place and out of place, forward and inverse."""
+    tile, then every second-pass tile); it must give the chain's bits, in place and out of place, forward and inverse.  Measured
+    slower than the two launches: part of `make DEV=1` builds of the library only."""
+    from pyfft_amd import _native as N
+    if N.lib.mifft_has_feature(N.FEATURE_SEQUENTIAL_LIST) != 1:
+        pytest.skip("development form: not in the default build of libmifft.so (make DEV=1)")
     data = _test_data(shape, dtype, batch, 93)
     monkeypatch.setenv("PYFFT_AMD_SMALL_FUSED", "0")
     want = _execute(ctx, shape, dtype, batch, data, expect="chain")
@@ -595,7 +602,8 @@ def test_split_planes_on_per_xcd_lists(ctx, monkeypatch, n, batch, expect):
     back = _execute_split(ctx, (n,), numpy.float32, batch, got[0], got[1], inverse=True, expect=expect)
     x = re + 1j * im
     assert numpy.abs((back[0] + 1j * back[1]) - x).sum() / numpy.abs(x).sum() < 1.1e-6
-    if n <= (1 << 18):
+    from pyfft_amd import _native as N
+    if n <= (1 << 18) and N.lib.mifft_has_feature(N.FEATURE_FUSED2X) == 1:      # (`make DEV=1` builds)
         monkeypatch.setenv("PYFFT_AMD_SPLIT_FUSEDX", "1")
         lists = _execute_split(ctx, (n,), numpy.float32, batch, re, im, expect="fused2x")
         assert numpy.array_equal(lists[0], got[0]) and numpy.array_equal(lists[1], got[1])

@@ -1,0 +1,315 @@
+"""Round 5 (GPU): BASELINE.json configs[4] as stated on one GPU -- the whole per-GPU share of 8192 transforms of 2^22 points, as the
+streaming loop over 32 resident chunks and as ONE in-place execute --, eight ranks of the real sharded path, persistent
+executes under stream capture, and the round's new kernels.  All through the C ABI (ctypes), against numpy.fft on the complex128-upcast
+input (the reference's own oracle, test/test_errors.py:5-16,35) with the reference's thresholds."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EPS_F, MAX_F = 1.1e-6, 1e-5
+
+N5 = 1 << 22           # configuration 5: 1-D c2c fp32 N = 2^22
+CHUNK5 = 256           # one resident chunk: 8 GiB in + 8 GiB out
+SHARE5 = 8192          # per GPU: 65536 transforms over 8 GPUs (BASELINE.json configs[4]; kernel.py:99-121: batch -> grid)
+BLK5 = 16              # the synthetic data set is periodic: 16 seeded transforms (512 MiB)
+
+_c5_cache = {}
+
+
+def _c5_block():
+    """The seeded block of configuration 5 and numpy's transform of every item of it (complex128), computed once per session."""
+    if "block" not in _c5_cache:
+        rng = numpy.random.default_rng(1005)
+        re = rng.standard_normal((BLK5, N5)).astype(numpy.float32)
+        im = rng.standard_normal((BLK5, N5)).astype(numpy.float32)
+        block = numpy.empty((BLK5, N5), numpy.complex64)
+        block.real = re
+        block.imag = im
+        _c5_cache["block"] = block
+        _c5_cache["refs"] = [numpy.fft.fft(block[i].astype(numpy.complex128)) for i in range(BLK5)]
+    return _c5_cache["block"], _c5_cache["refs"]
+
+
+def _fetch(N, ptr, item, size=N5):
+    out = numpy.empty(size, numpy.complex64)
+    N.check(N.lib.mifft_memcpy_d2h(out.ctypes.data, ptr + item * size * 8, out.nbytes, None))
+    return out
+
+
+def _close(got, ref):
+    got = got.astype(numpy.complex128)
+    return (numpy.abs(ref - got).sum() / numpy.abs(ref).sum() < EPS_F) and (numpy.abs(ref - got).max() <= MAX_F * numpy.abs(ref).max())
+
+
+def test_config5_per_gpu_share(ctx):
+    """The full per-GPU share of configuration 5 as the survey's streaming loop: 32 chunks of 256 transforms through ONE plan and
+    ONE pair of 8 GiB buffers.  Global transform g holds block item (g + g // 256) % 16 -- every chunk is the block rotated one item
+    further, so a chunk that was skipped, executed on stale data or mixed up with its neighbour cannot pass -- and the input buffer
+    is refilled between chunks from a device copy of the block.  First / middle / last transform of EVERY chunk against numpy."""
+    from pyfft_amd import _native as N
+    hip = ctx.hip
+    block, refs = _c5_block()
+    item_bytes = N5 * 8
+    dev_block = hip.to_gpu(block.reshape(-1))
+    a = hip.DeviceArray((CHUNK5 * N5,), numpy.complex64)
+    b = hip.DeviceArray((CHUNK5 * N5,), numpy.complex64)
+    plan = hip.Plan(N5, dtype=numpy.complex64)
+    assert plan.strategy(CHUNK5)[0] == "fused2"             # the persistent kernel of the stated configuration
+
+    def refill(c):
+        """a[s] <- block[(s + c) % 16] for the 256 transforms s of chunk c"""
+        rot = c % BLK5
+        head = (BLK5 - rot) * item_bytes
+        N.check(N.lib.mifft_memcpy_d2d(a.ptr, dev_block.ptr + rot * item_bytes, head, None))
+        if rot:
+            N.check(N.lib.mifft_memcpy_d2d(a.ptr + head, dev_block.ptr, rot * item_bytes, None))
+        done = BLK5 * item_bytes
+        while done < a.nbytes:
+            n = min(done, a.nbytes - done)
+            N.check(N.lib.mifft_memcpy_d2d(a.ptr + done, a.ptr, n, None))
+            done += n
+
+    chunks = SHARE5 // CHUNK5
+    checked = 0
+    for c in range(chunks):
+        refill(c)
+        plan.execute(a, b, batch=CHUNK5)
+        for s in (0, CHUNK5 // 2 + 1, CHUNK5 - 1):
+            g = c * CHUNK5 + s
+            assert _close(_fetch(N, b.ptr, s), refs[(g + g // CHUNK5) % BLK5]), ("chunk", c, "transform", g)
+            checked += 1
+        if c in (0, chunks // 2, chunks - 1):               # the input of an out-of-place execute stays what it was
+            assert numpy.array_equal(_fetch(N, a.ptr, CHUNK5 - 1), block[(CHUNK5 - 1 + c) % BLK5])
+    assert checked == 3 * chunks
+    # the last chunk's result, inverse in place: the round trip
+    plan.execute(b, batch=CHUNK5, inverse=True)
+    for s in (0, CHUNK5 - 1):
+        want = block[(s + chunks - 1) % BLK5].astype(numpy.complex128)
+        got = _fetch(N, b.ptr, s).astype(numpy.complex128)
+        assert numpy.abs(want - got).sum() / numpy.abs(want).sum() < EPS_F
+
+
+def test_config5_share_as_one_execute(ctx):
+    """The same share as ONE in-place execute(batch = 8192): 256 GiB resident (byte offsets up to 2^38, 2^35 elements, 16393 counters
+    per set), skipped with a message where the allocation is refused.  Sampled transforms against numpy, periodic input ->
+    bit-identical outputs across the whole buffer, inverse in place -> the input."""
+    from pyfft_amd import _native as N
+    hip = ctx.hip
+    block, refs = _c5_block()
+    try:
+        buf = hip.DeviceArray((SHARE5 * N5,), numpy.complex64)
+    except RuntimeError as e:
+        pytest.skip("mifft_malloc refuses 256 GiB on this device: %s" % (str(e)[:200],))
+    hb = block.reshape(-1).view(numpy.uint8)
+    N.check(N.lib.mifft_memcpy_h2d(buf.ptr, hb.ctypes.data, hb.nbytes, None))
+    done = hb.nbytes
+    while done < buf.nbytes:
+        n = min(done, buf.nbytes - done)
+        N.check(N.lib.mifft_memcpy_d2d(buf.ptr + done, buf.ptr, n, None))
+        done += n
+    N.check(N.lib.mifft_device_sync())
+    plan = hip.Plan(N5, dtype=numpy.complex64)
+    assert plan.strategy(SHARE5)[0] == "fused2"
+    plan.execute(buf, batch=SHARE5)
+    samples = [0, 1, BLK5 - 1, BLK5, SHARE5 // 2 - 1, SHARE5 // 2, SHARE5 // 2 + 5, SHARE5 - BLK5 - 3, SHARE5 - 2, SHARE5 - 1]
+    first = {}
+    for g in samples:
+        got = _fetch(N, buf.ptr, g)
+        assert _close(got, refs[g % BLK5]), g
+        # periodic input -> bit-identical output wherever the item lies in the 256 GiB
+        if g % BLK5 in first:
+            assert numpy.array_equal(first[g % BLK5].view(numpy.uint32), got.view(numpy.uint32)), g
+        else:
+            first[g % BLK5] = got
+    plan.execute(buf, batch=SHARE5, inverse=True)
+    for g in (0, SHARE5 // 2 + 5, SHARE5 - 1):
+        want = block[g % BLK5].astype(numpy.complex128)
+        got = _fetch(N, buf.ptr, g).astype(numpy.complex128)
+        assert numpy.abs(want - got).sum() / numpy.abs(want).sum() < EPS_F, g
+    plan.close()
+    del buf
+
+
+def test_eight_ranks_share_one_gpu(tmp_path):
+    """`bench.py --gpus 8` for real (the harness had never started more than two ranks): eight processes, each with its own plan,
+    stream and scratch, on ONE device (--share-gpu), gloo as the control plane, each rank's slice of the global batch checked
+    in-process and its first / last transform again here against numpy on the global data set.  rank 0 also times the CPU baseline
+    (numpy.fft on the host cores in the same run, at every world size)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    batch = 10                                                # per rank; 80 transforms of 8 MiB in all: the chain strategy
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--control", "gloo", "--share-gpu",
+                          "--config", "c2", "--batch", str(batch), "--steps", "2", "--warmup", "1", "--repeats", "0",
+                          "--dump-dir", str(tmp_path)],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["config"]["global_batch"] == 8 * batch and res["scaling"] == "weak"
+    ranks = res["config"]["ranks"]
+    assert [r["rank"] for r in ranks] == list(range(8))
+    assert [r["first_transform"] for r in ranks] == [batch * r for r in range(8)] and all(r["count"] == batch for r in ranks)
+    assert all(r["parity_ok"] for r in ranks) and all(r["device"] == 0 for r in ranks)
+    cpu = res["cpu_baseline"]
+    assert cpu is not None and cpu["kind"] == "reference" and cpu["value"] > 0 and cpu["best"]["value"] >= cpu["value"]
+    shape, dtname, _, seed = bench.CONFIGS["c2"]
+    for r in range(8):
+        for g in (r * batch, (r + 1) * batch - 1):
+            got = numpy.load(os.path.join(str(tmp_path), "xform_%d.npy" % g))
+            ref = numpy.fft.fft(bench.global_item(shape, dtname, batch, seed, g).astype(numpy.complex128))
+            assert numpy.abs(got - ref).sum() / numpy.abs(ref).sum() < EPS_F, g
+            assert numpy.abs(got - ref).max() <= MAX_F * numpy.abs(ref).max(), g
+    assert abs(res["transforms_per_s"] - 8 * batch * res["steps"] / (res["ms_per_step"] * 1e-3 * res["steps"])) < 1e-6 * res["transforms_per_s"]
+
+
+# ---- persistent executes under stream capture / hipGraph replay -----------------------------------------------------------------
+def _tiled_noise(count, dtype, seed):
+    rng = numpy.random.default_rng(seed)
+    cdt = numpy.dtype(dtype)
+    fdt = numpy.float32 if cdt == numpy.complex64 else numpy.float64
+    out = numpy.empty(count, cdt)
+    for part in ("real", "imag"):
+        blk = rng.standard_normal(min(count, (1 << 22) + 17)).astype(fdt)
+        setattr(out, part, numpy.resize(blk, count))
+    return out
+
+
+CAPTURE_CASES = [((1 << 18,), 160, numpy.complex64, "fused2"),        # 28 / 56 ring: the review's case
+                 ((1 << 20,), 64, numpy.complex64, "fused2"),         # BASELINE config 2's kernel
+                 ((128, 128, 128), 32, numpy.complex64, "fusedp"),
+                 ((1024, 1024), 64, numpy.complex64, "fused2"),       # the 2-D form
+                 ((1 << 16,), 96, numpy.complex64, "chain"),
+                 ((512, 1024), 80, numpy.complex128, "fused2")]
+
+
+@pytest.mark.parametrize("shape,batch,dtype,strategy", CAPTURE_CASES, ids=lambda v: getattr(v, "__name__", str(v)))
+def test_captured_execute_replays_bit_identically(ctx, shape, batch, dtype, strategy):
+    """One execute() recorded into a hipGraph (hip.Graph: mifft_stream_begin_capture / _end_capture) and replayed five times,
+    with eager executes of the same plan in between: every replay writes the bits of the eager result over the WHOLE array and the
+    error word stays clean.  (pyfft/plan.py:250-259: execute is an asynchronous enqueue on the caller's stream -- which a caller
+    may capture.  The two alternating counter sets of the persistent launches are host state: a captured launch has its own set
+    with the memset as a graph node.)"""
+    from pyfft_amd import _native as N
+    hip = ctx.hip
+    size = int(numpy.prod(shape))
+    data = _tiled_noise(size * batch, dtype, 501)
+    s = hip.Stream()
+    plan = hip.Plan(shape if len(shape) > 1 else shape[0], dtype=dtype, stream=s)
+    a = hip.to_gpu(data)
+    b = hip.DeviceArray((size * batch,), dtype)
+    assert plan.strategy(batch)[0] == strategy, plan.strategy(batch)
+    plan.execute(a, b, batch=batch)
+    s.synchronize()
+    want = b.get().view(numpy.uint32)
+    N.check(N.lib.mifft_memset(b.ptr, 0, b.nbytes, s.handle))
+    with hip.Graph(s) as g:
+        assert plan._context.capturing()
+        assert plan.execute(a, b, batch=batch) is s
+    assert not plan._context.capturing()
+    s.synchronize()
+    assert not b.get().any(), "a captured execute ran"
+    for i in range(5):
+        N.check(N.lib.mifft_memset(b.ptr, 0, b.nbytes, s.handle))
+        g.launch()
+        if i in (1, 2):
+            g.launch()                                  # back to back on the same counter set
+        s.synchronize()
+        assert numpy.array_equal(b.get().view(numpy.uint32), want), ("replay", i)
+        if i in (0, 3):                                 # eager executes in between keep alternating their own two sets
+            N.check(N.lib.mifft_memset(b.ptr, 0, b.nbytes, s.handle))
+            plan.execute(a, b, batch=batch)
+            if i == 3:
+                plan.execute(a, b, batch=batch)
+            s.synchronize()
+            assert numpy.array_equal(b.get().view(numpy.uint32), want), ("eager after replay", i)
+    plan.finish()                                       # raises if any launch reported a dependency time-out
+    # a batch the plan has not run yet cannot be captured (its scratch would be allocated inside the capture): loud, not wrong
+    with pytest.raises(RuntimeError):
+        with hip.Graph(s):
+            plan.execute(a, b, batch=batch - 1)
+    s.synchronize()
+
+
+def test_direct_abi_two_set_launch_refuses_capture_and_null_error_word(ctx):
+    """C-ABI users of mifft_launch_fused2: the two-set form on a capturing stream is MIFFT_E_INVALID (a replay would start on dirty
+    counters), and so is the two-set form without an error word of its own (the next launch would zero the default one)."""
+    import ctypes
+    from pyfft_amd import _native as N
+    hip = ctx.hip
+    n, batch = 1 << 18, 160
+    s = hip.Stream()
+    plan = hip.Plan(n, dtype=numpy.complex64, stream=s)
+    a = hip.DeviceArray((n * batch,), numpy.complex64)
+    N.check(N.lib.mifft_memset(a.ptr, 0, a.nbytes, s.handle))
+    plan.execute(a, batch=batch)
+    s.synchronize()
+    strat = plan.strategy(batch)
+    assert strat[0] == "fused2"
+    _, lag, ring, grid = strat
+    descs = plan._descriptors(batch, True, False)
+    base = plan._context.pointer_of(plan._counters)
+    nb = plan._counter_bytes
+    N.check(N.lib.mifft_memset(base, 0, 3 * nb, s.handle))
+    s.synchronize()
+    plan._counters_clean, plan._counter_set = True, 0
+    tmp = plan._context.pointer_of(plan._tempmemobj)
+
+    def launch(sync):
+        return N.lib.mifft_launch_fused2(ctypes.byref(descs[0]), ctypes.byref(descs[1]), a.ptr, None, a.ptr, None, tmp, None, ring, lag,
+                                         ctypes.byref(sync), grid, s.handle)
+
+    assert launch(N.MifftFusedSync(base, base + nb, None)) == N.E_INVALID
+    assert b"error word" in N.lib.mifft_last_error()
+    N.check(N.lib.mifft_stream_begin_capture(s.handle))
+    rc = launch(N.MifftFusedSync(base, base + nb, plan._errword.ptr))
+    msg = N.lib.mifft_last_error()
+    rc_single = launch(N.MifftFusedSync(base + 2 * nb, None, plan._errword.ptr))
+    h = ctypes.c_void_p()
+    N.check(N.lib.mifft_stream_end_capture(s.handle, ctypes.byref(h)))
+    N.lib.mifft_graph_destroy(h)
+    assert rc == N.E_INVALID and b"capturing" in msg
+    assert rc_single == 0
+    s.synchronize()
+
+
+def test_torch_cuda_graph_around_execute(ctx):
+    """torch.cuda.graph() around execute() of a plan built without stream= (it follows torch's current stream, cuda.py:116-134):
+    the persistent kernel of 2^18 x 160, replayed on new input values."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    hip = ctx.hip
+    n, batch = 1 << 18, 160
+    x = torch.view_as_complex(torch.randn(batch * n, 2, device="cuda", dtype=torch.float32))
+    y = torch.empty_like(x)
+    plan = hip.Plan(n, dtype=numpy.complex64, wait_for_finish=False)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        plan.execute(x, y, batch=batch)                 # warm-up on the side stream, as torch's graph recipe prescribes
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert plan.strategy(batch)[0] == "fused2"
+    want = torch.fft.fft(x.view(batch, n), dim=1).reshape(-1)
+    assert (y - want).abs().sum() / want.abs().sum() < 2e-6
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        plan.execute(x, y, batch=batch)
+    for k in range(3):
+        x.copy_(torch.view_as_complex(torch.randn(batch * n, 2, device="cuda", dtype=torch.float32)))
+        y.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        want = torch.fft.fft(x.view(batch, n), dim=1).reshape(-1)
+        assert (y - want).abs().sum() / want.abs().sum() < 2e-6, k
+    plan.finish()

@@ -33,7 +33,7 @@ def run(kind, cfg, outdir):
     opts = ["--kernel-trace", "--stats"] if kind == "stats" else ["--pmc", kind, "--kernel-trace"]
     steps = STATS_STEPS if kind == "stats" else STEPS
     cmd = ["rocprofv3"] + opts + ["--output-format", "csv", "-d", outdir, "--", "python3", os.path.join(ROOT, "bench.py"),
-           "--config", cfg, "--plain", "--steps", str(steps), "--warmup", str(WARMUP)]
+           "--config", cfg, "--plain", "--steps", str(steps), "--warmup", str(WARMUP)] + (["--chunk-only"] if cfg == "c5" else [])
     p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     line = [l for l in p.stdout.splitlines() if l.startswith("{")]
     if p.returncode != 0 or not line:
@@ -49,6 +49,19 @@ def counter_sum(outdir, name):
                 total += float(r["Counter_Value"])
                 rows += 1
     return total, rows
+
+
+def library_digest():
+    import hashlib
+    with open(os.path.join(ROOT, "pyfft_amd", "libmifft.so"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def tree_commit():
+    try:
+        return open(os.path.join(ROOT, ".tree_commit")).read().strip() or None
+    except OSError:
+        return None
 
 
 def main():
@@ -73,9 +86,12 @@ def main():
                "algorithmic_bytes_per_step": alg,
                "fetch_KiB_raw_per_step": fetch_kib / EXECUTES, "write_KiB_per_step": write_kib / EXECUTES,
                "dispatches_counted": [nf, nw], "executes_per_run": EXECUTES,
-               "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --config %s --plain --steps %d --warmup %d" % (cfg, STEPS, WARMUP),
+               "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --config %s --plain --steps %d --warmup %d%s" % (cfg, STEPS, WARMUP, " --chunk-only" if cfg == "c5" else ""),
                "method": "tools/pmc_traffic.py: separate passes per counter, every mifft:: dispatch of the run summed and divided by the %d executes; FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B); L2<->fabric bytes, Infinity-Cache hits included" % EXECUTES,
-               "bench_frac_under_profiler": line["roofline"]["frac"]}
+               "bench_frac_under_profiler": line["roofline"]["frac"],
+               # what was measured: the library by content, the tree by the commit gpurun shipped (.tree_commit, written by the caller:
+               # `git rev-parse HEAD > .tree_commit` -- the GPU box has no .git)
+               "libmifft_sha256_16": library_digest(), "commit": tree_commit()}
         json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_%s.json" % cfg), "w"), indent=1)
         print("%s: strategy %s  traffic %.3f x algorithmic  (fetch x2 %.2f GiB + write %.2f GiB per step)" % (
             cfg, out["strategy"], out["traffic_over_algorithmic"], 2 * fetch_kib / EXECUTES / 2**20, write_kib / EXECUTES / 2**20), flush=True)
