@@ -347,6 +347,7 @@ def main():
     ap.add_argument("--inplace", action="store_true", help="the K timed steps run in place (the default line times out of place)")
     ap.add_argument("--repeats", type=int, default=5, help="repeats of the out-of-place / in-place protocol blocks (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=24.0, help="seconds of host time the CPU baseline may take (default 24)")
     ap.add_argument("--plain", action="store_true", help="only parity + warm-up + the K timed steps (no protocol repeats, per-pass timing or CPU baseline): profiler runs")
     ap.add_argument("--chunk-only", action="store_true",
                     help="config c5: time K executes of ONE resident 256-transform chunk (8 GiB in + 8 GiB out, out of place) instead of "
@@ -401,7 +402,7 @@ def main():
     # initialises the GPU (the pool forks) -- numpy.fft on the box's host cores in the same run, as north_star words it
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(shape, dtname, host_c[:min(blk, 16)], flop_per_xform)
+        cpu = cpu_baseline(shape, dtname, host_c[:min(blk, 16)], flop_per_xform, budget_s=args.cpu_budget)
 
     torch = None
     try:

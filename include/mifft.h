@@ -179,6 +179,11 @@ int mifft_debug_get(int32_t key);
 #define MIFFT_FEATURE_XCD2 0            /* mifft_launch_xcd2: XCD-resident single-crossing form of 1024 x 1024 (0.32-0.34 against 0.44) */
 #define MIFFT_FEATURE_FUSED2X 1         /* mifft_launch_fused2x: one work list per XCD */
 #define MIFFT_FEATURE_SEQUENTIAL_LIST 2 /* lag == 0 in the persistent launchers: both passes of a tiny batch in one launch */
+#define MIFFT_FEATURE_AB_FORMS 3        /* the kernel forms only the development switches select (A/B measurements): 16-column tiles for
+                                         * every length and unpaired plane tiles in the persistent kernels (MIFFT_DEBUG_NARROW_TILES = 1),
+                                         * plain / write-through streams (MIFFT_DEBUG_FUSED_NO_NT, MIFFT_DEBUG_STORE), persistent and
+                                         * alternative long rows (MIFFT_DEBUG_PERSIST, MIFFT_DEBUG_ALT_ROWS), the two-transposing-pass form
+                                         * of split-complex 2-D squares; without it such a request fails with MIFFT_E_UNSUPPORTED */
 int mifft_has_feature(int32_t feature); /* 1 = built in, 0 = not */
 
 /* ---- runtime shim (replaces cuda.py Context: allocate / stream lifecycle / device limits) ---------- */
@@ -267,6 +272,11 @@ int mifft_launch_pass(const mifft_pass *pass, const void *in0, const void *in1, 
  */
 int mifft_pair_split(int32_t precision, int32_t layout, int32_t x, int32_t y, int32_t z);
 int mifft_pass_pair_supported(const mifft_pass *p0, const mifft_pass *p1);
+/* Round 5: 0 if the library has the pass-pair kernel itself -- kind 0 = (ROW x, COL y R0) keyed by (nx, R0, R1 = ny / R0), kind 1 =
+ * (COL y R1, COL z) keyed by (S0 = what is faster than the y digit, R1, nz) -- for interleaved data (layout MIFFT_SPLIT: planes on the
+ * user side of the pair).  What a planner asks before it builds a chain around ONE pair: a 2-D shape with a y axis too long for one
+ * strided pass (pair XY + one plain pass instead of three launches), a 3-D shape with short y and z behind a long x (ROW x + pair YZ). */
+int mifft_pair_kernel_supported(int32_t precision, int32_t layout, int32_t kind, int32_t k0, int32_t k1, int32_t k2);
 int mifft_launch_pass_pair(const mifft_pass *p0, const mifft_pass *p1, const void *in0, const void *in1, void *out0, void *out1,
                            mifft_stream_t stream);
 

@@ -42,7 +42,7 @@ DEBUG_NO_ND2, DEBUG_FUSED_NO_NT, DEBUG_NO_WAVE, DEBUG_FORCE_WAVE, DEBUG_PERSIST,
 DEBUG_ROWS_ND = 8
 DEBUG_NARROW_TILES = 9
 DEBUG_NO_ROWFIRST = 10
-FEATURE_XCD2, FEATURE_FUSED2X, FEATURE_SEQUENTIAL_LIST = 0, 1, 2     # mifft_has_feature: parts only `make DEV=1` builds
+FEATURE_XCD2, FEATURE_FUSED2X, FEATURE_SEQUENTIAL_LIST, FEATURE_AB_FORMS = 0, 1, 2, 3     # mifft_has_feature: parts only `make DEV=1` builds
 XCD2_TRACE = 2
 XCD2_TRACE_BYTES = 512 * 32 * 8
 
@@ -181,6 +181,7 @@ PROTOTYPES = {
     "mifft_launch_pass": (ctypes.c_int, [_pass_p, _vp, _vp, _vp, _vp, _vp]),
     "mifft_pair_split": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32]),
     "mifft_pass_pair_supported": (ctypes.c_int, [_pass_p, _pass_p]),
+    "mifft_pair_kernel_supported": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "mifft_launch_pass_pair": (ctypes.c_int, [_pass_p, _pass_p, _vp, _vp, _vp, _vp, _vp]),
     "mifft_launch_chain": (ctypes.c_int, [_pass_p, _i32, _vpp, _vpp, _vp]),
     "mifft_launch_chain_pipelined": (ctypes.c_int, [_pass_p, _i32, _vpp, _vpp, ctypes.c_int64, ctypes.c_int64,

@@ -41,6 +41,7 @@ extern "C" int mifft_col2_f32_eligible(int L, int tr, const mifft::TileArgs* a) 
 // of the 16-column tiles, in both directions (profiles/r04_r_plain_wide_tiles_ab.log: 2^16 x 512 0.395 / 0.399, 2^18 x 64
 // 0.336 / 0.357, (512, 512) x 128 0.372 / 0.351, pipelined 2^16 0.405 / 0.397), so the plain launches keep the 16 columns; the
 // instances stay for the A/B: MIFFT_DEBUG_NARROW_TILES = 2 runs them wherever they fit.
+#ifdef MIFFT_DEV_BUILD      // (A/B instances: `make DEV=1`, MIFFT_FEATURE_AB_FORMS)
 namespace {
 template <int A> int launch_w(int tr, const mifft::TileArgs* a, hipStream_t s) {
     const long long tiles = a->total / 32;
@@ -57,13 +58,16 @@ bool wide_ok(int L, int tr, const mifft::TileArgs* a) {
     return a->total / 32 >= 1024;
 }
 }  // namespace
+#endif
 
 extern "C" int mifft_col2x_f32_eligible(int L, int tr, const mifft::TileArgs* a);   // fft_col2x_f32.hip
 extern "C" int mifft_col2x_f32_launch(int L, int tr, const mifft::TileArgs* a, hipStream_t s);
 
 extern "C" int mifft_col2_f32_launch(int L, int tr, const mifft::TileArgs* a, hipStream_t s) {
     if (mifft_col2x_f32_eligible(L, tr, a)) return mifft_col2x_f32_launch(L, tr, a, s);   // split planes: whole lines per wave instruction
+#ifdef MIFFT_DEV_BUILD
     if (wide_ok(L, tr, a)) return L == 512 ? launch_w<2>(tr, a, s) : launch_w<1>(tr, a, s);
+#endif
     switch (L) {
         case 1024: return launch<4>(tr, a, s);
         case 512: return launch<2>(tr, a, s);

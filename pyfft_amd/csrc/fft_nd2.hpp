@@ -17,21 +17,22 @@
 
 namespace mifft {
 
-template <int AX_, int LA_, int SA_, int Ns_, int R_> struct Nd2StageDesc {
-    static constexpr int AX = AX_, LA = LA_, SA = SA_, Ns = Ns_, R = R_;
+// TS: the axis' twiddle table belongs to a transform TS times as long (fft_nd2z.hpp: half-length stages on the full axis' table)
+template <int AX_, int LA_, int SA_, int Ns_, int R_, int TS_ = 1> struct Nd2StageDesc {
+    static constexpr int AX = AX_, LA = LA_, SA = SA_, Ns = Ns_, R = R_, TS = TS_;
 };
 template <typename... S> struct Nd2StageList {};
 
 // stage descriptors of one axis from its radix list
-template <int AX, int LA, int SA, int Ns, typename RL, typename Acc> struct Nd2AxisStages;
-template <int AX, int LA, int SA, int Ns, typename... Acc>
-struct Nd2AxisStages<AX, LA, SA, Ns, RadixList<>, Nd2StageList<Acc...>> {
+template <int AX, int LA, int SA, int Ns, typename RL, typename Acc, int TS = 1> struct Nd2AxisStages;
+template <int AX, int LA, int SA, int Ns, typename... Acc, int TS>
+struct Nd2AxisStages<AX, LA, SA, Ns, RadixList<>, Nd2StageList<Acc...>, TS> {
     using type = Nd2StageList<Acc...>;
 };
-template <int AX, int LA, int SA, int Ns, int R, int... Rest, typename... Acc>
-struct Nd2AxisStages<AX, LA, SA, Ns, RadixList<R, Rest...>, Nd2StageList<Acc...>> {
+template <int AX, int LA, int SA, int Ns, int R, int... Rest, typename... Acc, int TS>
+struct Nd2AxisStages<AX, LA, SA, Ns, RadixList<R, Rest...>, Nd2StageList<Acc...>, TS> {
     using type = typename Nd2AxisStages<AX, LA, SA, Ns * R, RadixList<Rest...>,
-                                        Nd2StageList<Acc..., Nd2StageDesc<AX, LA, SA, Ns, R>>>::type;
+                                        Nd2StageList<Acc..., Nd2StageDesc<AX, LA, SA, Ns, R, TS>>, TS>::type;
 };
 
 template <typename T, int P, int NT, bool HALF, typename D> struct Nd2Stage {
@@ -133,7 +134,7 @@ template <typename T, int P, int NT, bool HALF, typename D> struct Nd2Stage {
                 int base, jb;
                 geom(b, tid, base, jb);
                 const int ai = (jb & (Ns - 1)) * (LA / (Ns * R));
-                row2_twiddle<T, R>(tw, ai, v + b * R);
+                row2_twiddle<T, R, D::TS>(tw, ai, v + b * R);
             }
             Dft<R, T>::run(v + b * R);
         });
@@ -347,6 +348,15 @@ template <typename T, int X, int Y, int Z> struct Nd2Auto {
 
 template <typename T, int X, int Y, int Z> static inline int launch_nd2_auto(const TileArgs* a, hipStream_t s) {
     using C = Nd2Auto<T, X, Y, Z>;
+#ifdef MIFFT_ND2_HUGE_AB
+    // round 5 A/B (MIFFT_DEBUG_ALT_ROWS = 4): the one-tile-per-CU fp32 shapes on 1024 threads x 32 points (four waves per SIMD, radices
+    // <= 16) instead of 512 threads x 64 points (two waves per SIMD, radix 32)
+    if constexpr (C::HUGE && C::F32) {
+        if (mifft_debug_get(MIFFT_DEBUG_ALT_ROWS) == 4)
+            return launch_nd2<T, X, Y, Z, C::P, 1024, true, 4, true, typename AutoRadix<X, 16, true>::type,
+                              typename AutoRadix<Y, 16, C::YF>::type, typename AutoRadix<Z, 16, false>::type>(a, s);
+    }
+#endif
     return launch_nd2<T, X, Y, Z, C::P, C::NT, C::HALF, C::OCC, C::EDGE_IN, typename C::RLX, typename C::RLY,
                       typename C::RLZ>(a, s);
 }

@@ -23,6 +23,19 @@ extern "C" int mifft_pair_f32(int kind, int k0, int k1, int k2, int split, const
     // persistent two-pair kernel runs the same list, fft_fusedp.hip)
     XY(128, 32, 4, 128, true, 1, RL(8, 16), RL(32), false)
     YZ(128 * 32, 4, 128, 16, 512, false, 1, RL(4), RL(8, 16), false)
+    // Round 5: pairs as the way out of a THIRD launch.  (a) 2-D shapes with a 4096-point y axis (two strided passes 64 x 64 after the row
+    // pass: three launches, (4096, 256) 0.257 of the roofline while its transpose runs 0.384): XY = ROW x + COL y (R0) on NX x R0 = 16384
+    // points, then ONE plain strided pass of R1 points.  (b) 3-D shapes with short y and z behind a long x ((32, 32, 2048): row + col y +
+    // col z 0.264, its transpose 0.355): YZ = COL y (all of it) + COL z on 16 adjacent x, whole (z, y) planes of <= 1024 points.
+    XY(256, 64, 64, 512, true, 4, RL(16, 16), RL(16, 4), false)
+    XY(512, 32, 128, 512, true, 4, RL(2, 16, 16), RL(8, 4), false)
+    XY(1024, 16, 256, 512, true, 4, RL(4, 16, 16), RL(16), false)
+    XY(2048, 8, 512, 512, true, 4, RL(8, 16, 16), RL(8), false)
+    XY(4096, 4, 1024, 512, true, 4, RL(16, 16, 16), RL(4), false)
+    YZ(2048, 32, 32, 16, 512, true, 4, RL(8, 4), RL(8, 4), false)
+    YZ(4096, 32, 32, 16, 512, true, 4, RL(8, 4), RL(8, 4), false)
+    YZ(2048, 16, 16, 16, 256, false, 1, RL(16), RL(16), false)
+    YZ(4096, 16, 16, 16, 256, false, 1, RL(16), RL(16), false)
 #undef XY
 #undef YZ
 #undef RL

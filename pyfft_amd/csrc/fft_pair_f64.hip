@@ -29,6 +29,16 @@ extern "C" int mifft_pair_f64(int kind, int k0, int k1, int k2, int split, const
     YZ(128 * 32, 4, 128, 8, 256, false, 1, RL(4), RL(8, 16), false)
     XY(256, 64, 4, 1024, true, 4, RL(16, 16), RL(16, 4), true)
     YZ(256 * 64, 4, 256, 16, 1024, true, 4, RL(4), RL(16, 16), true)
+    // Round 5 (see fft_pair_f32.hip): 2-D shapes with a 4096-point y axis -- XY on NX x R0 = 8192 points --, 3-D shapes with short y and z
+    // behind a long x -- YZ on 8 adjacent x (128-byte segments) x whole (z, y) planes
+    XY(256, 32, 128, 512, true, 4, RL(16, 16), RL(8, 4), false)
+    XY(512, 16, 256, 512, true, 4, RL(2, 16, 16), RL(16), false)
+    XY(1024, 8, 512, 512, true, 4, RL(4, 16, 16), RL(8), false)
+    XY(2048, 4, 1024, 512, true, 4, RL(8, 16, 16), RL(4), false)
+    YZ(1024, 32, 32, 8, 512, true, 4, RL(8, 4), RL(8, 4), false)
+    YZ(2048, 32, 32, 8, 512, true, 4, RL(8, 4), RL(8, 4), false)
+    YZ(1024, 16, 16, 8, 256, false, 1, RL(8, 2), RL(8, 2), false)
+    YZ(2048, 16, 16, 8, 256, false, 1, RL(8, 2), RL(8, 2), false)
 #undef XY
 #undef YZ
 #undef RL

@@ -18,10 +18,11 @@ namespace mifft {
 // v[k] *= w(L)^(k*ai), k < R, with few look-ups (the table competes with the data stream for the L1) and few live
 // registers: powers 1..7 (or 1..R-1 for R <= 8) by a product tree from one look-up, every further block of 8 from its own
 // look-up w(L)^(8h*ai) times the first seven -- no power is further than 4 products from a table entry.
-template <typename T, int R> __device__ __forceinline__ void row2_twiddle(const cplx<T>* twL, int ai, cplx<T>* v) {
+// TS: the table holds w(TS * L)^k -- every TS-th entry is used (round 5: the half-length stages of fft_nd2z.hpp read the full axis' table)
+template <typename T, int R, int TS = 1> __device__ __forceinline__ void row2_twiddle(const cplx<T>* twL, int ai, cplx<T>* v) {
     constexpr int Q = R < 8 ? R : 8;
     cplx<T> t[Q];
-    t[1] = twL[ai];
+    t[1] = twL[ai * TS];
     static_for<Q - 2>([&](auto kk) {
         constexpr int k = kk + 2;
         if constexpr ((k & 1) == 0) t[k] = cmul<T>(t[k / 2], t[k / 2]);
@@ -33,7 +34,7 @@ template <typename T, int R> __device__ __forceinline__ void row2_twiddle(const 
     });
     static_for<R / 8 - (R >= 8 ? 1 : 0)>([&](auto hh) {
         constexpr int h = (hh + 1) * 8;
-        const cplx<T> th = twL[h * ai];
+        const cplx<T> th = twL[h * ai * TS];
         v[h] = cmul<T>(v[h], th);
         static_for<7>([&](auto kk) {
             constexpr int k = kk + 1;

@@ -12,12 +12,16 @@ extern "C" int mifft_dispatch_row_f32(int L, int variant, const mifft::TileArgs*
         if (query_only) return 0;
         if (!a || (!a->split && a->split_out)) return -2;
         if (a->split) return mifft::launch_row2_lay<float, 32768, 1, 1024, mifft::RadixList<32, 32, 32>, true, 4>(a, s, 0);
+#ifdef MIFFT_DEV_BUILD      // (A/B instances: `make DEV=1`, MIFFT_FEATURE_AB_FORMS)
         if (mifft_debug_get(MIFFT_DEBUG_PERSIST))   // development: persistent + prefetching form (fft_row2.hpp)
             return mifft::launch_row2p<float, 32768, 1024, mifft::RadixList<8, 16, 16, 16>, true, 4>(a, s, 1);
         switch (mifft_debug_get(MIFFT_DEBUG_ALT_ROWS)) {   // development: A/B of the stage lists
             case 1: return mifft::launch_row2<float, 32768, 1, 1024, mifft::RadixList<8, 16, 16, 16>, true, 4>(a, s, 0);
             case 2: return mifft::launch_row2<float, 32768, 1, 512, mifft::RadixList<32, 32, 32>, true, 2>(a, s, 0);
         }
+#else
+        if (mifft_debug_get(MIFFT_DEBUG_PERSIST) || mifft_debug_get(MIFFT_DEBUG_ALT_ROWS)) return -2;
+#endif
         return mifft::launch_row2<float, 32768, 1, 1024, mifft::RadixList<32, 32, 32>, true, 4>(a, s, 0);
     }
     // both sides interleaved: register-edged kernels (fft_row2.hpp).  Shapes chosen by measurement (1 GiB buffers,
@@ -47,18 +51,22 @@ extern "C" int mifft_dispatch_row_f32(int L, int variant, const mifft::TileArgs*
         // development: persistent form of the long rows (the next row's loads are issued from the last stage of the current
         // one).  Measured at 1 GiB buffers (tools/row_probe.py): 4096 71.4 -> 73.5 %, 8192 66.1 -> 64.0 %, 16384 63.8 -> 56.3 %,
         // 32768 47.1 -> 47.2 %: the rows that fill a CU are bound by their LDS exchanges, not by exposed load latency
+#ifdef MIFFT_DEV_BUILD
         if (!query_only && mifft_debug_get(MIFFT_DEBUG_PERSIST)) {
             if (L == 4096) return launch_row2p<float, 4096, 256, RadixList<16, 16, 16>, false, 1>(a, s, 4);
             if (L == 8192) return launch_row2p<float, 8192, 256, RadixList<16, 16, 32>, true, 1>(a, s, 3);
             if (L == 16384) return launch_row2p<float, 16384, 512, RadixList<4, 16, 16, 16>, true, 4>(a, s, 2);
         }
+#endif
         if (L == 8192) return launch_row2<float, 8192, 1, 256, RadixList<16, 16, 32>, true>(a, s, query_only);
+#ifdef MIFFT_DEV_BUILD
         if (L == 16384 && !query_only) {
             switch (mifft_debug_get(MIFFT_DEBUG_ALT_ROWS)) {   // development: A/B of the stage lists
                 case 2: return launch_row2<float, 16384, 1, 512, RadixList<16, 32, 32>, true, 4>(a, s, 0);
                 case 3: return launch_row2<float, 16384, 1, 512, RadixList<32, 16, 32>, true, 4>(a, s, 0);
             }
         }
+#endif
         if (L == 16384) return launch_row2<float, 16384, 1, 512, RadixList<4, 16, 16, 16>, true, 4>(a, s, query_only);
     }
     switch (L) {

@@ -185,6 +185,12 @@ long long wave_bytes(const mifft_pass* p, const mifft::TileArgs* a) {   // bytes
     return a->total * p->L * (p->precision == MIFFT_F64 ? 16ll : 8ll);
 }
 
+// which of the two forms a one-tile-per-CU N-D shape runs: two work-groups per transform wherever that kernel exists (it is only
+// instantiated where it measured faster, at 32 MiB and at 1 GiB per side: fft_nd2z.hip); A/B: MIFFT_DEBUG_ALT_ROWS = 6 never
+bool nd2z_preferred(bool f64, int x, int y, int z) {
+    return g_debug[MIFFT_DEBUG_ALT_ROWS] != 6 && mifft_nd2z(f64 ? 1 : 0, x, y, z, nullptr, nullptr, 1) == 0;
+}
+
 int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0, void* out1, hipStream_t s) {
     // fixed-shape kernels (fft_nd2.hpp) for the common shapes, interleaved on both sides
     const bool no_nd2 = g_debug[MIFFT_DEBUG_NO_ND2] != 0;  // development switch: run-time-shaped kernel only
@@ -217,6 +223,14 @@ int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0,
         t.inverse = p->inverse ? 1 : 0;
         t.scale = p->scale;
         t.nt = stream_policy(p->flags);
+        // the one-tile-per-CU shapes (32768 points fp32 / 16384 fp64): two work-groups per transform, each on a half-size tile
+        // (fft_nd2z.hpp, round 5) -- out of place only
+        if (in0 != out0 && nd2z_preferred(f64nd, (int)p->L, (int)p->M, (int)p->S)) {
+            const int rz = mifft_nd2z(f64nd ? 1 : 0, (int)p->L, (int)p->M, (int)p->S, &t, s, 0);
+            if (rz == -1) return set_err(MIFFT_E_INVALID, "grid too large");
+            if (rz != 0) return hip_check((hipError_t)rz, "kernel launch");
+            return 0;
+        }
         const int rc = f64nd ? mifft_nd2_f64_launch((int)p->L, (int)p->M, (int)p->S, &t, s)
                              : mifft_nd2_f32_launch((int)p->L, (int)p->M, (int)p->S, &t, s);
         if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
@@ -472,7 +486,7 @@ int mifft_debug_set_default(int32_t key, int32_t value) {
 }
 int mifft_has_feature(int32_t feature) {
 #ifdef MIFFT_DEV_BUILD
-    return (feature == MIFFT_FEATURE_XCD2 || feature == MIFFT_FEATURE_FUSED2X || feature == MIFFT_FEATURE_SEQUENTIAL_LIST) ? 1 : 0;
+    return (feature >= MIFFT_FEATURE_XCD2 && feature <= MIFFT_FEATURE_AB_FORMS) ? 1 : 0;
 #else
     (void)feature;
     return 0;
@@ -697,6 +711,14 @@ int mifft_pair_split(int32_t precision, int32_t layout, int32_t x, int32_t y, in
             return r0;
     }
     return 0;
+}
+
+int mifft_pair_kernel_supported(int32_t precision, int32_t layout, int32_t kind, int32_t k0, int32_t k1, int32_t k2) {
+    if ((precision != MIFFT_F32 && precision != MIFFT_F64) || (layout != MIFFT_INTERLEAVED && layout != MIFFT_SPLIT) || (kind != 0 && kind != 1))
+        return MIFFT_E_UNSUPPORTED;
+    if (g_debug[MIFFT_DEBUG_PAIR] == 1) return MIFFT_E_UNSUPPORTED;      // (as mifft_pair_split: the switch acts when a plan is built)
+    const int key[3] = {k0, k1, k2};
+    return pair_call(precision, kind, key, layout == MIFFT_SPLIT ? 1 : 0, nullptr, nullptr, 1, nullptr) == 0 ? 0 : MIFFT_E_UNSUPPORTED;
 }
 
 int mifft_pass_pair_supported(const mifft_pass* p0, const mifft_pass* p1) {

@@ -73,6 +73,9 @@ class _SubContext(object):
     def stream_handle(self):
         return self._ctx.stream_handle()
 
+    def capturing(self):
+        return self._ctx.capturing()
+
     def wait(self):
         self._ctx.wait()
 

@@ -164,6 +164,15 @@ def build_chain(x, y, z, precision, interleaved=False):
     if ndims == 3 and (nd_ok(x, y, 1) or (not interleaved and N.lib.mifft_nd_shape_supported(precision, x, y, 1, N.VARIANT_SPLIT_ONLY) == 0)):
         return [PassSpec(N.PASS_ND, X_DIRECTION, x * y, x, y, 1, z, x * y, True)] + \
             col_chain(Z_DIRECTION, z, x * y, 1, precision, interleaved)
+    # Round 5: ONE pass pair where the chain below would take a third launch (csrc/fft_pair_f32.hip / _f64.hip list the shapes):
+    # a 3-D shape with short y and z behind a long x -- the y and z passes as one launch on whole (z, y) planes;
+    if ndims == 3 and _pair_kernel(precision, interleaved, 1, x, y, z):
+        return yz_pair_chain(x, y, z, precision, interleaved)
+    # a y axis too long for one strided pass behind a contiguous x axis -- the row pass and the first y pass as one launch
+    if x > 1 and y > col_max(precision) and x <= row_max(precision, interleaved):
+        r0 = xy_pair_split(x, y, precision, interleaved)
+        if r0:
+            return xy_pair_chain(x, y, z, r0, precision, interleaved)
     if x > 1:
         if x <= row_max(precision, interleaved):
             chain.append(PassSpec(N.PASS_ROW, X_DIRECTION, x, x, 1, 1, y * z, x, True))
@@ -197,6 +206,49 @@ class _Unit(object):
     def __init__(self, in_place_possible):
         self.in_place_possible = in_place_possible
         self.pair_with_next = False
+
+
+def _pair_kernel(precision, interleaved, kind, k0, k1, k2):
+    return N.lib.mifft_pair_kernel_supported(precision, N.INTERLEAVED if interleaved else N.SPLIT, kind, int(k0), int(k1), int(k2)) == 0
+
+
+def xy_pair_split(x, y, precision, interleaved):
+    """R0 of a (ROW x, COL y R0) pair kernel for a y axis that is too long for one strided pass -- the remaining R1 = y / R0 points
+    must be ONE plain pass -- or 0.  Round 5: (4096, 256) as pair + pass instead of row + col 64 + col 64 (three launches)."""
+    cmax = col_max(precision)
+    r0 = y // 2
+    while r0 >= 2:
+        r1 = y // r0
+        if r1 <= cmax and N.lib.mifft_pass_supported(N.PASS_COL, precision, r1, 0) == 0 and _pair_kernel(precision, interleaved, 0, x, r0, r1):
+            return r0
+        r0 //= 2
+    return 0
+
+
+def xy_pair_chain(x, y, z, r0, precision, interleaved):
+    """ROW x + COL y (r0) as one launch, the plain COL y (r1) pass, then the z chain (the chain's own factorisation of a long axis,
+    kernel.py:259-283, with its first two passes paired: csrc/fft_pair.hpp PairXY)."""
+    r1 = y // r0
+    chain = [PassSpec(N.PASS_ROW, X_DIRECTION, x, x, 1, 1, y * z, x, True),
+             PassSpec(N.PASS_COL, Y_DIRECTION, y, r0, r1, x, z, y * x, False),
+             PassSpec(N.PASS_COL, Y_DIRECTION, y, r1, 1, x * r0, z, y * x, True)]
+    chain[0].pair_with_next = True
+    if z > 1:
+        chain.extend(col_chain(Z_DIRECTION, z, x * y, 1, precision, interleaved))
+    return chain
+
+
+def yz_pair_chain(x, y, z, precision, interleaved):
+    """X passes, then COL y + COL z as one launch on whole (z, y) planes of 16 adjacent x (csrc/fft_pair.hpp PairYZ with the y axis
+    unsplit): a 3-D shape with short y and z behind a long x in two launches instead of three."""
+    if x <= row_max(precision, interleaved):
+        chain = [PassSpec(N.PASS_ROW, X_DIRECTION, x, x, 1, 1, y * z, x, True)]
+    else:
+        chain = col_chain(X_DIRECTION, x, 1, y * z, precision, interleaved)
+    chain += [PassSpec(N.PASS_COL, Y_DIRECTION, y, y, 1, x, z, y * x, True),
+              PassSpec(N.PASS_COL, Z_DIRECTION, z, z, 1, x * y, 1, x * y * z, True)]
+    chain[-2].pair_with_next = True
+    return chain
 
 
 def launch_units(chain):

@@ -484,6 +484,9 @@ class _FakeContext(object):
     def pointer_of(obj):
         return obj
 
+    def capturing(self):
+        return False
+
 
 def _strategy_on(machine, shape, dtype, batch):
     from pyfft_amd.plan import FFTPlan
@@ -704,11 +707,15 @@ def test_strategy_snapshot_of_the_table_driven_planner():
     from pyfft_amd import _native as N
     with gzip.open(os.path.join(ROOT, "tests", "golden", "strategy_snapshot.json.gz"), "rt") as f:
         want = json.load(f)
-    got = snap.snapshot()
+    got = snap.snapshot(with_chain_class=True)
     assert len(got) == len(want) > 30000
     # (the per-XCD work lists are part of `make DEV=1` builds only: 18 rows of the 16-column A/B mode)
     lists = N.lib.mifft_has_feature(N.FEATURE_FUSED2X) == 1
-    bad = [(w, g) for w, g in zip(want, got) if w != json.loads(json.dumps(g)) and (lists or w[5][0] != "fused2x")]
+    # shapes whose CHAIN changed in round 5 (one pass pair instead of a third launch: (4096, 256), (32, 32, 2048) ...) no longer run
+    # their leading passes slab-wise; they stay on the plain chain / the pipelined chunks
+    new_chain = [g for g in got if g[6]]
+    assert 0 < len(new_chain) < 2500 and all(g[5][0] in ("chain", "pipelined") for g in new_chain)
+    bad = [(w, g) for w, g in zip(want, got) if not g[6] and w != json.loads(json.dumps(g[:6])) and (lists or w[5][0] != "fused2x")]
     assert not bad, bad[:10]
     assert not lists or sum(1 for g in got if g[5][0] == "fused2x") == 18
     assert set(r[5][0] for r in want) == {"chain", "pipelined", "fused2", "fusedp", "fused2x"}

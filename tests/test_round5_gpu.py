@@ -149,7 +149,7 @@ def test_eight_ranks_share_one_gpu(tmp_path):
     batch = 10                                                # per rank; 80 transforms of 8 MiB in all: the chain strategy
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--control", "gloo", "--share-gpu",
                           "--config", "c2", "--batch", str(batch), "--steps", "2", "--warmup", "1", "--repeats", "0",
-                          "--dump-dir", str(tmp_path)],
+                          "--cpu-budget", "3", "--dump-dir", str(tmp_path)],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -313,3 +313,110 @@ def test_torch_cuda_graph_around_execute(ctx):
         want = torch.fft.fft(x.view(batch, n), dim=1).reshape(-1)
         assert (y - want).abs().sum() / want.abs().sum() < 2e-6, k
     plan.finish()
+
+
+# ---- one pass pair instead of a third launch (csrc/fft_pair_f32.hip / _f64.hip, pyfft_amd/passes.py) ---------------------------------
+PAIR_CHAIN_CASES = [((4096, 256), numpy.complex64, 3), ((4096, 512), numpy.complex64, 2),
+                    ((4096, 256), numpy.complex128, 2), ((4096, 512), numpy.complex128, 1),
+                    ((32, 32, 2048), numpy.complex64, 3), ((32, 32, 4096), numpy.complex64, 1), ((16, 16, 2048), numpy.complex64, 5),
+                    ((16, 16, 4096), numpy.complex64, 2), ((32, 32, 1024), numpy.complex128, 3), ((32, 32, 2048), numpy.complex128, 1),
+                    ((16, 16, 1024), numpy.complex128, 5), ((16, 16, 2048), numpy.complex128, 2), ((2, 4096, 256), numpy.complex64, 2)]
+# the biggest planes (16 ... 128 MiB per transform: numpy takes seconds per case) run with the soak switch, as tests/test_random_sweep_gpu.py's extra cases
+if os.environ.get("PYFFT_AMD_SWEEP"):
+    PAIR_CHAIN_CASES += [((4096, 1024), numpy.complex64, 3), ((4096, 2048), numpy.complex64, 1), ((4096, 4096), numpy.complex64, 1),
+                         ((4096, 1024), numpy.complex128, 2), ((4096, 2048), numpy.complex128, 1)]
+
+
+@pytest.mark.parametrize("shape,dtype,batch", PAIR_CHAIN_CASES, ids=lambda v: getattr(v, "__name__", str(v)).replace(" ", ""))
+def test_pair_chains_two_launches(ctx, shape, dtype, batch):
+    """Shapes that ran THREE launches through round 4 -- a 2-D shape with a 4096-point y axis (row + two strided passes: the reference's
+    own factorisation of a long axis, pyfft/kernel.py:259-283) and a 3-D shape with short y and z behind a long x (one chain per axis,
+    pyfft/plan.py:160-167) -- now run one pass PAIR and one single pass.  The reference's six-assertion protocol against numpy
+    (test/test_errors.py:18-114: out of place, in place, forward, inverse, input untouched) at ragged batches, and the chain really has
+    two launches."""
+    from test_errors_gpu import run_protocol
+    from pyfft_amd.passes import launch_units
+    plan = ctx.getPlan(shape, dtype=dtype)
+    units = launch_units(plan.pass_list())
+    assert len(units) == (3 if len(shape) == 3 and shape[0] == 2 else 2), plan.pass_list()
+    assert sum(1 for k in plan.pass_list() if k.pair_with_next) == 1
+    run_protocol(ctx, shape, dtype, batch, seed=5150 + batch)
+
+
+@pytest.mark.parametrize("shape,dtype,batch", [((4096, 256), numpy.complex64, 320), ((32, 32, 2048), numpy.complex64, 160), ((4096, 512), numpy.complex128, 96)],
+                         ids=lambda v: getattr(v, "__name__", str(v)).replace(" ", ""))
+def test_pair_chains_pipelined_chunks(ctx, shape, dtype, batch):
+    """The same chains beyond the chain threshold: cache-sized chunks on two streams, a pair launch + a single launch per chunk.
+    The whole array against the plain chain's (same kernels: identical bits), sampled transforms against numpy."""
+    hip = ctx.hip
+    size = int(numpy.prod(shape))
+    cdt = numpy.dtype(dtype)
+    data = _tiled_noise(size * batch, dtype, 777)
+    tol, tol_max = (1.1e-6, 1e-5) if cdt == numpy.complex64 else (1e-11, 1e-10)
+    outs = {}
+    for strat in ("chain", "auto"):
+        os.environ["PYFFT_AMD_STRATEGY"] = strat
+        try:
+            plan = hip.Plan(shape, dtype=dtype)
+            st = plan.strategy(batch)[0]
+            assert st == ("chain" if strat == "chain" else "pipelined"), st
+            a, b = hip.to_gpu(data), hip.DeviceArray((size * batch,), dtype)
+            plan.execute(a, b, batch=batch)
+            outs[strat] = b.get()
+        finally:
+            os.environ.pop("PYFFT_AMD_STRATEGY", None)
+    assert numpy.array_equal(outs["chain"].view(numpy.uint8), outs["auto"].view(numpy.uint8))
+    for item in (0, batch // 2, batch - 1):
+        ref = numpy.fft.fftn(data[item * size:(item + 1) * size].astype(numpy.complex128).reshape(shape)).reshape(-1)
+        got = outs["auto"][item * size:(item + 1) * size].astype(numpy.complex128)
+        assert numpy.abs(ref - got).sum() / numpy.abs(ref).sum() < tol and numpy.abs(ref - got).max() <= tol_max * numpy.abs(ref).max()
+
+
+# ---- one-tile-per-CU N-D shapes as two work-groups per transform (csrc/fft_nd2z.hpp) ------------------------------------------------
+ND2Z_SHAPES = {numpy.complex64: [(1024, 32), (512, 64), (256, 128), (128, 256), (32, 1024), (8, 64, 64), (16, 16, 128)],
+               numpy.complex128: [(512, 32), (256, 64), (64, 256), (32, 512), (16, 32, 32), (16, 16, 64)]}
+
+
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
+def test_two_work_groups_per_transform_nd(ctx, dtype):
+    """The N-D shapes of 32768 points (fp32) / 16384 points (fp64) as TWO work-groups per transform (one decimation-in-frequency step
+    along the slowest axis folded into the loads, each half on a two-per-CU tile; numpy shapes = (z, y, x)): every such shape at a
+    ragged batch against numpy with the reference's thresholds (test/test_errors.py:20-23), forward and inverse, against the
+    one-tile-per-CU kernel to rounding, and an in-place call -- which must take the one-tile kernel -- bit-identical to it."""
+    from pyfft_amd import _native as N
+    hip = ctx.hip
+    cdt = numpy.dtype(dtype)
+    tol, tol_max, tol_same = (1.1e-6, 1e-5, 5e-7) if cdt == numpy.complex64 else (1e-11, 1e-10, 1e-14)
+    for shape in ND2Z_SHAPES[dtype]:
+        size = int(numpy.prod(shape))
+        batch = 11
+        data = _tiled_noise(size * batch, dtype, 4400 + shape[0])
+        plan = hip.Plan(shape, dtype=dtype)
+        assert len(plan.pass_list()) == 1 and plan.pass_list()[0].kind == N.PASS_ND, (shape, plan.pass_list())
+        a = hip.to_gpu(data)
+        outs = {}
+        for alt in (6, 5):                       # 6: the one-tile-per-CU kernel, 5 (= the default): two work-groups per transform
+            N.check(N.lib.mifft_debug_set(N.DEBUG_ALT_ROWS, alt), "debug_set")
+            try:
+                b = hip.DeviceArray((size * batch,), dtype)
+                plan.execute(a, b, batch=batch)
+                outs[alt] = b.get()
+                if alt == 5:
+                    plan.execute(b, batch=batch, inverse=True)          # in place: the one-tile kernel whatever the switch says
+                    back = b.get()
+                    c = hip.DeviceArray((size * batch,), dtype)
+                    plan.execute(hip.to_gpu(outs[5]), c, batch=batch, inverse=True)     # out of place: the two-work-group form
+                    back2 = c.get()
+            finally:
+                N.check(N.lib.mifft_debug_set(N.DEBUG_ALT_ROWS, 0), "debug_set")
+        assert numpy.array_equal(a.get(), data), "input modified"
+        for item in range(batch):
+            sl = slice(item * size, (item + 1) * size)
+            ref = numpy.fft.fftn(data[sl].astype(numpy.complex128).reshape(shape)).reshape(-1)
+            got = outs[5][sl].astype(numpy.complex128)
+            assert numpy.abs(ref - got).sum() / numpy.abs(ref).sum() < tol, (shape, item)
+            assert numpy.abs(ref - got).max() <= tol_max * numpy.abs(ref).max(), (shape, item)
+        d = numpy.abs(outs[5].astype(numpy.complex128) - outs[6]).sum() / numpy.abs(outs[6]).sum()
+        assert d < tol_same, (shape, d)
+        for inv in (back, back2):
+            assert numpy.abs(inv.astype(numpy.complex128) - data).sum() / numpy.abs(data).sum() < tol, shape

@@ -3,8 +3,14 @@ profiles/r04_fused_sweep.log): every variant builds a fresh plan in this process
 pyfft_amd/_debug.py set, checks sampled transforms against numpy and times back-to-back executes between two HIP events.
 
     python3 tools/fused_sweep.py [SHAPE DTYPE GIB VARIANTS]...      e.g.  524288 complex64 1 auto,f:14:28,x:4:8:0
-    variants: auto | chain | pipelined | f:LAG:RING (fused2 / fusedp) | x:LAG:RING:WT (fusedx, per XCD) | seq | any of them + @ENV=VALUE
+    variants: auto | chain | pipelined | fused | f:LAG:RING (fused2 / fusedp) | x:LAG:RING:WT (fusedx, per XCD) | seq | any of them + @ENV=VALUE
     GIB may be a fraction (0.03125 = the reference's 32 MiB protocol)
+
+    python3 tools/fused_sweep.py --emit OUT.json [--gib 2]
+        regenerates the planner's tuning table (pyfft_amd/tuning_gfx950.json, round 5): for every rule and every shape class the rule
+        answers for, the rule's persistent launch (PYFFT_AMD_STRATEGY=fused: the table's own tile width, work-groups per CU and ring
+        rule) against the pipelined chunks at GIB per side; writes the table with the fractions under `measured` and with `on_request`
+        set where the persistent form loses on this device (cleared where it wins), everything else as loaded.
 """
 import os
 import sys
@@ -27,7 +33,7 @@ def variant_env(v):
     t = head.split(":")
     if t[0] == "auto":
         pass
-    elif t[0] in ("chain", "pipelined"):
+    elif t[0] in ("chain", "pipelined", "fused"):
         env["PYFFT_AMD_STRATEGY"] = t[0]
     elif t[0] == "f":
         env["PYFFT_AMD_STRATEGY"] = "fused"
@@ -55,7 +61,9 @@ def fill(buf, blk):
     N.check(N.lib.mifft_device_sync())
 
 
-def sweep(shape, dtype, gib, variants, reps=5, iters=10):
+def sweep(shape, dtype, gib, variants, reps=5, iters=10, quiet=False):
+    """[(variant, strategy tuple or None, ms per execute, fraction of 8 TB/s, worst L1-relative error vs numpy)]"""
+    results = []
     dt = numpy.dtype(dtype)
     split = dt.kind == "f"               # float32 / float64: two scalar planes per side (GIB counts both)
     cbytes = dt.itemsize * (2 if split else 1)
@@ -108,17 +116,92 @@ def sweep(shape, dtype, gib, variants, reps=5, iters=10):
                 best = min(best, e1.time_since(e0) / iters)
             plan.finish()
             frac = 2.0 * size * batch * cbytes / (best * 1e-3) / 8e12
+            results.append((v, tuple(plan.strategy(batch)[:5]), best, frac, worst))
             print("%-16s %-10s x %-6d %-28s %-40s %9.3f ms  %.3f  err %.1e" % (
                 "x".join(str(s) for s in shape), dt.name, batch, v, str(plan.strategy(batch)[:5]), best, frac, worst), flush=True)
             plan.close()
         except Exception as e:      # a variant the shape has no kernel for: say so and go on
+            results.append((v, None, None, None, None))
             print("%-16s %-10s x %-6d %-28s FAILED %r" % ("x".join(str(s) for s in shape), dt.name, batch, v, e), flush=True)
     for k in KEYS:
         os.environ.pop(k, None)
+    return results
+
+
+def rule_cases(tuning, rule):
+    """(shape, dtype name) of every shape class `rule` answers for under the default switches (first match wins: a later rule only
+    gets what the earlier ones leave)."""
+    out = []
+    precs = [rule["precision"]] if rule.get("precision") else ["f32", "f64"]
+    lays = [rule["layout"]] if rule.get("layout") else ["interleaved", "split"]
+    when = rule.get("when", {})
+    narrow, rowfirst = bool(when.get("narrow_tiles", False)), bool(when.get("rowfirst", True))
+    if narrow or not rowfirst:
+        return out            # (forms behind development switches: not re-measured here)
+    for prec in precs:
+        for lay in lays:
+            dt = {("f32", "interleaved"): "complex64", ("f32", "split"): "float32", ("f64", "interleaved"): "complex128",
+                  ("f64", "split"): "float64"}[(prec, lay)]
+            if rule["kind"] == "1d":
+                for L0 in rule["L0"]:
+                    for L1 in rule["L1"]:
+                        cls = {"kind": "1d", "precision": prec, "layout": lay, "L0": L0, "L1": L1, "M": L1}
+                        if L0 >= L1 and tuning.match(cls, narrow, rowfirst) is rule:
+                            out.append(((L0 * L1,), dt))
+            elif rule["kind"] == "2d":
+                for ny in rule["ny"]:
+                    for nx in rule["nx"]:
+                        cls = {"kind": "2d", "precision": prec, "layout": lay, "ny": ny, "nx": nx}
+                        if tuning.match(cls, narrow, rowfirst) is rule:
+                            out.append(((ny, nx), dt))
+            elif rule["kind"] == "3d":
+                for shape in ((128, 128, 128), (64, 64, 64), (64, 128, 128)):
+                    out.append((shape, dt))
+    return out
+
+
+def emit(path, gib):
+    """Re-measure every rule of the tuning table against the pipelined chunks and write the table back (see the module docstring)."""
+    import copy
+    import json
+    from pyfft_amd import tuning as T
+    base = T.default()
+    table = copy.deepcopy(base.table)
+    for rule, new in zip(base.rules, table["rules"]):
+        measured = []
+        for shape, dt in rule_cases(base, rule):
+            res = sweep(shape, dt, gib, ["fused", "pipelined"], reps=3, iters=8)
+            by = {v: (st, frac) for v, st, ms, frac, err in res}
+            fused, pipe = by.get("fused", (None, None)), by.get("pipelined", (None, None))
+            if fused[0] is None or fused[0][0] not in ("fused2", "fusedp") or pipe[1] is None:
+                continue          # (no persistent launch came out: batch too small for the ring at this size, or no kernel)
+            measured.append({"shape": list(shape), "dtype": dt, "gib_per_side": gib, "persistent": round(fused[1], 4),
+                             "pipelined": round(pipe[1], 4), "lag_ring_grid": list(fused[0][1:4])})
+        if measured:
+            new["measured"] = measured
+            wins = [m["persistent"] >= 0.99 * m["pipelined"] for m in measured]
+            if all(wins):
+                new.pop("on_request", None)
+            elif not any(wins):
+                new["on_request"] = True
+        print("rule %-90s %s" % (rule["name"][:90], "on request" if new.get("on_request") else "default"), flush=True)
+    out = "{\n"
+    for k, v in table.items():
+        if k != "rules":
+            out += " %s: %s,\n" % (json.dumps(k), json.dumps(v))
+    out += ' "rules": [\n' + ",\n".join("  " + json.dumps(r) for r in table["rules"]) + "\n ]\n}\n"
+    with open(path, "w") as f:
+        f.write(out)
+    changed = [r["name"] for r, n in zip(base.rules, table["rules"]) if bool(r.get("on_request")) != bool(n.get("on_request"))]
+    print("wrote %s; rules whose default changed: %s" % (path, changed or "none"))
 
 
 if __name__ == "__main__":
     args = sys.argv[1:]
+    if args and args[0] == "--emit":
+        gib = float(args[args.index("--gib") + 1]) if "--gib" in args else 2.0
+        emit(args[1], gib)
+        args = []
     while len(args) >= 4:
         shape = tuple(int(t) for t in args[0].split("x"))
         sweep(shape, args[1], float(args[2]), args[3].split(","))
