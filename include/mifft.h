@@ -241,8 +241,11 @@ int mifft_nd_max_points_for(int32_t precision);
 /* 0 if one MIFFT_PASS_ND launch can transform the (z, y, x) shape, else MIFFT_E_UNSUPPORTED: every shape up to
  * mifft_nd_max_points_for(); with variant MIFFT_VARIANT_INTERLEAVED_ONLY also the larger fixed shapes that exist for
  * interleaved data on both sides only; with MIFFT_VARIANT_SPLIT_ONLY those that exist for split-complex planes on BOTH
- * sides (a single-pass plan of a split-complex layout).  (No counterpart in the reference, whose kernels are generated per plan.) */
+ * sides (a single-pass plan of a split-complex layout); with MIFFT_VARIANT_OUT_OF_PLACE_ONLY (round 5) those whose kernel runs several
+ * work-groups per transform (csrc/fft_nd2z.hpp): interleaved data on both sides AND input != output -- a caller keeps another chain for
+ * its in-place executes.  (No counterpart in the reference, whose kernels are generated per plan.) */
 #define MIFFT_VARIANT_SPLIT_ONLY 3
+#define MIFFT_VARIANT_OUT_OF_PLACE_ONLY 4
 int mifft_nd_shape_supported(int32_t precision, int32_t x, int32_t y, int32_t z, int32_t variant);
 
 /* 0 if a compiled kernel exists for (kind, precision, L, variant), else MIFFT_E_UNSUPPORTED.

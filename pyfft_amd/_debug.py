@@ -73,6 +73,12 @@ def no_split_rowfirst():
     return off
 
 
+def no_oop_nd():
+    """PYFFT_AMD_NO_OOP_ND=1: out-of-place executes run the plan's chain even where a one-launch kernel with several work-groups per
+    transform exists (csrc/fft_nd2z.hpp; A/B, tests)"""
+    return bool(os.environ.get("PYFFT_AMD_NO_OOP_ND"))
+
+
 def no_fusedp_alt():
     """PYFFT_AMD_NO_FUSEDP_ALT=1: no persistent two-pair launch for shapes whose chain is a plane pass + a z pass (A/B, tests)"""
     return bool(os.environ.get("PYFFT_AMD_NO_FUSEDP_ALT"))

@@ -10,7 +10,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmifft.so")
+# PYFFT_AMD_DEV_BUILD=1: the `make DEV=1` library (development strategies and A/B kernel forms, pyfft_amd/csrc/Makefile)
+LIB_PATH = os.path.join(_HERE, "libmifft_dev.so" if os.environ.get("PYFFT_AMD_DEV_BUILD") else "libmifft.so")
 
 ABI_VERSION = 4
 
@@ -22,6 +23,7 @@ F32, F64 = 0, 1
 INTERLEAVED, SPLIT = 0, 1
 VARIANT_INTERLEAVED_ONLY = 2
 VARIANT_SPLIT_ONLY = 3
+VARIANT_OUT_OF_PLACE_ONLY = 4     # mifft_nd_shape_supported: several work-groups per transform, interleaved, input != output
 PASS_COL, PASS_ROW, PASS_ND = 0, 1, 2
 FLAG_SRC_INTERLEAVED, FLAG_DST_INTERLEAVED = 1, 2
 FLAG_STREAM_SRC, FLAG_STREAM_DST = 4, 8

@@ -1,0 +1,58 @@
+// (fp64 half of fft_nd2z_f32.hip)
+// Instances of the two-work-groups-per-transform form (fft_nd2z.hpp) for the one-tile shapes of 32768 points (fp32) / 16384 points (fp64)
+// that tools/gen_nd2_tables.py lists as HUGE: each half runs on the "big" tile form (16384 / 8192 points, 512 threads, half-exchange
+// stages, radices <= 16 / 8, two work-groups per CU).  Measured against the one-tile-per-CU kernel (profiles/r05_nd2z_two_work_groups_ab.log,
+// 1 GiB per side | the reference's 32 MiB protocol): fp32 (16, 16, 128) 0.505 -> 0.637 | 0.316 -> 0.427, (128, 256) 0.480 -> 0.655 | 0.295 ->
+// 0.458, (256, 128) 0.489 -> 0.620, (512, 64) 0.478 -> 0.616 | 0.289 -> 0.460, (8, 64, 64) 0.453 -> 0.570, (32, 1024) 0.550 -> 0.569, (1024, 32)
+// 0.444 -> 0.474; fp64 (64, 256) 0.621 -> 0.693, (16, 16, 64) 0.634 -> 0.684, (256, 64) 0.624 -> 0.679, (16, 32, 32) 0.593 -> 0.659, (32, 512)
+// 0.555 -> 0.648, (512, 32) 0.556 -> 0.633.  Three shapes LOSE and have no instance here: fp32 32^3 (0.460 / 0.455: five stages of radix <=
+// 16 against three of radix 32), fp64 (128, 128) (0.631 -> 0.533) and fp64 numpy (64, 16, 16) (0.508 -> 0.486) -- their kernels spill 20-96
+// bytes per lane at the two-per-CU register budget.
+#include "mifft_internal.h"
+#include "fft_nd2z.hpp"
+
+using namespace mifft;
+
+namespace {
+// query: 1 = is there a kernel; 2 = is there one that is preferred at EVERY buffer size (the one-tile-per-CU shapes)
+template <typename T, int X, int Y, int Z> int go(const TileArgs* a, hipStream_t s, int query) {
+    constexpr bool F32 = sizeof(T) == 4;
+    if (query) return (query == 2 && X * Y * Z != (F32 ? 32768 : 16384)) ? -2 : 0;
+    constexpr int MAXR = F32 ? 16 : 8;
+    constexpr int HY = Z > 1 ? Y : Y / 2, HZ = Z > 1 ? Z / 2 : 1;
+    // halves of 16384 (fp32) / 8192 (fp64) points: the "big" tile form, half-exchange stages; halves of half that size (the two-per-CU
+    // shapes themselves split in two, for SMALL launches only, see below): full-complex exchanges through 64 KiB of LDS, 16 / 8 points per thread
+    constexpr int HP = X * HY * HZ;
+    constexpr bool BIGHALF = HP == (F32 ? 16384 : 8192);
+    static_assert(BIGHALF || HP == (F32 ? 8192 : 4096), "no tile form for this half");
+    using CFG = Nd2zCfg<T, X, Y, Z, 512, BIGHALF, 4, typename AutoRadix<X, MAXR, true>::type, typename AutoRadix<HY, MAXR, false>::type,
+                        typename AutoRadix<HZ, MAXR, false>::type>;
+    return launch_nd2z<T, CFG>(a, s);
+}
+
+// FOUR work-groups per transform: shapes of four two-per-CU tiles (65536 points fp32 / 32768 fp64), query 3 = is there such a kernel
+template <typename T, int X, int Y, int Z> int go4(const TileArgs* a, hipStream_t s, int query) {
+    constexpr bool F32 = sizeof(T) == 4;
+    if (query) return query == 2 ? -2 : 0;
+    constexpr int MAXR = F32 ? 16 : 8;
+    constexpr int QY = Z > 1 ? Y : Y / 4, QZ = Z > 1 ? Z / 4 : 1;
+    static_assert(X * QY * QZ == (F32 ? 16384 : 8192), "the quarters are big tiles");
+    using CFG = Nd2zCfg<T, X, Y, Z, 512, true, 4, typename AutoRadix<X, MAXR, true>::type, typename AutoRadix<QY, MAXR, false>::type,
+                        typename AutoRadix<QZ, MAXR, false>::type, 4>;
+    return launch_nd2z<T, CFG>(a, s);
+}
+}  // namespace
+
+extern "C" int mifft_nd2z_f64(int x, int y, int z, const TileArgs* a, hipStream_t s, int query) {
+#define SHAPE(T, X, Y, Z) \
+    if (x == X && y == Y && z == Z) return go<T, X, Y, Z>(a, s, query);
+    SHAPE(double, 32, 512, 1) SHAPE(double, 64, 256, 1) SHAPE(double, 256, 64, 1) SHAPE(double, 512, 32, 1)
+    SHAPE(double, 32, 32, 16) SHAPE(double, 64, 16, 16)
+    // (two-per-CU shapes, small launches only: see fft_nd2z_f32.hip)
+    SHAPE(double, 16, 512, 1) SHAPE(double, 32, 256, 1) SHAPE(double, 64, 128, 1) SHAPE(double, 128, 64, 1) SHAPE(double, 256, 32, 1)
+    SHAPE(double, 512, 16, 1) SHAPE(double, 32, 16, 16) SHAPE(double, 16, 32, 16) SHAPE(double, 16, 16, 32)
+    // (four work-groups per transform: the fp64 kernels spill 370-550 bytes per lane at the two-per-CU register budget -- four 16-byte
+    // operands per kept point in flight -- and are not instantiated)
+#undef SHAPE
+    return -2;
+}

@@ -62,7 +62,7 @@ int mifft_mixed_nd_launch(int f64, int nx, int ny, int nz, long long transforms,
 int mifft_bluestein_launch(int f64, int n, int m, long long rows, long long stride_in, long long stride_out, const void* in, void* out,
                            const void* tw, const void* chirp, const void* bhat, int flags, double scale, hipStream_t s);
 int mifft_xcd2_f32_launch(const mifft::Xcd2Args* f, int split, int prefetch, int mode, unsigned grid, hipStream_t s);
-// fft_nd2z.hip: 0 = launched (query: a kernel exists), -2 = none, -1 = grid too large
+// fft_nd2z.hip: 0 = launched (query 1: a kernel exists; query 2: one that is preferred at every buffer size), -2 = none, -1 = grid too large
 int mifft_nd2z(int f64, int x, int y, int z, const mifft::TileArgs* a, hipStream_t s, int query);
 }
 

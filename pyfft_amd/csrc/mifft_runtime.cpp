@@ -82,8 +82,10 @@ int validate(const mifft_pass* p) {
         const bool both_interleaved = p->layout != MIFFT_SPLIT || ((p->flags & MIFFT_FLAG_SRC_INTERLEAVED) && (p->flags & MIFFT_FLAG_DST_INTERLEAVED));
         // (planes on the input side at least: the tiled fixed-shape kernel takes planes -> planes and planes -> interleaved)
         const bool both_split = p->layout == MIFFT_SPLIT && !(p->flags & MIFFT_FLAG_SRC_INTERLEAVED);
-        if (n < 4 || mifft_nd_shape_supported(p->precision, p->L, (int32_t)p->M, (int32_t)p->S,
-                                              both_interleaved ? MIFFT_VARIANT_INTERLEAVED_ONLY : both_split ? MIFFT_VARIANT_SPLIT_ONLY : 0) != 0)
+        // (interleaved shapes that exist out of place only: launch_nd refuses an in-place call, with its own message)
+        if (n < 4 || (mifft_nd_shape_supported(p->precision, p->L, (int32_t)p->M, (int32_t)p->S,
+                                               both_interleaved ? MIFFT_VARIANT_INTERLEAVED_ONLY : both_split ? MIFFT_VARIANT_SPLIT_ONLY : 0) != 0 &&
+                      !(both_interleaved && mifft_nd_shape_supported(p->precision, p->L, (int32_t)p->M, (int32_t)p->S, MIFFT_VARIANT_OUT_OF_PLACE_ONLY) == 0)))
             return set_err(MIFFT_E_UNSUPPORTED, "ND pass: no kernel for %d x %lld x %lld (%lld points)", p->L, (long long)p->M, (long long)p->S, n);
         if ((p->L > 1 && !p->tw_L) || (p->M > 1 && !p->tw_lo) || (p->S > 1 && !p->tw_hi)) return set_err(MIFFT_E_INVALID, "ND pass: twiddle table missing");
         return 0;
@@ -185,10 +187,11 @@ long long wave_bytes(const mifft_pass* p, const mifft::TileArgs* a) {   // bytes
     return a->total * p->L * (p->precision == MIFFT_F64 ? 16ll : 8ll);
 }
 
-// which of the two forms a one-tile-per-CU N-D shape runs: two work-groups per transform wherever that kernel exists (it is only
-// instantiated where it measured faster, at 32 MiB and at 1 GiB per side: fft_nd2z.hip); A/B: MIFFT_DEBUG_ALT_ROWS = 6 never
-bool nd2z_preferred(bool f64, int x, int y, int z) {
-    return g_debug[MIFFT_DEBUG_ALT_ROWS] != 6 && mifft_nd2z(f64 ? 1 : 0, x, y, z, nullptr, nullptr, 1) == 0;
+// which form a fixed N-D shape runs: two work-groups per transform (fft_nd2z.hip) for the one-tile-per-CU shapes wherever that kernel
+// exists (it is only instantiated where it measured faster, at 32 MiB and at 1 GiB per side), for the two-per-CU shapes in SMALL launches
+// only -- the plan marks those with MIFFT_FLAG_WRITE_THROUGH (up to half the last-level cache per side).  A/B: MIFFT_DEBUG_ALT_ROWS = 6 never
+bool nd2z_preferred(bool f64, int x, int y, int z, bool small_launch) {
+    return g_debug[MIFFT_DEBUG_ALT_ROWS] != 6 && mifft_nd2z(f64 ? 1 : 0, x, y, z, nullptr, nullptr, small_launch ? 1 : 2) == 0;
 }
 
 int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0, void* out1, hipStream_t s) {
@@ -212,6 +215,26 @@ int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0,
     const bool f64nd = p->precision == MIFFT_F64;
     const int have_nd2 = f64nd ? mifft_nd2_f64_supported((int)p->L, (int)p->M, (int)p->S)
                                : mifft_nd2_f32_supported((int)p->L, (int)p->M, (int)p->S);
+    const bool inter_both = p->layout != MIFFT_SPLIT || ((p->flags & MIFFT_FLAG_SRC_INTERLEAVED) && (p->flags & MIFFT_FLAG_DST_INTERLEAVED));
+    // Several work-groups per transform (fft_nd2z.hpp, round 5; out of place only): the one-tile-per-CU shapes always, the two-per-CU
+    // shapes in small launches, and shapes of FOUR two-per-CU tiles, which have no other one-launch kernel (the plan only builds such a
+    // pass for its out-of-place executes)
+    if (inter_both && !no_nd2 && in0 != out0 &&
+        (have_nd2 == 0 ? nd2z_preferred(f64nd, (int)p->L, (int)p->M, (int)p->S, (p->flags & MIFFT_FLAG_WRITE_THROUGH) != 0)
+                       : mifft_nd2z(f64nd ? 1 : 0, (int)p->L, (int)p->M, (int)p->S, nullptr, nullptr, 1) == 0)) {
+        mifft::TileArgs t;
+        memset(&t, 0, sizeof(t));
+        t.in0 = in0; t.out0 = out0;
+        t.tw_L = p->tw_L; t.tw_lo = p->tw_lo; t.tw_hi = p->tw_hi;
+        t.total = p->outer * p->L * p->M * p->S;
+        t.inverse = p->inverse ? 1 : 0;
+        t.scale = p->scale;
+        t.nt = stream_policy(p->flags);
+        const int rz = mifft_nd2z(f64nd ? 1 : 0, (int)p->L, (int)p->M, (int)p->S, &t, s, 0);
+        if (rz == -1) return set_err(MIFFT_E_INVALID, "grid too large");
+        if (rz != 0) return hip_check((hipError_t)rz, "kernel launch");
+        return 0;
+    }
     if (have_nd2 == 0 &&
         (p->layout != MIFFT_SPLIT || ((p->flags & MIFFT_FLAG_SRC_INTERLEAVED) && (p->flags & MIFFT_FLAG_DST_INTERLEAVED))) &&
         !no_nd2) {
@@ -223,14 +246,6 @@ int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0,
         t.inverse = p->inverse ? 1 : 0;
         t.scale = p->scale;
         t.nt = stream_policy(p->flags);
-        // the one-tile-per-CU shapes (32768 points fp32 / 16384 fp64): two work-groups per transform, each on a half-size tile
-        // (fft_nd2z.hpp, round 5) -- out of place only
-        if (in0 != out0 && nd2z_preferred(f64nd, (int)p->L, (int)p->M, (int)p->S)) {
-            const int rz = mifft_nd2z(f64nd ? 1 : 0, (int)p->L, (int)p->M, (int)p->S, &t, s, 0);
-            if (rz == -1) return set_err(MIFFT_E_INVALID, "grid too large");
-            if (rz != 0) return hip_check((hipError_t)rz, "kernel launch");
-            return 0;
-        }
         const int rc = f64nd ? mifft_nd2_f64_launch((int)p->L, (int)p->M, (int)p->S, &t, s)
                              : mifft_nd2_f32_launch((int)p->L, (int)p->M, (int)p->S, &t, s);
         if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
@@ -263,6 +278,10 @@ int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0,
         if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
         return 0;
     }
+    if ((long long)p->L * p->M * p->S > mifft_nd_max_points(f64nd))
+        return set_err(MIFFT_E_UNSUPPORTED, "ND pass %d x %d x %d: this shape has a one-launch kernel for interleaved data out of place only "
+                       "(several work-groups per transform, mifft_nd_shape_supported with MIFFT_VARIANT_OUT_OF_PLACE_ONLY)",
+                       (int)p->S, (int)p->M, (int)p->L);
     mifft::NdArgs a;
     memset(&a, 0, sizeof(a));
     a.in0 = in0; a.in1 = in1; a.out0 = out0; a.out1 = out1;
@@ -643,6 +662,9 @@ int mifft_nd_shape_supported(int32_t precision, int32_t x, int32_t y, int32_t z,
         // rows, measured 0.285 against 0.307 for its two passes and keeps them -- profiles/r04_at_rows_split.log)
         return (g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 && g_debug[MIFFT_DEBUG_NO_ND2] == 0 && x * (precision == MIFFT_F64 ? 8 : 4) >= 256 &&
                 mifft_nd2t_split(precision == MIFFT_F64, x, y, z, nullptr, nullptr, nullptr, 1) == 0) ? 0 : MIFFT_E_UNSUPPORTED;
+    if (variant == MIFFT_VARIANT_OUT_OF_PLACE_ONLY)   // interleaved on both sides AND out of place: several work-groups per transform (fft_nd2z.hpp)
+        return (g_debug[MIFFT_DEBUG_NO_ND2] == 0 && g_debug[MIFFT_DEBUG_ALT_ROWS] != 6 &&
+                mifft_nd2z(precision == MIFFT_F64 ? 1 : 0, x, y, z, nullptr, nullptr, 1) == 0) ? 0 : MIFFT_E_UNSUPPORTED;
     if (variant != MIFFT_VARIANT_INTERLEAVED_ONLY) return MIFFT_E_UNSUPPORTED;
     const int rc = precision == MIFFT_F64 ? mifft_nd2_f64_supported(x, y, z) : mifft_nd2_f32_supported(x, y, z);
     return rc == 0 ? 0 : MIFFT_E_UNSUPPORTED;

@@ -169,6 +169,15 @@ class FFTPlan(object):
 
         self._tables = {}      # key -> device allocation
         self._table_ptrs = self._pass_tables(self._kernels)   # per pass: (tw_L, tw_lo, tw_hi, shift)
+        # Round 5: shapes of four two-per-CU tiles (65536 points fp32: (256, 256), (32, 32, 64) ...) have a ONE-launch kernel that runs
+        # four work-groups per transform (csrc/fft_nd2z.hpp) -- for interleaved data, out of place only (a work-group overwrites
+        # planes its partners still read).  The plan keeps its chain for in-place executes and this one-pass list for the others.
+        self._oop_nd = None
+        self._oop_tables = None
+        if not p.split and len(P.launch_units(self._kernels)) >= 2 and \
+                N.lib.mifft_nd_shape_supported(p.precision, int(p.x), int(p.y), int(p.z), N.VARIANT_OUT_OF_PLACE_ONLY) == 0:
+            self._oop_nd = [P.PassSpec(N.PASS_ND, P.X_DIRECTION, p.size, int(p.x), int(p.y), int(p.z), 1, p.size, True)]
+            self._oop_tables = self._pass_tables(self._oop_nd)
         # 3-D shapes whose chain is a plane pass + a strided z pass but that have a persistent two-pair kernel (64- and 128-point axes,
         # csrc/fft_fusedp2.hip): the four-pass list with the y axis factored R0 x R1 exists for that launch alone
         self._pair_alt = None
@@ -221,14 +230,15 @@ class FFTPlan(object):
 
     def _descriptors(self, batch, is_inplace, inverse, alt=False):
         """Pass descriptor array for (batch, schedule, direction); cached like the reference's
-        kernel.prepare(batch) (kernel.py:85-93).  alt: the four-pass list of the persistent two-pair launch (_pair_alt)."""
+        kernel.prepare(batch) (kernel.py:85-93).  alt: 1 = the four-pass list of the persistent two-pair launch (_pair_alt), 2 = the
+        one-pass list of out-of-place executes (_oop_nd)."""
         key = (batch, is_inplace, inverse, alt)
         d = self._desc_cache.get(key)
         if d is not None:
             return d
         p = self._params
         mach = self._context.machine
-        kernels, tables = (self._pair_alt, self._pair_alt_tables) if alt else (self._kernels, self._table_ptrs)
+        kernels, tables = ((self._kernels, self._table_ptrs), (self._pair_alt, self._pair_alt_tables), (self._oop_nd, self._oop_tables))[int(alt)]
         _, sched = P.buffer_schedule(kernels, is_inplace, self._via_temp and not alt)
         arr = (N.MifftPass * max(1, len(kernels)))()
         last = len(kernels) - 1
@@ -487,8 +497,15 @@ class FFTPlan(object):
 
     def _enqueue(self, batch, is_inplace, inverse, bufs0, bufs1):
         ctx = self._context
-        descs = self._descriptors(batch, is_inplace, bool(inverse))
         stream = ctx.stream_handle()
+        if self._oop_nd is not None and not is_inplace and not D.no_oop_nd() and D.forced_strategy() == "auto" and \
+                batch * self._params.size * self._params.complex_nbytes > ctx.machine.write_through_max_bytes:
+            # one launch, several work-groups per transform (csrc/fft_nd2z.hpp); needs no scratch.  Beyond half the last-level cache per
+            # side: (256, 256) at 256 MiB 0.339 -> 0.444, at 2 GiB 0.464 (persistent) -> 0.501; at 32 MiB the two launches win (0.404 / 0.356)
+            descs = self._descriptors(batch, False, bool(inverse), alt=2)
+            N.check(N.lib.mifft_launch_chain(descs, 1, bufs0, bufs1, stream), "mifft_launch_chain")
+            return
+        descs = self._descriptors(batch, is_inplace, bool(inverse))
         strat = self._strategy
         if strat[0] == "xcd2":
             if ctx.capturing():

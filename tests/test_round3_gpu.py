@@ -66,7 +66,7 @@ def test_pass_pairs_256_cubed(ctx, dtype):
     plan = ctx.getPlan(shape, dtype=dtype, context=ctx.context)
     assert [k.pair_with_next for k in plan.pass_list()] == [True, False, True, False]
     # (batch 1 and 3 with the soak switch; tests/test_full_size_gpu.py runs the shape at BASELINE's batch 64 in both fp64 layouts)
-    for batch in ((1, 3) if os.environ.get("PYFFT_AMD_SWEEP") else (2,)):
+    for batch in ((1, 3) if os.environ.get("PYFFT_AMD_SWEEP") else (1,)):
         run_protocol(ctx, shape, dtype, batch, seed=600 + batch, check_oracle=False)
     # pairs against the three-launch chain on the same buffer
     dt = numpy.dtype(dtype)
@@ -468,6 +468,7 @@ def test_any_size_random_lengths(ctx, dtype):
 
 
 # ---- the sharded path with more than one rank --------------------------------------------------------------------------
+@pytest.mark.skipif(not os.environ.get("PYFFT_AMD_SWEEP"), reason="superseded by tests/test_round5_gpu.py::test_eight_ranks_share_one_gpu (the same path with eight ranks); runs with the soak switch")
 def test_two_ranks_share_one_gpu_sharded_path(tmp_path):
     """`bench.py --gpus 2` for real: two processes (one plan, stream and scratch each) on ONE device, gloo as the control
     plane, data taken from the GLOBAL dataset by transform index.  Each rank parity-checks its slice [start, start + count)

@@ -11,6 +11,8 @@ import pyfft_oracle as oracle
 from test_errors_gpu import run_protocol
 
 pytestmark = pytest.mark.gpu
+# the driver's GPU step has a time limit: the cases that repeat a kernel family on one more shape run with the soak switch PYFFT_AMD_SWEEP
+_SOAK = bool(os.environ.get("PYFFT_AMD_SWEEP"))
 
 
 def _noise(rng, count, dtype):
@@ -548,13 +550,21 @@ def test_fused_2d_256_sides(ctx, monkeypatch, shape, batch, dtype):
     data = _test_data(shape, cd, batch, 1300 + ny // 256 + nx // 64)
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
     got = _execute(ctx, shape, cd, batch, data, expect="fused2")
-    assert numpy.array_equal(_execute(ctx, shape, cd, batch, data, inplace=True, expect="fused2"), got)
+    inp = _execute(ctx, shape, cd, batch, data, inplace=True, expect="fused2")
+    if ctx.getPlan(shape, dtype=cd)._oop_nd is not None:
+        # round 5: (256, 256) fp32 runs ONE launch with four work-groups per transform when it is out of place (csrc/fft_nd2z.hpp) and the
+        # persistent kernel in place: two factorisations of one transform, equal to rounding (the reference's protocol asks no more:
+        # test/test_errors.py:97-103)
+        assert oracle.difference(inp, got, batch) < 5e-7
+        got = inp             # (what follows is about the persistent kernel)
+    else:
+        assert numpy.array_equal(inp, got)
     for item in (0, 1, batch // 2, batch - 1):
         sl = slice(item * ny, (item + 1) * ny)
         ref = numpy.fft.fft2(data[sl].astype(numpy.complex128))
         assert numpy.abs(ref - got[sl]).sum() / numpy.abs(ref).sum() < eps
         assert numpy.abs(ref - got[sl]).max() <= mx * numpy.abs(ref).max()
-    back = _execute(ctx, shape, cd, batch, got, inverse=True, expect="fused2")
+    back = _execute(ctx, shape, cd, batch, got, inverse=True, inplace=True, expect="fused2")
     assert oracle.difference(data, back, batch) < eps
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
     want = _execute(ctx, shape, cd, batch, data, expect="chain")
@@ -652,7 +662,6 @@ def test_fused_pair_small_axes(ctx, monkeypatch, shape, batch, dtype):
 
 # (every shape of {64, 128}^3 has its own tile pair: a cube, a shape with one 64-point axis in each position and one with two per precision run
 # by default, the other combinations with the soak switch PYFFT_AMD_SWEEP -- the driver's GPU step has a time limit)
-_SOAK = bool(os.environ.get("PYFFT_AMD_SWEEP"))
 _PAIR_SPLIT_CASES = [((64, 64, 64), numpy.float32, 141), ((64, 128, 128), numpy.float32, 59), ((128, 64, 64), numpy.float32, 113),
                      ((128, 128, 128), numpy.float64, 15), ((128, 128, 64), numpy.float64, 30), ((128, 64, 128), numpy.float64, 31)]
 if _SOAK:
@@ -694,8 +703,8 @@ def test_fused_pair_split_planes(ctx, monkeypatch, shape, rdtype, batch):
 
 
 # ---- split-complex fp32 2-D plans on the row-first persistent kernel (csrc/fft_fused2r.hpp) ------------------------------------------
-@pytest.mark.parametrize("shape,batch", [((1024, 1024), 37), ((512, 512), 140), ((256, 256), 530), ((512, 1024), 70), ((1024, 512), 67), ((256, 1024), 135),
-                                         ((1024, 256), 131), ((256, 512), 261), ((512, 256), 259)], ids=str)   # ((256, 256): on request only)
+@pytest.mark.parametrize("shape,batch", [((1024, 1024), 37), ((512, 512), 140), ((256, 256), 530), ((512, 1024), 70), ((1024, 256), 131), ((256, 512), 261)] +
+                         ([((1024, 512), 67), ((256, 1024), 135), ((512, 256), 259)] if _SOAK else []), ids=str)   # ((256, 256): on request only)
 def test_fused_2d_split_row_first(ctx, monkeypatch, shape, batch):
     """float32 planes, 2-D, beyond the chain threshold: ROW x from the planes and COL y to the planes on the persistent work list (the
     chain's own order, pyfft/plan.py:135-171, instead of two transposing passes whose 16-column tiles read half lines of the planes).
@@ -728,7 +737,8 @@ def test_fused_2d_split_row_first(ctx, monkeypatch, shape, batch):
 
 
 # ---- split-complex fp64 (float64 planes) on the persistent kernels, planes streamed non-temporally -----------------------------------
-@pytest.mark.parametrize("shape,batch", [((1 << 16,), 270), ((1 << 17,), 131), ((1 << 18,), 67), ((1 << 19,), 35), ((1 << 20,), 29), ((1024, 1024), 30)], ids=str)
+@pytest.mark.parametrize("shape,batch", [((1 << 16,), 270), ((1 << 18,), 67), ((1 << 20,), 29), ((1024, 1024), 30)] +
+                         ([((1 << 17,), 131), ((1 << 19,), 35)] if _SOAK else []), ids=str)
 def test_fused_split_planes_fp64(ctx, monkeypatch, shape, batch):
     """float64 planes beyond the chain threshold: 1-D 2^16 ... 2^20 and the published 1024 x 1024 on the persistent kernels (16 columns
     of an fp64 plane are a whole 128-byte line; the tiles stream the planes with non-temporal loads and stores, second batch of

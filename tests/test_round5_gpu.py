@@ -146,7 +146,7 @@ def test_eight_ranks_share_one_gpu(tmp_path):
     import bench
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["OMP_NUM_THREADS"] = "1"
-    batch = 10                                                # per rank; 80 transforms of 8 MiB in all: the chain strategy
+    batch = 64                                                # per rank: 512 MiB per side -- the persistent kernel of the headline path in every process
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--control", "gloo", "--share-gpu",
                           "--config", "c2", "--batch", str(batch), "--steps", "2", "--warmup", "1", "--repeats", "0",
                           "--cpu-budget", "3", "--dump-dir", str(tmp_path)],
@@ -160,6 +160,7 @@ def test_eight_ranks_share_one_gpu(tmp_path):
     assert [r["rank"] for r in ranks] == list(range(8))
     assert [r["first_transform"] for r in ranks] == [batch * r for r in range(8)] and all(r["count"] == batch for r in ranks)
     assert all(r["parity_ok"] for r in ranks) and all(r["device"] == 0 for r in ranks)
+    assert res["config"]["strategy"] == "fused2"
     cpu = res["cpu_baseline"]
     assert cpu is not None and cpu["kind"] == "reference" and cpu["value"] > 0 and cpu["best"]["value"] >= cpu["value"]
     shape, dtname, _, seed = bench.CONFIGS["c2"]
@@ -373,8 +374,11 @@ def test_pair_chains_pipelined_chunks(ctx, shape, dtype, batch):
 
 
 # ---- one-tile-per-CU N-D shapes as two work-groups per transform (csrc/fft_nd2z.hpp) ------------------------------------------------
-ND2Z_SHAPES = {numpy.complex64: [(1024, 32), (512, 64), (256, 128), (128, 256), (32, 1024), (8, 64, 64), (16, 16, 128)],
-               numpy.complex128: [(512, 32), (256, 64), (64, 256), (32, 512), (16, 32, 32), (16, 16, 64)]}
+ND2Z_SHAPES = {numpy.complex64: [(1024, 32), (512, 64), (256, 128), (128, 256), (32, 1024), (8, 64, 64), (16, 16, 128),
+                                 # (two-per-CU shapes: split in small launches only -- 11 transforms are one)
+                                 (1024, 16), (512, 32), (256, 64), (128, 128), (64, 256), (32, 512), (16, 1024), (16, 32, 32), (32, 16, 32), (32, 32, 16)],
+               numpy.complex128: [(512, 32), (256, 64), (64, 256), (32, 512), (16, 32, 32), (16, 16, 64),
+                                  (512, 16), (256, 32), (128, 64), (64, 128), (32, 256), (16, 512), (16, 16, 32), (16, 32, 16), (32, 16, 16)]}
 
 
 @pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
@@ -420,3 +424,43 @@ def test_two_work_groups_per_transform_nd(ctx, dtype):
         assert d < tol_same, (shape, d)
         for inv in (back, back2):
             assert numpy.abs(inv.astype(numpy.complex128) - data).sum() / numpy.abs(data).sum() < tol, shape
+
+
+OOP_ND_SHAPES = [(256, 256), (512, 128), (1024, 64), (64, 1024), (16, 64, 64)]
+
+
+@pytest.mark.parametrize("shape", OOP_ND_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_four_work_groups_per_transform_out_of_place(ctx, shape, monkeypatch):
+    """Shapes of 65536 points (fp32): two launches as a chain, ONE launch with four work-groups per transform for out-of-place
+    executes (csrc/fft_nd2z.hpp; the plan keeps its chain for in-place ones).  The reference's thresholds against numpy at a ragged
+    batch, forward and inverse, out of place and in place, and the chain's result to rounding."""
+    hip = ctx.hip
+    dtype = numpy.complex64
+    size = int(numpy.prod(shape))
+    batch = 261                                                   # 130.5 MiB per side: beyond half the cache, where the plan uses it
+    data = _tiled_noise(size * batch, dtype, 4500 + shape[0])
+    plan = hip.Plan(shape, dtype=dtype)
+    assert plan._oop_nd is not None and len(plan.pass_list()) == 2, plan.pass_list()
+    assert batch * size * 8 > plan._context.machine.write_through_max_bytes
+    a = hip.to_gpu(data)
+    b = hip.DeviceArray((size * batch,), dtype)
+    plan.execute(a, b, batch=batch)
+    got = b.get()
+    assert numpy.array_equal(a.get(), data), "input modified"
+    for item in (0, 1, 7, 8, 9, batch // 2, batch - 6, batch - 5, batch - 1):      # (groups of eight transforms share an XCD: both ends of the last, ragged group)
+        sl = slice(item * size, (item + 1) * size)
+        ref = numpy.fft.fftn(data[sl].astype(numpy.complex128).reshape(shape)).reshape(-1)
+        g = got[sl].astype(numpy.complex128)
+        assert numpy.abs(ref - g).sum() / numpy.abs(ref).sum() < EPS_F, (shape, item)
+        assert numpy.abs(ref - g).max() <= MAX_F * numpy.abs(ref).max(), (shape, item)
+    c = hip.to_gpu(data)
+    plan.execute(c, batch=batch)                                  # in place: the chain
+    inplace = c.get()
+    assert numpy.abs(inplace.astype(numpy.complex128) - got).sum() / numpy.abs(got).sum() < 5e-7
+    monkeypatch.setenv("PYFFT_AMD_NO_OOP_ND", "1")
+    d = hip.DeviceArray((size * batch,), dtype)
+    hip.Plan(shape, dtype=dtype).execute(a, d, batch=batch)       # out of place on the chain
+    assert numpy.array_equal(d.get(), inplace)
+    monkeypatch.delenv("PYFFT_AMD_NO_OOP_ND")
+    plan.execute(b, a, batch=batch, inverse=True)                 # inverse, out of place
+    assert numpy.abs(a.get().astype(numpy.complex128) - data).sum() / numpy.abs(data).sum() < EPS_F

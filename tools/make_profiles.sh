@@ -1,11 +1,11 @@
 #!/bin/bash
 # Regenerates the round's evidence under profiles/ ON THE GPU BOX (run through gpurun from the repo root):
-#     gpurun --timeout 3000 -- 'bash tools/make_profiles.sh r04'
+#     git rev-parse HEAD > .tree_commit; gpurun --timeout 3000 -- 'bash tools/make_profiles.sh r05'
 # Everything is written to gpurun_out/<tag>/ (scratch, merged back by gpurun); the summaries that are judged are gathered in
 # gpurun_out/<tag>/to_profiles/ under their final names -- back in the build container:
 #     cp gpurun_out/r04/to_profiles/* profiles/  rocprofv3 gets the program directly after `--` (no env/bash hop), counters in their own runs.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT/to_profiles profiles
 P=$OUT/to_profiles
@@ -19,10 +19,14 @@ cp profiles/traffic_*.json profiles/${TAG}_*_kernel_stats.csv $P/ 2>/dev/null
 
 # 2. the bench lines (after the traffic files exist, so that every line carries roofline.traffic): default line (c2) and every other BASELINE configuration
 timeout 600 python3 bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
-for c in c1 c3 c4 c4s c5 cube cubed c2s c3s; do
+for c in c1 c3 c4 c4s cube cubed c2s c3s; do
     timeout 600 python3 bench.py --config $c --steps 10 --warmup 2 > $OUT/bench_$c.json 2> $OUT/bench_$c.err
 done
-for c in c1 c2 c3 c4 c4s c5 cube cubed c2s c3s; do cp $OUT/bench_$c.json $P/${TAG}_bench_$c.json; done
+# configuration 5 as BASELINE.json states it: the per-GPU share of 8192 transforms resident (256 GiB), 32 chunk executes = one sweep; and the
+# rounds 1-4 form (one resident chunk, out of place) next to it
+timeout 900 python3 bench.py --config c5 --warmup 2 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
+timeout 600 python3 bench.py --config c5 --chunk-only --steps 10 --warmup 2 > $OUT/bench_c5chunk.json 2> $OUT/bench_c5chunk.err
+for c in c1 c2 c3 c4 c4s c5 c5chunk cube cubed c2s c3s; do cp $OUT/bench_$c.json $P/${TAG}_bench_$c.json; done
 
 # 3. the reference's published shapes (test/test_performance.py method), the vendor yardstick (cuda/test.cu counterpart) and its
 #    value cross-check
@@ -47,6 +51,13 @@ timeout 600 python3 tools/mixed_probe.py > $OUT/mixed.log 2>&1; cp $OUT/mixed.lo
 timeout 300 python3 tools/small_batch_probe.py sp > $OUT/small_batch.log 2>&1
 timeout 300 python3 tools/small_batch_probe.py dp >> $OUT/small_batch.log 2>&1
 cp $OUT/small_batch.log $P/${TAG}_small_batch_32MiB.log
+
+# 5b. round 5: pass-pair chains and the kernels with several work-groups per transform; the tail survey again
+timeout 900 python3 tools/quick_bench.py r5 2>&1 | sed 's/passes=\[.*\]//' > $OUT/r5_shapes.log; cp $OUT/r5_shapes.log $P/${TAG}_round5_shapes.log
+timeout 900 python3 tools/quick_bench.py tail 2>&1 | sed 's/passes=\[.*\]//' > $OUT/tail.log; cp $OUT/tail.log $P/${TAG}_tail_survey.log
+# 5c. the planner's tuning table re-measured (every rule's persistent launch against the pipelined chunks, 2 GiB per side)
+timeout 1500 python3 tools/fused_sweep.py --emit $OUT/tuning_emitted.json --gib 2 > $OUT/tuning_emit.log 2>&1
+cp $OUT/tuning_emit.log $P/${TAG}_tuning_emit.log; cp $OUT/tuning_emitted.json $P/${TAG}_tuning_emitted.json
 
 # 6. SQ counters of the long fp32 rows (occupancy / LDS pressure)
 timeout 900 python3 tools/row_counters.py 32768 complex64 8192 16384 complex64 16384 8192 complex64 32768 > $OUT/row_counters.log 2>&1

@@ -110,6 +110,16 @@ if __name__ == "__main__":
                  ((4096, 4096), c64, 16), ((1 << 20,), f32, 256), ((1 << 18,), f32, 1024), ((1024, 1024), f32, 256), ((128, 128, 128), f32, 128),
                  ((1 << 20,), f64, 128), ((32, 32, 2048), c64, 128), ((2048, 32, 32), c64, 128), ((1 << 23,), c64, 32), ((1 << 24,), c64, 16),
                  ((512, 512, 512), c64, 2), ((2048, 2048), c128, 32)]
+    elif len(sys.argv) > 1 and sys.argv[1] == "r5":                  # round 5: pass-pair chains, several work-groups per transform (1 GiB per side)
+        def nb(shape, dt, gib=1.0):
+            d = numpy.dtype(dt)
+            return max(1, int(gib * (1 << 30)) // (int(numpy.prod(shape)) * d.itemsize))
+        shapes = [((4096, 256), c64), ((4096, 1024), c64), ((4096, 4096), c64), ((32, 32, 2048), c64), ((16, 16, 2048), c64), ((4096, 512), c128), ((32, 32, 1024), c128),
+                  ((16, 16, 128), c64), ((128, 256), c64), ((256, 128), c64), ((512, 64), c64), ((8, 64, 64), c64), ((32, 1024), c64), ((1024, 32), c64), ((32, 32, 32), c64),
+                  ((64, 256), c128), ((256, 64), c128), ((16, 32, 32), c128), ((16, 16, 64), c128), ((32, 512), c128), ((512, 32), c128), ((128, 128), c128),
+                  ((256, 256), c64), ((512, 128), c64), ((1024, 64), c64), ((64, 1024), c64), ((16, 64, 64), c64)]
+        cases = [(s, d, nb(s, d)) for s, d in shapes] + [(s, d, nb(s, d, 0.03125)) for s, d in shapes[7:22]] + \
+            [((128, 128), c64, 256), ((128, 128), c128, 128), ((256, 64), c64, 256), ((16, 32, 32), c64, 256), ((128, 64), c128, 256)]
     elif len(sys.argv) > 1 and sys.argv[1] == "1d":
         cases = [((1 << k,), c64, max(64, (1 << 31) >> (k + 3))) for k in (13, 14, 15, 16, 17, 18, 19, 20, 21, 22)]
     else:
