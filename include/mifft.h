@@ -250,7 +250,11 @@ int mifft_nd_shape_supported(int32_t precision, int32_t x, int32_t y, int32_t z,
 
 /* 0 if a compiled kernel exists for (kind, precision, L, variant), else MIFFT_E_UNSUPPORTED.
  * Counterpart of Function.isExecutable (cuda.py:48-49) for AOT kernels.  variant 0: a kernel that takes either layout;
- * MIFFT_VARIANT_INTERLEAVED_ONLY (ROW passes): also count kernels that need interleaved data on both sides. */
+ * MIFFT_VARIANT_INTERLEAVED_ONLY (ROW passes): also count kernels that need interleaved data on both sides.
+ * The query knows no layout: the longest rows (32768 points fp32, 16384 fp64) exist for interleaved -> interleaved, planes -> planes and
+ * planes -> interleaved; an interleaved -> planes ROW pass of that length (MIFFT_FLAG_SRC_INTERLEAVED without _DST_INTERLEAVED on a
+ * MIFFT_SPLIT pass) is refused by mifft_launch_pass with MIFFT_E_UNSUPPORTED although the query says 0 -- no plan builds one (a ROW pass
+ * is a plan's first pass: its input is the user's layout). */
 #define MIFFT_VARIANT_INTERLEAVED_ONLY 2
 int mifft_pass_supported(int32_t kind, int32_t precision, int32_t L, int32_t variant);
 

@@ -29,18 +29,27 @@ template <typename T, int X, int Y, int Z> int go(const TileArgs* a, hipStream_t
     return launch_nd2z<T, CFG>(a, s);
 }
 
-// FOUR work-groups per transform: shapes of four two-per-CU tiles (65536 points fp32 / 32768 fp64), query 3 = is there such a kernel
-template <typename T, int X, int Y, int Z> int go4(const TileArgs* a, hipStream_t s, int query) {
+// FOUR work-groups per transform: shapes of four two-per-CU tiles (65536 points fp32 / 32768 fp64), or one-tile fp64 shapes whose halves
+// spill, as quarters of 4096 points.  ALWAYS: preferred at every buffer size (query 2), else in small launches / where nothing else exists
+template <typename T, int X, int Y, int Z, bool ALWAYS = false> int go4(const TileArgs* a, hipStream_t s, int query) {
     constexpr bool F32 = sizeof(T) == 4;
-    if (query) return query == 2 ? -2 : 0;
+    if (query) return (query == 2 && !ALWAYS) ? -2 : 0;
     constexpr int MAXR = F32 ? 16 : 8;
     constexpr int QY = Z > 1 ? Y : Y / 4, QZ = Z > 1 ? Z / 4 : 1;
-    static_assert(X * QY * QZ == (F32 ? 16384 : 8192), "the quarters are big tiles");
-    using CFG = Nd2zCfg<T, X, Y, Z, 512, true, 4, typename AutoRadix<X, MAXR, true>::type, typename AutoRadix<QY, MAXR, false>::type,
+    constexpr int QP = X * QY * QZ;
+    constexpr bool BIGQ = QP == (F32 ? 16384 : 8192);
+    static_assert(BIGQ || QP == (F32 ? 8192 : 4096), "no tile form for this quarter");
+    using CFG = Nd2zCfg<T, X, Y, Z, 512, BIGQ, 4, typename AutoRadix<X, MAXR, true>::type, typename AutoRadix<QY, MAXR, false>::type,
                         typename AutoRadix<QZ, MAXR, false>::type, 4>;
     return launch_nd2z<T, CFG>(a, s);
 }
 }  // namespace
+
+// explicit stage lists (where the automatic radix <= 16 lists lose): RS work-groups per transform on the big tile form
+template <typename T, int X, int Y, int Z, typename RLX, typename RLY, typename RLZ, int RS, bool ALWAYS> int gox(const TileArgs* a, hipStream_t s, int query) {
+    if (query) return (query == 2 && !ALWAYS) ? -2 : 0;
+    return launch_nd2z<T, Nd2zCfg<T, X, Y, Z, 512, true, 4, RLX, RLY, RLZ, RS>>(a, s);
+}
 
 extern "C" int mifft_nd2z_f64(int x, int y, int z, const TileArgs* a, hipStream_t s, int query);   // fft_nd2z_f64.hip
 
@@ -53,6 +62,12 @@ extern "C" int mifft_nd2z(int f64, int x, int y, int z, const TileArgs* a, hipSt
     if (x == X && y == Y && z == Z) return go4<T, X, Y, Z>(a, s, query);
     SHAPE(float, 32, 1024, 1) SHAPE(float, 64, 512, 1) SHAPE(float, 128, 256, 1) SHAPE(float, 256, 128, 1) SHAPE(float, 1024, 32, 1)
     SHAPE(float, 64, 64, 8) SHAPE(float, 128, 16, 16)
+    // 32^3: the x and y axes as ONE radix-32 stage each (three stages like the one-tile kernel; the automatic radix <= 16 lists take five
+    // and measured 0.460 / 0.455): 0.467 -> 0.555 at 1 GiB, 0.434 -> 0.472 at 256 MiB, 0.323 -> 0.386 at 32 MiB
+    // (profiles/r05_nd2z_cube32_radix32_and_eight_way_ab.log).  EIGHT work-groups per transform for (32, 32, 128) -- 131072 points, a shape
+    // of the reference's own benchmark list, two launches otherwise -- measured in the same log and LOST at every size (0.406 -> 0.305 at
+    // 256 MiB, 0.373 -> 0.333 at 1 GiB: eight loads per kept point, the L2 and the address path become the bound): not instantiated.
+    if (x == 32 && y == 32 && z == 32) return gox<float, 32, 32, 32, RadixList<32>, RadixList<32>, RadixList<16>, 2, true>(a, s, query);
     // The two-per-CU shapes (16384 points fp32 / 8192 fp64) split in two as well -- for launches of up to half the last-level cache per
     // side (the planner's write-through rule), where a launch is a single wave of tiles and twice as many, half as long, finish sooner:
     // at the reference's 32 MiB protocol (128, 128) x 256 0.421 -> 0.573, (256, 64) 0.423 -> 0.592, (16, 32, 32) 0.393 -> 0.511, fp64

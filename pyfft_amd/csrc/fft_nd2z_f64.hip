@@ -30,14 +30,17 @@ template <typename T, int X, int Y, int Z> int go(const TileArgs* a, hipStream_t
     return launch_nd2z<T, CFG>(a, s);
 }
 
-// FOUR work-groups per transform: shapes of four two-per-CU tiles (65536 points fp32 / 32768 fp64), query 3 = is there such a kernel
-template <typename T, int X, int Y, int Z> int go4(const TileArgs* a, hipStream_t s, int query) {
+// FOUR work-groups per transform: shapes of four two-per-CU tiles (65536 points fp32 / 32768 fp64), or one-tile fp64 shapes whose halves
+// spill, as quarters of 4096 points.  ALWAYS: preferred at every buffer size (query 2), else in small launches / where nothing else exists
+template <typename T, int X, int Y, int Z, bool ALWAYS = false> int go4(const TileArgs* a, hipStream_t s, int query) {
     constexpr bool F32 = sizeof(T) == 4;
-    if (query) return query == 2 ? -2 : 0;
+    if (query) return (query == 2 && !ALWAYS) ? -2 : 0;
     constexpr int MAXR = F32 ? 16 : 8;
     constexpr int QY = Z > 1 ? Y : Y / 4, QZ = Z > 1 ? Z / 4 : 1;
-    static_assert(X * QY * QZ == (F32 ? 16384 : 8192), "the quarters are big tiles");
-    using CFG = Nd2zCfg<T, X, Y, Z, 512, true, 4, typename AutoRadix<X, MAXR, true>::type, typename AutoRadix<QY, MAXR, false>::type,
+    constexpr int QP = X * QY * QZ;
+    constexpr bool BIGQ = QP == (F32 ? 16384 : 8192);
+    static_assert(BIGQ || QP == (F32 ? 8192 : 4096), "no tile form for this quarter");
+    using CFG = Nd2zCfg<T, X, Y, Z, 512, BIGQ, 4, typename AutoRadix<X, MAXR, true>::type, typename AutoRadix<QY, MAXR, false>::type,
                         typename AutoRadix<QZ, MAXR, false>::type, 4>;
     return launch_nd2z<T, CFG>(a, s);
 }
@@ -51,8 +54,13 @@ extern "C" int mifft_nd2z_f64(int x, int y, int z, const TileArgs* a, hipStream_
     // (two-per-CU shapes, small launches only: see fft_nd2z_f32.hip)
     SHAPE(double, 16, 512, 1) SHAPE(double, 32, 256, 1) SHAPE(double, 64, 128, 1) SHAPE(double, 128, 64, 1) SHAPE(double, 256, 32, 1)
     SHAPE(double, 512, 16, 1) SHAPE(double, 32, 16, 16) SHAPE(double, 16, 32, 16) SHAPE(double, 16, 16, 32)
-    // (four work-groups per transform: the fp64 kernels spill 370-550 bytes per lane at the two-per-CU register budget -- four 16-byte
-    // operands per kept point in flight -- and are not instantiated)
+    // (four work-groups per transform for 32768-point shapes: the fp64 kernels spill 370-550 bytes per lane at the two-per-CU register
+    // budget -- four 16-byte operands per kept point in flight, 16 points per thread -- and are not instantiated)
+    // the two one-tile fp64 shapes whose HALVES spill (84-96 bytes per lane), as FOUR quarters of 4096 points (8 points per thread, no
+    // spills; profiles/r05_nd2z_fp64_quarters_ab.log, 32 MiB | 256 MiB | 1 GiB per side): numpy (64, 16, 16) 0.373 -> 0.502 | 0.466 -> 0.505 |
+    // 0.509 -> 0.561: always; (128, 128) 0.462 -> 0.514 | 0.524 -> 0.545 | 0.606 -> 0.578: small launches only
+    if (x == 16 && y == 16 && z == 64) return go4<double, 16, 16, 64, true>(a, s, query);
+    if (x == 128 && y == 128 && z == 1) return go4<double, 128, 128, 1, false>(a, s, query);
 #undef SHAPE
     return -2;
 }

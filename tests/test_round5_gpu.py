@@ -374,10 +374,10 @@ def test_pair_chains_pipelined_chunks(ctx, shape, dtype, batch):
 
 
 # ---- one-tile-per-CU N-D shapes as two work-groups per transform (csrc/fft_nd2z.hpp) ------------------------------------------------
-ND2Z_SHAPES = {numpy.complex64: [(1024, 32), (512, 64), (256, 128), (128, 256), (32, 1024), (8, 64, 64), (16, 16, 128),
+ND2Z_SHAPES = {numpy.complex64: [(1024, 32), (512, 64), (256, 128), (128, 256), (32, 1024), (8, 64, 64), (16, 16, 128), (32, 32, 32),
                                  # (two-per-CU shapes: split in small launches only -- 11 transforms are one)
                                  (1024, 16), (512, 32), (256, 64), (128, 128), (64, 256), (32, 512), (16, 1024), (16, 32, 32), (32, 16, 32), (32, 32, 16)],
-               numpy.complex128: [(512, 32), (256, 64), (64, 256), (32, 512), (16, 32, 32), (16, 16, 64),
+               numpy.complex128: [(512, 32), (256, 64), (64, 256), (32, 512), (16, 32, 32), (16, 16, 64), (128, 128), (64, 16, 16),
                                   (512, 16), (256, 32), (128, 64), (64, 128), (32, 256), (16, 512), (16, 16, 32), (16, 32, 16), (32, 16, 16)]}
 
 

@@ -179,10 +179,10 @@ def emit(path, gib):
                              "pipelined": round(pipe[1], 4), "lag_ring_grid": list(fused[0][1:4])})
         if measured:
             new["measured"] = measured
-            wins = [m["persistent"] >= 0.99 * m["pipelined"] for m in measured]
-            if all(wins):
+            # (hysteresis: a default only changes on a clear verdict -- every shape of the rule 2 % ahead, or every shape 2 % behind)
+            if all(m["persistent"] >= 1.02 * m["pipelined"] for m in measured):
                 new.pop("on_request", None)
-            elif not any(wins):
+            elif all(m["persistent"] <= 0.98 * m["pipelined"] for m in measured):
                 new["on_request"] = True
         print("rule %-90s %s" % (rule["name"][:90], "on request" if new.get("on_request") else "default"), flush=True)
     out = "{\n"
