@@ -7,6 +7,7 @@
 // 0.555 -> 0.648, (512, 32) 0.556 -> 0.633.  Three shapes LOSE and have no instance here: fp32 32^3 (0.460 / 0.455: five stages of radix <=
 // 16 against three of radix 32), fp64 (128, 128) (0.631 -> 0.533) and fp64 numpy (64, 16, 16) (0.508 -> 0.486) -- their kernels spill 20-96
 // bytes per lane at the two-per-CU register budget.
+#include "../../include/mifft.h"
 #include "mifft_internal.h"
 #include "fft_nd2z.hpp"
 
@@ -60,8 +61,12 @@ extern "C" int mifft_nd2z(int f64, int x, int y, int z, const TileArgs* a, hipSt
     if (x == X && y == Y && z == Z) return go<T, X, Y, Z>(a, s, query);
 #define SHAPE4(T, X, Y, Z) \
     if (x == X && y == Y && z == Z) return go4<T, X, Y, Z>(a, s, query);
-    SHAPE(float, 32, 1024, 1) SHAPE(float, 64, 512, 1) SHAPE(float, 128, 256, 1) SHAPE(float, 256, 128, 1) SHAPE(float, 1024, 32, 1)
-    SHAPE(float, 64, 64, 8) SHAPE(float, 128, 16, 16)
+    SHAPE(float, 64, 512, 1) SHAPE(float, 128, 256, 1) SHAPE(float, 256, 128, 1) SHAPE(float, 64, 64, 8) SHAPE(float, 128, 16, 16)
+    // a 32-point axis as ONE radix-32 stage (three stages instead of five; profiles/r05_nd2z_radix32_lists_ab.log): numpy (1024, 32) 0.466 ->
+    // 0.536 at 1 GiB, 0.369 -> 0.417 at 32 MiB; (32, 1024) 0.566 -> 0.657, 0.404 -> 0.452.  (Radix-32 stages next to a small remainder --
+    // 64 = 2 x 32, 128 = 4 x 32 -- LOSE 3-7 points against 16 x 4 / 8 x 16 on the other shapes: those keep the automatic lists.)
+    if (x == 32 && y == 1024 && z == 1) return gox<float, 32, 1024, 1, RadixList<32>, RadixList<16, 32>, RadixList<>, 2, true>(a, s, query);
+    if (x == 1024 && y == 32 && z == 1) return gox<float, 1024, 32, 1, RadixList<32, 32>, RadixList<16>, RadixList<>, 2, true>(a, s, query);
     // 32^3: the x and y axes as ONE radix-32 stage each (three stages like the one-tile kernel; the automatic radix <= 16 lists take five
     // and measured 0.460 / 0.455): 0.467 -> 0.555 at 1 GiB, 0.434 -> 0.472 at 256 MiB, 0.323 -> 0.386 at 32 MiB
     // (profiles/r05_nd2z_cube32_radix32_and_eight_way_ab.log).  EIGHT work-groups per transform for (32, 32, 128) -- 131072 points, a shape
