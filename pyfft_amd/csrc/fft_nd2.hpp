@@ -340,8 +340,13 @@ template <typename T, int X, int Y, int Z> struct Nd2Auto {
     // first axis with more than one point takes the remainder factor first
     static constexpr bool XF = X > 1, YF = !XF && Y > 1;
     using RLX = typename AutoRadix<X, MAXR, true>::type;
-    using RLY = typename AutoRadix<Y, MAXR, YF>::type;
-    using RLZ = typename AutoRadix<Z, MAXR, false>::type;
+    // round 5: on the two-per-CU fp32 tiles (32 points per thread) a 32-point y or z axis is ONE radix-32 stage instead of 16 x 2 -- one
+    // LDS exchange less: (16, 32, 32) 0.647 -> 0.710, (32, 16, 32) 0.649 -> 0.714, (8, 32, 64) 0.635 -> 0.698, (32, 512) 0.587 -> 0.641,
+    // (32, 32, 16) 0.584 -> 0.624 at 1 GiB (profiles/r05_nd2_radix32_yz_axes_ab.log).  Not the x axis: a radix-32 FIRST stage measured 4-6
+    // points slower ((512, 32) 0.628 -> 0.592)
+    static constexpr bool R32 = BIG && F32;
+    using RLY = typename std::conditional<(R32 && Y == 32), RadixList<32>, typename AutoRadix<Y, MAXR, YF>::type>::type;
+    using RLZ = typename std::conditional<(R32 && Z == 32), RadixList<32>, typename AutoRadix<Z, MAXR, false>::type>::type;
     // the first stage reads runs of (X / first radix) points: straight from HBM when that is >= 128 bytes
     static constexpr bool EDGE_IN = HALF || (X > 1 && (X / RadixFirst<RLX>::value) * (int)sizeof(cplx<T>) >= 128);
 };
