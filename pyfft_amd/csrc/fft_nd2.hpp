@@ -345,6 +345,8 @@ template <typename T, int X, int Y, int Z> struct Nd2Auto {
     // (32, 32, 16) 0.584 -> 0.624 at 1 GiB (profiles/r05_nd2_radix32_yz_axes_ab.log).  Not the x axis: a radix-32 FIRST stage measured 4-6
     // points slower ((512, 32) 0.628 -> 0.592)
     static constexpr bool R32 = BIG && F32;
+    // (the fp64 analogue -- a 16-point y / z axis as one radix-16 stage on the 16-points-per-thread tiles -- measured no gain: (16, 16, 32)
+    // 0.711, (32, 16, 16) 0.711 against 0.713 / 0.701: those tiles already run at 0.70)
     using RLY = typename std::conditional<(R32 && Y == 32), RadixList<32>, typename AutoRadix<Y, MAXR, YF>::type>::type;
     using RLZ = typename std::conditional<(R32 && Z == 32), RadixList<32>, typename AutoRadix<Z, MAXR, false>::type>::type;
     // the first stage reads runs of (X / first radix) points: straight from HBM when that is >= 128 bytes
