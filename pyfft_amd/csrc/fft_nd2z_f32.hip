@@ -61,6 +61,8 @@ extern "C" int mifft_nd2z(int f64, int x, int y, int z, const TileArgs* a, hipSt
     if (x == X && y == Y && z == Z) return go<T, X, Y, Z>(a, s, query);
 #define SHAPE4(T, X, Y, Z) \
     if (x == X && y == Y && z == Z) return go4<T, X, Y, Z>(a, s, query);
+    // (the one-tile shapes as FOUR quarters of 8192 points in small launches: + 1-6 points at 32 MiB, - 4-10 at 128 MiB against two halves --
+    // profiles/r05_nd2z_small_launch_quarters_ab.log -- not adopted)
     SHAPE(float, 64, 512, 1) SHAPE(float, 128, 256, 1) SHAPE(float, 256, 128, 1) SHAPE(float, 64, 64, 8) SHAPE(float, 128, 16, 16)
     // a 32-point axis as ONE radix-32 stage (three stages instead of five; profiles/r05_nd2z_radix32_lists_ab.log): numpy (1024, 32) 0.466 ->
     // 0.536 at 1 GiB, 0.369 -> 0.417 at 32 MiB; (32, 1024) 0.566 -> 0.657, 0.404 -> 0.452.  (Radix-32 stages next to a small remainder --
