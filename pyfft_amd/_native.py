@@ -24,6 +24,7 @@ INTERLEAVED, SPLIT = 0, 1
 VARIANT_INTERLEAVED_ONLY = 2
 VARIANT_SPLIT_ONLY = 3
 VARIANT_OUT_OF_PLACE_ONLY = 4     # mifft_nd_shape_supported: several work-groups per transform, interleaved, input != output
+VARIANT_OUT_OF_PLACE_ANY_SIZE = 5  # ... and preferred at every buffer size
 PASS_COL, PASS_ROW, PASS_ND = 0, 1, 2
 FLAG_SRC_INTERLEAVED, FLAG_DST_INTERLEAVED = 1, 2
 FLAG_STREAM_SRC, FLAG_STREAM_DST = 4, 8

@@ -14,10 +14,12 @@
 using namespace mifft;
 
 namespace {
-// query: 1 = is there a kernel; 2 = is there one that is preferred at EVERY buffer size (the one-tile-per-CU shapes)
-template <typename T, int X, int Y, int Z> int go(const TileArgs* a, hipStream_t s, int query) {
+// query: 1 = is there a kernel; 2 = is there one that is preferred in LARGE launches too (beyond half the last-level cache per side): the
+// 32768 / 16384-point shapes unless LARGE_ONLY says the opposite -- preferred in large launches, not in small ones (shapes without a
+// one-tile kernel, where the plan chooses between this launch and its two-launch chain)
+template <typename T, int X, int Y, int Z, bool LARGE_ONLY = false> int go(const TileArgs* a, hipStream_t s, int query) {
     constexpr bool F32 = sizeof(T) == 4;
-    if (query) return (query == 2 && X * Y * Z != (F32 ? 32768 : 16384)) ? -2 : 0;
+    if (query) return (query == 2 && (LARGE_ONLY || X * Y * Z != (F32 ? 32768 : 16384))) ? -2 : 0;
     constexpr int MAXR = F32 ? 16 : 8;
     constexpr int HY = Z > 1 ? Y : Y / 2, HZ = Z > 1 ? Z / 2 : 1;
     // halves of 16384 (fp32) / 8192 (fp64) points: the "big" tile form, half-exchange stages; halves of half that size (the two-per-CU
@@ -64,6 +66,17 @@ extern "C" int mifft_nd2z(int f64, int x, int y, int z, const TileArgs* a, hipSt
     // (the one-tile shapes as FOUR quarters of 8192 points in small launches: + 1-6 points at 32 MiB, - 4-10 at 128 MiB against two halves --
     // profiles/r05_nd2z_small_launch_quarters_ab.log -- not adopted)
     SHAPE(float, 64, 512, 1) SHAPE(float, 128, 256, 1) SHAPE(float, 256, 128, 1) SHAPE(float, 64, 64, 8) SHAPE(float, 128, 16, 16)
+    // the other 32768-point shapes with axes of 16 points and up: they have NO one-tile kernel (tools/gen_nd2_tables.py lists eight) and ran
+    // two launches; out of place they are one launch now (the plan keeps its chain for in-place executes: MIFFT_VARIANT_OUT_OF_PLACE_ONLY).
+    // 1 GiB per side, two launches -> one (profiles/r05_nd2z_shapes_without_one_tile_kernel_ab.log): (16, 2048) 0.366 -> 0.583, (2048, 16) 0.343 ->
+    // 0.520, (64, 8, 64) 0.395 -> 0.538, (16, 128, 16) 0.358 -> 0.550, (128, 16, 16) 0.367 -> 0.542, (32, 16, 64) 0.350 -> 0.601, (32, 64, 16)
+    // 0.339 -> 0.524, (16, 64, 32) 0.388 -> 0.515, (16, 32, 64) 0.376 -> 0.485, (64, 16, 32) 0.388 -> 0.466, (64, 512) 0.379 -> 0.443; (64, 32, 16)
+    // lost (0.369 -> 0.337: its kernel spills 76 bytes per lane) and has no instance.  At 32 MiB five of them lose 1-6 points: LARGE_ONLY
+#define SHAPEL(T, X, Y, Z) \
+    if (x == X && y == Y && z == Z) return go<T, X, Y, Z, true>(a, s, query);
+    SHAPEL(float, 512, 64, 1) SHAPE(float, 2048, 16, 1) SHAPE(float, 16, 2048, 1) SHAPE(float, 64, 8, 64) SHAPEL(float, 16, 128, 16) SHAPE(float, 16, 16, 128)
+    SHAPEL(float, 64, 32, 16) SHAPE(float, 64, 16, 32) SHAPEL(float, 32, 64, 16) SHAPEL(float, 32, 16, 64) SHAPE(float, 16, 64, 32)
+#undef SHAPEL
     // a 32-point axis as ONE radix-32 stage (three stages instead of five; profiles/r05_nd2z_radix32_lists_ab.log): numpy (1024, 32) 0.466 ->
     // 0.536 at 1 GiB, 0.369 -> 0.417 at 32 MiB; (32, 1024) 0.566 -> 0.657, 0.404 -> 0.452.  (Radix-32 stages next to a small remainder --
     // 64 = 2 x 32, 128 = 4 x 32 -- LOSE 3-7 points against 16 x 4 / 8 x 16 on the other shapes: those keep the automatic lists.)

@@ -14,10 +14,12 @@
 using namespace mifft;
 
 namespace {
-// query: 1 = is there a kernel; 2 = is there one that is preferred at EVERY buffer size (the one-tile-per-CU shapes)
-template <typename T, int X, int Y, int Z> int go(const TileArgs* a, hipStream_t s, int query) {
+// query: 1 = is there a kernel; 2 = is there one that is preferred in LARGE launches too (beyond half the last-level cache per side): the
+// 32768 / 16384-point shapes unless LARGE_ONLY says the opposite -- preferred in large launches, not in small ones (shapes without a
+// one-tile kernel, where the plan chooses between this launch and its two-launch chain)
+template <typename T, int X, int Y, int Z, bool LARGE_ONLY = false> int go(const TileArgs* a, hipStream_t s, int query) {
     constexpr bool F32 = sizeof(T) == 4;
-    if (query) return (query == 2 && X * Y * Z != (F32 ? 32768 : 16384)) ? -2 : 0;
+    if (query) return (query == 2 && (LARGE_ONLY || X * Y * Z != (F32 ? 32768 : 16384))) ? -2 : 0;
     constexpr int MAXR = F32 ? 16 : 8;
     constexpr int HY = Z > 1 ? Y : Y / 2, HZ = Z > 1 ? Z / 2 : 1;
     // halves of 16384 (fp32) / 8192 (fp64) points: the "big" tile form, half-exchange stages; halves of half that size (the two-per-CU
@@ -51,6 +53,15 @@ extern "C" int mifft_nd2z_f64(int x, int y, int z, const TileArgs* a, hipStream_
     if (x == X && y == Y && z == Z) return go<T, X, Y, Z>(a, s, query);
     SHAPE(double, 32, 512, 1) SHAPE(double, 64, 256, 1) SHAPE(double, 256, 64, 1) SHAPE(double, 512, 32, 1)
     SHAPE(double, 32, 32, 16) SHAPE(double, 64, 16, 16)
+    // the other 16384-point shapes with x >= 16 (no one-tile kernel: two launches in place, one launch out of place -- see fft_nd2z_f32.hip)
+    // 1 GiB per side, two launches -> one: (16, 1024) 0.357 -> 0.524, (1024, 16) 0.339 -> 0.538, (8, 32, 64) 0.382 -> 0.656, (32, 8, 64) 0.388 -> 0.639,
+    // (8, 64, 32) 0.387 -> 0.642, (64, 8, 32) 0.371 -> 0.691, (4, 64, 64) 0.392 -> 0.683, (64, 4, 64) 0.360 -> 0.690, (32, 16, 32) 0.380 -> 0.602, (16, 64, 16)
+    // 0.382 -> 0.535, (32, 32, 16) 0.383 -> 0.470; the last two lose 1-4 points at 32 MiB: LARGE_ONLY
+#define SHAPEL(T, X, Y, Z) \
+    if (x == X && y == Y && z == Z) return go<T, X, Y, Z, true>(a, s, query);
+    SHAPE(double, 1024, 16, 1) SHAPE(double, 16, 1024, 1) SHAPE(double, 64, 32, 8) SHAPE(double, 64, 8, 32) SHAPE(double, 32, 64, 8) SHAPE(double, 32, 8, 64)
+    SHAPEL(double, 16, 64, 16) SHAPE(double, 32, 16, 32) SHAPEL(double, 16, 32, 32) SHAPE(double, 64, 64, 4) SHAPE(double, 64, 4, 64)
+#undef SHAPEL
     // (two-per-CU shapes, small launches only: see fft_nd2z_f32.hip)
     SHAPE(double, 16, 512, 1) SHAPE(double, 32, 256, 1) SHAPE(double, 64, 128, 1) SHAPE(double, 128, 64, 1) SHAPE(double, 256, 32, 1)
     SHAPE(double, 512, 16, 1) SHAPE(double, 32, 16, 16) SHAPE(double, 16, 32, 16) SHAPE(double, 16, 16, 32)

@@ -662,9 +662,11 @@ int mifft_nd_shape_supported(int32_t precision, int32_t x, int32_t y, int32_t z,
         // rows, measured 0.285 against 0.307 for its two passes and keeps them -- profiles/r04_at_rows_split.log)
         return (g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 && g_debug[MIFFT_DEBUG_NO_ND2] == 0 && x * (precision == MIFFT_F64 ? 8 : 4) >= 256 &&
                 mifft_nd2t_split(precision == MIFFT_F64, x, y, z, nullptr, nullptr, nullptr, 1) == 0) ? 0 : MIFFT_E_UNSUPPORTED;
-    if (variant == MIFFT_VARIANT_OUT_OF_PLACE_ONLY)   // interleaved on both sides AND out of place: several work-groups per transform (fft_nd2z.hpp)
+    if (variant == MIFFT_VARIANT_OUT_OF_PLACE_ONLY || variant == MIFFT_VARIANT_OUT_OF_PLACE_ANY_SIZE)
+        // interleaved on both sides AND out of place: several work-groups per transform (fft_nd2z.hpp)
         return (g_debug[MIFFT_DEBUG_NO_ND2] == 0 && g_debug[MIFFT_DEBUG_ALT_ROWS] != 6 &&
-                mifft_nd2z(precision == MIFFT_F64 ? 1 : 0, x, y, z, nullptr, nullptr, 1) == 0) ? 0 : MIFFT_E_UNSUPPORTED;
+                mifft_nd2z(precision == MIFFT_F64 ? 1 : 0, x, y, z, nullptr, nullptr, variant == MIFFT_VARIANT_OUT_OF_PLACE_ONLY ? 1 : 2) == 0)
+                   ? 0 : MIFFT_E_UNSUPPORTED;
     if (variant != MIFFT_VARIANT_INTERLEAVED_ONLY) return MIFFT_E_UNSUPPORTED;
     const int rc = precision == MIFFT_F64 ? mifft_nd2_f64_supported(x, y, z) : mifft_nd2_f32_supported(x, y, z);
     return rc == 0 ? 0 : MIFFT_E_UNSUPPORTED;

@@ -174,10 +174,13 @@ class FFTPlan(object):
         # planes its partners still read).  The plan keeps its chain for in-place executes and this one-pass list for the others.
         self._oop_nd = None
         self._oop_tables = None
+        self._oop_any_size = False
         if not p.split and len(P.launch_units(self._kernels)) >= 2 and \
                 N.lib.mifft_nd_shape_supported(p.precision, int(p.x), int(p.y), int(p.z), N.VARIANT_OUT_OF_PLACE_ONLY) == 0:
             self._oop_nd = [P.PassSpec(N.PASS_ND, P.X_DIRECTION, p.size, int(p.x), int(p.y), int(p.z), 1, p.size, True)]
             self._oop_tables = self._pass_tables(self._oop_nd)
+            # (two halves on two-per-CU tiles: better than the two launches at every size; four quarters: beyond half the cache per side)
+            self._oop_any_size = N.lib.mifft_nd_shape_supported(p.precision, int(p.x), int(p.y), int(p.z), N.VARIANT_OUT_OF_PLACE_ANY_SIZE) == 0
         # 3-D shapes whose chain is a plane pass + a strided z pass but that have a persistent two-pair kernel (64- and 128-point axes,
         # csrc/fft_fusedp2.hip): the four-pass list with the y axis factored R0 x R1 exists for that launch alone
         self._pair_alt = None
@@ -499,7 +502,7 @@ class FFTPlan(object):
         ctx = self._context
         stream = ctx.stream_handle()
         if self._oop_nd is not None and not is_inplace and not D.no_oop_nd() and D.forced_strategy() == "auto" and \
-                batch * self._params.size * self._params.complex_nbytes > ctx.machine.write_through_max_bytes:
+                (self._oop_any_size or batch * self._params.size * self._params.complex_nbytes > ctx.machine.write_through_max_bytes):
             # one launch, several work-groups per transform (csrc/fft_nd2z.hpp); needs no scratch.  Beyond half the last-level cache per
             # side: (256, 256) at 256 MiB 0.339 -> 0.444, at 2 GiB 0.464 (persistent) -> 0.501; at 32 MiB the two launches win (0.404 / 0.356)
             descs = self._descriptors(batch, False, bool(inverse), alt=2)
