@@ -67,6 +67,9 @@ extern "C" int mifft_nd2z_f64(int x, int y, int z, const TileArgs* a, hipStream_
     SHAPE(double, 512, 16, 1) SHAPE(double, 32, 16, 16) SHAPE(double, 16, 32, 16) SHAPE(double, 16, 16, 32)
     // (four work-groups per transform for 32768-point shapes: the fp64 kernels spill 370-550 bytes per lane at the two-per-CU register
     // budget -- four 16-byte operands per kept point in flight, 16 points per thread -- and are not instantiated)
+    // (fp64 (16, 16, 128), 32768 points, a shape of the reference's own benchmark list: four quarters of 8192 points on 1024 threads x 8 points
+    // -- the 512-thread form spills 488 bytes per lane -- measured 0.347 against 0.401 for its two launches at 256 MiB and 0.369 / 0.369 at 1 GiB:
+    // not instantiated)
     // the two one-tile fp64 shapes whose HALVES spill (84-96 bytes per lane), as FOUR quarters of 4096 points (8 points per thread, no
     // spills; profiles/r05_nd2z_fp64_quarters_ab.log, 32 MiB | 256 MiB | 1 GiB per side): numpy (64, 16, 16) 0.373 -> 0.502 | 0.466 -> 0.505 |
     // 0.509 -> 0.561: always; (128, 128) 0.462 -> 0.514 | 0.524 -> 0.545 | 0.606 -> 0.578: small launches only
