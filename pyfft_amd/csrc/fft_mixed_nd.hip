@@ -130,8 +130,9 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) ff
         const cplx<T>* src = first ? gin : lds;
         cplx<T>* dst = last ? gout : lds;
         const int total = points / R;
-        if (first && last) nd_switch<T, NT, true, true>(R, src, dst, tw, a.st_n[s], a.st_inner[s], a.st_ns[s], a.inv_inner[s], a.inv_lr[s], a.inv_ns[s], total, csign, sx, sy);
-        else if (first) nd_switch<T, NT, true, false>(R, src, dst, tw, a.st_n[s], a.st_inner[s], a.st_ns[s], a.inv_inner[s], a.inv_lr[s], a.inv_ns[s], total, csign, sx, sy);
+        // (a list has at least two stages -- the launcher sees to it: rows of a single radix, n <= 16, run the row kernel of fft_mixed.hip;
+        // the HBM -> HBM form of every radix would be a quarter of this unit's compile time)
+        if (first) nd_switch<T, NT, true, false>(R, src, dst, tw, a.st_n[s], a.st_inner[s], a.st_ns[s], a.inv_inner[s], a.inv_lr[s], a.inv_ns[s], total, csign, sx, sy);
         else if (last) nd_switch<T, NT, false, true>(R, src, dst, tw, a.st_n[s], a.st_inner[s], a.st_ns[s], a.inv_inner[s], a.inv_lr[s], a.inv_ns[s], total, csign, sx, sy);
         else nd_switch<T, NT, false, false>(R, src, dst, tw, a.st_n[s], a.st_inner[s], a.st_ns[s], a.inv_inner[s], a.inv_lr[s], a.inv_ns[s], total, csign, sx, sy);
     }
@@ -206,7 +207,7 @@ extern "C" int mifft_mixed_nd_supported_impl(int f64, int nx, int ny, int nz) {
 extern "C" int mifft_mixed_nd_rows_ok_impl(int f64, int n) {
     if (n < 2 || n > (f64 ? kNdTilePoints64 : kNdTilePoints32)) return -2;
     int hold = 0;
-    if (nd_stages(f64, n, 1, 1, nullptr, &hold) < 1) return -2;
+    if (nd_stages(f64, n, 1, 1, nullptr, &hold) < 2) return -2;
     return n <= 512 * hold ? 0 : -2;
 }
 
@@ -216,7 +217,7 @@ extern "C" int mifft_mixed_nd_launch(int f64, int nx, int ny, int nz, long long 
     MixedNdArgs a;
     int hold = 0;
     a.nstages = nd_stages(f64, nx, ny, nz, &a, &hold);
-    if (a.nstages < 1 || (long long)nx * ny * nz > 512ll * hold) return -2;
+    if (a.nstages < 2 || (long long)nx * ny * nz > 512ll * hold) return -2;
     a.in = in; a.out = out;
     a.tw[0] = twx; a.tw[1] = twy; a.tw[2] = twz;
     a.transforms = transforms;

@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 
 # 1. kernel stats + PMC traffic of the same command, per configuration (writes profiles/traffic_<c>.json and
 #    profiles/<tag>_<c>_kernel_stats.csv)
-timeout 2400 python3 tools/pmc_traffic.py --tag $TAG c2 c3 c4 c4s c5 cube cubed c2s > $OUT/pmc_traffic.log 2>&1
+timeout 2400 python3 tools/pmc_traffic.py --tag $TAG c2 c3 c4 c4s c5 cube cubed c2s c3s > $OUT/pmc_traffic.log 2>&1
 cp $OUT/pmc_traffic.log $P/${TAG}_pmc_traffic.log
 cp profiles/traffic_*.json profiles/${TAG}_*_kernel_stats.csv $P/ 2>/dev/null
 
