@@ -234,7 +234,8 @@ def test_fused_two_pass_kernel(ctx, monkeypatch, n, batch):
         assert numpy.array_equal(want, got), "fused kernel differs from the two-launch chain"
     got_ip = _run_strategy(ctx, monkeypatch, "fused", (n,), batch, data, inplace=True)
     assert numpy.array_equal(got, got_ip), "fused in-place differs"
-    for item in (0, batch // 2, batch - 1):
+    # (2^21 has no bit-identity with the chain to lean on: every fourth transform against numpy instead of three)
+    for item in (range(0, batch, 4) if n == 1 << 21 else (0, batch // 2, batch - 1)):
         ref = numpy.fft.fft(data[item * n:(item + 1) * n].astype(numpy.complex128))
         g = got[item * n:(item + 1) * n]
         assert numpy.abs(ref - g).sum() / numpy.abs(ref).sum() < 1.1e-6

@@ -190,7 +190,8 @@ CAPTURE_CASES = [((1 << 18,), 160, numpy.complex64, "fused2"),        # 28 / 56 
                  ((128, 128, 128), 32, numpy.complex64, "fusedp"),
                  ((1024, 1024), 64, numpy.complex64, "fused2"),       # the 2-D form
                  ((1 << 16,), 96, numpy.complex64, "chain"),
-                 ((512, 1024), 80, numpy.complex128, "fused2")]
+                 ((512, 1024), 80, numpy.complex128, "fused2"),
+                 ((256, 4096), 40, numpy.complex64, "pipelined")]     # chunks on the plan's side streams: forked from and joined to the capturing stream
 
 
 @pytest.mark.parametrize("shape,batch,dtype,strategy", CAPTURE_CASES, ids=lambda v: getattr(v, "__name__", str(v)))
@@ -239,6 +240,60 @@ def test_captured_execute_replays_bit_identically(ctx, shape, batch, dtype, stra
         with hip.Graph(s):
             plan.execute(a, b, batch=batch - 1)
     s.synchronize()
+
+
+THREAD_CASES = [((1 << 18,), 160, numpy.complex64, "fused2"), ((128, 128, 128), 32, numpy.complex64, "fusedp"),
+                ((1024, 1024), 40, numpy.complex128, "fused2"), ((16, 16, 128), 512, numpy.complex64, "chain")]
+
+
+def test_plans_of_four_host_threads_run_side_by_side(ctx):
+    """The library keeps no mutable state between plans (re-entrant): four host threads, each with a plan, a stream,
+    scratch and counters of its own -- three of them persistent launches, which then share the CUs and poll their own counters -- execute
+    concurrently, six executes each, alternating out of place and in place.  Every thread's results carry the bits of the same plan run
+    alone, the error words stay clean.  (One PLAN is one thread's at a time, as the reference's: pyfft/plan.py:200-259 keeps the temp
+    buffer in the plan.)"""
+    import threading
+    hip = ctx.hip
+    jobs = []
+    for i, (shape, batch, dtype, strategy) in enumerate(THREAD_CASES):
+        size = int(numpy.prod(shape))
+        data = _tiled_noise(size * batch, dtype, 700 + i)
+        st = hip.Stream()
+        plan = hip.Plan(shape if len(shape) > 1 else shape[0], dtype=dtype, stream=st)
+        assert plan.strategy(batch)[0] == strategy, plan.strategy(batch)
+        a, b = hip.to_gpu(data), hip.DeviceArray((size * batch,), dtype)
+        plan.execute(a, b, batch=batch)
+        st.synchronize()
+        want = b.get().view(numpy.uint32)
+        plan.execute(b, batch=batch, inverse=True)          # (in place, the other direction: the second thing every thread does)
+        st.synchronize()
+        back = b.get().view(numpy.uint32)
+        jobs.append(dict(plan=plan, stream=st, a=a, b=b, batch=batch, want=want, back=back, errors=[]))
+    gate = threading.Barrier(len(jobs))
+
+    def work(j):
+        try:
+            gate.wait(timeout=60)
+            for rep in range(3):
+                j["plan"].execute(j["a"], j["b"], batch=j["batch"])
+                j["stream"].synchronize()
+                if not numpy.array_equal(j["b"].get().view(numpy.uint32), j["want"]):
+                    j["errors"].append(("forward", rep))
+                j["plan"].execute(j["b"], batch=j["batch"], inverse=True)
+                j["stream"].synchronize()
+                if not numpy.array_equal(j["b"].get().view(numpy.uint32), j["back"]):
+                    j["errors"].append(("inverse in place", rep))
+            j["plan"].finish()
+        except Exception as e:                               # (a worker's exception must fail the test, not vanish with the thread)
+            j["errors"].append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a worker hangs"
+    assert [j["errors"] for j in jobs] == [[] for _ in jobs]
 
 
 def test_direct_abi_two_set_launch_refuses_capture_and_null_error_word(ctx):
