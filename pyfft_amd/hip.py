@@ -15,6 +15,7 @@ doc/source/index.rst:243-246, cuda.py:36-39).
 """
 
 import ctypes
+import gc
 
 import numpy
 
@@ -191,24 +192,46 @@ class Graph(object):
 
     A captured execute of a persistent strategy runs on a counter set of its own with the memset as a node of the graph, so replays
     and eager executes of the same plan may alternate on one stream.  A torch.cuda.graph() capture around execute() works the
-    same way (the plan follows torch's current stream)."""
+    same way (the plan follows torch's current stream).
+
+    Do not drop the last reference to a plan, a stream or a pinned buffer inside the block: releasing them synchronises the device,
+    which invalidates an active capture (measured: one run in four of the capture tests failed with "operation not permitted when
+    stream is capturing" when the cyclic collector happened to fire inside the window -- hence the collect-and-pause in __enter__)."""
 
     def __init__(self, stream):
         self.stream = stream
         self.handle = None
 
     def __enter__(self):
-        N.check(N.lib.mifft_stream_begin_capture(_stream_handle(self.stream)), "mifft_stream_begin_capture")
+        # an object that frees device memory when it is collected (a DeviceArray, a plan's scratch) would do so at an arbitrary point of
+        # the capture window -- hipFree synchronises the device, which a capturing stream refuses and which invalidates the capture:
+        # collect now, and keep the cyclic collector off until the capture has ended (torch.cuda.graph() collects first for the same reason)
+        gc.collect()
+        self._gc_was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            N.check(N.lib.mifft_stream_begin_capture(_stream_handle(self.stream)), "mifft_stream_begin_capture")
+        except Exception:
+            if self._gc_was_enabled:
+                gc.enable()
+            raise
         return self
 
     def __exit__(self, etype, evalue, tb):
         h = ctypes.c_void_p()
-        rc = N.lib.mifft_stream_end_capture(_stream_handle(self.stream), ctypes.byref(h))
+        try:
+            rc = N.lib.mifft_stream_end_capture(_stream_handle(self.stream), ctypes.byref(h))
+        finally:
+            if self._gc_was_enabled:
+                gc.enable()
         if etype is None:
             N.check(rc, "mifft_stream_end_capture")
             self.handle = h.value
         elif rc == 0 and h.value:
             N.lib.mifft_graph_destroy(h.value)
+        elif rc != 0:
+            # the body failed AND the capture could not be ended (it was invalidated): say both, the stream may still be capturing
+            raise RuntimeError("pyfft_amd: the capture could not be ended after %r: %s" % (evalue, N.last_error())) from evalue
         return False
 
     def launch(self, stream=None):

@@ -236,9 +236,10 @@ def test_captured_execute_replays_bit_identically(ctx, shape, batch, dtype, stra
             assert numpy.array_equal(b.get().view(numpy.uint32), want), ("eager after replay", i)
     plan.finish()                                       # raises if any launch reported a dependency time-out
     # a batch the plan has not run yet cannot be captured (its scratch would be allocated inside the capture): loud, not wrong
-    with pytest.raises(RuntimeError):
+    with pytest.raises(RuntimeError, match="eager execute"):
         with hip.Graph(s):
             plan.execute(a, b, batch=batch - 1)
+    assert not plan._context.capturing()                # (the failed body left no capture behind)
     s.synchronize()
 
 
