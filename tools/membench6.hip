@@ -40,7 +40,8 @@ template <int U, bool NTL, bool NTS> __global__ void __launch_bounds__(256) k_ch
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool only2 = argc > 1 && argv[1][0] == '2';
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const size_t MAXB = (size_t)4 << 30;
@@ -58,6 +59,7 @@ int main() {
     };
     size_t sizes[] = {256, 1024, 4096};
     for (size_t mib : sizes) {
+        if (only2) break;
         const size_t bytes = mib << 20, n = bytes / 16;
         const f4* a = (const f4*)A; f4* b = (f4*)B;
         printf("---- %zu MiB per side (GB/s, read + write)\n", mib);
@@ -69,6 +71,26 @@ int main() {
 #define CHUNK(U, NTL, NTS) for (int k : {1, 2, 4, 8}) printf("chunk-owner  ntl=%d nts=%d U=%-2d grid=256x%-2d %8.0f\n", NTL, NTS, U, k, timeit([&] { hipLaunchKernelGGL((k_chunk<U, NTL, NTS>), dim3(256 * k), dim3(256), 0, st, a, b, n); }, bytes));
         CHUNK(4, false, false) CHUNK(8, false, false) CHUNK(8, true, true)
         fflush(stdout);
+    }
+    // two-step copy A -> X -> B over 4 GiB in chunks, X a scratch of the given size that is reused every chunk (the shape of a two-pass
+    // transform whose intermediate lives in the Infinity Cache): one-shot kernels, A streamed in with / without the non-temporal hint, X
+    // written and read with plain accesses, B streamed out with / without the hint; chunk c + 1's first step is queued behind chunk c's second
+    {
+        const size_t total = (size_t)4 << 30;
+        char* X; CK(hipMalloc(&X, (size_t)512 << 20));
+        printf("---- two-step copy A -> X -> B, 4 GiB per side; GB/s algorithmic = 2 x 4 GiB / time (the fabric sees twice that)\n");
+        for (size_t xm : {32, 64, 96, 128, 192}) {
+            const size_t xb = xm << 20, xn = xb / 16;
+#define TWOSTEP(U, NT) { \
+                auto fn = [&] { for (size_t off = 0; off + xb <= total; off += xb) { \
+                    hipLaunchKernelGGL((k_tile<U, NT, false>), dim3((unsigned)(xn / (256 * U))), dim3(256), 0, st, (const f4*)(A + off), (f4*)X, xn); \
+                    hipLaunchKernelGGL((k_tile<U, false, NT>), dim3((unsigned)(xn / (256 * U))), dim3(256), 0, st, (const f4*)X, (f4*)(B + off), xn); } }; \
+                fn(); CK(hipStreamSynchronize(st)); float best = 1e30f; \
+                for (int r3 = 0; r3 < 3; ++r3) { CK(hipEventRecord(e0, st)); fn(); fn(); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms / 2 < best) best = ms / 2; } \
+                printf("X = %3zu MiB  U=%-2d nt=%d   %8.0f\n", xm, U, (int)NT, 2.0 * (total / xb * xb) / best / 1e6); }
+            TWOSTEP(1, false) TWOSTEP(4, false) TWOSTEP(4, true) TWOSTEP(8, true) TWOSTEP(16, false)
+            fflush(stdout);
+        }
     }
     return 0;
 }
