@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5: whole GPU suite on the default library, then the development library's own tests (PYFFT_AMD_DEV_BUILD=1 -> libmifft_dev.so)
 set -u
-OUT=gpurun_out/r05v
+OUT=gpurun_out/r05v2
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 timeout 1500 python -m pytest tests -m gpu -x -q --durations=12 > $OUT/tests_gpu.log 2>&1
