@@ -337,6 +337,15 @@ def stats(xs):
     return {"median": med, "min": xs[0], "max": xs[-1], "n": n}
 
 
+_T0 = time.perf_counter()
+
+
+def _trace(label):
+    """BENCH_TRACE=1: where a run's wall time goes, per rank, on stderr (development)."""
+    if os.environ.get("BENCH_TRACE"):
+        sys.stderr.write("bench.py trace rank %s %7.2f s  %s\n" % (os.environ.get("RANK", "0"), time.perf_counter() - _T0, label))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -397,12 +406,14 @@ def main():
 
     # ---- synthetic data: one host block of <= 64 transforms (tiled across the batch on the device further down)
     blk, host_re, host_im, host_c = make_host_block(shape, dtname, batch, seed, gstart)
+    _trace("host block made")
 
     # ---- CPU baseline first: rank 0 (at every world size: the other ranks wait in init_process_group), before this process
     # initialises the GPU (the pool forks) -- numpy.fft on the box's host cores in the same run, as north_star words it
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(shape, dtname, host_c[:min(blk, 16)], flop_per_xform, budget_s=args.cpu_budget)
+    _trace("cpu baseline done (rank 0 only)")
 
     torch = None
     try:
@@ -423,6 +434,7 @@ def main():
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ["MASTER_PORT"] = str(_free_port())
         dist.init_process_group(args.control, rank=rank, world_size=world)
+    _trace("process group up")
 
     from pyfft_amd import _native as N
     from pyfft_amd.hip import Plan, DeviceArray, Event, device_props
@@ -459,6 +471,7 @@ def main():
     del host_re, host_im
 
     plan = Plan(shape if len(shape) > 1 else shape[0], dtype=dtype, wait_for_finish=False)
+    _trace("device buffers filled, plan built")
     stream = plan._context.getQueue()
 
     def execute(inplace, inverse=False):
@@ -568,6 +581,7 @@ def main():
         if not parity["ok"]:
             raise SystemExit("PARITY FAILURE: %r" % (parity,))
 
+    _trace("parity gate passed")
     # ---- warm-up, then EXACTLY K timed steps bracketed by barrier + device sync on both sides
     for w in range(args.warmup):
         if resident:
@@ -605,6 +619,7 @@ def main():
         rank_report = [{"rank": r, "first_transform": int(g[0].item()), "count": int(g[1].item()), "parity_ok": bool(g[2].item() > 0.5),
                         "difference": float(g[3].item()), "device": int(g[4].item())} for r, g in enumerate(gathered)]
 
+    _trace("timed steps done, ranks gathered")
     # ---- the reference's timing protocol (untimed for `value`): out of place AND in place, median of >= 5 repeats of a
     # block of back-to-back executes between two HIP events (test/test_performance.py:22-30 times 10 executes once;
     # cuda/test.cu:37-64 times both forms).  In place alternates forward / inverse so that the values stay bounded.

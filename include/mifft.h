@@ -304,6 +304,8 @@ int mifft_launch_chain(const mifft_pass *passes, int32_t npasses, void *const bu
  *     (per plane for split layout);  bufs*[2] (temp), when the schedule uses it, must hold nside * chunk items.
  *   - ordering: side streams wait for everything enqueued on `stream` so far; `stream` waits for all side
  *     streams before the call's work counts as done.  events[0..nside] are caller-owned scratch events.
+ *   - nside == 1 with side[0] == stream: the chunks run in order on `stream` itself, no fork, no join, no event is touched -- what to
+ *     pass while `stream` is being captured (a linear graph; forked captures of this launch crashed hipGraphLaunch now and then).
  */
 int mifft_launch_chain_pipelined(const mifft_pass *passes, int32_t npasses, void *const bufs0[3], void *const bufs1[3],
                                  int64_t batch, int64_t chunk, int64_t item_elems, mifft_stream_t stream,

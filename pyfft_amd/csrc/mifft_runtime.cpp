@@ -1133,13 +1133,19 @@ int mifft_launch_chain_pipelined(const mifft_pass* passes, int32_t npasses, void
         if (passes[i].dst == 2 && (passes[i].flags & MIFFT_FLAG_DST_INTERLEAVED)) tmp_interleaved = true;
     }
     const int64_t tbytes = (tmp_interleaved ? 2 : 1) * (f64 ? 8 : 4);
-    int rc = hip_check(hipEventRecord((hipEvent_t)events[0], (hipStream_t)stream), "hipEventRecord");
-    if (rc) return rc;
+    // nside == 1 with side[0] == stream: the chunks in order on the caller's own stream, no fork and no join (what a plan asks for when
+    // its stream is being captured into a graph: a linear graph)
+    const bool inline_chunks = nside == 1 && side[0] == stream;
+    int rc = 0;
     const int64_t nchunks = (batch + chunk - 1) / chunk;
     const int used = (int)(nchunks < nside ? nchunks : nside);
-    for (int s = 0; s < used; ++s) {
-        rc = hip_check(hipStreamWaitEvent((hipStream_t)side[s], (hipEvent_t)events[0], 0), "hipStreamWaitEvent");
+    if (!inline_chunks) {
+        rc = hip_check(hipEventRecord((hipEvent_t)events[0], (hipStream_t)stream), "hipEventRecord");
         if (rc) return rc;
+        for (int s = 0; s < used; ++s) {
+            rc = hip_check(hipStreamWaitEvent((hipStream_t)side[s], (hipEvent_t)events[0], 0), "hipStreamWaitEvent");
+            if (rc) return rc;
+        }
     }
     for (int64_t c = 0; c < nchunks; ++c) {
         const int64_t nb = (c + 1) * chunk <= batch ? chunk : batch - c * chunk;
@@ -1163,7 +1169,7 @@ int mifft_launch_chain_pipelined(const mifft_pass* passes, int32_t npasses, void
             i += used;
         }
     }
-    for (int s = 0; s < used; ++s) {
+    for (int s = 0; s < used && !inline_chunks; ++s) {
         rc = hip_check(hipEventRecord((hipEvent_t)events[1 + s], (hipStream_t)side[s]), "hipEventRecord");
         if (rc) return rc;
         rc = hip_check(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)events[1 + s], 0), "hipStreamWaitEvent");

@@ -552,8 +552,16 @@ class FFTPlan(object):
                 raise
         elif strat[0] == "pipelined":
             _, chunk, nside, nslab = strat
-            side = (ctypes.c_void_p * nside)(*[s.handle for s in self._side_streams])
-            evs = (ctypes.c_void_p * (nside + 1))(*[e.handle for e in self._side_events])
+            if ctx.capturing():
+                # recorded into a graph: the chunks one after the other on the capturing stream itself (the library skips the fork / join
+                # when the only "side" stream IS the caller's) -- the same launches on the same chunks, hence the same bits, as a LINEAR
+                # graph.  A forked capture replayed correctly most of the time and took the process down in hipGraphLaunch once in
+                # five runs (ROCm 7.2: profiles/r05_capture_pipelined_crash.log), and a replayed graph has no launch gaps to hide anyway.
+                nside = 1
+                side = (ctypes.c_void_p * 1)(stream)
+            else:
+                side = (ctypes.c_void_p * nside)(*[s.handle for s in self._side_streams])
+            evs = (ctypes.c_void_p * (nside + 1))(*[e.handle for e in self._side_events[:nside + 1]])
             npass = len(self._kernels)
             first = 0
             if nslab > 1:
