@@ -190,7 +190,7 @@ def _pool_fft(i):
     return 0
 
 
-def cpu_baseline(shape, dtype, host_items, flop_per_xform, budget_s=24.0):
+def cpu_baseline(shape, dtype, host_items, flop_per_xform, budget_s=24.0, max_workers=0):
     """CPU figures on this box's host cores for the same transforms.  Runs BEFORE this process
     initialises the GPU (the process pool forks).  host_items: array [n, *shape] of the very data the GPU transforms.
     The reference has no CPU implementation of its own: its CPU path is numpy.fft (test/test_errors.py:5-16,35), which is
@@ -200,7 +200,9 @@ def cpu_baseline(shape, dtype, host_items, flop_per_xform, budget_s=24.0):
     global _POOL_ITEMS
     res = {}
     axes = tuple(range(1, host_items.ndim))
-    cores = os.cpu_count() or 1
+    cores = host_cores = os.cpu_count() or 1
+    if max_workers > 0:                 # (tests: a pool of 256 processes costs ten seconds to start and stop whatever the budget)
+        cores = min(cores, max_workers)
     n = host_items.shape[0]
     part = budget_s / 4.0
     # (1) numpy.fft (pocketfft, one thread)
@@ -286,7 +288,7 @@ def cpu_baseline(shape, dtype, host_items, flop_per_xform, budget_s=24.0):
            "impl": impl + " -- the reference's own CPU path (test/test_errors.py:35)",
            "sample": "%d transforms drawn from %d items of the same %s %s data the GPU transforms (host copy), nominal 5*N*log2(N) flop" %
                      (sample, n, "x".join(map(str, shape)), dtype),
-           "host_cores": cores}
+           "host_cores": host_cores}
     out.update(res)
     return out
 
@@ -357,6 +359,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="repeats of the out-of-place / in-place protocol blocks (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=24.0, help="seconds of host time the CPU baseline may take (default 24)")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="cap on the host cores the CPU baseline uses (default 0 = all of them; tests)")
     ap.add_argument("--plain", action="store_true", help="only parity + warm-up + the K timed steps (no protocol repeats, per-pass timing or CPU baseline): profiler runs")
     ap.add_argument("--chunk-only", action="store_true",
                     help="config c5: time K executes of ONE resident 256-transform chunk (8 GiB in + 8 GiB out, out of place) instead of "
@@ -412,7 +415,7 @@ def main():
     # initialises the GPU (the pool forks) -- numpy.fft on the box's host cores in the same run, as north_star words it
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(shape, dtname, host_c[:min(blk, 16)], flop_per_xform, budget_s=args.cpu_budget)
+        cpu = cpu_baseline(shape, dtname, host_c[:min(blk, 16)], flop_per_xform, budget_s=args.cpu_budget, max_workers=args.cpu_workers)
     _trace("cpu baseline done (rank 0 only)")
 
     torch = None

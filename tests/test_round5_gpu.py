@@ -149,7 +149,7 @@ def test_eight_ranks_share_one_gpu(tmp_path):
     batch = 64                                                # per rank: 512 MiB per side -- the persistent kernel of the headline path in every process
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--control", "gloo", "--share-gpu",
                           "--config", "c2", "--batch", str(batch), "--steps", "2", "--warmup", "1", "--repeats", "0",
-                          "--cpu-budget", "1", "--dump-dir", str(tmp_path)],
+                          "--cpu-budget", "1", "--cpu-workers", "16", "--dump-dir", str(tmp_path)],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
