@@ -19,7 +19,7 @@ import numpy
 from pyfft_amd.hip import Plan, DeviceArray, Event
 from pyfft_amd import _native as N
 
-KEYS = ("PYFFT_AMD_STRATEGY", "PYFFT_AMD_FUSED_RING", "PYFFT_AMD_FUSEDX", "PYFFT_AMD_FUSED3", "PYFFT_AMD_FUSED_WGS", "PYFFT_AMD_PIPE_MB",
+KEYS = ("PYFFT_AMD_STRATEGY", "PYFFT_AMD_FUSED_RING", "PYFFT_AMD_FUSEDX", "PYFFT_AMD_FUSED3", "PYFFT_AMD_FUSED_WGS", "PYFFT_AMD_PIPE_MB", "PYFFT_AMD_PIPE_STREAMS",
         "PYFFT_AMD_FUSED_MEMSET", "PYFFT_AMD_NO_FUSEDX", "PYFFT_AMD_SMALL_FUSED", "MIFFT_PAIR", "MIFFT_NARROW_TILES", "PYFFT_AMD_SPLIT_FUSEDX", "PYFFT_AMD_NO_SPLIT_ROWFIRST", "MIFFT_STORE", "PYFFT_AMD_NO_OOP_ND")
 
 
