@@ -112,7 +112,8 @@ typedef struct mifft_pass {
     int32_t layout;      /* MIFFT_INTERLEAVED | MIFFT_SPLIT (same for input and output) */
     int32_t inverse;     /* 0 forward (numpy.fft.fft sign), 1 inverse (unnormalised unless `scale`) */
     int32_t L;           /* transform length of this launch (the radix of the pass) */
-    int32_t variant;     /* kernel variant selector, 0 = library default (the only value a launch takes) */
+    int32_t variant;     /* kernel variant selector: 0 = library default; 1 = the generic kernel of the kind (COL / ROW: the LDS tile kernel; ND: the
+                          * run-time-shaped kernel instead of the shape's fixed instance -- the plan's choice for the shapes listed in the tuning table) */
     int64_t M;           /* not-yet-transformed extent of the axis after this pass (COL), 1 for ROW */
     int64_t S;           /* extent of everything faster than the digit being transformed (COL), 1 for ROW */
     int64_t outer;       /* number of independent matrices / rows */

@@ -15,6 +15,11 @@ def pipeline_chunk_bytes(default):
     return (int(os.environ.get("PYFFT_AMD_PIPE_MB", "0")) << 20) or default
 
 
+def no_nd_generic():
+    """A/B: one-launch N-D passes always on the shape's fixed instance (ignore the tuning table's "nd_generic" list)."""
+    return bool(os.environ.get("PYFFT_AMD_NO_ND_GENERIC"))
+
+
 def pipeline_streams(default):
     return int(os.environ.get("PYFFT_AMD_PIPE_STREAMS", "0")) or default
 

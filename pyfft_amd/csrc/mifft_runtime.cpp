@@ -196,7 +196,9 @@ bool nd2z_preferred(bool f64, int x, int y, int z, bool small_launch) {
 
 int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0, void* out1, hipStream_t s) {
     // fixed-shape kernels (fft_nd2.hpp) for the common shapes, interleaved on both sides
-    const bool no_nd2 = g_debug[MIFFT_DEBUG_NO_ND2] != 0;  // development switch: run-time-shaped kernel only
+    // the run-time-shaped kernel only: the development switch, or variant 1 of the pass (the plan asks for it where that kernel measured
+    // faster than the shape's fixed instance: pyfft_amd/tuning_gfx950.json, "nd_generic")
+    const bool no_nd2 = g_debug[MIFFT_DEBUG_NO_ND2] != 0 || p->variant == 1;
     // the (16, 16) fp32 plane, interleaved: wave-autonomous kernel (no LDS, DPP exchange; csrc/fft_wave.hpp)
     // -- measured slower than the fixed-shape LDS kernel at the reference's 32 MiB buffer (0.62 vs 0.68 of the roofline) and
     // equal at 128 MiB (profiles/r02_h_small_n.log), so it only runs on request (MIFFT_DEBUG_FORCE_WAVE; parity-tested)

@@ -761,3 +761,30 @@ def test_planner_follows_a_doctored_tuning_table():
         assert "cols0" in str(e)
     else:
         raise AssertionError("a rule without cols0 was accepted")
+
+
+def test_round5_tiny_nd_shapes_take_the_run_time_shaped_kernel(monkeypatch):
+    """One-launch N-D shapes whose fixed instance measured slower than the run-time-shaped kernel (profiles/r05_nd2_table_value.log: two- and
+    four-point rows) are marked variant 1 by the plan -- always, or in launches beyond write_through_max per side, as the tuning table's
+    "nd_generic" lists say; the lists are data: a table without them, or PYFFT_AMD_NO_ND_GENERIC, gives variant 0 everywhere."""
+    import copy
+    import numpy
+    from pyfft_amd import tuning
+    from pyfft_amd.machine import Machine
+    from pyfft_amd.plan import FFTPlan
+    c64, c128 = numpy.complex64, numpy.complex128
+
+    def variant(shape, dtype, batch, table=None):
+        mach = Machine(256, 8, 4 << 20, 256 << 20, tuning=tuning.Tuning(table, "doctored") if table is not None else None)
+        return FFTPlan(_FakeContext(mach), shape, dtype=dtype)._descriptors(batch, False, False)[0].variant
+
+    assert variant((16, 2), c64, 3) == 1 and variant((16, 2), c64, 1 << 22) == 1              # "always"
+    assert variant((2, 8), c64, 100) == 0 and variant((2, 8), c64, 1 << 22) == 1               # "big": 16 points x 8 bytes x 2^22 = 512 MiB
+    assert variant((4, 4), c128, 100) == 0 and variant((4, 4), c128, 1 << 22) == 1
+    assert variant((16, 16), c64, 1 << 20) == 0 and variant((16, 16, 16), c64, 1 << 16) == 0   # the published shapes stay on their instances
+    assert variant((16, 2), numpy.float32, 1 << 22) == 0                                       # planes: other kernels, not in the sweep
+    bare = copy.deepcopy(tuning.default().table)
+    del bare["nd_generic"]
+    assert variant((16, 2), c64, 1 << 22, bare) == 0
+    monkeypatch.setenv("PYFFT_AMD_NO_ND_GENERIC", "1")
+    assert variant((16, 2), c64, 1 << 22) == 0

@@ -525,3 +525,53 @@ def test_four_work_groups_per_transform_out_of_place(ctx, shape, dtype, monkeypa
     monkeypatch.delenv("PYFFT_AMD_NO_OOP_ND")
     plan.execute(b, a, batch=batch, inverse=True)                 # inverse, out of place
     assert numpy.abs(a.get().astype(numpy.complex128) - data).sum() / numpy.abs(data).sum() < EPS
+
+
+# ---- tiny one-launch N-D shapes routed to the run-time-shaped kernel (tuning table "nd_generic") -------------------------------------------
+@pytest.mark.parametrize("shape,dtype,batch", [((16, 2), numpy.complex64, 37), ((2, 8), numpy.complex64, 100), ((4, 4), numpy.complex128, 61)],
+                         ids=lambda v: getattr(v, "__name__", str(v)).replace(" ", ""))
+def test_tiny_nd_shapes_small_launches(ctx, monkeypatch, shape, dtype, batch):
+    """Shapes of the tuning table's "nd_generic" lists in small launches (the "always" shape on the run-time-shaped kernel, the "big" ones on
+    their fixed instances): the reference's six-assertion protocol against numpy (test/test_errors.py:18-114), either way round."""
+    from test_errors_gpu import run_protocol
+    run_protocol(ctx, shape, dtype, batch, seed=977)
+    monkeypatch.setenv("PYFFT_AMD_NO_ND_GENERIC", "1")
+    run_protocol(ctx, shape, dtype, batch, seed=977, check_oracle=False)
+
+
+@pytest.mark.parametrize("shape,dtype,batch", [((16, 2), numpy.complex64, 700001), ((8, 8), numpy.complex64, 270001), ((4, 4), numpy.complex128, 530001),
+                                               ((4, 2), numpy.complex64, 2100001), ((2, 8), numpy.complex64, 1100001), ((8, 2), numpy.complex128, 600001)],
+                         ids=lambda v: getattr(v, "__name__", str(v)).replace(" ", ""))
+def test_tiny_nd_shapes_big_launches(ctx, monkeypatch, shape, dtype, batch):
+    """The same shapes in launches beyond the size rule (130-270 MiB per side, ragged batches), where the plan marks the pass variant 1: the
+    run-time-shaped kernel's result against the fixed instance's over the WHOLE array (same transform, another operation order: the
+    reference's L1 threshold and the north star's max-norm bound), 64 sampled transforms against numpy, in place == out of place, the
+    input untouched, and the inverse round trip."""
+    hip = ctx.hip
+    size = int(numpy.prod(shape))
+    cdt = numpy.dtype(dtype)
+    eps, mx = (1.1e-6, 1e-5) if cdt == numpy.complex64 else (1e-11, 1e-11)
+    data = _tiled_noise(size * batch, dtype, 611)
+    plan = hip.Plan(shape, dtype=dtype, wait_for_finish=True)
+    assert plan._descriptors(batch, False, False)[0].variant == 1
+    a, b = hip.to_gpu(data), hip.DeviceArray((size * batch,), dtype)
+    plan.execute(a, b, batch=batch)
+    got = b.get()
+    assert numpy.array_equal(a.get(), data), "an out-of-place execute touched its input"
+    c = hip.to_gpu(data)
+    plan.execute(c, batch=batch)
+    assert numpy.array_equal(c.get(), got), "in place differs from out of place"
+    plan.execute(c, batch=batch, inverse=True)
+    back = c.get()
+    assert numpy.abs(back - data).sum() / numpy.abs(data).sum() < eps
+    for item in numpy.linspace(0, batch - 1, 64).astype(int):
+        ref = numpy.fft.fftn(data[item * size:(item + 1) * size].reshape(shape).astype(numpy.complex128)).reshape(-1)
+        g = got[item * size:(item + 1) * size]
+        assert numpy.abs(ref - g).sum() / numpy.abs(ref).sum() < eps and numpy.abs(ref - g).max() <= max(mx, 1e-5 if cdt == numpy.complex64 else 1e-11) * numpy.abs(ref).max(), item
+    monkeypatch.setenv("PYFFT_AMD_NO_ND_GENERIC", "1")
+    fixed = hip.Plan(shape, dtype=dtype, wait_for_finish=True)
+    assert fixed._descriptors(batch, False, False)[0].variant == 0
+    fixed.execute(a, b, batch=batch)
+    want = b.get()
+    assert numpy.abs(want - got).sum() / numpy.abs(want).sum() < eps
+    assert numpy.abs(want - got).max() <= 1e-5 * numpy.abs(want).max()

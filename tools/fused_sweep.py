@@ -20,7 +20,7 @@ from pyfft_amd.hip import Plan, DeviceArray, Event
 from pyfft_amd import _native as N
 
 KEYS = ("PYFFT_AMD_STRATEGY", "PYFFT_AMD_FUSED_RING", "PYFFT_AMD_FUSEDX", "PYFFT_AMD_FUSED3", "PYFFT_AMD_FUSED_WGS", "PYFFT_AMD_PIPE_MB", "PYFFT_AMD_PIPE_STREAMS",
-        "PYFFT_AMD_FUSED_MEMSET", "PYFFT_AMD_NO_FUSEDX", "PYFFT_AMD_SMALL_FUSED", "MIFFT_PAIR", "MIFFT_NARROW_TILES", "PYFFT_AMD_SPLIT_FUSEDX", "PYFFT_AMD_NO_SPLIT_ROWFIRST", "MIFFT_STORE", "PYFFT_AMD_NO_OOP_ND")
+        "PYFFT_AMD_FUSED_MEMSET", "PYFFT_AMD_NO_FUSEDX", "PYFFT_AMD_SMALL_FUSED", "MIFFT_PAIR", "MIFFT_NARROW_TILES", "PYFFT_AMD_SPLIT_FUSEDX", "PYFFT_AMD_NO_SPLIT_ROWFIRST", "MIFFT_STORE", "PYFFT_AMD_NO_OOP_ND", "MIFFT_NO_ND2", "PYFFT_AMD_NO_ND_GENERIC")
 
 
 def variant_env(v):
@@ -91,6 +91,7 @@ def sweep(shape, dtype, gib, variants, reps=5, iters=10, quiet=False):
         N.lib.mifft_debug_set(N.DEBUG_PAIR, int(os.environ.get("MIFFT_PAIR", "0")))     # (library switches: read at import otherwise)
         N.lib.mifft_debug_set(N.DEBUG_NARROW_TILES, int(os.environ.get("MIFFT_NARROW_TILES", "0")))
         N.lib.mifft_debug_set(N.DEBUG_STORE, int(os.environ.get("MIFFT_STORE", "0")))
+        N.lib.mifft_debug_set(N.DEBUG_NO_ND2, int(os.environ.get("MIFFT_NO_ND2", "0")))
         try:
             plan = Plan(shape if len(shape) > 1 else shape[0], dtype=dt, wait_for_finish=True)
             for b in outs:
@@ -160,6 +161,18 @@ def rule_cases(tuning, rule):
     return out
 
 
+def write_table(path, table):
+    """The tuning table in the layout of pyfft_amd/tuning_gfx950.json: one key per line, one rule per line."""
+    import json
+    out = "{\n"
+    for k, v in table.items():
+        if k != "rules":
+            out += " %s: %s,\n" % (json.dumps(k), json.dumps(v))
+    out += ' "rules": [\n' + ",\n".join("  " + json.dumps(r) for r in table["rules"]) + "\n ]\n}\n"
+    with open(path, "w") as f:
+        f.write(out)
+
+
 def emit(path, gib):
     """Re-measure every rule of the tuning table against the pipelined chunks and write the table back (see the module docstring)."""
     import copy
@@ -185,13 +198,7 @@ def emit(path, gib):
             elif all(m["persistent"] <= 0.98 * m["pipelined"] for m in measured):
                 new["on_request"] = True
         print("rule %-90s %s" % (rule["name"][:90], "on request" if new.get("on_request") else "default"), flush=True)
-    out = "{\n"
-    for k, v in table.items():
-        if k != "rules":
-            out += " %s: %s,\n" % (json.dumps(k), json.dumps(v))
-    out += ' "rules": [\n' + ",\n".join("  " + json.dumps(r) for r in table["rules"]) + "\n ]\n}\n"
-    with open(path, "w") as f:
-        f.write(out)
+    write_table(path, table)
     changed = [r["name"] for r, n in zip(base.rules, table["rules"]) if bool(r.get("on_request")) != bool(n.get("on_request"))]
     print("wrote %s; rules whose default changed: %s" % (path, changed or "none"))
 
