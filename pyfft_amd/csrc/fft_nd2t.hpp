@@ -119,29 +119,47 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(OCC))) 
         const T csign = a.inverse ? (T)-1 : (T)1;
         static_for<PPT>([&](auto i) { v[i].y *= csign; });
     }
+    // small launches (MIFFT_FLAG_WRITE_THROUGH -> nt bit 2, round 5): agent-scope write-through stores, so that the result does not wait
+    // dirty in the L2s for the end-of-kernel write-back (planes at the reference's 32 MiB: fp64 (16, 16) 0.50 -> 0.79 of the roofline,
+    // profiles/r05_fp64_write_through_rows.log); a scalar of a plane goes out as a relaxed agent-scope atomic store (= global_store sc1)
+    const bool wt = (a.nt & 4) != 0;
     auto sink = [&](auto stc, const cplx<T>* vv) __attribute__((always_inline)) {
         using St = decltype(stc);
-        static_for<St::NB>([&](auto bb) {
-            constexpr int b = bb;
-            int base, jb;
-            St::geom(b, tid, base, jb);
-            const long long off = Addr::at(g, g0, base + St::idxd(jb) * St::SA);
-            const long long step = (long long)St::Ns * pitch[St::AX];
-            if (off >= 0) {
-                static_for<St::R>([&](auto kk) {
-                    constexpr int k = kk;
-                    cplx<T> p = vv[b * St::R + k];
-                    p.x *= sx;
-                    p.y *= sy;
-                    if constexpr (SPLIT_OUT) {
-                        out_re[off + k * step] = p.x;
-                        out_im[off + k * step] = p.y;
-                    } else {
-                        out[off + k * step] = p;
-                    }
-                });
-            }
-        });
+        using Bits = typename std::conditional<sizeof(T) == 4, unsigned, unsigned long long>::type;
+        auto stores = [&](auto wtc) __attribute__((always_inline)) {
+            constexpr bool WT = decltype(wtc)::value != 0;
+            static_for<St::NB>([&](auto bb) {
+                constexpr int b = bb;
+                int base, jb;
+                St::geom(b, tid, base, jb);
+                const long long off = Addr::at(g, g0, base + St::idxd(jb) * St::SA);
+                const long long step = (long long)St::Ns * pitch[St::AX];
+                if (off >= 0) {
+                    static_for<St::R>([&](auto kk) {
+                        constexpr int k = kk;
+                        cplx<T> p = vv[b * St::R + k];
+                        p.x *= sx;
+                        p.y *= sy;
+                        if constexpr (SPLIT_OUT) {
+                            if constexpr (WT) {
+                                // (scalars first: __builtin_bit_cast of the vector ELEMENT p.y took element 0 -- both planes got the real part)
+                                const T pre = p.x, pim = p.y;
+                                __hip_atomic_store(reinterpret_cast<Bits*>(out_re + off + k * step), __builtin_bit_cast(Bits, pre), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(reinterpret_cast<Bits*>(out_im + off + k * step), __builtin_bit_cast(Bits, pim), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            } else {
+                                out_re[off + k * step] = p.x;
+                                out_im[off + k * step] = p.y;
+                            }
+                        } else {
+                            if constexpr (WT) store_wt_ptr<T>(out + off + k * step, p);
+                            else out[off + k * step] = p;
+                        }
+                    });
+                }
+            });
+        };
+        if (wt) stores(IC<1>{});
+        else stores(IC<0>{});
     };
     nd2_chain_sink<T, P, NT, HALF, true, SL>(lds, v, tw, tid, sink);
 }

@@ -98,7 +98,14 @@ template <typename T, int V, bool NT = false> __device__ __forceinline__ void lo
     }
 }
 template <typename T, int V, int NT = 0> __device__ __forceinline__ void store_vec(const TileArgs& a, long long g, const cplx<T>* p) {
-    if constexpr (V == 2) {
+    if constexpr (V == 1) {
+        // one 16-byte point per lane, interleaved output, write-through: the fp64 form of the small-launch store policy.  (A lane's PAIR
+        // of fp64 points is 32 bytes = two 16-byte store instructions that each cover every other 16 bytes of a line; written through,
+        // every line then reaches the memory side as interleaved fragments: fp64 N = 64 at the reference's 32 MiB 0.50 of the roofline
+        // against 0.65 with non-temporal and 0.56 with plain stores -- profiles/r05_fp64_write_through_rows.log.)
+        static_assert(NT == 2 && sizeof(cplx<T>) == 16, "single points: fp64 write-through only");
+        store_vec_wt(reinterpret_cast<cplx<T>*>(a.out0) + g, p[0]);
+    } else if constexpr (V == 2) {
         store_pair<T, NT>(a, g, p[0], p[1]);
     } else {
         using V4 = T __attribute__((ext_vector_type(4)));
@@ -349,14 +356,20 @@ __global__ void __launch_bounds__(NT) fft_tile_kernel(const TileArgs a) {
             if (valid) store_vec<T, V, NTS>(a, g, p);
         });
     };
+    // fp64, interleaved output, write-through: point by point, so that a store instruction covers whole lines (store_vec, V == 1)
+    constexpr bool kPointWise = sizeof(cplx<T>) == 16;
     if constexpr (kQuadShape) {
-        if (quad_out && (a.nt & 4)) store_phase(IC<4>{}, IC<2>{});   // (planes in small launches: write-through 16-byte stores, second batch of round 4)
-        else if (quad_out) store_phase(IC<4>{}, IC<0>{});
+        // (planes in small launches: write-through 16-byte stores, second batch of round 4; fp64 planes: PAIRS -- four doubles are 32 bytes
+        // per lane and plane, the fragmenting form again: fp64 planes N = 512 at 32 MiB 0.47 written through in fours, 0.51 plain)
+        if (quad_out && (a.nt & 4) && !kPointWise) store_phase(IC<4>{}, IC<2>{});
+        else if (quad_out && !(a.nt & 4)) store_phase(IC<4>{}, IC<0>{});
+        else if ((a.nt & 4) && kPointWise && !a.split_out) store_phase(IC<kPointWise ? 1 : 2>{}, IC<2>{});
         else if (a.nt & 4) store_phase(IC<2>{}, IC<2>{});
         else if (a.nt & 2) store_phase(IC<2>{}, IC<1>{});
         else store_phase(IC<2>{}, IC<0>{});
     } else {
-        if (a.nt & 4) store_phase(IC<2>{}, IC<2>{});
+        if ((a.nt & 4) && kPointWise && !a.split_out) store_phase(IC<kPointWise ? 1 : 2>{}, IC<2>{});
+        else if (a.nt & 4) store_phase(IC<2>{}, IC<2>{});
         else if (a.nt & 2) store_phase(IC<2>{}, IC<1>{});
         else store_phase(IC<2>{}, IC<0>{});
     }

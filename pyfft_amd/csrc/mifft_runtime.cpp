@@ -269,6 +269,7 @@ int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0,
         t.in0 = in0; t.in1 = in1; t.out0 = out0; t.out1 = planes_in_only ? nullptr : out1;
         t.split = 1;
         t.split_out = planes_in_only ? 0 : 1;
+        t.nt = stream_policy(p->flags) & 4;      // (the kernel knows the write-through form of the small launches only)
         t.tw_L = p->tw_L; t.tw_lo = p->tw_lo; t.tw_hi = p->tw_hi;
         t.inverse = p->inverse ? 1 : 0;
         t.scale = p->scale;

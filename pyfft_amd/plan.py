@@ -288,9 +288,9 @@ class FFTPlan(object):
                 d.flags |= N.FLAG_STREAM_DST
             # one-launch N-D shapes whose fixed-shape instance measured slower than the run-time-shaped kernel (tiny transforms with two- or
             # four-point rows: (16, 2) 0.094 against 0.693 of the roofline): variant 1 (tuning table "nd_generic", tools/nd2_value_sweep.py)
-            if k.kind == N.PASS_ND and not p.split and not alt and not D.no_nd_generic() and \
+            if k.kind == N.PASS_ND and not alt and not D.no_nd_generic() and \
                     mach.tuning.nd_runs_generic(p.precision == N.F64, (int(k.L), int(k.M), int(k.S)),
-                                                batch * p.size * p.complex_nbytes > mach.write_through_max_bytes):
+                                                batch * p.size * p.complex_nbytes > mach.write_through_max_bytes, bool(p.split)):
                 d.variant = 1
             # small launches: write-through stores, so that the output does not wait dirty in the L2s for the end-of-kernel
             # write-back (32 MiB launches: (16, 16, 16) 14.3 -> 9.1 us, (1024,) 13.5 -> 10.5 us; neutral from 256 MiB on)

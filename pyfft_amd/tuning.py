@@ -29,7 +29,7 @@ class Tuning(object):
         # one-launch N-D shapes that run the run-time-shaped kernel: {precision: (always, big)} as sets of (x, y, z)
         ng = table.get("nd_generic", {})
         self.nd_generic = {prec: (frozenset(tuple(t) for t in ng.get(prec, {}).get("always", [])),
-                                  frozenset(tuple(t) for t in ng.get(prec, {}).get("big", []))) for prec in ("f32", "f64")}
+                                  frozenset(tuple(t) for t in ng.get(prec, {}).get("big", []))) for prec in ("f32", "f64", "f32_split", "f64_split")}
         for r in self.rules:
             for key in ("name", "kind", "strategy", "extent0", "cols0", "per_cu"):
                 if key not in r:
@@ -45,9 +45,9 @@ class Tuning(object):
         num, den = self.fractions[name]
         return int(value) * num // den
 
-    def nd_runs_generic(self, f64, xyz, big_launch):
-        """The plan's one-launch N-D pass of shape (x, y, z) takes the run-time-shaped kernel (pass variant 1)."""
-        always, big = self.nd_generic["f64" if f64 else "f32"]
+    def nd_runs_generic(self, f64, xyz, big_launch, split=False):
+        """The plan's N-D pass of shape (x, y, z) takes the run-time-shaped kernel (pass variant 1)."""
+        always, big = self.nd_generic[("f64" if f64 else "f32") + ("_split" if split else "")]
         return xyz in always or (big_launch and xyz in big)
 
     def match(self, shape_class, narrow_tiles, rowfirst):

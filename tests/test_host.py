@@ -782,7 +782,8 @@ def test_round5_tiny_nd_shapes_take_the_run_time_shaped_kernel(monkeypatch):
     assert variant((2, 8), c64, 100) == 0 and variant((2, 8), c64, 1 << 22) == 1               # "big": 16 points x 8 bytes x 2^22 = 512 MiB
     assert variant((4, 4), c128, 100) == 0 and variant((4, 4), c128, 1 << 22) == 1
     assert variant((16, 16), c64, 1 << 20) == 0 and variant((16, 16, 16), c64, 1 << 16) == 0   # the published shapes stay on their instances
-    assert variant((16, 2), numpy.float32, 1 << 22) == 0                                       # planes: other kernels, not in the sweep
+    assert variant((16, 2), numpy.float32, 1 << 22) == 0                                       # planes: lists of their own (f32_split / f64_split)
+    assert variant((32, 32), numpy.float32, 100) == 1 and variant((32, 32), c64, 100) == 0
     bare = copy.deepcopy(tuning.default().table)
     del bare["nd_generic"]
     assert variant((16, 2), c64, 1 << 22, bare) == 0
