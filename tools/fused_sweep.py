@@ -20,7 +20,7 @@ from pyfft_amd.hip import Plan, DeviceArray, Event
 from pyfft_amd import _native as N
 
 KEYS = ("PYFFT_AMD_STRATEGY", "PYFFT_AMD_FUSED_RING", "PYFFT_AMD_FUSEDX", "PYFFT_AMD_FUSED3", "PYFFT_AMD_FUSED_WGS", "PYFFT_AMD_PIPE_MB", "PYFFT_AMD_PIPE_STREAMS",
-        "PYFFT_AMD_FUSED_MEMSET", "PYFFT_AMD_NO_FUSEDX", "PYFFT_AMD_SMALL_FUSED", "MIFFT_PAIR", "MIFFT_NARROW_TILES", "PYFFT_AMD_SPLIT_FUSEDX", "PYFFT_AMD_NO_SPLIT_ROWFIRST", "MIFFT_STORE", "PYFFT_AMD_NO_OOP_ND", "MIFFT_NO_ND2", "PYFFT_AMD_NO_ND_GENERIC", "MIFFT_NO_WAVE", "MIFFT_FORCE_WAVE")
+        "PYFFT_AMD_FUSED_MEMSET", "PYFFT_AMD_NO_FUSEDX", "PYFFT_AMD_SMALL_FUSED", "MIFFT_PAIR", "MIFFT_NARROW_TILES", "PYFFT_AMD_SPLIT_FUSEDX", "PYFFT_AMD_NO_SPLIT_ROWFIRST", "MIFFT_STORE", "PYFFT_AMD_NO_OOP_ND", "MIFFT_NO_ND2", "PYFFT_AMD_NO_ND_GENERIC", "MIFFT_NO_WAVE", "MIFFT_FORCE_WAVE", "MIFFT_ALT_ROWS")
 
 
 def variant_env(v):
@@ -94,6 +94,7 @@ def sweep(shape, dtype, gib, variants, reps=5, iters=10, quiet=False):
         N.lib.mifft_debug_set(N.DEBUG_NO_ND2, int(os.environ.get("MIFFT_NO_ND2", "0")))
         N.lib.mifft_debug_set(N.DEBUG_NO_WAVE, int(os.environ.get("MIFFT_NO_WAVE", "0")))
         N.lib.mifft_debug_set(N.DEBUG_FORCE_WAVE, int(os.environ.get("MIFFT_FORCE_WAVE", "0")))
+        N.lib.mifft_debug_set(N.DEBUG_ALT_ROWS, int(os.environ.get("MIFFT_ALT_ROWS", "0")))
         try:
             plan = Plan(shape if len(shape) > 1 else shape[0], dtype=dt, wait_for_finish=True)
             for b in outs:
