@@ -36,6 +36,12 @@ extern "C" int mifft_pair_f32(int kind, int k0, int k1, int k2, int split, const
     YZ(4096, 32, 32, 16, 512, true, 4, RL(8, 4), RL(8, 4), false)
     YZ(2048, 16, 16, 16, 256, false, 1, RL(16), RL(16), false)
     YZ(4096, 16, 16, 16, 256, false, 1, RL(16), RL(16), false)
+    // (c) after the shape survey (profiles/r05_shape_grid_survey.log): (z, 256, 256) with z in {64, 128} on the two pairs of 256^3 -- y = 64 x 4,
+    // its XY tile, YZ tiles of 4096 / 8192 points on 16 adjacent x -- instead of three launches: 0.245 -> 0.329, 0.269 -> 0.321 at 1 GiB.
+    // (The y = 128 shapes -- 64 x 2 -- already run two launches, the 32768-point (y, x) plane as one tile + the z pass: the pairs measured
+    // + 1 ... + 5 % at 1 GiB and - 8 % at 32 MiB against them; not instantiated.  profiles/r05_pass_pairs_256_point_rows.log)
+    YZ(256 * 64, 4, 128, 16, 512, false, 1, RL(4), RL(8, 16), false)
+    YZ(256 * 64, 4, 64, 16, 256, false, 1, RL(4), RL(8, 8), false)
 #undef XY
 #undef YZ
 #undef RL

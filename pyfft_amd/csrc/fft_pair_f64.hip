@@ -39,6 +39,15 @@ extern "C" int mifft_pair_f64(int kind, int k0, int k1, int k2, int split, const
     YZ(2048, 32, 32, 8, 512, true, 4, RL(8, 4), RL(8, 4), false)
     YZ(1024, 16, 16, 8, 256, false, 1, RL(8, 2), RL(8, 2), false)
     YZ(2048, 16, 16, 8, 256, false, 1, RL(8, 2), RL(8, 2), false)
+    // Round 5, after the shape survey (profiles/r05_shape_grid_survey.log: fp64 3-D shapes with 256-point x rows next to a shorter axis ran
+    // THREE launches, 0.20-0.26): pass pairs for (z, y, 256) with y in {128, 256} and z in {64, 128, 256} -- y = 32 x 8 or 32 x 4, the XY tile
+    // of 256^3, YZ tiles of 2048 ... 8192 points on 8 adjacent x
+    XY(256, 32, 4, 512, true, 4, RL(16, 16), RL(8, 4), false)
+    YZ(256 * 32, 8, 128, 8, 512, true, 4, RL(8), RL(8, 16), false)
+    YZ(256 * 32, 8, 64, 8, 256, false, 1, RL(8), RL(8, 8), false)
+    YZ(256 * 32, 4, 256, 8, 512, true, 4, RL(4), RL(16, 16), false)
+    YZ(256 * 32, 4, 128, 8, 256, false, 1, RL(4), RL(8, 16), false)
+    YZ(256 * 32, 4, 64, 8, 256, false, 1, RL(4), RL(8, 8), false)
 #undef XY
 #undef YZ
 #undef RL

@@ -575,3 +575,31 @@ def test_tiny_nd_shapes_big_launches(ctx, monkeypatch, shape, dtype, batch):
     want = b.get()
     assert numpy.abs(want - got).sum() / numpy.abs(want).sum() < eps
     assert numpy.abs(want - got).max() <= 1e-5 * numpy.abs(want).max()
+
+
+# ---- 3-D shapes with 256-point rows next to a shorter axis: the two pass pairs of 256^3 instead of three launches ---------------------------
+_LATE_PAIR_SHAPES = [((64, 128, 256), numpy.complex128, 1), ((64, 256, 256), numpy.complex64, 1)]
+if os.environ.get("PYFFT_AMD_SWEEP"):
+    _LATE_PAIR_SHAPES += [((128, 256, 256), numpy.complex128, 1), ((64, 256, 256), numpy.complex128, 1), ((128, 128, 256), numpy.complex128, 2),
+                          ((256, 128, 256), numpy.complex128, 1), ((128, 256, 256), numpy.complex64, 1)]
+
+
+@pytest.mark.parametrize("shape,dtype,batch", _LATE_PAIR_SHAPES, ids=lambda v: getattr(v, "__name__", str(v)).replace(" ", ""))
+def test_pass_pairs_for_256_point_rows(ctx, monkeypatch, shape, dtype, batch):
+    """(z, y, 256) with y in {128, 256}, z in {64, 128, 256} in complex128 and (z, 256, 256), z in {64, 128}, in complex64: (ROW x, COL y R0) and
+    (COL y R1, COL z) as two launches (csrc/fft_pair_f64.hip: y = 32 x 8 / 32 x 4; fft_pair_f32.hip: 64 x 4; pyfft/kernel.py:259-283
+    splits a long axis the same way).  The reference's six-assertion protocol against numpy, and the same data through the one-pass-per-axis chain (pairs
+    switched off) within the same thresholds."""
+    from test_errors_gpu import run_protocol
+    from pyfft_amd import _native as N
+    from pyfft_amd.passes import launch_units
+    plan = ctx.getPlan(shape, dtype=dtype)
+    assert len(launch_units(plan.pass_list())) == 2 and sum(1 for k in plan.pass_list() if k.pair_with_next) == 2, plan.pass_list()
+    run_protocol(ctx, shape, dtype, batch, seed=8100 + shape[0])
+    N.lib.mifft_debug_set(N.DEBUG_PAIR, 1)
+    try:
+        chain = ctx.getPlan(shape, dtype=dtype)
+        assert len(launch_units(chain.pass_list())) == 3
+        run_protocol(ctx, shape, dtype, batch, seed=8100 + shape[0], check_oracle=False)
+    finally:
+        N.lib.mifft_debug_set(N.DEBUG_PAIR, 0)
