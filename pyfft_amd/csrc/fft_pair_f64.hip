@@ -48,6 +48,14 @@ extern "C" int mifft_pair_f64(int kind, int k0, int k1, int k2, int split, const
     YZ(256 * 32, 4, 256, 8, 512, true, 4, RL(4), RL(16, 16), false)
     YZ(256 * 32, 4, 128, 8, 256, false, 1, RL(4), RL(8, 16), false)
     YZ(256 * 32, 4, 64, 8, 256, false, 1, RL(4), RL(8, 8), false)
+    // ... z = 32 behind 256-point rows, and (z, 256, 128) with z in {32 ... 256}: 128^3's XY tile, YZ tiles of 2048 ... 16384 points
+    YZ(256 * 32, 8, 32, 8, 256, false, 1, RL(8), RL(8, 4), false)
+    YZ(256 * 32, 4, 32, 8, 128, false, 1, RL(4), RL(8, 4), false)
+    XY(128, 32, 8, 256, false, 1, RL(8, 16), RL(8, 4), false)
+    YZ(128 * 32, 8, 256, 8, 1024, true, 4, RL(8), RL(16, 16), false)
+    YZ(128 * 32, 8, 128, 8, 512, true, 4, RL(8), RL(8, 16), false)
+    YZ(128 * 32, 8, 64, 8, 256, false, 1, RL(8), RL(8, 8), false)
+    YZ(128 * 32, 8, 32, 8, 256, false, 1, RL(8), RL(8, 4), false)
 #undef XY
 #undef YZ
 #undef RL

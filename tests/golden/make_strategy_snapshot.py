@@ -82,10 +82,10 @@ def snapshot(with_chain_class=False):
                     rows.append([sname, mname, list(shape), dt, batch, list(st)])
                     if with_chain_class:
                         # chains with exactly ONE pass pair are round 5's (the snapshot predates them): the test treats them apart -- as it does
-                        # the interleaved shapes (z, y, 256) with y in {128, 256} that got the two pairs of 256^3 late in round 5 (three launches before)
+                        # the interleaved 3-D shapes with 256-point axes that got the two pairs of 256^3 late in round 5 (three launches before; round 4 had pairs for the two cubes only)
                         npairs = sum(1 for k in plans[key]._kernels if k.pair_with_next)
-                        late = dt in ("complex128", "complex64") and len(shape) == 3 and shape[2] == 256 and shape[1] in (128, 256) and \
-                            shape[0] in (64, 128, 256) and tuple(shape) != (256, 256, 256) and npairs == 2
+                        late = dt in ("complex128", "complex64") and len(shape) == 3 and npairs == 2 and \
+                            tuple(shape) not in ((256, 256, 256), (128, 128, 128))
                         rows[-1].append(npairs == 1 or late)
     finally:
         N.lib.mifft_debug_set(N.DEBUG_NARROW_TILES, 0)

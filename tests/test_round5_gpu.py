@@ -578,15 +578,17 @@ def test_tiny_nd_shapes_big_launches(ctx, monkeypatch, shape, dtype, batch):
 
 
 # ---- 3-D shapes with 256-point rows next to a shorter axis: the two pass pairs of 256^3 instead of three launches ---------------------------
-_LATE_PAIR_SHAPES = [((64, 128, 256), numpy.complex128, 1), ((64, 256, 256), numpy.complex64, 1)]
+_LATE_PAIR_SHAPES = [((64, 128, 256), numpy.complex128, 1), ((64, 256, 256), numpy.complex64, 1), ((32, 256, 128), numpy.complex128, 3)]
 if os.environ.get("PYFFT_AMD_SWEEP"):
-    _LATE_PAIR_SHAPES += [((128, 256, 256), numpy.complex128, 1), ((64, 256, 256), numpy.complex128, 1), ((128, 128, 256), numpy.complex128, 2),
+    _LATE_PAIR_SHAPES += [((64, 256, 128), numpy.complex128, 1), ((128, 256, 128), numpy.complex128, 1), ((256, 256, 128), numpy.complex128, 1),
+                          ((32, 256, 256), numpy.complex128, 1), ((32, 128, 256), numpy.complex128, 2),
+                          ((128, 256, 256), numpy.complex128, 1), ((64, 256, 256), numpy.complex128, 1), ((128, 128, 256), numpy.complex128, 2),
                           ((256, 128, 256), numpy.complex128, 1), ((128, 256, 256), numpy.complex64, 1)]
 
 
 @pytest.mark.parametrize("shape,dtype,batch", _LATE_PAIR_SHAPES, ids=lambda v: getattr(v, "__name__", str(v)).replace(" ", ""))
 def test_pass_pairs_for_256_point_rows(ctx, monkeypatch, shape, dtype, batch):
-    """(z, y, 256) with y in {128, 256}, z in {64, 128, 256} in complex128 and (z, 256, 256), z in {64, 128}, in complex64: (ROW x, COL y R0) and
+    """(z, y, 256) with y in {128, 256}, z in {32 ... 256}, and (z, 256, 128) in complex128; (z, 256, 256), z in {64, 128}, in complex64: (ROW x, COL y R0) and
     (COL y R1, COL z) as two launches (csrc/fft_pair_f64.hip: y = 32 x 8 / 32 x 4; fft_pair_f32.hip: 64 x 4; pyfft/kernel.py:259-283
     splits a long axis the same way).  The reference's six-assertion protocol against numpy, and the same data through the one-pass-per-axis chain (pairs
     switched off) within the same thresholds."""
