@@ -42,6 +42,7 @@ extern "C" int mifft_pair_f32(int kind, int k0, int k1, int k2, int split, const
     // + 1 ... + 5 % at 1 GiB and - 8 % at 32 MiB against them; not instantiated.  profiles/r05_pass_pairs_256_point_rows.log)
     YZ(256 * 64, 4, 128, 16, 512, false, 1, RL(4), RL(8, 16), false)
     YZ(256 * 64, 4, 64, 16, 256, false, 1, RL(4), RL(8, 8), false)
+    YZ(256 * 64, 4, 32, 16, 256, false, 1, RL(4), RL(8, 4), false)      // (32, 256, 256): 0.271 on three launches
 #undef XY
 #undef YZ
 #undef RL

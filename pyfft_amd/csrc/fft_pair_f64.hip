@@ -56,6 +56,12 @@ extern "C" int mifft_pair_f64(int kind, int k0, int k1, int k2, int split, const
     YZ(128 * 32, 8, 128, 8, 512, true, 4, RL(8), RL(8, 16), false)
     YZ(128 * 32, 8, 64, 8, 256, false, 1, RL(8), RL(8, 8), false)
     YZ(128 * 32, 8, 32, 8, 256, false, 1, RL(8), RL(8, 4), false)
+    // ... and (z, 256, 64): XY tile of 2048 points
+    XY(64, 32, 8, 256, false, 1, RL(8, 8), RL(8, 4), false)
+    YZ(64 * 32, 8, 256, 8, 1024, true, 4, RL(8), RL(16, 16), false)
+    YZ(64 * 32, 8, 128, 8, 512, true, 4, RL(8), RL(8, 16), false)
+    YZ(64 * 32, 8, 64, 8, 256, false, 1, RL(8), RL(8, 8), false)
+    YZ(64 * 32, 8, 32, 8, 256, false, 1, RL(8), RL(8, 4), false)
 #undef XY
 #undef YZ
 #undef RL

@@ -582,6 +582,8 @@ _LATE_PAIR_SHAPES = [((64, 128, 256), numpy.complex128, 1), ((64, 256, 256), num
 if os.environ.get("PYFFT_AMD_SWEEP"):
     _LATE_PAIR_SHAPES += [((64, 256, 128), numpy.complex128, 1), ((128, 256, 128), numpy.complex128, 1), ((256, 256, 128), numpy.complex128, 1),
                           ((32, 256, 256), numpy.complex128, 1), ((32, 128, 256), numpy.complex128, 2),
+                          ((128, 256, 64), numpy.complex128, 1), ((32, 256, 64), numpy.complex128, 5), ((256, 256, 64), numpy.complex128, 1),
+                          ((64, 256, 64), numpy.complex128, 2), ((32, 256, 256), numpy.complex64, 3),
                           ((128, 256, 256), numpy.complex128, 1), ((64, 256, 256), numpy.complex128, 1), ((128, 128, 256), numpy.complex128, 2),
                           ((256, 128, 256), numpy.complex128, 1), ((128, 256, 256), numpy.complex64, 1)]
 
@@ -601,7 +603,8 @@ def test_pass_pairs_for_256_point_rows(ctx, monkeypatch, shape, dtype, batch):
     N.lib.mifft_debug_set(N.DEBUG_PAIR, 1)
     try:
         chain = ctx.getPlan(shape, dtype=dtype)
-        assert len(launch_units(chain.pass_list())) == 3
+        # (three launches, or two where the (y, x) plane has a one-tile kernel: (z, 256, 64) in fp64 -- the pairs measured 0.29 -> 0.39 there)
+        assert len(launch_units(chain.pass_list())) in (2, 3) and not any(k.pair_with_next for k in chain.pass_list())
         run_protocol(ctx, shape, dtype, batch, seed=8100 + shape[0], check_oracle=False)
     finally:
         N.lib.mifft_debug_set(N.DEBUG_PAIR, 0)

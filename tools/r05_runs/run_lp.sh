@@ -6,4 +6,4 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 PYFFT_AMD_SWEEP=1 timeout 900 python -m pytest tests/test_round5_gpu.py -m gpu -x -q -k "pass_pairs_for_256" --durations=6 2>&1 | tail -12
 V=auto,auto@MIFFT_PAIR=1
-timeout 1200 python tools/fused_sweep.py 64x256x128 complex128 1 $V 128x256x128 complex128 1 $V 256x256x128 complex128 1 $V 32x256x128 complex128 1 $V 32x256x256 complex128 1 $V 32x128x256 complex128 1 $V 64x256x128 complex128 0.03125 $V 32x128x256 complex128 0.03125 $V 2>&1 | cut -c1-150 | tee $OUT/late_pairs2.log
+timeout 1200 python tools/fused_sweep.py 128x256x64 complex128 1 $V 64x256x64 complex128 1 $V 32x256x64 complex128 1 $V 256x256x64 complex128 1 $V 32x256x256 complex64 1 $V 64x256x64 complex128 0.03125 $V 32x256x256 complex64 0.03125 $V 2>&1 | cut -c1-150 | tee $OUT/late_pairs3.log
