@@ -27,6 +27,7 @@ extern "C" int mifft_pair_f32(int kind, int k0, int k1, int k2, int split, const
     // pass: three launches, (4096, 256) 0.257 of the roofline while its transpose runs 0.384): XY = ROW x + COL y (R0) on NX x R0 = 16384
     // points, then ONE plain strided pass of R1 points.  (b) 3-D shapes with short y and z behind a long x ((32, 32, 2048): row + col y +
     // col z 0.264, its transpose 0.355): YZ = COL y (all of it) + COL z on 16 adjacent x, whole (z, y) planes of <= 1024 points.
+    XY(128, 128, 32, 512, true, 4, RL(8, 16), RL(16, 8), false)         // (4096, 128): 0.265 on three launches (profiles/r05_shape_grid_survey.log)
     XY(256, 64, 64, 512, true, 4, RL(16, 16), RL(16, 4), false)
     XY(512, 32, 128, 512, true, 4, RL(2, 16, 16), RL(8, 4), false)
     XY(1024, 16, 256, 512, true, 4, RL(4, 16, 16), RL(16), false)

@@ -35,6 +35,8 @@ extern "C" int mifft_pair_f64(int kind, int k0, int k1, int k2, int split, const
     XY(512, 16, 256, 512, true, 4, RL(2, 16, 16), RL(16), false)
     XY(1024, 8, 512, 512, true, 4, RL(4, 16, 16), RL(8), false)
     XY(2048, 4, 1024, 512, true, 4, RL(8, 16, 16), RL(4), false)
+    XY(128, 64, 64, 512, true, 4, RL(8, 16), RL(16, 4), false)          // (4096, 128): 0.231 on three launches (profiles/r05_shape_grid_survey.log)
+    XY(4096, 2, 2048, 512, true, 4, RL(16, 16, 16), RL(2), false)       // (4096, 4096): 0.211
     YZ(1024, 32, 32, 8, 512, true, 4, RL(8, 4), RL(8, 4), false)
     YZ(2048, 32, 32, 8, 512, true, 4, RL(8, 4), RL(8, 4), false)
     YZ(1024, 16, 16, 8, 256, false, 1, RL(8, 2), RL(8, 2), false)

@@ -714,7 +714,8 @@ def test_strategy_snapshot_of_the_table_driven_planner():
     # shapes whose CHAIN changed in round 5 (one pass pair instead of a third launch: (4096, 256), (32, 32, 2048) ...) no longer run
     # their leading passes slab-wise; they stay on the plain chain / the pipelined chunks
     new_chain = [g for g in got if g[6]]
-    assert 0 < len(new_chain) < 2500 and all(g[5][0] in ("chain", "pipelined") for g in new_chain)
+    # (2.6 k of the 38 k rows by the end of round 5: the 4096-point y axes, short (y, z) behind long rows, the 3-D shapes with a 256-point y axis)
+    assert 0 < len(new_chain) < 4000 and all(g[5][0] in ("chain", "pipelined") for g in new_chain)
     bad = [(w, g) for w, g in zip(want, got) if not g[6] and w != json.loads(json.dumps(g[:6])) and (lists or w[5][0] != "fused2x")]
     assert not bad, bad[:10]
     assert not lists or sum(1 for g in got if g[5][0] == "fused2x") == 18

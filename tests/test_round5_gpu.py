@@ -379,8 +379,10 @@ PAIR_CHAIN_CASES = [((4096, 256), numpy.complex64, 2), ((4096, 512), numpy.compl
                     ((16, 16, 4096), numpy.complex64, 1), ((32, 32, 1024), numpy.complex128, 2), ((32, 32, 2048), numpy.complex128, 1),
                     ((16, 16, 1024), numpy.complex128, 5), ((16, 16, 2048), numpy.complex128, 2), ((2, 4096, 256), numpy.complex64, 1)]
 # the biggest planes (16 ... 128 MiB per transform: numpy takes seconds per case) run with the soak switch, as tests/test_random_sweep_gpu.py's extra cases
+PAIR_CHAIN_CASES += [((4096, 128), numpy.complex128, 3), ((4096, 128), numpy.complex64, 5)]      # (late in round 5: 128-point rows)
 if os.environ.get("PYFFT_AMD_SWEEP"):
-    PAIR_CHAIN_CASES += [((4096, 1024), numpy.complex64, 3), ((4096, 2048), numpy.complex64, 1), ((4096, 4096), numpy.complex64, 1),
+    PAIR_CHAIN_CASES += [((4096, 4096), numpy.complex128, 1),
+                         ((4096, 1024), numpy.complex64, 3), ((4096, 2048), numpy.complex64, 1), ((4096, 4096), numpy.complex64, 1),
                          ((4096, 1024), numpy.complex128, 2), ((4096, 2048), numpy.complex128, 1)]
 
 
