@@ -268,8 +268,8 @@ def test_generic_plans_build_only_what_they_run(ctx):
 
 
 # ---- rectangular 2-D shapes on the fused kernel ---------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape,batch", [((512, 1024), 66), ((1024, 512), 113), ((1024, 2048), 18), ((2048, 1024), 29), ((512, 2048), 33),
-                                         ((2048, 512), 57)], ids=str)   # ((512, 2048) runs the kernel on request only: pipelined is faster)
+@pytest.mark.parametrize("shape,batch", [((512, 1024), 66), ((1024, 512), 113), ((1024, 2048), 18), ((2048, 1024), 29)] +
+                         ([((512, 2048), 33), ((2048, 512), 57)] if _SOAK else []), ids=str)   # ((512, 2048) runs the kernel on request only: pipelined is faster)
 def test_fused_2d_rectangles(ctx, monkeypatch, shape, batch):
     """(ny, nx) in {512, 1024, 2048}^2 with ny != nx, fp32 interleaved, beyond the chain threshold: one persistent launch of two
     transposing passes (round 3: squares only; pyfft/kernel.mako:857-874 vertical mode, plan.py:135-171).  The reference's
