@@ -141,3 +141,8 @@ def apply_native_switches(native):
         native.lib.mifft_debug_set_default(native.DEBUG_NARROW_TILES, int(os.environ["MIFFT_NARROW_TILES"]))
     if os.environ.get("MIFFT_PAIR"):        # pass pairs: 1 = off, 2 = the alternative y split
         native.lib.mifft_debug_set_default(native.DEBUG_PAIR, int(os.environ["MIFFT_PAIR"]))
+    # the row-first switch steers the planner AND the launcher: the process default follows the environment here, so that a plan
+    # prepared on one host thread and executed on another launches the kernel its planner sized the grid for (no_split_rowfirst()
+    # keeps the per-thread override for tests that flip the variable at run time)
+    if os.environ.get("PYFFT_AMD_NO_SPLIT_ROWFIRST"):
+        native.lib.mifft_debug_set_default(native.DEBUG_NO_ROWFIRST, 1)

@@ -15,13 +15,14 @@ streaming helper kernels of the C ABI (`mifft_aux_copy`, `mifft_aux_mul_rows`):
               * a SMOOTH length n = 2^a 3^b 5^c 7^d up to 4096 (fp32) / 2048 (fp64): the lines gathered into dense rows, ONE
                 mixed-radix launch (csrc/fft_mixed.hip: radix-3 / 5 / 7 butterflies next to the power-of-two ones), scattered back
               * any other length n: Bluestein -- rows a[j] = x[j] * c[j] zero-padded to m = 2^k >= 2n - 1 with the chirp
-                c[j] = exp(-i pi j^2 / n), A = FFT_m(a), A *= FFT_m(b) (b = conj chirp, wrapped; computed once on the
-                host in float64), y = IFFT_m(A), X[k] = y[k] * c[k]
+                c[j] = exp(-i pi j^2 / n), A = FFT_m(a), A *= FFT_m(b) (b = conj chirp, wrapped, evaluated on the host in
+                float64; its spectrum is computed ONCE, when the plan is built, by this engine's own float64 kernels on the
+                device: _device_fft), y = IFFT_m(A), X[k] = y[k] * c[k]
     scatter  work array -> user output, with the plan's scale rule (kernel.py:23-37) and the conjugation trick for the
              inverse transform
 
 Cost: two streaming passes around every axis (six to ten HBM round trips per non-power-of-two axis); results match
-numpy.fft within the tolerances stated in tests/test_round2_gpu.py.
+the host FFT of the complex128-upcast input within the tolerances stated in tests/test_generic_gpu.py.
 """
 
 import ctypes
@@ -67,7 +68,7 @@ class _SubContext(object):
     def createQueue(self, buffers=()):
         pass
 
-    def order_scratch(self):
+    def order_scratch(self, capturing=None):
         pass            # (the outer execute() has ordered the stream of this call behind the previous one)
 
     def stream_handle(self):
@@ -187,7 +188,7 @@ class GenericFFTPlan(object):
                 k = numpy.arange(m, dtype=numpy.float64)
                 ang = -2.0 * numpy.pi * k / float(m)
                 ax.blue = (m, self._upload((numpy.cos(ang) + 1j * numpy.sin(ang)).astype(self._cdtype)),
-                           self._upload(c.astype(self._cdtype)), self._upload((numpy.fft.fft(b) / m).astype(self._cdtype)))
+                           self._upload(c.astype(self._cdtype)), self._upload((self._device_fft(b) / m).astype(self._cdtype)))
                 ax.m, ax.plan, ax.chirp, ax.bhat = n, None, None, None
                 self._axes.append(ax)
                 continue
@@ -200,7 +201,7 @@ class GenericFFTPlan(object):
                 b[:n] = numpy.conj(c)
                 b[ax.m - n + 1:] = numpy.conj(c[1:][::-1])
                 ax.chirp = self._upload(c.astype(self._cdtype))
-                ax.bhat = self._upload(numpy.fft.fft(b).astype(self._cdtype))
+                ax.bhat = self._upload(self._device_fft(b).astype(self._cdtype))
             self._axes.append(ax)
         # 1-D smooth length, interleaved, dense: the mixed-radix launch reads the user's input and writes the user's output itself
         # (conjugation of the inverse direction and the scale included): one HBM round trip, no work array
@@ -250,6 +251,8 @@ class GenericFFTPlan(object):
         self._work = None
         self._rows = None
         self._last_batch = 0
+        self._captured = False
+        self._capture_keepalive = []
         if self._split:
             self.execute = self._executeSplit
         else:
@@ -260,6 +263,55 @@ class GenericFFTPlan(object):
         if m not in self._rowplans:
             self._rowplans[m] = FFTPlan(self._sub, (m,), dtype=self._cdtype, normalize=True, wait_for_finish=False)
         return self._rowplans[m]
+
+    def _device_fft(self, b):
+        """FFT_m of the host vector `b` (complex128) computed ON THE DEVICE by this engine's own float64 kernels, returned as a
+        host complex128 array: the spectrum of Bluestein's wrapped conjugate chirp, a plan-build-time constant (an FFT engine
+        transforms its own chirp; the reference lists non-power-of-two sizes as a TODO, TODO.txt:8).  Always float64, also for
+        fp32 plans, so that the table is rounded ONCE to the working precision like every other table of the engine
+        (plan._twiddle_table).  m a power of two: a dense FFTPlan of m points; m smooth: the mixed-radix row kernel, or the
+        two-launch long form beyond its tile (include/mifft.h: mifft_launch_mixed_rows / mifft_launch_mixed_long)."""
+        ctx = self._context
+        cd = numpy.dtype(numpy.complex128)
+        host = numpy.ascontiguousarray(b, dtype=cd)
+        m = int(host.shape[0])
+        stream = ctx.stream_handle()
+        keep = []
+
+        def dev(arr):
+            arr = numpy.ascontiguousarray(arr)
+            mem = ctx.allocate_raw(arr.nbytes)
+            ctx.upload(mem, arr)
+            keep.append(mem)
+            return ctx.pointer_of(mem)
+
+        def roots(count, step, period):
+            k = numpy.arange(count, dtype=numpy.float64) * float(step)
+            ang = -2.0 * numpy.pi * numpy.fmod(k, float(period)) / float(period)
+            return dev((numpy.cos(ang) + 1j * numpy.sin(ang)).astype(cd))
+
+        src = dev(host)
+        dst = src
+        if _is_pow2(m):
+            plan = FFTPlan(self._sub, (m,), dtype=cd, normalize=False, wait_for_finish=True)
+            plan.execute(src)
+            plan.close()
+        elif N.lib.mifft_mixed_supported(N.F64, m) == 0:
+            N.check(N.lib.mifft_launch_mixed_rows(N.F64, m, 1, m, m, src, src, roots(m, 1, m), 0, 1.0, stream), "mifft_launch_mixed_rows")
+        else:
+            n1, n2 = ctypes.c_int32(0), ctypes.c_int32(0)
+            N.check(N.lib.mifft_mixed_long_split(N.F64, m, ctypes.byref(n1), ctypes.byref(n2)), "mifft_mixed_long_split(%d)" % m)
+            shift = max(1, (int(m - 1).bit_length() + 1) // 2)
+            dst = dev(numpy.zeros(m, cd))
+            N.check(N.lib.mifft_launch_mixed_long(N.F64, n1.value, n2.value, 1, src, dst, dst, roots(n1.value, 1, n1.value),
+                                                  roots(n2.value, 1, n2.value), roots(1 << shift, 1, m),
+                                                  roots(((m - 1) >> shift) + 1, 1 << shift, m), shift, 0, 1.0, stream),
+                    "mifft_launch_mixed_long")
+        out = numpy.empty(m, cd)
+        N.check(N.lib.mifft_memcpy_d2h(out.ctypes.data, dst, out.nbytes, stream), "mifft_memcpy_d2h")
+        N.check(N.lib.mifft_stream_sync(stream), "mifft_stream_sync")
+        del keep[:]
+        return out
 
     def _upload(self, host):
         host = numpy.ascontiguousarray(host)
@@ -318,6 +370,8 @@ class GenericFFTPlan(object):
     def _prepare(self, batch):
         if batch == self._last_batch:
             return
+        if self._captured and (self._work is not None or self._rows is not None):
+            self._capture_keepalive.append((self._work, self._rows))      # (a recorded graph replays on them: hip.Graph docstring)
         self._last_batch = batch
         if not self._uses_work:
             self._work = None           # no work arrays (a long smooth transform in place allocates its scratch on demand)
@@ -339,6 +393,12 @@ class GenericFFTPlan(object):
         ptr = ctx.pointer_of
         ctx.createQueue(ins + outs)
         ctx.order_scratch()
+        if ctx.capturing():
+            # recorded into a graph (work arrays must exist: one eager execute of the batch first): the graph keeps this plan alive,
+            # the plan keeps the work arrays of the recorded batch
+            from .hip import Graph
+            self._captured = True
+            Graph.retain(self)
         if self._tiled:
             return self._execute_tiled(wait_for_finish, bool(inverse), batch, [ptr(b) for b in ins], [ptr(b) for b in outs])
         if self._direct_nd1:

@@ -16,6 +16,7 @@ doc/source/index.rst:243-246, cuda.py:36-39).
 
 import ctypes
 import gc
+import threading
 
 import numpy
 
@@ -194,26 +195,75 @@ class Graph(object):
     and eager executes of the same plan may alternate on one stream.  A torch.cuda.graph() capture around execute() works the
     same way (the plan follows torch's current stream).
 
+    LIFETIME.  A recorded execute bakes RAW DEVICE ADDRESSES into the graph: the caller's buffers and the plan's twiddle tables,
+    ring / temp buffer, counter sets and pinned error word.  Two things keep them valid: (i) a Graph holds a reference to every plan
+    that executed inside its `with` block, so dropping the plan while the Graph lives frees nothing; (ii) a plan that has been captured
+    keeps the scratch of the captured launch alive when a later execute() of another batch, strategy() or close() replaces it
+    (FFTPlan._retain_captured_scratch) until the plan is collected or plan.release_captured() is called.  With torch.cuda.graph()
+    (or any capture API other than this class) only (ii) applies: keep the plan alive as long as the graph, like the tensors.
+
+    ONE STREAM PER PLAN AT A TIME.  Every captured launch of a plan replays on the SAME third counter set and the same ring / temp
+    buffer: launch the graphs recorded from one plan on one stream (replays then queue up behind each other), and do not run an
+    eager execute of that plan on ANOTHER stream while a replay is in flight -- the plan orders a later eager execute behind the
+    stream the capture was recorded on (Context.order_scratch), not behind a stream a graph was merely launched on.
+
     Do not drop the last reference to a plan, a stream or a pinned buffer inside the block: releasing them synchronises the device,
     which invalidates an active capture (measured: one run in four of the capture tests failed with "operation not permitted when
-    stream is capturing" when the cyclic collector happened to fire inside the window -- hence the collect-and-pause in __enter__)."""
+    stream is capturing" when the cyclic collector happened to fire inside the window -- hence the collect-and-pause in __enter__;
+    the pause is process-wide and reference-counted: the collector comes back when the LAST open capture of any thread ends).
+    execute(..., wait_for_finish=True) inside the block is a RuntimeError (waiting synchronises the stream)."""
+
+    _lock = threading.Lock()
+    _open = []                 # every Graph between __enter__ and __exit__, of any thread
+    _gc_paused = False         # ... while that list is non-empty the cyclic collector is off, if it was on
+    _gc_was_enabled = False
+
+    @classmethod
+    def _pause_gc(cls, graph):
+        with cls._lock:
+            if not cls._open:
+                cls._gc_was_enabled = gc.isenabled()
+                gc.disable()
+                cls._gc_paused = True
+            cls._open.append(graph)
+
+    @classmethod
+    def _resume_gc(cls, graph):
+        with cls._lock:
+            if graph in cls._open:
+                cls._open.remove(graph)
+            if not cls._open and cls._gc_paused:
+                cls._gc_paused = False
+                if cls._gc_was_enabled:
+                    gc.enable()
+
+    @classmethod
+    def retain(cls, plan):
+        """Called by a plan whose execute() is being recorded: every open Graph on the plan's capturing stream keeps the plan alive."""
+        try:
+            h = plan._context.stream_handle()
+        except Exception:
+            h = None
+        with cls._lock:
+            for g in cls._open:
+                if g.handle is None and _stream_handle(g.stream) == h and not any(p is plan for p in g._plans):
+                    g._plans.append(plan)
 
     def __init__(self, stream):
         self.stream = stream
         self.handle = None
+        self._plans = []           # plans recorded into this graph: alive as long as the graph is
 
     def __enter__(self):
         # an object that frees device memory when it is collected (a DeviceArray, a plan's scratch) would do so at an arbitrary point of
         # the capture window -- hipFree synchronises the device, which a capturing stream refuses and which invalidates the capture:
         # collect now, and keep the cyclic collector off until the capture has ended (torch.cuda.graph() collects first for the same reason)
         gc.collect()
-        self._gc_was_enabled = gc.isenabled()
-        gc.disable()
+        Graph._pause_gc(self)
         try:
             N.check(N.lib.mifft_stream_begin_capture(_stream_handle(self.stream)), "mifft_stream_begin_capture")
         except Exception:
-            if self._gc_was_enabled:
-                gc.enable()
+            Graph._resume_gc(self)
             raise
         return self
 
@@ -222,8 +272,7 @@ class Graph(object):
         try:
             rc = N.lib.mifft_stream_end_capture(_stream_handle(self.stream), ctypes.byref(h))
         finally:
-            if self._gc_was_enabled:
-                gc.enable()
+            Graph._resume_gc(self)
         if etype is None:
             N.check(rc, "mifft_stream_end_capture")
             self.handle = h.value
@@ -463,22 +512,24 @@ class Context(object):
         if prev is not None:
             N.check(N.lib.mifft_set_device(prev), "mifft_set_device")
 
-    def order_scratch(self):
+    def order_scratch(self, capturing=None):
         """Called before an execute() touches plan-owned scratch (temp buffer, ring, counters): when this call runs on a
         different stream than the previous one (a plan built without stream= follows torch's current stream per call), the
         new stream first waits for the work the old one still has in flight.  The reference plan ran on ONE stream
-        (cuda.py:94-107,129), where that order is implicit."""
+        (cuda.py:94-107,129), where that order is implicit.  `capturing`: the caller already knows whether the stream records."""
         h = self.stream_handle()
         last = self._last_stream_handle
-        if last is not None and last[0] != h and self.capturing():
-            # a capturing stream cannot wait for work outside its graph (and enqueues nothing now): the caller orders the replays
-            # behind the plan's earlier work, as with any captured graph
-            return
         if last is not None and last[0] != h:
-            if self._order_event is None:
-                self._order_event = Event()
-            self._order_event.record(last[1])
-            N.check(N.lib.mifft_stream_wait_event(h, self._order_event.handle), "mifft_stream_wait_event")
+            if capturing is None:
+                capturing = self.capturing()
+            if not capturing:
+                if self._order_event is None:
+                    self._order_event = Event()
+                self._order_event.record(last[1])
+                N.check(N.lib.mifft_stream_wait_event(h, self._order_event.handle), "mifft_stream_wait_event")
+            # (a capturing stream cannot wait for work outside its graph, and enqueues nothing now: the caller orders the replays
+            # behind the plan's earlier work, as with any captured graph -- but the capture stream becomes the plan's "last" stream, so
+            # that the next eager execute on another stream waits for what has been replayed on this one by then)
         if last is None or last[0] != h:
             self._last_stream_handle = (h, self._call_stream)     # (keeps the stream object alive)
 

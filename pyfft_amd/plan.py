@@ -133,6 +133,9 @@ class FFTPlan(object):
         self._last_call = None
         self._side_streams = None
         self._side_events = None
+        self._scratch_ready = False  # scratch of the current batch's strategy exists (allocated by the first execute that needs it)
+        self._captured = False       # some execute() of this plan was recorded into a graph (hip.Graph, torch.cuda.graph())
+        self._capture_keepalive = [] # scratch a captured launch baked the addresses of: kept until the plan itself goes away
 
         if self._params.split:
             self.execute = self._executeSplit
@@ -446,15 +449,42 @@ class FFTPlan(object):
     PERSISTENT = ("fused2", "fused2x", "fusedp")
 
     def _prepare(self, batch):
-        """(Re)allocate the plan-owned scratch when the batch changes (plan.py:179-192)."""
-        ctx = self._context
-        p = self._params
+        """Choose the strategy when the batch changes (plan.py:179-192); the plan-owned scratch of that strategy is allocated by the
+        first execute that needs it (_ensure_scratch): an out-of-place execute that takes the one-launch route (_runs_oop_nd) needs none."""
         if self._last_batch_size == batch:
             return
+        self._retain_captured_scratch()
         self._last_batch_size = batch
         self._last_call_key = None
         self._strategy = self._select_strategy(batch)
         self._tempmemobj = None
+        self._scratch_ready = False
+
+    def _retain_captured_scratch(self):
+        """A captured launch holds raw device addresses of this plan's scratch (ring / temp buffer, counter sets, pinned error word,
+        side streams): once an execute() has been recorded into a graph, scratch that is about to be replaced or released moves to
+        a keep-alive list instead of being freed, so that later replays of that graph still find it (hip.Graph docstring)."""
+        if self._captured:
+            held = (self._tempmemobj, self._counters, self._errword, self._xcd2_scratch, self._side_streams, self._side_events)
+            if any(h is not None for h in held) and not any(k is held or k == held for k in self._capture_keepalive):
+                self._capture_keepalive.append(held)
+
+    def _scratch_needed(self):
+        return self._strategy[0] == "xcd2" or self._temp_buffer_needed or self._strategy[0] in self.PERSISTENT or \
+            (self._strategy[0] == "pipelined" and self._side_streams is None)
+
+    def _ensure_scratch(self):
+        """(Re)allocate the plan-owned scratch of the current batch's strategy (plan.py:179-192)."""
+        if self._scratch_ready:
+            return
+        ctx = self._context
+        p = self._params
+        batch = self._last_batch_size
+        if self._scratch_needed() and ctx.capturing():
+            # scratch, counters and side streams are allocated here, which a capturing stream cannot record
+            raise RuntimeError("pyfft_amd: execute() on a capturing stream needs one eager execute() of the same batch (and the same "
+                               "in-place / out-of-place form) first")
+        self._scratch_ready = True
         if self._strategy[0] == "pipelined" and self._side_streams is None:
             from .hip import Stream, Event
             self._side_streams = [Stream() for _ in range(self._strategy[2])]
@@ -485,14 +515,14 @@ class FFTPlan(object):
         # plan.py:189-190; same total size)
         self._tempmemobj = ctx.allocate(p.size * items * p.complex_nbytes)
 
-    def _fused_sync(self, stream):
+    def _fused_sync(self, stream, capturing=False):
         """mifft_fused_sync of the coming persistent launch: the counter set it runs on (zero: the previous launch cleared it, or
         the memset below), the set it clears for the next launch, the pinned error word.  A launch that is being CAPTURED into a
         graph replays on the same set every time, so it takes the third set in the single-set form -- the library zeroes it with a
         memset node in front of the kernel -- and leaves the alternation of the eager launches alone."""
         base = self._context.pointer_of(self._counters)
         nb = self._counter_bytes
-        if self._context.capturing():
+        if capturing:
             return N.MifftFusedSync(base + 2 * nb, None, self._errword.ptr)
         if D.fused_memset():            # development A/B: one counter set, zeroed by a memset in front of every launch
             return N.MifftFusedSync(base, None, self._errword.ptr)
@@ -504,11 +534,17 @@ class FFTPlan(object):
         self._counter_set = 1 - cur
         return N.MifftFusedSync(base + cur * nb, base + (1 - cur) * nb, self._errword.ptr)
 
-    def _enqueue(self, batch, is_inplace, inverse, bufs0, bufs1):
+    def _runs_oop_nd(self, batch):
+        """An OUT-OF-PLACE execute of this batch takes the one-launch kernel with several work-groups per transform (csrc/fft_nd2z.hpp)
+        instead of the plan's chain / strategy: always for the shapes whose two halves run on two-per-CU tiles, beyond half the
+        last-level cache per side for the four-quarter shapes."""
+        return self._oop_nd is not None and not D.no_oop_nd() and D.forced_strategy() == "auto" and \
+            (self._oop_any_size or batch * self._params.size * self._params.complex_nbytes > self._context.machine.write_through_max_bytes)
+
+    def _enqueue(self, batch, is_inplace, inverse, bufs0, bufs1, capturing=False):
         ctx = self._context
         stream = ctx.stream_handle()
-        if self._oop_nd is not None and not is_inplace and not D.no_oop_nd() and D.forced_strategy() == "auto" and \
-                (self._oop_any_size or batch * self._params.size * self._params.complex_nbytes > ctx.machine.write_through_max_bytes):
+        if not is_inplace and self._runs_oop_nd(batch):
             # one launch, several work-groups per transform (csrc/fft_nd2z.hpp); needs no scratch.  Beyond half the last-level cache per
             # side: (256, 256) at 256 MiB 0.339 -> 0.444, at 2 GiB 0.464 (persistent) -> 0.501; at 32 MiB the two launches win (0.404 / 0.356)
             descs = self._descriptors(batch, False, bool(inverse), alt=2)
@@ -517,7 +553,7 @@ class FFTPlan(object):
         descs = self._descriptors(batch, is_inplace, bool(inverse))
         strat = self._strategy
         if strat[0] == "xcd2":
-            if ctx.capturing():
+            if capturing:
                 raise RuntimeError("pyfft_amd: the development strategy xcd2 cannot be captured into a graph")
             d0, d1 = descs[0], descs[1]
             in1 = bufs1[d0.src] if bufs1 is not None else None
@@ -527,7 +563,7 @@ class FFTPlan(object):
                                             strat[1], stream), "mifft_launch_xcd2")
             self._post_error_word(stream)
         elif strat[0] in self.PERSISTENT:
-            sync = self._fused_sync(stream)
+            sync = self._fused_sync(stream, capturing)
             try:
                 if strat[0] == "fused2x":
                     _, lag, ring, grid = strat
@@ -558,7 +594,7 @@ class FFTPlan(object):
                 raise
         elif strat[0] == "pipelined":
             _, chunk, nside, nslab = strat
-            if ctx.capturing():
+            if capturing:
                 # recorded into a graph: the chunks one after the other on the capturing stream itself (the library skips the fork / join
                 # when the only "side" stream IS the caller's) -- the same launches on the same chunks, hence the same bits, as a LINEAR
                 # graph.  A forked capture replayed correctly most of the time and took the process down in hipGraphLaunch once in
@@ -656,11 +692,17 @@ class FFTPlan(object):
             raise ValueError("batch must be positive")
         if self._mailbox is not None or self._errword is not None:
             self.check()
+        ctx.createQueue(args)
+        # global wait setting has lower priority than the local one (plan.py:250-253)
+        wait = self._wait_for_finish
+        if wait_for_finish is not None:
+            wait = wait_for_finish
+        capturing = ctx.capturing()
+        if capturing and wait:
+            # finish() synchronises the stream, which a capturing stream refuses and which invalidates the capture
+            raise RuntimeError("pyfft_amd: execute() on a capturing stream cannot wait for the result: build the plan with stream= "
+                               "(or wait_for_finish=False), or pass wait_for_finish=False to this call")
         if self._last_batch_size != batch:
-            ctx.createQueue(args)
-            if ctx.capturing():
-                # scratch, counters and side streams are allocated here, which a capturing stream cannot record
-                raise RuntimeError("pyfft_amd: execute() on a capturing stream needs one eager execute() of the same batch first")
             self._prepare(batch)
         # small transforms are launch-bound (a 32 MiB execute is ~12 us of device time): the pointer triples of the last
         # call are kept, so that repeated executes on the same buffers skip rebuilding them
@@ -670,21 +712,30 @@ class FFTPlan(object):
             self._last_call = self._buffers(is_inplace, args)
             self._last_call_key = key
         is_inplace, bufs0, bufs1 = self._last_call
+        if not self._scratch_ready and (is_inplace or not self._runs_oop_nd(batch)):
+            self._ensure_scratch()
+            if self._tempmemobj is not None:
+                self._last_call = self._buffers(is_inplace, args)      # (the triple carries the temp buffer's address)
+                is_inplace, bufs0, bufs1 = self._last_call
 
-        ctx.createQueue(args)
-        ctx.order_scratch()
-        self._enqueue(batch, is_inplace, inverse, bufs0, bufs1)
-
-        # global wait setting has lower priority than the local one (plan.py:250-253)
-        wait = self._wait_for_finish
-        if wait_for_finish is not None:
-            wait = wait_for_finish
+        ctx.order_scratch(capturing)
+        if capturing:
+            self._note_capture()
+        self._enqueue(batch, is_inplace, inverse, bufs0, bufs1, capturing)
 
         if wait:
             self.finish()
         else:
             ctx.flush()
             return ctx.getQueue()
+
+    def _note_capture(self):
+        """This execute() is being recorded into a graph: the graph bakes in the addresses of the plan's scratch and tables.  The plan
+        keeps that scratch alive for as long as it lives itself (_retain_captured_scratch), and an open hip.Graph takes a reference to
+        the plan, so that `del plan` with the graph still around frees nothing the graph replays on."""
+        self._captured = True
+        from .hip import Graph
+        Graph.retain(self)
 
     def _executeInterleaved(self, data_in, data_out=None, inverse=False, batch=1, wait_for_finish=None):
         """Execute plan for interleaved complex array (plan.py:261-271)."""
@@ -711,10 +762,14 @@ class FFTPlan(object):
 
     def close(self):
         """Wait for outstanding work and release the plan's device resources now (temp buffer, counters, scratch, side
-        streams and events) instead of at garbage collection.  The plan stays usable: everything is re-created on demand."""
+        streams and events) instead of at garbage collection.  The plan stays usable: everything is re-created on demand.
+        Scratch that a captured graph replays on (an execute() of this plan was recorded by hip.Graph / torch.cuda.graph()) is NOT
+        released here: it lives until the plan is collected, or until release_captured() says that no such graph will run again."""
         try:
             self.finish()
         finally:
+            self._retain_captured_scratch()      # (a plan that was captured into a graph keeps what the graph replays on)
+            self._scratch_ready = False
             self._tempmemobj = None
             self._counters = None
             self._xcd2_scratch = None
@@ -725,14 +780,29 @@ class FFTPlan(object):
             self._last_batch_size = 0
             self._last_call_key = None
 
+    def release_captured(self):
+        """The caller guarantees that no graph recorded from this plan will be launched again: waits for the plan's stream and frees
+        the scratch kept alive for such graphs (replaced rings, counter sets, error words)."""
+        self.finish()
+        self._capture_keepalive = []
+        self._captured = False
+
     # ------------------------------------------------------------------------------------
     # introspection helpers used by bench.py / tests (not part of the reference API)
-    def pass_list(self):
+    def pass_list(self, inplace=True):
+        """The plan's pass chain; inplace=False: what an OUT-OF-PLACE execute launches where that differs (the one-pass list of the
+        shapes with a several-work-groups-per-transform kernel, csrc/fft_nd2z.hpp -- whether a given batch takes it: strategy())."""
+        if not inplace and self._oop_nd is not None and not D.no_oop_nd() and D.forced_strategy() == "auto":
+            return list(self._oop_nd)
         return list(self._kernels)
 
     @on_plan_device
-    def strategy(self, batch):
+    def strategy(self, batch, inplace=True):
+        """(name, ...) of the execution strategy of this batch.  inplace=False: what an out-of-place execute runs -- ("nd_oop",)
+        where it bypasses the chain for the one-launch kernel (_runs_oop_nd; needs no scratch), else the same as in place."""
         self._prepare(int(batch))
+        if not inplace and self._runs_oop_nd(int(batch)):
+            return ("nd_oop",)
         return self._strategy
 
     @on_plan_device
@@ -744,6 +814,8 @@ class FFTPlan(object):
         batch = int(batch)
         self._prepare(batch)
         args = (bufs_in[0], bufs_in[1], bufs_out[0], bufs_out[1]) if self._params.split else (bufs_in[0], bufs_out[0])
+        if is_inplace or not self._runs_oop_nd(batch):
+            self._ensure_scratch()
         is_inplace, bufs0, bufs1 = self._buffers(is_inplace, args)
         ctx.createQueue()
         e0, e1 = Event(), Event()

@@ -268,8 +268,10 @@ def test_generic_plans_build_only_what_they_run(ctx):
 
 
 # ---- rectangular 2-D shapes on the fused kernel ---------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape,batch", [((512, 1024), 66), ((1024, 512), 113), ((1024, 2048), 18), ((2048, 1024), 29)] +
-                         ([((512, 2048), 33), ((2048, 512), 57)] if _SOAK else []), ids=str)   # ((512, 2048) runs the kernel on request only: pipelined is faster)
+RECT_2D_CASES = [((512, 1024), 66), ((1024, 512), 113), ((1024, 2048), 18), ((2048, 1024), 29), ((512, 2048), 33), ((2048, 512), 57)]
+
+
+@pytest.mark.parametrize("shape,batch", RECT_2D_CASES, ids=str)   # ((512, 2048) runs the kernel on request only: pipelined is faster)
 def test_fused_2d_rectangles(ctx, monkeypatch, shape, batch):
     """(ny, nx) in {512, 1024, 2048}^2 with ny != nx, fp32 interleaved, beyond the chain threshold: one persistent launch of two
     transposing passes (round 3: squares only; pyfft/kernel.mako:857-874 vertical mode, plan.py:135-171).  The reference's
@@ -447,7 +449,10 @@ def test_fused_2d_fp64_512_sides(ctx, monkeypatch, shape, batch):
     assert oracle.difference(want, got, batch) < 1e-14
 
 
-@pytest.mark.parametrize("n,batch", [(1 << 16, 1040), (1 << 18, 161)] + ([(1 << 17, 530), (1 << 18, 260)] if _SOAK else []), ids=str)
+WIDE_TILE_CASES = [(1 << 16, 1040), (1 << 17, 530), (1 << 18, 161)] + ([(1 << 18, 260)] if _SOAK else [])      # (soak: a second batch of one size)
+
+
+@pytest.mark.parametrize("n,batch", WIDE_TILE_CASES, ids=str)
 def test_wide_tiles_fp32_mid_sizes(ctx, monkeypatch, n, batch):
     """fp32 N = 2^16 ... 2^18 in the persistent kernel on 32-column tiles (csrc/fft_col2w.hpp: a thread owns two adjacent columns,
     16-byte lanes, 256-byte row segments) by the plan's own choice: the bits of the chain (same butterflies, same table factors) and
@@ -586,8 +591,10 @@ def _execute_split(ctx, shape, rdtype, batch, re, im, inplace=False, inverse=Fal
     return b_re.get(), b_im.get()
 
 
-@pytest.mark.parametrize("n,batch,expect", [(1 << 16, 1100, "fused2"), (1 << 18, 259, "fused2"), (1 << 20, 70, "fused2")] +
-                         ([(1 << 17, 515, "fused2"), (1 << 19, 130, "fused2")] if _SOAK else []), ids=str)
+SPLIT_1D_CASES = [(1 << 16, 1100, "fused2"), (1 << 17, 515, "fused2"), (1 << 18, 259, "fused2"), (1 << 19, 130, "fused2"), (1 << 20, 70, "fused2")]
+
+
+@pytest.mark.parametrize("n,batch,expect", SPLIT_1D_CASES, ids=str)
 def test_split_planes_on_per_xcd_lists(ctx, monkeypatch, n, batch, expect):
     """float32 planes (the reference's split layout, pyfft/plan.py:10-63 dtype rule) on the persistent 1-D kernels by the plan's own
     choice: the two 16-column tiles that share every 128-byte line of a plane run in one 512-thread work-group, interleaved at lane
@@ -622,9 +629,12 @@ def test_split_planes_on_per_xcd_lists(ctx, monkeypatch, n, batch, expect):
 
 
 # ---- persistent two-pair kernel for 3-D shapes with 64- and 128-point axes (csrc/fft_fusedp2.hip) --------------------------------
+PAIR_SMALL_AXES_CASES = [((64, 64, 64), 141), ((64, 128, 128), 59), ((128, 128, 64), 57), ((128, 64, 128), 61),
+                         ((64, 128, 64), 115), ((64, 64, 128), 117), ((128, 64, 64), 113)]
+
+
 @pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
-@pytest.mark.parametrize("shape,batch", [((64, 64, 64), 141), ((64, 128, 128), 59), ((128, 128, 64), 57), ((128, 64, 128), 61)] +
-                         ([((64, 128, 64), 115), ((64, 64, 128), 117), ((128, 64, 64), 113)] if os.environ.get("PYFFT_AMD_SWEEP") else []), ids=str)
+@pytest.mark.parametrize("shape,batch", PAIR_SMALL_AXES_CASES, ids=str)
 def test_fused_pair_small_axes(ctx, monkeypatch, shape, batch, dtype):
     """3-D shapes whose chain is one plane pass + one strided z pass (pyfft/plan.py:160-167: one chain per axis) and that have a
     persistent two-pair kernel: beyond the chain threshold the plan factors the y axis R0 x R1 FOR THAT LAUNCH ALONE (four passes as
@@ -660,13 +670,12 @@ def test_fused_pair_small_axes(ctx, monkeypatch, shape, batch, dtype):
     assert ctx.getPlan(shape, dtype=cd).strategy(batch)[0] == "pipelined"
 
 
-# (every shape of {64, 128}^3 has its own tile pair: a cube, a shape with one 64-point axis in each position and one with two per precision run
-# by default, the other combinations with the soak switch PYFFT_AMD_SWEEP -- the driver's GPU step has a time limit)
+# (every shape of {64, 128}^3 has its own tile pair in both precisions: every instance a default plan can select runs in the default suite)
 _PAIR_SPLIT_CASES = [((64, 64, 64), numpy.float32, 141), ((64, 128, 128), numpy.float32, 59), ((128, 64, 64), numpy.float32, 113),
-                     ((128, 128, 128), numpy.float64, 15), ((128, 128, 64), numpy.float64, 30), ((128, 64, 128), numpy.float64, 31)]
-if _SOAK:
-    _PAIR_SPLIT_CASES += [((64, 128, 64), numpy.float32, 115), ((64, 64, 128), numpy.float32, 117), ((64, 64, 64), numpy.float64, 71),
-                          ((128, 64, 64), numpy.float64, 57), ((64, 128, 128), numpy.float64, 29), ((128, 128, 128), numpy.float32, 29)]
+                     ((128, 128, 128), numpy.float64, 15), ((128, 128, 64), numpy.float64, 30), ((128, 64, 128), numpy.float64, 31),
+                     ((64, 128, 64), numpy.float32, 115), ((64, 64, 128), numpy.float32, 117), ((64, 64, 64), numpy.float64, 71),
+                     ((128, 64, 64), numpy.float64, 57), ((64, 128, 128), numpy.float64, 29), ((128, 128, 128), numpy.float32, 29),
+                     ((128, 128, 64), numpy.float32, 57), ((128, 64, 128), numpy.float32, 61), ((64, 128, 64), numpy.float64, 58), ((64, 64, 128), numpy.float64, 59)]
 
 
 @pytest.mark.parametrize("shape,rdtype,batch", _PAIR_SPLIT_CASES, ids=str)
@@ -703,8 +712,11 @@ def test_fused_pair_split_planes(ctx, monkeypatch, shape, rdtype, batch):
 
 
 # ---- split-complex fp32 2-D plans on the row-first persistent kernel (csrc/fft_fused2r.hpp) ------------------------------------------
-@pytest.mark.parametrize("shape,batch", [((1024, 1024), 37), ((512, 512), 140), ((256, 256), 530), ((512, 1024), 70), ((1024, 256), 131), ((256, 512), 261)] +
-                         ([((1024, 512), 67), ((256, 1024), 135), ((512, 256), 259)] if _SOAK else []), ids=str)   # ((256, 256): on request only)
+SPLIT_2D_ROWFIRST_CASES = [((1024, 1024), 37), ((512, 512), 140), ((256, 256), 530), ((512, 1024), 70), ((1024, 256), 131), ((256, 512), 261),
+                           ((1024, 512), 67), ((256, 1024), 135), ((512, 256), 259)]
+
+
+@pytest.mark.parametrize("shape,batch", SPLIT_2D_ROWFIRST_CASES, ids=str)   # ((256, 256): on request only)
 def test_fused_2d_split_row_first(ctx, monkeypatch, shape, batch):
     """float32 planes, 2-D, beyond the chain threshold: ROW x from the planes and COL y to the planes on the persistent work list (the
     chain's own order, pyfft/plan.py:135-171, instead of two transposing passes whose 16-column tiles read half lines of the planes).
@@ -737,8 +749,10 @@ def test_fused_2d_split_row_first(ctx, monkeypatch, shape, batch):
 
 
 # ---- split-complex fp64 (float64 planes) on the persistent kernels, planes streamed non-temporally -----------------------------------
-@pytest.mark.parametrize("shape,batch", [((1 << 16,), 270), ((1 << 18,), 67), ((1 << 20,), 29), ((1024, 1024), 30)] +
-                         ([((1 << 17,), 131), ((1 << 19,), 35)] if _SOAK else []), ids=str)
+SPLIT_FP64_CASES = [((1 << 16,), 270), ((1 << 17,), 131), ((1 << 18,), 67), ((1 << 19,), 35), ((1 << 20,), 29), ((1024, 1024), 30)]
+
+
+@pytest.mark.parametrize("shape,batch", SPLIT_FP64_CASES, ids=str)
 def test_fused_split_planes_fp64(ctx, monkeypatch, shape, batch):
     """float64 planes beyond the chain threshold: 1-D 2^16 ... 2^20 and the published 1024 x 1024 on the persistent kernels (16 columns
     of an fp64 plane are a whole 128-byte line; the tiles stream the planes with non-temporal loads and stores, second batch of

@@ -378,12 +378,12 @@ PAIR_CHAIN_CASES = [((4096, 256), numpy.complex64, 2), ((4096, 256), numpy.compl
                     ((32, 32, 1024), numpy.complex128, 2), ((16, 16, 1024), numpy.complex128, 5), ((2, 4096, 256), numpy.complex64, 1)]
 _PAIR_CHAIN_SOAK = [((4096, 512), numpy.complex64, 1), ((4096, 512), numpy.complex128, 1), ((32, 32, 4096), numpy.complex64, 1),
                     ((16, 16, 4096), numpy.complex64, 1), ((32, 32, 2048), numpy.complex128, 1), ((16, 16, 2048), numpy.complex128, 2)]
-# the biggest planes (16 ... 128 MiB per transform: numpy takes seconds per case) run with the soak switch, as tests/test_random_sweep_gpu.py's extra cases
 PAIR_CHAIN_CASES += [((4096, 128), numpy.complex128, 3), ((4096, 128), numpy.complex64, 5)]      # (late in round 5: 128-point rows)
-if os.environ.get("PYFFT_AMD_SWEEP"):
-    PAIR_CHAIN_CASES += _PAIR_CHAIN_SOAK + [((4096, 4096), numpy.complex128, 1),
-                         ((4096, 1024), numpy.complex64, 3), ((4096, 2048), numpy.complex64, 1), ((4096, 4096), numpy.complex64, 1),
-                         ((4096, 1024), numpy.complex128, 2), ((4096, 2048), numpy.complex128, 1)]
+# every one of these is a pair-kernel instance of its own (csrc/fft_pair_f32.hip / _f64.hip) that a default plan selects: all in the default suite
+# (round 6; the biggest planes are 16 ... 256 MiB per transform: numpy takes a second or two per case)
+PAIR_CHAIN_CASES += _PAIR_CHAIN_SOAK + [((4096, 4096), numpy.complex128, 1),
+                                        ((4096, 1024), numpy.complex64, 3), ((4096, 2048), numpy.complex64, 1), ((4096, 4096), numpy.complex64, 1),
+                                        ((4096, 1024), numpy.complex128, 2), ((4096, 2048), numpy.complex128, 1)]
 
 
 @pytest.mark.parametrize("shape,dtype,batch", PAIR_CHAIN_CASES, ids=lambda v: getattr(v, "__name__", str(v)).replace(" ", ""))
@@ -581,7 +581,7 @@ def test_tiny_nd_shapes_big_launches(ctx, monkeypatch, shape, dtype, batch):
 
 # ---- 3-D shapes with 256-point rows next to a shorter axis: the two pass pairs of 256^3 instead of three launches ---------------------------
 _LATE_PAIR_SHAPES = [((64, 128, 256), numpy.complex128, 1), ((64, 256, 256), numpy.complex64, 1), ((32, 256, 128), numpy.complex128, 3)]
-if os.environ.get("PYFFT_AMD_SWEEP"):
+if True:      # (round 6: every shape is a pair-kernel instance of its own -- all in the default suite)
     _LATE_PAIR_SHAPES += [((64, 256, 128), numpy.complex128, 1), ((128, 256, 128), numpy.complex128, 1), ((256, 256, 128), numpy.complex128, 1),
                           ((32, 256, 256), numpy.complex128, 1), ((32, 128, 256), numpy.complex128, 2),
                           ((128, 256, 64), numpy.complex128, 1), ((32, 256, 64), numpy.complex128, 5), ((256, 256, 64), numpy.complex128, 1),
