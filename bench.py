@@ -55,12 +55,11 @@ C5_SHARE = 8192     # transforms per GPU of BASELINE.json configs[4] (65536 over
 
 
 def shard_batch(global_batch, rank, world):
-    """Contiguous slice [start, start+count) of the batch axis owned by `rank`:
-    independent transforms, no exchange."""
-    base, extra = divmod(global_batch, world)
-    count = base + (1 if rank < extra else 0)
-    start = rank * base + min(rank, extra)
-    return start, count
+    """Contiguous slice [start, start+count) of the batch axis owned by `rank`: independent transforms, no
+    exchange.  The library's own rule (pyfft_amd/sharded.py: the split ShardedPlan makes); imported lazily so that the parent of a
+    self-launched job loads nothing."""
+    from pyfft_amd.sharded import shard_batch as _sb
+    return _sb(global_batch, rank, world)
 
 
 def dist_env():
@@ -348,6 +347,176 @@ def _trace(label):
         sys.stderr.write("bench.py trace rank %s %7.2f s  %s\n" % (os.environ.get("RANK", "0"), time.perf_counter() - _T0, label))
 
 
+def main_single_process(args, auto_steps=False):
+    """`--gpus N --single-process`: the same job as one process per GPU, driven from ONE process through the library's
+    ShardedPlan (pyfft_amd/sharded.py): one plan, stream and scratch per device, the global batch cut into contiguous slices, every
+    shard's execute enqueued asynchronously, one synchronisation per device on either side of the K timed steps.  No collective and
+    no torch.distributed.  Same JSON line (`n_gpus` = N, `config.parallelism` names the orchestration), so that an 8-GPU box can
+    A/B the two orchestrations without a code change.  --share-gpu: shard r on device r % (visible devices)."""
+    import numpy
+    shape, dtname, batch, seed = CONFIGS[args.config]
+    if args.batch:
+        batch = args.batch
+    dtype = numpy.dtype(dtname)
+    split = dtype.kind == "f"
+    cdtype = numpy.dtype(numpy.complex64 if dtype in (numpy.complex64, numpy.float32) else numpy.complex128)
+    size = int(numpy.prod(shape))
+    log2n = sum(int(round(numpy.log2(v))) for v in shape)
+    flop_per_xform = 5.0 * size * log2n
+    alg_bytes_per_xform = 2.0 * size * cdtype.itemsize
+    cpu = None
+    if not args.no_cpu_baseline:
+        _, _, _, host0 = make_host_block(shape, dtname, batch, seed, 0)
+        cpu = cpu_baseline(shape, dtname, host0[:min(len(host0), 16)], flop_per_xform, budget_s=args.cpu_budget, max_workers=args.cpu_workers)
+        del host0
+    try:
+        import torch  # noqa: F401  (first, so that this process uses one HIP runtime for torch and libmifft)
+    except Exception:
+        pass
+    from pyfft_amd import _native as N
+    from pyfft_amd.hip import DeviceArray, Event, device_count, device_props
+    from pyfft_amd.sharded import ShardedPlan, _OnDevice
+    import pyfft_amd.hip as hip
+    ndev = device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py: no GPU visible")
+    n = args.gpus
+    note = None
+    if args.share_gpu:
+        devices = [r % ndev for r in range(n)]
+    else:
+        if n > ndev:
+            note = "requested %d GPUs, %d visible: ran %d shards" % (n, ndev, ndev)
+            n = ndev
+        devices = list(range(n))
+    splan = ShardedPlan(shape if len(shape) > 1 else shape[0], dtype, devices=devices, threads=args.shard_threads, wait_for_finish=False)
+    gb = batch * n
+    slices = splan.slices(gb)
+    nplanes = 2 if split else 1
+    ins = [[None] * n for _ in range(nplanes)]
+    outs = [[None] * n for _ in range(nplanes)]
+    blocks = []
+    for i, ((start, count), d) in enumerate(zip(slices, devices)):
+        blk, host_re, host_im, host_c = make_host_block(shape, dtname, batch, seed, start)
+        blocks.append((blk, host_c))
+        with _OnDevice(hip, d):
+            for pl, host in enumerate((host_re, host_im) if split else (host_c,)):
+                ins[pl][i] = DeviceArray((size * count,), dtype)
+                outs[pl][i] = ins[pl][i] if args.inplace else DeviceArray((size * count,), dtype)
+                fill_device(N, ins[pl][i].ptr, ins[pl][i].nbytes, host)
+        del host_re, host_im
+
+    def step():
+        if args.inplace:
+            splan.execute(*ins, batch=gb, wait_for_finish=False)
+        else:
+            splan.execute(*(ins + outs), batch=gb, wait_for_finish=False)
+
+    def sync_all():
+        for d in sorted(set(devices)):
+            with _OnDevice(hip, d):
+                N.check(N.lib.mifft_device_sync(), "sync")
+
+    # ---- parity gate: first / middle / last transform of EVERY shard against numpy on the global data set
+    parity = None
+    rank_report = []
+    if not args.inplace:
+        step()
+        splan.finish()
+        eps, mx = (1.1e-6, 1e-5) if cdtype == numpy.complex64 else (1e-11, 1e-10)
+        worst_diff = worst_max = 0.0
+        isz = dtype.itemsize
+        for i, ((start, count), d) in enumerate(zip(slices, devices)):
+            blk, host_c = blocks[i]
+            sd = 0.0
+            with _OnDevice(hip, d):
+                for sidx in sorted(set([0, count // 2, count - 1])):
+                    parts = []
+                    for pl in range(nplanes):
+                        got = numpy.empty(size, dtype)
+                        N.check(N.lib.mifft_memcpy_d2h(got.ctypes.data, outs[pl][i].ptr + sidx * size * isz, size * isz, None), "d2h")
+                        parts.append(got)
+                    got = (parts[0].astype(numpy.complex128) + 1j * parts[1]) if split else parts[0].astype(numpy.complex128)
+                    ref = numpy.fft.fftn(host_c[sidx % blk].astype(numpy.complex128)).reshape(-1)
+                    sd = max(sd, float(numpy.abs(ref - got).sum() / numpy.abs(ref).sum()))
+                    worst_max = max(worst_max, float(numpy.abs(ref - got).max() / numpy.abs(ref).max()))
+                    if args.dump_dir and sidx in (0, count - 1):
+                        numpy.save(os.path.join(args.dump_dir, "xform_%d.npy" % (start + sidx)), got)
+            worst_diff = max(worst_diff, sd)
+            rank_report.append({"rank": i, "first_transform": start, "count": count, "parity_ok": bool(sd < eps), "difference": sd, "device": d})
+        parity = {"samples": 3 * n, "difference": worst_diff, "max_rel": worst_max, "tol_difference": eps, "tol_max_rel": mx,
+                  "ok": bool(worst_diff < eps and worst_max <= mx)}
+        if not parity["ok"]:
+            raise SystemExit("PARITY FAILURE: %r" % (parity,))
+
+    def timed(k):
+        """device time of k steps: HIP events on every shard's own stream, the slowest shard counts"""
+        ev = []
+        for s_ in splan.streams:
+            ev.append((Event().record(s_), Event()))
+        for _ in range(k):
+            step()
+        for (e0, e1), s_ in zip(ev, splan.streams):
+            e1.record(s_)
+        ms = []
+        for e0, e1 in ev:
+            e1.synchronize()
+            ms.append(e1.time_since(e0))
+        return max(ms)
+
+    est_step_ms = timed(2) / 2
+    if not args.no_spin_up:
+        k = max(2, min(400, int(100.0 / max(1e-3, est_step_ms))))
+        est_step_ms = timed(k) / k
+    if auto_steps:
+        args.steps = max(10, int(250.0 / max(1e-3, est_step_ms)) + 1)
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    dev_ms = timed(args.steps)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    splan.finish()           # raises if a persistent kernel of any shard reported a dependency time-out
+
+    strategies = splan.strategy(gb, inplace=bool(args.inplace))
+    total_xforms = gb * args.steps
+    ms_per_step = elapsed * 1e3 / args.steps
+    gflops = flop_per_xform * total_xforms / elapsed / 1e9
+    alg_gbs = alg_bytes_per_xform * total_xforms / elapsed / 1e9
+    chain_ms = dev_ms / args.steps
+    achieved = alg_bytes_per_xform * batch / (chain_ms * 1e-3) / 1e9          # per device: the slowest shard's kernel
+    props = device_props(devices[0])
+    result = {
+        "metric": "batched_c2c_fft_gflops_5NlogN_1d_n2^20" if args.config == "c2" else "batched_c2c_fft_gflops_5NlogN_" + args.config,
+        "value": gflops, "unit": "GFLOPS", "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if cdtype == numpy.complex64 else "f64",
+        "data": "synthetic",
+        "config": {"workload": "%s: %s c2c %s, batch %d per GPU, %s, %s" % (
+            args.config, "x".join(map(str, shape)), dtname, batch, "split re/im planes" if split else "interleaved",
+            "in place" if args.inplace else "out of place"),
+            "global_batch": gb, "first_transform_of_rank0": 0,
+            "parallelism": "batch-sharded x%d from ONE process (pyfft_amd.sharded.ShardedPlan: a plan and a stream per device, no "
+                           "collective, enqueue %s)" % (n, "on a host thread per shard" if args.shard_threads else "on the calling thread"),
+            "ranks": rank_report, "passes": [repr(p) for p in splan.plans[0].pass_list(inplace=bool(args.inplace))],
+            "strategy": strategies[0][0] if strategies[0] else None, "devices": devices},
+        "transforms_per_s": total_xforms / elapsed,
+        "algorithmic_GBps": alg_gbs,
+        "hbm_fraction_of_8TBps": alg_gbs / n / HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "%s on every shard (the slowest shard's HIP-event time)" % (strategies[0][0] if strategies[0] else "-"),
+                     "algorithmic_bytes_per_step": alg_bytes_per_xform * batch, "chain_ms_hip_events": chain_ms},
+        "protocol": None,
+        "parity": parity,
+        "device": "%s (%s), %d CUs" % (props.name.decode(), props.gcn_arch.decode(), props.compute_units),
+        "cpu_baseline": cpu,
+    }
+    if note:
+        result["note"] = note
+    print(json.dumps(result))
+    splan.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -374,6 +543,12 @@ def main():
                          "xform_<global index>.npy (test: checked against numpy on the global dataset)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rank r uses device r %% (visible devices): runs the real sharded path with more ranks than GPUs (test)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N driven from ONE process through pyfft_amd.sharded.ShardedPlan (one plan, stream and scratch per "
+                         "device, every shard enqueued asynchronously, one sync per device) instead of one process per GPU: the same "
+                         "JSON line, `config.parallelism` says which orchestration ran")
+    ap.add_argument("--shard-threads", action="store_true", help="--single-process: one host thread per shard for the enqueue")
+    ap.add_argument("--no-spin-up", action="store_true", help="skip the untimed clock spin-up in front of the warm-up steps (A/B)")
     args = ap.parse_args()
 
     if args.plain:
@@ -381,9 +556,12 @@ def main():
         args.no_cpu_baseline = True
     # config 5 as BASELINE.json states it: 65536 transforms of 2^22 points over 8 GPUs = 8192 per GPU = 256 GiB per GPU, run as a
     # streaming loop over 256-transform chunks.  One step = one chunk; the default K is one sweep over the share.
-    share_mode = args.config == "c5" and not args.chunk_only and not args.batch
+    share_mode = args.config == "c5" and not args.chunk_only and not args.batch and not args.single_process
+    auto_steps = args.steps <= 0 and not share_mode      # K chosen after the warm-up so that the timed region is >= 250 ms
     if args.steps <= 0:
         args.steps = C5_SHARE // CONFIGS["c5"][2] if share_mode else 10
+    if args.single_process:
+        return main_single_process(args, auto_steps)
     if args.gpus > 1 and "RANK" not in os.environ:
         return self_launch(args, sys.argv[1:])       # never returns
     if args.selftest_dist:
@@ -585,6 +763,77 @@ def main():
             raise SystemExit("PARITY FAILURE: %r" % (parity,))
 
     _trace("parity gate passed")
+    # ---- clock spin-up (untimed, not a step of the contract): a device that has idled through the host-side parity check starts its
+    # first kernels at a low clock, and a timed region of a few short steps right behind two warm-up steps reads the ramp (C3: 0.4255 on
+    # the K-step line against 0.445 on >= 20 ms blocks).  ~100 ms of back-to-back steps first; their duration also
+    # gives the step time the default K and the protocol's block length are sized from.
+    def timed_steps(n):
+        e0, e1 = Event(), Event()
+        e0.record(stream)
+        for _ in range(n):
+            if resident:
+                execute_chunk(0)
+                execute_chunk(0, inverse=True)
+            else:
+                step()
+        e1.record(stream)
+        e1.synchronize()
+        return e1.time_since(e0) / (n * (2 if resident else 1))
+
+    est_step_ms = timed_steps(2)
+    if not args.no_spin_up:
+        est_step_ms = timed_steps(max(2, min(400, int(100.0 / max(1e-3, est_step_ms)))))
+    if auto_steps:
+        args.steps = max(10, int(250.0 / max(1e-3, est_step_ms)) + 1)
+    _trace("spin-up done: %.3f ms per step, K = %d" % (est_step_ms, args.steps))
+    # ---- the reference's timing protocol (untimed for `value`; run BEFORE the timed steps since round 6: it is also what keeps the
+    # clocks up until they start): out of place AND in place, median of >= 5 repeats of a
+    # block of back-to-back executes between two HIP events (test/test_performance.py:22-30 times 10 executes once;
+    # cuda/test.cu:37-64 times both forms).  In place alternates forward / inverse so that the values stay bounded.
+    protocol = None
+    if resident and args.repeats > 0:
+        # the same share as ONE in-place execute (batch = 8192: element offsets beyond 2^35), forward then inverse, HIP events
+        protocol = {"one_execute_of_the_share": {"batch": share, "repeats": min(args.repeats, 3)}}
+        ms = []
+        for _ in range(min(args.repeats, 3)):
+            for inv in (False, True):
+                e0, e1 = Event(), Event()
+                e0.record(stream)
+                plan.execute(ins[0], batch=share, inverse=inv)
+                e1.record(stream)
+                e1.synchronize()
+                ms.append(e1.time_since(e0))
+        plan.finish()
+        st = stats(ms)
+        protocol["one_execute_of_the_share"].update({
+            "ms_per_execute": st, "strategy": plan.strategy(share)[0],
+            "frac_median": alg_bytes_per_xform * share / (st["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "transforms_per_s_median": share / (st["median"] * 1e-3)})
+    elif args.repeats > 0 and world == 1 and not args.inplace:
+        # blocks of >= 20 ms of back-to-back executes (a burst of a few short launches behind a synchronisation measures the clock
+        # ramp and the fill / drain of the first launch: 3-4 points at 1 GiB per side, DESIGN.md section 7)
+        per = max(2, min(args.steps, 10), int(20.0 / max(1e-3, est_step_ms)) + 1)
+        per += per & 1
+        protocol = {"executes_per_repeat": per, "repeats": args.repeats}
+        for name, inpl in (("out_of_place", False), ("in_place", True)):
+            ms = []
+            for _ in range(args.repeats):
+                e0, e1 = Event(), Event()
+                e0.record(stream)
+                for j in range(per):
+                    execute(inpl, inverse=bool(inpl and (j & 1)))
+                e1.record(stream)
+                e1.synchronize()
+                ms.append(e1.time_since(e0) / per)
+            plan.finish()
+            st = stats(ms)
+            protocol[name] = {"ms_per_execute": st,
+                              "gflops_median": flop_per_xform * batch / (st["median"] * 1e-3) / 1e9,
+                              "frac_median": alg_bytes_per_xform * batch / (st["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "frac_min_max": [alg_bytes_per_xform * batch / (st["max"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                               alg_bytes_per_xform * batch / (st["min"] * 1e-3) / 1e9 / HBM_PEAK_GBS],
+                              "strategy": plan.strategy(batch, inplace=inpl)[0]}
+
     # ---- warm-up, then EXACTLY K timed steps bracketed by barrier + device sync on both sides
     for w in range(args.warmup):
         if resident:
@@ -623,58 +872,13 @@ def main():
                         "difference": float(g[3].item()), "device": int(g[4].item())} for r, g in enumerate(gathered)]
 
     _trace("timed steps done, ranks gathered")
-    # ---- the reference's timing protocol (untimed for `value`): out of place AND in place, median of >= 5 repeats of a
-    # block of back-to-back executes between two HIP events (test/test_performance.py:22-30 times 10 executes once;
-    # cuda/test.cu:37-64 times both forms).  In place alternates forward / inverse so that the values stay bounded.
-    protocol = None
-    if resident and args.repeats > 0:
-        # the same share as ONE in-place execute (batch = 8192: element offsets beyond 2^35), forward then inverse, HIP events
-        protocol = {"one_execute_of_the_share": {"batch": share, "repeats": min(args.repeats, 3)}}
-        ms = []
-        for _ in range(min(args.repeats, 3)):
-            for inv in (False, True):
-                e0, e1 = Event(), Event()
-                e0.record(stream)
-                plan.execute(ins[0], batch=share, inverse=inv)
-                e1.record(stream)
-                e1.synchronize()
-                ms.append(e1.time_since(e0))
-        plan.finish()
-        st = stats(ms)
-        protocol["one_execute_of_the_share"].update({
-            "ms_per_execute": st, "strategy": plan.strategy(share)[0],
-            "frac_median": alg_bytes_per_xform * share / (st["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "transforms_per_s_median": share / (st["median"] * 1e-3)})
-    elif args.repeats > 0 and world == 1 and not args.inplace:
-        # blocks of >= 20 ms of back-to-back executes (a burst of a few short launches behind a synchronisation measures the clock
-        # ramp and the fill / drain of the first launch: 3-4 points at 1 GiB per side, DESIGN.md section 7)
-        per = max(2, min(args.steps, 10), int(0.020 / max(1e-6, elapsed / args.steps)) + 1)
-        per += per & 1
-        protocol = {"executes_per_repeat": per, "repeats": args.repeats}
-        for name, inpl in (("out_of_place", False), ("in_place", True)):
-            ms = []
-            for _ in range(args.repeats):
-                e0, e1 = Event(), Event()
-                e0.record(stream)
-                for j in range(per):
-                    execute(inpl, inverse=bool(inpl and (j & 1)))
-                e1.record(stream)
-                e1.synchronize()
-                ms.append(e1.time_since(e0) / per)
-            plan.finish()
-            st = stats(ms)
-            protocol[name] = {"ms_per_execute": st,
-                              "gflops_median": flop_per_xform * batch / (st["median"] * 1e-3) / 1e9,
-                              "frac_median": alg_bytes_per_xform * batch / (st["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "frac_min_max": [alg_bytes_per_xform * batch / (st["max"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                               alg_bytes_per_xform * batch / (st["min"] * 1e-3) / 1e9 / HBM_PEAK_GBS],
-                              "strategy": plan.strategy(batch)[0]}
-
     # ---- per-pass device time (separate, untimed-for-value measurement; HIP events between launches).
     # Only meaningful for the one-launch-per-pass strategy; the fused / pipelined strategies own a small scratch.
     import ctypes
-    strategy = plan.strategy(batch)
-    npass = len(plan.pass_list())
+    timed_inplace = bool(args.inplace or resident)
+    strategy = plan.strategy(batch, inplace=timed_inplace)     # (out of place: ("nd_oop",) where the one-launch kernel bypasses the chain)
+    timed_passes = plan.pass_list(inplace=timed_inplace)
+    npass = len(timed_passes)
     pass_ms = None
     if strategy[0] == "chain" and not args.plain:
         descs = plan._descriptors(batch, args.inplace, False)
@@ -705,8 +909,8 @@ def main():
             e1.synchronize()
             pass_ms.append(e1.time_since(e0) / reps)
             i += count
-    nlaunch = len(launch_units(plan.pass_list()))
-    if strategy[0] == "chain":
+    nlaunch = len(launch_units(timed_passes))
+    if strategy[0] in ("chain", "nd_oop"):
         launches = "%d launches per step" % nlaunch
     elif strategy[0] in ("fused2", "fused2x", "fusedp"):
         what = {"fused2": "both passes", "fused2x": "both passes, one work list per XCD", "fusedp": "both pass pairs"}[strategy[0]]
@@ -775,12 +979,15 @@ def main():
             "global_batch": share * world, "first_transform_of_rank0": gstart,
             "parallelism": "batch-sharded x%d, no collective%s" % (world, " (control plane: %s)" % args.control if dist is not None else ""),
             "ranks": rank_report,
-            "passes": [repr(p) for p in plan.pass_list()], "strategy": strategy[0]},
+            "passes": [repr(p) for p in timed_passes], "strategy": strategy[0]},
         "transforms_per_s": total_xforms / elapsed,
         "algorithmic_GBps": alg_gbs,
         "hbm_fraction_of_8TBps": alg_gbs / world / HBM_PEAK_GBS,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     # (the protocol's median over >= 20 ms blocks of the same executes, for lines whose K steps are short)
+                     "frac_protocol_median": (protocol or {}).get("in_place" if timed_inplace else "out_of_place", {}).get("frac_median"),
+                     "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "%s: %s" % (strategy[0], launches),
                      "algorithmic_bytes_per_step": alg_bytes_per_xform * batch,
                      "chain_ms_hip_events": chain_ms, "pass_ms_hip_events": pass_ms},

@@ -460,6 +460,12 @@ typedef struct mifft_copy {
 } mifft_copy;
 int mifft_aux_copy(const mifft_copy *copy, const void *src0, const void *src1, void *dst0, void *dst1, mifft_stream_t stream);
 int mifft_aux_mul_rows(int32_t precision, void *a, const void *b, int64_t rows, int64_t n, mifft_stream_t stream);
+/* Verification helper (round 6; no counterpart in the reference, whose tests copy everything to the host: test/test_errors.py:66-114):
+ * ADDS to *count the number of 16-byte words in which a[0 .. nbytes) and b[0 .. nbytes) differ.  a, b 16-byte aligned device buffers,
+ * nbytes a multiple of 16; count = any 8-byte aligned uint64 the device can add to atomically (device memory, or pinned host memory from
+ * mifft_host_alloc, which the host then reads after synchronising `stream`).  Lets a caller check a periodic data set's result -- every
+ * transform bit-identical to its period-mate -- over a buffer far too large to copy back. */
+int mifft_aux_count_mismatch(const void *a, const void *b, size_t nbytes, uint64_t *count, mifft_stream_t stream);
 
 /*
  * Mixed-radix rows (csrc/fft_mixed.hip; the reference's TODO.txt:8): `rows` contiguous transforms of SMOOTH length

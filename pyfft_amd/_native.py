@@ -200,6 +200,7 @@ PROTOTYPES = {
     "mifft_launch_nd_tiled_split": (ctypes.c_int, [_pass_p, ctypes.POINTER(MifftTiling), _vp, _vp, _vp, _vp, _vp]),
     "mifft_aux_copy": (ctypes.c_int, [ctypes.POINTER(MifftCopy), _vp, _vp, _vp, _vp, _vp]),
     "mifft_aux_mul_rows": (ctypes.c_int, [_i32, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp]),
+    "mifft_aux_count_mismatch": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, _vp]),
     "mifft_mixed_supported": (ctypes.c_int, [_i32, _i32]),
     "mifft_launch_mixed_rows": (ctypes.c_int, [_i32, _i32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _vp, _i32,
                                                 ctypes.c_double, _vp]),

@@ -133,3 +133,25 @@ extern "C" int mifft_aux_mul_rows_launch(int f64, void* a, const void* b, long l
     else hipLaunchKernelGGL(aux_mul_rows_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, (mifft::cplx<float>*)a, (const mifft::cplx<float>*)b, total, n);
     return (int)hipGetLastError();
 }
+
+// Verification helper (round 6): how many 16-byte words of two device buffers differ.  A periodic data set must transform into a periodic
+// result wherever an item lies in a 256 GiB buffer; comparing every item with its period-mate on the device reads the buffer at the
+// streaming rate instead of copying it to the host.  Each wave adds its count to *count (device-accessible, e.g. pinned host memory).
+__global__ void __launch_bounds__(256) aux_mismatch_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, unsigned long long words,
+                                                          unsigned long long* count) {
+    unsigned long long bad = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < words; i += (unsigned long long)gridDim.x * 256u) {
+        const uint4 x = a[i], y = b[i];
+        bad += (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
+    }
+    for (int off = 32; off > 0; off >>= 1) bad += __shfl_down(bad, off, 64);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, bad);
+}
+
+extern "C" int mifft_aux_mismatch_launch(const void* a, const void* b, unsigned long long words, unsigned long long* count, hipStream_t s) {
+    if (words == 0) return 0;
+    const unsigned long long want = (words + 255u) / 256u;
+    const unsigned grid = (unsigned)(want < 16384ull ? want : 16384ull);
+    hipLaunchKernelGGL(aux_mismatch_kernel, dim3(grid), dim3(256), 0, s, (const uint4*)a, (const uint4*)b, words, count);
+    return (int)hipGetLastError();
+}

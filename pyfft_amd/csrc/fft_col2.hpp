@@ -37,7 +37,14 @@ template <int A, int E, typename T> __device__ __forceinline__ cplx<T> mul_w16A(
 template <typename T> struct ColStageTw {
     cplx<T> s1, s2, s3, s4, s5, s6, s7, s8;
     __device__ __forceinline__ void init(const cplx<T>* twL, int i0, int step = 1) {
+        load(twL, i0, step);
+        finish();
+    }
+    // the same in two steps: the four look-ups (issue them early, in one batch with the caller's other look-ups), then the products
+    __device__ __forceinline__ void load(const cplx<T>* twL, int i0, int step = 1) {
         s1 = twL[step * i0]; s2 = twL[2 * step * i0]; s4 = twL[4 * step * i0]; s8 = twL[8 * step * i0];
+    }
+    __device__ __forceinline__ void finish() {
         s3 = cmul<T>(s1, s2); s5 = cmul<T>(s4, s1); s6 = cmul<T>(s4, s2); s7 = cmul<T>(s4, s3);
     }
     template <int k> __device__ __forceinline__ cplx<T> get() const {
@@ -150,16 +157,27 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
             });
         }
     }
+    // The table factors of the two register stages, looked up in ONE batch right behind the tile's own loads (a wave's loads return
+    // in order: they arrive with the tile's last rows).  Round 6, see fft_col3.hpp: left to the scheduler such look-ups were issued
+    // in groups with a full wait behind each.
+    // ---- stage 1: radix-16 over b1 (A butterflies), twiddle w(L)^(b0*qb1) [table] * w(16A)^(a*qb1) [constant]
+    // The 15 table twiddles s^k, s = w(L)^b0, are four look-ups (k = 1, 2, 4, 8) plus products of at most three
+    // of them, and are held only as long as needed (saves ~14 VGPRs against 15 look-ups held across the stage).
+    const cplx<T> s1 = twL[b0], s2 = twL[2 * b0], s4 = twL[4 * b0], s8 = twL[8 * b0];
+    cplx<T> twA[A > 1 ? A - 1 : 1];
+    if constexpr (A > 1) {
+        static_for<A - 1>([&](auto qq) {
+            constexpr int qa = qq + 1;
+            twA[qq] = twL[16 * b0 * qa];
+        });
+    }
+    __builtin_amdgcn_sched_barrier(0);
     static_for<PPT>([&](auto kk) {
         constexpr int k = kk;
         v[k].y *= csign;
     });
 
-    // ---- stage 1: radix-16 over b1 (A butterflies), twiddle w(L)^(b0*qb1) [table] * w(16A)^(a*qb1) [constant]
-    // The 15 table twiddles s^k, s = w(L)^b0, are four look-ups (k = 1, 2, 4, 8) plus products of at most three
-    // of them, and are held only as long as needed (saves ~14 VGPRs against 15 look-ups held across the stage).
     {
-        const cplx<T> s1 = twL[b0], s2 = twL[2 * b0], s4 = twL[4 * b0], s8 = twL[8 * b0];
         const cplx<T> s3 = cmul<T>(s1, s2), s5 = cmul<T>(s4, s1), s6 = cmul<T>(s4, s2), s7 = cmul<T>(s4, s3);
         auto tw = [&](auto kk) -> cplx<T> {
             constexpr int k = kk;  // s^k, k = 1..15
@@ -193,11 +211,6 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
     }
     // ---- stage 2: radix-A over a (16 butterflies), twiddle w(16A)^(b0*qa) = w(L)^(16*b0*qa)
     if constexpr (A > 1) {
-        cplx<T> twA[A - 1];
-        static_for<A - 1>([&](auto qq) {
-            constexpr int qa = qq + 1;
-            twA[qq] = twL[16 * b0 * qa];
-        });
         static_for<16>([&](auto bb) {
             constexpr int qb1 = bb;
             cplx<T> t[A];
@@ -244,6 +257,29 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
     // TR (S == 1): out[o][l][q] -> uniform o*ostride + rem0*L + qconst ; thread c2*L + u
     const long long oubase = TR ? (a.ostride_out * o_out + rem0 * L) : (a.ostride_out * o_out + ((l0 * L) << logS) + jp0);
     const unsigned ovoff = TR ? ((unsigned)c2g * L + (unsigned)u) : ((((unsigned)dl * L + (unsigned)u) << logS) + djp);
+
+    // The anchors of the inter-pass twiddle (TW) are looked up ONE ROUND AHEAD, in one batch issued before the previous round's
+    // stores: the wait for them then covers stores that are a whole round old.  (Round 6: issued inside their own round they sat
+    // behind the sixteen write-through stores just issued, and a wave waited for those to be acknowledged -- three times per tile.)
+    cplx<T> nlo[TW ? 4 : 1], nhi[TW ? 4 : 1], sstep_lo, sstep_hi;
+    auto look_ahead = [&](auto qq) {
+        constexpr int qa = qq;
+        if constexpr (TW) {
+            static_for<4>([&](auto jj) {
+                constexpr int j = jj;
+                const unsigned e = l * (unsigned)(qa * 16 + u + 64 * A * j);
+                nlo[j] = twlo[e & lomask];
+                nhi[j] = twhi[e >> tw_shift];
+            });
+        }
+    };
+    if constexpr (TW) {
+        const unsigned e = l * (16u * A);
+        sstep_lo = twlo[e & lomask];
+        sstep_hi = twhi[e >> tw_shift];
+        look_ahead(IC<0>{});
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     static_for<A>([&](auto rr) {
         constexpr int qa = rr;
@@ -292,17 +328,27 @@ __device__ __forceinline__ void col2_tile(const TileArgs& a, const long long o_i
                 });
             });
         }
+        cplx<T> anchor[TW ? 4 : 1];
+        cplx<T> sstep;
+        if constexpr (TW) {
+            // this round's anchors (in flight since the previous round), then the next round's look-ups before this round's stores
+            static_for<4>([&](auto jj) { anchor[jj] = cmul<T>(nlo[jj], nhi[jj]); });
+            sstep = cmul<T>(sstep_lo, sstep_hi);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (qa + 1 < A) {
+                look_ahead(IC<qa + 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         Dft<16, T>::run(x);
         if constexpr (TW) {
             // w(L*M)^(l*q) for q = qb0*16A + qlow, qlow = qa*16 + u.  Four anchors (qb0 = 0, 4, 8, 12) come from
             // the two-level table (tw_lo * tw_hi); the three factors after each anchor are one multiplication by
             // s = w^(l*16A) each.  Depth <= 3 keeps the fp32 twiddle error at ~2.5e-7 max while only ~10 VGPRs are
             // live (15 table factors held at once made this kernel spill).
-            auto look = [&](unsigned e) { return cmul<T>(twlo[e & lomask], twhi[e >> tw_shift]); };
-            const cplx<T> sstep = look(l * (16u * A));
             static_for<4>([&](auto jj) {
                 constexpr int j = jj;
-                cplx<T> cur = look(l * (unsigned)(qa * 16 + u + 64 * A * j));
+                cplx<T> cur = anchor[j];
                 static_for<4>([&](auto ii) {
                     constexpr int qb0 = 4 * j + ii;
                     x[qb0] = cmul<T>(x[qb0], cur);

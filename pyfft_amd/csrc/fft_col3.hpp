@@ -129,12 +129,26 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
             });
         }
     }
+    // The table factors of the two register stages: ONE batch of look-ups issued right behind the tile's own loads (the memory
+    // system returns a wave's loads in order, so they arrive with the last rows of the tile).  Round 6: left to the scheduler the
+    // look-ups were issued in three groups with a full wait after each, and the look-ups of every exchange round below sat behind
+    // the previous round's stores -- a wave then waited for those stores to be acknowledged and for up to six table look-ups ONE
+    // AFTER THE OTHER, four times per tile (profiles/r06_fused3_counters.log: waves parked 41 % of their cycles; ISA in DESIGN.md).
+    ColStageTw<T> tw;
+    cplx<T> twA[A > 1 ? A - 1 : 1];
+    tw.load(twL, b0, 2);          // s = w(L')^b0 = w(L)^(2*b0)
+    if constexpr (A > 1) {
+        static_for<A - 1>([&](auto qq) {
+            constexpr int qa = qq + 1;
+            twA[qq] = twL[32 * b0 * qa];          // w(16A)^(b0*qa) = w(L)^(32*b0*qa)
+        });
+    }
+    __builtin_amdgcn_sched_barrier(0);
     static_for<PPT>([&](auto kk) { v[kk].y *= csign; });
 
     // ---- stage 1 (radix-16 over b1) and stage 2 (radix-A over a) of the L'-point half: w(L')^j = w(L)^(2j)
     {
-        ColStageTw<T> tw;
-        tw.init(twL, b0, 2);          // s = w(L')^b0 = w(L)^(2*b0)
+        tw.finish();
         static_for<A>([&](auto aa) {
             constexpr int ia = aa;
             Dft<16, T>::run(v + ia * 16);
@@ -148,11 +162,6 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
         });
     }
     if constexpr (A > 1) {                     // (A == 1: L = 512 = 2 x 256, no radix-A stage -- the rectangles of round 4)
-        cplx<T> twA[A - 1];
-        static_for<A - 1>([&](auto qq) {
-            constexpr int qa = qq + 1;
-            twA[qq] = twL[32 * b0 * qa];          // w(16A)^(b0*qa) = w(L)^(32*b0*qa)
-        });
         static_for<16>([&](auto bb) {
             constexpr int qb1 = bb;
             cplx<T> t[A];
@@ -189,6 +198,30 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
     const long long oubase = TR ? (a.ostride_out * o_out + rem0 * L) : (a.ostride_out * o_out + ((l0 * L) << logS) + jp0);
     const unsigned ovoff = TR ? ((unsigned)c2 * L + (unsigned)u + (unsigned)(L / 2) * (unsigned)h)
                               : ((((unsigned)dl * L + (unsigned)u + (unsigned)(L / 2) * (unsigned)h) << logS) + djp);
+
+    // The table factors of an exchange round -- w(L)^(qa*16 + u) of the odd half and, with TW, the four anchors of the inter-pass
+    // twiddle (two-level table: lo * hi) -- are looked up ONE ROUND AHEAD, in one batch issued before the previous round's stores:
+    // the wait for them then covers stores that are a whole round old instead of the sixteen just issued.
+    cplx<T> nw0, nlo[TW ? 4 : 1], nhi[TW ? 4 : 1], sstep_lo, sstep_hi;
+    auto look_ahead = [&](auto qq) {
+        constexpr int qa = qq;
+        nw0 = twL[qa * 16 + u];
+        if constexpr (TW) {
+            static_for<4>([&](auto jj) {
+                constexpr int j = jj;
+                const unsigned e = l * ((unsigned)(qa * 16 + 64 * A * j) + (unsigned)u + (unsigned)(L / 2) * (unsigned)h);
+                nlo[j] = twlo[e & lomask];
+                nhi[j] = twhi[e >> tw_shift];
+            });
+        }
+    };
+    if constexpr (TW) {
+        const unsigned e = l * (16u * A);
+        sstep_lo = twlo[e & lomask];
+        sstep_hi = twhi[e >> tw_shift];
+    }
+    look_ahead(IC<0>{});
+    __builtin_amdgcn_sched_barrier(0);
 
     static_for<A>([&](auto rr) {
         constexpr int qa = rr;
@@ -228,11 +261,23 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
                 });
             });
         }
+        // this round's factors (in flight since the previous round), then the next round's look-ups before this round's stores
+        const cplx<T> w0 = nw0;
+        cplx<T> anchor[TW ? 4 : 1];
+        cplx<T> sstep;
+        if constexpr (TW) {
+            static_for<4>([&](auto jj) { anchor[jj] = cmul<T>(nlo[jj], nhi[jj]); });
+            sstep = cmul<T>(sstep_lo, sstep_hi);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (qa + 1 < A) {
+            look_ahead(IC<qa + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
         Dft<16, T>::run(x);
         // x[qb0] = E[q'] (lower lanes) or O[q'] (upper lanes), q' = qb0*16A + qa*16 + u.  The odd half is multiplied by
         // w(L)^q' = w(L)^(qa*16 + u) [one look-up] * w(32)^qb0 [constants: L / 16A = 32]; then the radix-2 across the halves.
         {
-            const cplx<T> w0 = twL[qa * 16 + u];
             static_for<16>([&](auto qq) {
                 constexpr int qb0 = qq;
                 const cplx<T> t = mul_w32<qb0, T>(cmul<T>(x[qb0], w0));
@@ -243,11 +288,9 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
             });
         }
         if constexpr (TW) {
-            auto look = [&](unsigned e) { return cmul<T>(twlo[e & lomask], twhi[e >> tw_shift]); };
-            const cplx<T> sstep = look(l * (16u * A));
             static_for<4>([&](auto jj) {
                 constexpr int j = jj;
-                cplx<T> cur = look(l * ((unsigned)(qa * 16 + 64 * A * j) + (unsigned)u + (unsigned)(L / 2) * (unsigned)h));
+                cplx<T> cur = anchor[j];
                 static_for<4>([&](auto ii) {
                     constexpr int qb0 = 4 * j + ii;
                     x[qb0] = cmul<T>(x[qb0], cur);

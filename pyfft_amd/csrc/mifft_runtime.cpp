@@ -1246,6 +1246,14 @@ int mifft_aux_mul_rows(int32_t precision, void* a, const void* b, int64_t rows, 
     return 0;
 }
 
+int mifft_aux_count_mismatch(const void* a, const void* b, size_t nbytes, uint64_t* count, mifft_stream_t stream) {
+    if (!a || !b || !count) return set_err(MIFFT_E_INVALID, "null argument");
+    if ((nbytes & 15) || (((uintptr_t)a | (uintptr_t)b) & 15) || ((uintptr_t)count & 7))
+        return set_err(MIFFT_E_INVALID, "mifft_aux_count_mismatch: buffers and size in whole 16-byte words, an 8-byte aligned counter");
+    const int rc = mifft_aux_mismatch_launch(a, b, (unsigned long long)(nbytes / 16), (unsigned long long*)count, (hipStream_t)stream);
+    return rc ? set_err(MIFFT_E_HIP, "mifft_aux_count_mismatch: launch failed") : 0;
+}
+
 int mifft_mixed_supported(int32_t precision, int32_t n) {
     if (precision != MIFFT_F32 && precision != MIFFT_F64) return MIFFT_E_UNSUPPORTED;
     return mifft_mixed_supported_impl(precision == MIFFT_F64, n) == 0 ? 0 : MIFFT_E_UNSUPPORTED;

@@ -5,6 +5,9 @@ answer and the CPU oracle's restatement of the reference chain as a second check
 Tolerances are the reference's own: L1-relative `difference` < 1.1e-6 (fp32) / 1e-11 (fp64)
 (test_errors.py:20-23), plus the north star's max-norm bound max|out-ref| <= 1e-5 * max|ref|.
 """
+import json
+import os
+
 import numpy
 import pytest
 
@@ -12,6 +15,8 @@ import pyfft_oracle as oracle
 from helpers import COMPLEX_DTYPES, DOUBLE_DTYPES, getDimensions
 
 pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run_protocol(ctx, shape, dtype, batch, seed=1234, fast_math=True, check_oracle=True):
@@ -379,3 +384,69 @@ def test_split_plane_strategies(ctx, monkeypatch, n, batch, strat):
         ref = numpy.fft.fft(re[sl].astype(numpy.float64) + 1j * im[sl])
         got = outs[strat][0][sl].astype(numpy.float64) + 1j * outs[strat][1][sl]
         assert numpy.abs(ref - got).sum() / numpy.abs(ref).sum() < 1.1e-6
+
+
+GOLDEN = os.path.join(ROOT, "tests", "golden", "fft_vectors.npz")
+
+
+def _golden_index():
+    z = numpy.load(GOLDEN)
+    return json.loads(bytes(z["index_json"]).decode())
+
+
+@pytest.mark.parametrize("entry", _golden_index(), ids=lambda e: e["key"])
+def test_golden_fixture_through_hip(ctx, entry):
+    """Every entry of tests/golden/fft_vectors.npz (seeded input + numpy.fft.fftn of the complex128-upcast input,
+    generated by tests/golden/make_golden.py) through Plan()/execute(): forward against the stored output with the
+    reference's thresholds (test/test_errors.py:20-23) and the north star's max-norm bound, then inverse against the input."""
+    z = numpy.load(GOLDEN)
+    data, want = z[entry["key"] + "_in"], z[entry["key"] + "_fw"]
+    shape, batch = tuple(entry["shape"]), entry["batch"]
+    dtype = numpy.dtype(entry["dtype"])
+    eps, mx = (1.1e-6, 1e-5) if dtype == numpy.complex64 else (1e-11, 1e-10)
+    plan = ctx.getPlan(shape, dtype=dtype, context=ctx.context)
+    a = ctx.toGpu(data)
+    b = ctx.allocate(data.shape, data.dtype)
+    plan.execute(a, b, batch=batch)
+    got = ctx.fromGpu(b, data.shape, data.dtype)
+    assert oracle.difference(want, got.astype(numpy.complex128), batch) < eps
+    assert numpy.abs(got - want).max() <= mx * numpy.abs(want).max()
+    assert numpy.array_equal(ctx.fromGpu(a, data.shape, data.dtype), data)
+    plan.execute(b, inverse=True, batch=batch)
+    assert oracle.difference(data, ctx.fromGpu(b, data.shape, data.dtype), batch) < eps
+
+
+# ---- the reference's error grid, verbatim (test/test_errors.py:125-145) ------------------------------------------------
+def _reference_grid():
+    shapes = []
+    for x in [3, 8, 9, 10, 11, 13, 20]:                       # 1D
+        shapes.append((2 ** x,))
+    for x in [4, 7, 8, 10]:                                   # 2D
+        for y in [4, 7, 8, 10]:
+            shapes.append((2 ** x, 2 ** y))
+    for x in [4, 7, 10]:                                      # 3D
+        for y in [4, 7, 10]:
+            for z in [4, 7, 10]:
+                shapes.append((2 ** x, 2 ** y, 2 ** z))
+    batch_sizes = [1, 16, 128, 1024, 4096]
+    buffer_size = 32                                          # MiB (test/test_errors.py default)
+    cases = []
+    for double in (False, True):
+        dtypes = [numpy.float64, numpy.complex128] if double else [numpy.float32, numpy.complex64]
+        for dtype in dtypes:
+            for shape in shapes:
+                for batch in batch_sizes:
+                    x, y, z = getDimensions(shape)
+                    if x * y * z * batch * dtype().nbytes > buffer_size * 1024 * 1024:
+                        continue                              # (test_errors.py:143-145: skipped, not failed)
+                    cases.append((shape, dtype, batch))
+    return cases
+
+
+@pytest.mark.parametrize("shape,dtype,batch", _reference_grid(),
+                         ids=lambda v: numpy.dtype(v).name if isinstance(v, type) else str(v).replace(" ", ""))
+def test_reference_error_grid(ctx, shape, dtype, batch):
+    """7 + 16 + 27 shapes x batch {1, 16, 128, 1024, 4096} x both layouts per precision under the 32 MiB cap, the six
+    assertions of testErrors (test/test_errors.py:18-114) with its thresholds, plus the north star's max-norm bound."""
+    x, y, z = getDimensions(shape)
+    run_protocol(ctx, shape, dtype, batch, seed=4321, check_oracle=(x * y * z * batch <= (1 << 16)))

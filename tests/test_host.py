@@ -464,28 +464,7 @@ def test_round3_entry_points_reject_bad_arguments_without_touching_the_gpu():
 
 
 # ---- round 4: the planner sizes everything from the device's properties (pyfft_amd/machine.py) --------------------------
-class _FakeContext(object):
-    """A context without a device: tables are "uploaded" nowhere.  What FFTPlan._select_strategy reads is `machine`."""
-    _guard = False
-
-    def __init__(self, machine):
-        self.machine = machine
-        self.compute_units = machine.compute_units
-
-    def allocate_raw(self, nbytes):
-        return 4096
-
-    allocate = allocate_raw
-
-    def upload(self, mem, host):
-        pass
-
-    @staticmethod
-    def pointer_of(obj):
-        return obj
-
-    def capturing(self):
-        return False
+from helpers import FakeContext as _FakeContext      # (a context without a device; shared with tests/kernel_coverage.py)
 
 
 def _strategy_on(machine, shape, dtype, batch):

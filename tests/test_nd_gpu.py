@@ -1,0 +1,167 @@
+"""GPU tests of the one-launch N-D kernels beyond the fixed-shape table (that table: tests/test_errors_gpu.py::test_fixed_shape_nd_kernels):
+several work-groups per transform (csrc/fft_nd2z.hpp) and the tiny shapes the tuning table routes to the run-time-shaped kernel
+(csrc/fft_nd.hpp).  Reference: one chain per axis, pyfft/plan.py:135-171."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy
+import pytest
+
+import pyfft_oracle as oracle
+from helpers import EPS_F, MAX_F, getDimensions, _execute, _execute_split, _noise, _test_data, _tiled_noise
+from test_errors_gpu import run_protocol
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- one-tile-per-CU N-D shapes as two work-groups per transform (csrc/fft_nd2z.hpp) ------------------------------------------------
+ND2Z_SHAPES = {numpy.complex64: [(1024, 32), (512, 64), (256, 128), (128, 256), (32, 1024), (8, 64, 64), (16, 16, 128), (32, 32, 32),
+                                 # (two-per-CU shapes: split in small launches only -- 11 transforms are one)
+                                 (1024, 16), (512, 32), (256, 64), (128, 128), (64, 256), (32, 512), (16, 1024), (16, 32, 32), (32, 16, 32), (32, 32, 16)],
+               numpy.complex128: [(512, 32), (256, 64), (64, 256), (32, 512), (16, 32, 32), (16, 16, 64), (128, 128), (64, 16, 16),
+                                  (512, 16), (256, 32), (128, 64), (64, 128), (32, 256), (16, 512), (16, 16, 32), (16, 32, 16), (32, 16, 16)]}
+
+
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
+def test_two_work_groups_per_transform_nd(ctx, dtype):
+    """The N-D shapes of 32768 points (fp32) / 16384 points (fp64) as TWO work-groups per transform (one decimation-in-frequency step
+    along the slowest axis folded into the loads, each half on a two-per-CU tile; numpy shapes = (z, y, x)): every such shape at a
+    ragged batch against numpy with the reference's thresholds (test/test_errors.py:20-23), forward and inverse, against the
+    one-tile-per-CU kernel to rounding, and an in-place call -- which must take the one-tile kernel -- bit-identical to it."""
+    from pyfft_amd import _native as N
+    hip = ctx.hip
+    cdt = numpy.dtype(dtype)
+    tol, tol_max, tol_same = (1.1e-6, 1e-5, 5e-7) if cdt == numpy.complex64 else (1e-11, 1e-10, 1e-14)
+    for shape in ND2Z_SHAPES[dtype]:
+        size = int(numpy.prod(shape))
+        batch = 11
+        data = _tiled_noise(size * batch, dtype, 4400 + shape[0])
+        plan = hip.Plan(shape, dtype=dtype)
+        assert len(plan.pass_list()) == 1 and plan.pass_list()[0].kind == N.PASS_ND, (shape, plan.pass_list())
+        a = hip.to_gpu(data)
+        outs = {}
+        for alt in (6, 5):                       # 6: the one-tile-per-CU kernel, 5 (= the default): two work-groups per transform
+            N.check(N.lib.mifft_debug_set(N.DEBUG_ALT_ROWS, alt), "debug_set")
+            try:
+                b = hip.DeviceArray((size * batch,), dtype)
+                plan.execute(a, b, batch=batch)
+                outs[alt] = b.get()
+                if alt == 5:
+                    plan.execute(b, batch=batch, inverse=True)          # in place: the one-tile kernel whatever the switch says
+                    back = b.get()
+                    c = hip.DeviceArray((size * batch,), dtype)
+                    plan.execute(hip.to_gpu(outs[5]), c, batch=batch, inverse=True)     # out of place: the two-work-group form
+                    back2 = c.get()
+            finally:
+                N.check(N.lib.mifft_debug_set(N.DEBUG_ALT_ROWS, 0), "debug_set")
+        assert numpy.array_equal(a.get(), data), "input modified"
+        for item in range(batch):
+            sl = slice(item * size, (item + 1) * size)
+            ref = numpy.fft.fftn(data[sl].astype(numpy.complex128).reshape(shape)).reshape(-1)
+            got = outs[5][sl].astype(numpy.complex128)
+            assert numpy.abs(ref - got).sum() / numpy.abs(ref).sum() < tol, (shape, item)
+            assert numpy.abs(ref - got).max() <= tol_max * numpy.abs(ref).max(), (shape, item)
+        d = numpy.abs(outs[5].astype(numpy.complex128) - outs[6]).sum() / numpy.abs(outs[6]).sum()
+        assert d < tol_same, (shape, d)
+        for inv in (back, back2):
+            assert numpy.abs(inv.astype(numpy.complex128) - data).sum() / numpy.abs(data).sum() < tol, shape
+
+
+OOP_ND_CASES = [(sh, numpy.complex64) for sh in [(256, 256), (512, 128), (1024, 64), (64, 1024), (16, 64, 64),
+                                                  # 32768-point shapes without a one-tile kernel: two work-groups per transform
+                                                  (64, 512), (16, 2048), (2048, 16), (64, 8, 64), (16, 128, 16), (128, 16, 16), (32, 16, 64), (32, 64, 16)]] + \
+               [(sh, numpy.complex128) for sh in [(16, 1024), (1024, 16), (8, 32, 64), (64, 8, 32), (4, 64, 64), (64, 4, 64), (32, 16, 32), (16, 64, 16), (32, 32, 16)]]
+
+
+@pytest.mark.parametrize("shape,dtype", OOP_ND_CASES, ids=lambda v: getattr(v, "__name__", "x".join(map(str, v)) if isinstance(v, tuple) else str(v)))
+def test_four_work_groups_per_transform_out_of_place(ctx, shape, dtype, monkeypatch):
+    """Shapes with a one-launch kernel for OUT-OF-PLACE executes only (csrc/fft_nd2z.hpp; two launches as a chain, which the plan keeps for
+    in-place executes): 65536 points (fp32) on four work-groups per transform, and the 32768-point (fp32) / 16384-point (fp64) shapes that
+    have no one-tile kernel on two.  The reference's thresholds against numpy at a ragged batch, forward and inverse, out of place and in
+    place, and the chain's result to rounding."""
+    hip = ctx.hip
+    size = int(numpy.prod(shape))
+    csz = numpy.dtype(dtype).itemsize
+    batch = (261 * 65536 * 8) // (size * csz)                     # 130.5 MiB per side: beyond half the cache, where the plan uses every such kernel
+    EPS, MAXN, SAME = (EPS_F, MAX_F, 5e-7) if numpy.dtype(dtype) == numpy.complex64 else (1e-11, 1e-10, 1e-14)
+    data = _tiled_noise(size * batch, dtype, 4500 + shape[0])
+    plan = hip.Plan(shape, dtype=dtype)
+    assert plan._oop_nd is not None and len(plan.pass_list()) == 2, plan.pass_list()
+    assert batch * size * csz > plan._context.machine.write_through_max_bytes
+    a = hip.to_gpu(data)
+    b = hip.DeviceArray((size * batch,), dtype)
+    plan.execute(a, b, batch=batch)
+    got = b.get()
+    assert numpy.array_equal(a.get(), data), "input modified"
+    for item in (0, 1, 7, 8, 9, batch // 2, batch - 6, batch - 5, batch - 1):      # (groups of eight transforms share an XCD: both ends of the last, ragged group)
+        sl = slice(item * size, (item + 1) * size)
+        ref = numpy.fft.fftn(data[sl].astype(numpy.complex128).reshape(shape)).reshape(-1)
+        g = got[sl].astype(numpy.complex128)
+        assert numpy.abs(ref - g).sum() / numpy.abs(ref).sum() < EPS, (shape, item)
+        assert numpy.abs(ref - g).max() <= MAXN * numpy.abs(ref).max(), (shape, item)
+    c = hip.to_gpu(data)
+    plan.execute(c, batch=batch)                                  # in place: the chain
+    inplace = c.get()
+    assert numpy.abs(inplace.astype(numpy.complex128) - got).sum() / numpy.abs(got).sum() < SAME
+    monkeypatch.setenv("PYFFT_AMD_NO_OOP_ND", "1")
+    d = hip.DeviceArray((size * batch,), dtype)
+    hip.Plan(shape, dtype=dtype).execute(a, d, batch=batch)       # out of place on the chain
+    assert numpy.array_equal(d.get(), inplace)
+    monkeypatch.delenv("PYFFT_AMD_NO_OOP_ND")
+    plan.execute(b, a, batch=batch, inverse=True)                 # inverse, out of place
+    assert numpy.abs(a.get().astype(numpy.complex128) - data).sum() / numpy.abs(data).sum() < EPS
+
+
+# ---- tiny one-launch N-D shapes routed to the run-time-shaped kernel (tuning table "nd_generic") -------------------------------------------
+@pytest.mark.parametrize("shape,dtype,batch", [((16, 2), numpy.complex64, 37), ((2, 8), numpy.complex64, 100), ((4, 4), numpy.complex128, 61)],
+                         ids=lambda v: getattr(v, "__name__", str(v)).replace(" ", ""))
+def test_tiny_nd_shapes_small_launches(ctx, monkeypatch, shape, dtype, batch):
+    """Shapes of the tuning table's "nd_generic" lists in small launches (the "always" shape on the run-time-shaped kernel, the "big" ones on
+    their fixed instances): the reference's six-assertion protocol against numpy (test/test_errors.py:18-114), either way round."""
+    from test_errors_gpu import run_protocol
+    run_protocol(ctx, shape, dtype, batch, seed=977)
+    monkeypatch.setenv("PYFFT_AMD_NO_ND_GENERIC", "1")
+    run_protocol(ctx, shape, dtype, batch, seed=977, check_oracle=False)
+
+
+@pytest.mark.parametrize("shape,dtype,batch", [((16, 2), numpy.complex64, 700001), ((8, 8), numpy.complex64, 270001), ((4, 4), numpy.complex128, 530001),
+                                               ((4, 2), numpy.complex64, 2100001), ((2, 8), numpy.complex64, 1100001), ((8, 2), numpy.complex128, 600001)],
+                         ids=lambda v: getattr(v, "__name__", str(v)).replace(" ", ""))
+def test_tiny_nd_shapes_big_launches(ctx, monkeypatch, shape, dtype, batch):
+    """The same shapes in launches beyond the size rule (130-270 MiB per side, ragged batches), where the plan marks the pass variant 1: the
+    run-time-shaped kernel's result against the fixed instance's over the WHOLE array (same transform, another operation order: the
+    reference's L1 threshold and the north star's max-norm bound), 64 sampled transforms against numpy, in place == out of place, the
+    input untouched, and the inverse round trip."""
+    hip = ctx.hip
+    size = int(numpy.prod(shape))
+    cdt = numpy.dtype(dtype)
+    eps, mx = (1.1e-6, 1e-5) if cdt == numpy.complex64 else (1e-11, 1e-11)
+    data = _tiled_noise(size * batch, dtype, 611)
+    plan = hip.Plan(shape, dtype=dtype, wait_for_finish=True)
+    assert plan._descriptors(batch, False, False)[0].variant == 1
+    a, b = hip.to_gpu(data), hip.DeviceArray((size * batch,), dtype)
+    plan.execute(a, b, batch=batch)
+    got = b.get()
+    assert numpy.array_equal(a.get(), data), "an out-of-place execute touched its input"
+    c = hip.to_gpu(data)
+    plan.execute(c, batch=batch)
+    assert numpy.array_equal(c.get(), got), "in place differs from out of place"
+    plan.execute(c, batch=batch, inverse=True)
+    back = c.get()
+    assert numpy.abs(back - data).sum() / numpy.abs(data).sum() < eps
+    for item in numpy.linspace(0, batch - 1, 64).astype(int):
+        ref = numpy.fft.fftn(data[item * size:(item + 1) * size].reshape(shape).astype(numpy.complex128)).reshape(-1)
+        g = got[item * size:(item + 1) * size]
+        assert numpy.abs(ref - g).sum() / numpy.abs(ref).sum() < eps and numpy.abs(ref - g).max() <= max(mx, 1e-5 if cdt == numpy.complex64 else 1e-11) * numpy.abs(ref).max(), item
+    monkeypatch.setenv("PYFFT_AMD_NO_ND_GENERIC", "1")
+    fixed = hip.Plan(shape, dtype=dtype, wait_for_finish=True)
+    assert fixed._descriptors(batch, False, False)[0].variant == 0
+    fixed.execute(a, b, batch=batch)
+    want = b.get()
+    assert numpy.abs(want - got).sum() / numpy.abs(want).sum() < eps
+    assert numpy.abs(want - got).max() <= 1e-5 * numpy.abs(want).max()

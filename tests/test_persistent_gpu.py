@@ -1,64 +1,126 @@
-"""Round-4 GPU tests: the persistent two-pair kernel of the cache-sized cubes (128^3), the per-XCD work lists as a default
-strategy, the sequential single-launch form of tiny batches, launches without memset / copy-back (two alternating counter sets,
-pinned error word), the device properties the planner sizes everything from, Plan(stream=, context=i)."""
+"""GPU tests of the persistent launches (csrc/fft_fused2.hpp, fft_fusedp.hpp, fft_fused2r.hpp, fft_fusedx_f64.hip): both passes -- or both
+pass pairs -- of every transform of a batch in ONE launch, the intermediate in a ring that stays in the last-level cache.  Every shape class
+of the planner's tuning table (pyfft_amd/tuning_gfx950.json) in both precisions and layouts, the counter sets and error word the launches
+synchronise through, and BASELINE.json configs[4] as stated on one GPU.  Whole arrays against the plain chain (same tile code: same bits)
+where that holds, sampled transforms against numpy.fft with the reference's thresholds (test/test_errors.py:20-23)."""
 import ctypes
+import json
 import os
+import subprocess
+import sys
 
 import numpy
 import pytest
 
 import pyfft_oracle as oracle
+from helpers import EPS_F, MAX_F, getDimensions, _execute, _execute_split, _noise, _test_data, _tiled_noise
 from test_errors_gpu import run_protocol
 
 pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_async_error_mailbox(ctx):
+    """Asynchronous executes of the fused kernel report through the plan's pinned error word (round 4: the kernel writes host
+    memory itself; rounds 2-3 copied a device word back behind every launch): check() never blocks, finish() synchronises, a
+    non-zero word raises once at the next host-visible point."""
+    n, batch = 1 << 20, 64
+    stream = ctx.hip.Stream()
+    plan = ctx.getPlan((n,), dtype=numpy.complex64, stream=stream)
+    a = ctx.toGpu(numpy.ones(n * batch, dtype=numpy.complex64))
+    b = ctx.allocate((n * batch,), numpy.complex64)
+    assert plan.strategy(batch)[0] == "fused2"
+    for _ in range(5):
+        assert plan.execute(a, b, batch=batch) is stream
+    plan.check()
+    assert plan._errword is not None and plan._mailbox is None
+    plan.finish()
+    res = b.get().reshape(batch, n)
+    assert numpy.allclose(res[:, 0], n) and numpy.abs(res[:, 1:]).max() < 1e-2
+    # what a timed-out persistent launch leaves behind: the word is non-zero -> raised once, and the counters are re-zeroed
+    plan._errword._word.value = 1
+    with pytest.raises(RuntimeError, match="time-out"):
+        plan.check()
+    plan.check()
+    assert plan._counters_clean is False
+    plan._errword._word.value = 1
+    with pytest.raises(RuntimeError, match="time-out"):
+        plan.execute(a, b, batch=batch)
+    N = ctx.hip.N
+    N.check(N.lib.mifft_memset(b.ptr, 0, b.nbytes, None), "memset")
+    plan.execute(a, b, batch=batch, wait_for_finish=True)                   # and the plan works again
+    res = b.get().reshape(batch, n)
+    assert numpy.allclose(res[:, 0], n) and numpy.abs(res[:, 1:]).max() < 1e-2
+    # the copy-back mailbox (development strategy xcd2) still turns a non-zero word into the same error
+    plan._handle_errors([])
+    with pytest.raises(RuntimeError):
+        plan._handle_errors([("fused2", 1)])
+
+
+@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.float32], ids=["interleaved", "split"])
+def test_xcd2_strategy_bit_identical_and_in_place(ctx, dtype, monkeypatch):
+    """The XCD-cooperative kernel (csrc/fft_xcd2.hpp, development strategy 'xcd'): bit-identical to the chain strategy,
+    forward and inverse, out of place and in place (it needs no temp buffer), and its error word stays clear.  The kernel is part
+    of `make DEV=1` builds of the library only (mifft_has_feature)."""
+    from pyfft_amd import _native as N
+    if N.lib.mifft_has_feature(N.FEATURE_XCD2) != 1:
+        pytest.skip("development strategy: not in the default build of libmifft.so (make DEV=1)")
+    n, batch = 1 << 20, 72
+    split = numpy.dtype(dtype).kind == "f"
+    rng = numpy.random.default_rng(77)
+    re = rng.standard_normal(n * batch).astype(numpy.float32)
+    im = rng.standard_normal(n * batch).astype(numpy.float32)
+    host = [re, im] if split else [(re + 1j * im).astype(numpy.complex64)]
+
+    def run(strategy, inverse, inplace):
+        monkeypatch.setenv("PYFFT_AMD_STRATEGY", strategy)
+        plan = ctx.getPlan((n,), dtype=dtype, context=ctx.context)
+        assert plan.strategy(batch)[0] == ("xcd2" if strategy == "xcd" else "chain")
+        src = [ctx.toGpu(h) for h in host]
+        dst = src if inplace else [ctx.allocate(h.shape, h.dtype) for h in host]
+        if inplace:
+            plan.execute(*src, inverse=inverse, batch=batch)
+        else:
+            plan.execute(*(src + dst), inverse=inverse, batch=batch)
+            for s_, h in zip(src, host):
+                assert numpy.array_equal(s_.get(), h)
+        return [d.get() for d in dst]
+
+    for inverse in (False, True):
+        want = run("chain", inverse, False)
+        for inplace in (False, True):
+            got = run("xcd", inverse, inplace)
+            for w, g in zip(want, got):
+                assert numpy.array_equal(w.view(numpy.uint32), g.view(numpy.uint32))
+    ref = numpy.fft.fft((re[:n].astype(numpy.float64) + 1j * im[:n]))
+    fw = run("xcd", False, False)
+    got = (fw[0][:n] + 1j * fw[1][:n]) if split else fw[0][:n]
+    assert numpy.abs(got - ref).max() <= 1e-5 * numpy.abs(ref).max()
+
+
+# ---- robustness --------------------------------------------------------------------------------------------------------
+def test_error_mailbox_keeps_the_oldest_word_when_the_ring_is_full(ctx):
+    """ErrorMailbox.post with SLOTS launches pending: the oldest entry is retired (its word read and kept) before its slot is
+    reused; nothing is reported twice."""
+    hip = ctx.hip
+    box = hip.ErrorMailbox()
+    bad = ctx.toGpu(numpy.array([7], dtype=numpy.uint32))
+    good = ctx.toGpu(numpy.array([0], dtype=numpy.uint32))
+    stream = hip.Stream()
+    box.post(bad.ptr, stream, "first")
+    for i in range(box.SLOTS + 5):
+        box.post(good.ptr, stream, "later%d" % i)
+    assert len(box._pending) <= box.SLOTS
+    errors = box.collect(True)
+    assert errors == [("first", 7)]
+    assert box.collect(True) == [] and box._pending == []
+    box.post(bad.ptr, stream, "again")
+    assert box.collect(True) == [("again", 7)]
+
+
 # the driver's GPU step has a time limit: the cases that repeat a kernel family on one more shape run with the soak switch PYFFT_AMD_SWEEP
 _SOAK = bool(os.environ.get("PYFFT_AMD_SWEEP"))
-
-
-def _noise(rng, count, dtype):
-    """`count` N(0, 1) numbers: a seeded block of 2^22 + 17 draws, repeated (the period is no multiple of any transform size, so every
-    transform of a batch sees different numbers; drawing 300 MiB afresh for every case took most of the suite's time)."""
-    blk = rng.standard_normal(min(int(count), (1 << 22) + 17)).astype(dtype)
-    return numpy.resize(blk, int(count))
-
-
-def _test_data(shape, dtype, batch, seed):
-    """Interleaved test data of `batch` transforms (the layout of oracle.get_test_data: the first axis times batch) from tiled noise."""
-    rng = numpy.random.default_rng(seed)
-    dtype = numpy.dtype(dtype)
-    fdt = numpy.float32 if dtype == numpy.complex64 else numpy.float64
-    full = [int(v) for v in (shape if isinstance(shape, tuple) else (shape,))]
-    full[0] *= batch
-    count = int(numpy.prod(full))
-    out = numpy.empty(count, dtype)
-    out.real = _noise(rng, count, fdt)
-    out.imag = _noise(rng, count, fdt)
-    return out.reshape(full)
-
-
-def _execute(ctx, shape, dtype, batch, data, inplace=False, inverse=False, expect=None):
-    plan = ctx.getPlan(shape, dtype=dtype)
-    if expect is not None:
-        assert plan.strategy(batch)[0] == expect, plan.strategy(batch)
-    a = ctx.toGpu(data)
-    if inplace:
-        plan.execute(a, batch=batch, inverse=inverse)
-        return a.get()
-    b = ctx.allocate(data.shape, data.dtype)
-    plan.execute(a, b, batch=batch, inverse=inverse)
-    assert numpy.array_equal(a.get(), data), "an out-of-place execute touched its input"
-    return b.get()
-
-
-def test_device_properties_describe_the_memory_system(ctx):
-    """mifft_device_props carries what the planner needs (include/mifft.h): on an MI355X 256 CUs in 8 XCDs with 4 MiB of L2
-    each and the 256 MiB Infinity Cache -- read from the HSA agent, not hard-wired."""
-    props = ctx.hip.device_props()
-    m = ctx.hip.Machine.from_props(props)
-    assert props.compute_units >= 1 and props.num_xcc >= 1 and props.llc_bytes >= 0
-    if props.gcn_arch.decode().startswith("gfx950") and props.compute_units == 256:
-        assert props.num_xcc == 8 and props.llc_bytes == 256 << 20 and props.l2_bytes == 4 << 20, (props.num_xcc, props.llc_bytes, props.l2_bytes)
-        assert m.xcd_cooperative and m.ring_bytes == 224 << 20
 
 
 # ---- persistent two-pair kernel: 128^3 -----------------------------------------------------------------------------------
@@ -206,67 +268,6 @@ def test_alternating_counter_sets_and_memset_form_agree(ctx, monkeypatch):
     assert oracle.difference(ref, outs[""][0][:2 * n], 2) < 2e-6      # (eleven transforms deep)
 
 
-def test_plan_with_stream_and_context_index(ctx):
-    """Plan(stream=s, context=i): the device comes from `context` also when a stream is given (cuda.py:121-134); the plan is
-    asynchronous by default and guarded for device i.  With several GPUs the last one is used from device 0."""
-    hip = ctx.hip
-    N = hip.N
-    ndev = hip.device_count()
-    dev = ndev - 1
-    cur = ctypes.c_int()
-    N.check(N.lib.mifft_get_device(ctypes.byref(cur)), "get")
-    home = cur.value
-    N.check(N.lib.mifft_set_device(dev), "set")
-    stream = hip.Stream()
-    data = _test_data((8192,), numpy.complex64, 3, 95)
-    a = ctx.toGpu(data)
-    N.check(N.lib.mifft_set_device(home), "set")
-    plan = ctx.getPlan((8192,), dtype=numpy.complex64, stream=stream, context=dev)
-    assert plan._context.device == dev and plan._context._guard and plan._wait_for_finish is False
-    assert plan.execute(a, batch=3) is stream
-    plan.finish()
-    N.check(N.lib.mifft_get_device(ctypes.byref(cur)), "get")
-    assert cur.value == home
-    N.check(N.lib.mifft_set_device(dev), "set")
-    got = a.get()
-    N.check(N.lib.mifft_set_device(home), "set")
-    assert oracle.difference(oracle.numpy_fft(numpy.fft.fft, data, 3), got, 3) < 1.1e-6
-
-    class FakeTorchStream(object):                 # a stream that knows its device (torch.cuda.Stream.device_index)
-        cuda_stream = stream.handle
-        device_index = dev + 1
-    with pytest.raises(ValueError, match="stream belongs to device"):
-        ctx.getPlan((8192,), dtype=numpy.complex64, stream=FakeTorchStream(), context=dev)
-
-
-def test_generic_plans_build_only_what_they_run(ctx):
-    """a tiled-batch plan with a one-launch kernel and an all-smooth N-D plan hold no inner power-of-two plans
-    (nothing to allocate, nothing for finish() / check() to walk); the work-array paths still build theirs."""
-    tiled = ctx.getPlan((16, 16), parent_shape=(64, 64), dtype=numpy.complex64)
-    assert tiled._tiled and tiled._inner_plans() == [] and tiled._tiled_tables[0] and tiled._tiled_tables[2] is None
-    nd = ctx.getPlan((60, 16), dtype=numpy.complex64, any_size=True)
-    assert nd._direct_nd is not None and nd._inner_plans() == [] and nd._rowplans == {}
-    assert ctx.getPlan((16, 16), parent_shape=(64, 64), dtype=numpy.float32)._tiled     # (split planes: one launch too, second batch of round 4)
-    work = ctx.getPlan((16, 4), parent_shape=(64, 64), dtype=numpy.complex64)           # a tile shape without a one-launch kernel: gather / N-D plan / scatter
-    assert not work._tiled and len(work._inner_plans()) == 1
-    blue = ctx.getPlan((4099, 4), dtype=numpy.complex64, any_size=True)                 # a long prime axis: padded power-of-two rows
-    assert len(blue._inner_plans()) >= 1
-    for plan, shape, batch in ((tiled, (64, 64), 2), (nd, (60, 16), 3)):
-        data = _test_data(shape, numpy.complex64, batch, 96)
-        a = ctx.toGpu(data)
-        plan.execute(a, batch=batch)
-        got = a.get().reshape((batch,) + shape)
-        src = data.reshape((batch,) + shape).astype(numpy.complex128)
-        if plan is tiled:
-            ref = numpy.empty_like(src)
-            for i in range(4):
-                for j in range(4):
-                    ref[:, 16 * i:16 * i + 16, 16 * j:16 * j + 16] = numpy.fft.fft2(src[:, 16 * i:16 * i + 16, 16 * j:16 * j + 16])
-        else:
-            ref = numpy.fft.fft2(src)
-        assert numpy.abs(ref - got).sum() / numpy.abs(ref).sum() < 1.1e-6
-
-
 # ---- rectangular 2-D shapes on the fused kernel ---------------------------------------------------------------------------------
 RECT_2D_CASES = [((512, 1024), 66), ((1024, 512), 113), ((1024, 2048), 18), ((2048, 1024), 29), ((512, 2048), 33), ((2048, 512), 57)]
 
@@ -295,55 +296,6 @@ def test_fused_2d_rectangles(ctx, monkeypatch, shape, batch):
     # split planes: the row-first kernel where both sides are <= 1024 (test_fused_2d_split_row_first), else the pipelined chunks
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
     assert ctx.getPlan(shape, dtype=numpy.float32).strategy(batch)[0] == ("fused2" if max(shape) <= 1024 else "pipelined")
-
-
-# ---- f4 tails: smooth N-D shapes in one launch, Bluestein rows up to 5000 points in one launch ----------------------------------
-@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
-@pytest.mark.parametrize("shape,batch", [((100, 100), 5), ((60, 60), 7), ((30, 20, 10), 3), ((12, 20), 301), ((6, 10, 14), 33), ((100, 64), 2),
-                                         ((70, 70), 3), ((9, 1, 25), 11), ((15, 16), 64)], ids=str)
-def test_smooth_nd_single_launch(ctx, monkeypatch, shape, dtype, batch):
-    """Every axis a smooth length and the transform inside one tile (csrc/fft_mixed_nd.hip; the reference's TODO.txt:8): ONE launch
-    against numpy with the reference's thresholds, out of place (input untouched), the inverse in place, ragged last work-group,
-    and against the round-3 form (one launch per axis) -- the same butterflies in the same order, so the same bits."""
-    from test_round2_gpu import _run_generic
-    N = ctx.hip.N
-    prec = N.F32 if numpy.dtype(dtype) == numpy.complex64 else N.F64
-    x, y, z = (tuple(reversed(shape)) + (1, 1))[:3]
-    plan = ctx.getPlan(shape, dtype=dtype, any_size=True)
-    one = N.lib.mifft_mixed_nd_supported(prec, x, y, z) == 0
-    assert plan._direct_nd1 == one and plan._inner_plans() == []
-    if shape == (100, 100):
-        assert one == (prec == N.F32)                  # 10000 points: one fp32 tile (80 KB per LDS buffer), two launches in fp64
-    _run_generic(ctx, shape, dtype, batch, seed=sum(shape))
-    if one:
-        rng = numpy.random.default_rng(5)
-        full = (batch * shape[0],) + tuple(shape[1:])
-        data = (rng.standard_normal(full) + 1j * rng.standard_normal(full)).astype(dtype)
-        a = ctx.toGpu(data)
-        plan.execute(a, batch=batch)
-        monkeypatch.setenv("PYFFT_AMD_NO_MIXED_ND", "1")
-        per_axis = ctx.getPlan(shape, dtype=dtype, any_size=True)
-        assert not per_axis._direct_nd1 and per_axis._direct_nd is not None
-        b = ctx.toGpu(data)
-        per_axis.execute(b, batch=batch)
-        assert numpy.array_equal(a.get(), b.get())
-
-
-@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
-@pytest.mark.parametrize("n,batch", [(2049, 9), (4099, 5), (5000, 3), (3001, 4), (2500, 7)], ids=str)
-def test_bluestein_rows_beyond_one_small_tile(ctx, n, batch, dtype):
-    """Lengths with a large prime factor whose padded rows take up to the whole LDS of a CU (n <= 5000 fp32 / 2500 fp64): ONE launch
-    (round 3: five launches at 0.029 of the roofline for n = 4099); longer ones keep the composition.  numpy, reference thresholds."""
-    from test_round2_gpu import _run_generic
-    N = ctx.hip.N
-    prec = N.F32 if numpy.dtype(dtype) == numpy.complex64 else N.F64
-    m = ctypes.c_int32(0)
-    one = N.lib.mifft_bluestein_padded(prec, n, ctypes.byref(m)) == 0
-    assert one == (n <= (5000 if prec == N.F32 else 2500))
-    plan = ctx.getPlan((n,), dtype=dtype, any_size=True)
-    smooth = N.lib.mifft_mixed_supported(prec, n) == 0 or plan._direct_long is not None
-    assert plan._direct_blue == (one and not smooth)
-    _run_generic(ctx, (n,), dtype, batch, seed=n)
 
 
 # ---- fp64 2^21 / 2^22 on the persistent kernel (stage-chain strided tiles) ------------------------------------------------------
@@ -380,22 +332,6 @@ def test_fused_long_fp64(ctx, monkeypatch, n, batch):
     # split planes have no such kernel: the pipelined chunks
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "auto")
     assert ctx.getPlan((n,), dtype=numpy.float64).strategy(batch)[0] in ("pipelined", "chain")
-
-
-@pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
-@pytest.mark.parametrize("shape,batch", [((60, 60, 60), 2), ((24, 100, 100), 3), ((7, 90, 50), 5)], ids=str)
-def test_smooth_3d_as_planes_and_lines(ctx, shape, dtype, batch):
-    """3-D smooth shapes beyond one tile whose (y, x) planes fit one: the planes in ONE launch (they are more transforms of the
-    2-D kernel), then the z lines -- two HBM round trips instead of three (round 3: one launch per axis).  numpy, reference
-    thresholds, out of place with the input untouched, the normalised inverse in place."""
-    from test_round2_gpu import _run_generic
-    N = ctx.hip.N
-    prec = N.F32 if numpy.dtype(dtype) == numpy.complex64 else N.F64
-    z, y, x = shape
-    plan = ctx.getPlan(shape, dtype=dtype, any_size=True)
-    planes = N.lib.mifft_mixed_nd_supported(prec, x, y, z) != 0 and N.lib.mifft_mixed_nd_supported(prec, x, y, 1) == 0
-    assert plan._direct_nd_planes == planes and not plan._direct_nd1 and plan._inner_plans() == []
-    _run_generic(ctx, shape, dtype, batch, seed=sum(shape))
 
 
 @pytest.mark.parametrize("n,batch,forced", [(1 << 19, 34, "auto"), (1 << 18, 66, "auto"), (1 << 17, 130, "auto"), (1 << 16, 260, "auto")], ids=str)
@@ -484,57 +420,6 @@ def test_wide_tiles_fp32_mid_sizes(ctx, monkeypatch, n, batch):
     assert oracle.difference(data, back, batch) < 1.1e-6
 
 
-# ---- tiled batches on split-complex parents in one launch (csrc/fft_nd2t.hpp, SPLIT; the reference's TODO.txt:6-7) -------
-@pytest.mark.parametrize("dtype", [numpy.float32, numpy.float64], ids=["f32", "f64"])
-@pytest.mark.parametrize("shape,parent", [((8, 8), (24, 40)), ((16, 16), (48, 80)), ((32, 32), (96, 64)), ((64, 64), (192, 128)),
-                                          ((128, 128), (256, 384)), ((16, 32), (32, 96)), ((32, 64), (96, 64)), ((64, 128), (128, 384)),
-                                          ((8, 8, 8), (16, 24, 8)), ((16, 16, 16), (32, 16, 48)), ((8, 16, 16), (8, 48, 32)),
-                                          ((8, 32, 32), (24, 32, 64)), ((32, 32, 32), (64, 32, 96))], ids=str)
-def test_tiled_batch_split_planes_single_launch(ctx, shape, parent, dtype, monkeypatch):
-    """The tiles of split-complex parent arrays (re / im planes) transformed where they lie, ONE launch and no work array: the bits
-    of the interleaved one-launch form on the same numbers, numpy tile by tile with the reference's thresholds, the input planes
-    untouched, in place, the inverse, and the gather / dense plan / scatter form of the same plan."""
-    from test_round2_gpu import _numpy_tiles
-    if shape == (32, 32, 32) and numpy.dtype(dtype) == numpy.float64:
-        shape, parent = (16, 32, 32), (32, 32, 96)
-    batch = 3
-    rd = numpy.dtype(dtype)
-    cd = numpy.dtype(numpy.complex64 if rd == numpy.float32 else numpy.complex128)
-    eps, mx = (1e-11, 1e-10) if rd == numpy.float64 else (1.1e-6, 1e-5)
-    full = (batch * parent[0],) + tuple(parent[1:])
-    rng = numpy.random.default_rng(177 + sum(parent))
-    re, im = rng.standard_normal(full).astype(rd), rng.standard_normal(full).astype(rd)
-    x = (re + 1j * im).astype(cd)
-    ref = _numpy_tiles(x, batch, shape, parent)
-    plan = ctx.getPlan(shape, dtype=dtype, parent_shape=parent)
-    assert plan._tiled and plan._work is None and plan._inner_plans() == []
-    a_re, a_im, b_re, b_im = ctx.toGpu(re), ctx.toGpu(im), ctx.allocate(full, rd), ctx.allocate(full, rd)
-    plan.execute(a_re, a_im, b_re, b_im, batch=batch)
-    got = b_re.get() + 1j * b_im.get()
-    assert numpy.array_equal(a_re.get(), re) and numpy.array_equal(a_im.get(), im), "out-of-place execute modified its input"
-    assert numpy.abs(got - ref).sum() / numpy.abs(ref).sum() < eps
-    assert numpy.abs(got - ref).max() <= mx * numpy.abs(ref).max()
-    # the interleaved one-launch form: same butterflies, same table factors
-    iplan = ctx.getPlan(shape, dtype=cd, parent_shape=parent)
-    assert iplan._tiled
-    c, d = ctx.toGpu(x), ctx.allocate(full, cd)
-    iplan.execute(c, d, batch=batch)
-    assert numpy.array_equal(d.get(), got.astype(cd))
-    plan.execute(a_re, a_im, batch=batch)                      # in place
-    assert numpy.array_equal(a_re.get(), b_re.get()) and numpy.array_equal(a_im.get(), b_im.get())
-    plan.execute(a_re, a_im, inverse=True, batch=batch)
-    back = a_re.get() + 1j * a_im.get()
-    assert numpy.abs(back - x).sum() / numpy.abs(x).sum() < 2 * eps
-    assert plan._work is None
-    monkeypatch.setenv("PYFFT_AMD_NO_TILED", "1")
-    plan3 = ctx.getPlan(shape, dtype=dtype, parent_shape=parent)
-    assert not plan3._tiled
-    e_re, e_im = ctx.allocate(full, rd), ctx.allocate(full, rd)
-    plan3.execute(ctx.toGpu(re), ctx.toGpu(im), e_re, e_im, batch=batch)
-    three = e_re.get() + 1j * e_im.get()
-    assert numpy.abs(three - got).sum() / numpy.abs(got).sum() < eps
-
-
 # ---- 2-D shapes with a 256-point axis on the persistent kernels (second batch of round 4) ---------------------------------------
 @pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
 @pytest.mark.parametrize("shape,batch", [((256, 256), 530), ((256, 512), 270), ((512, 256), 265), ((256, 1024), 140), ((1024, 256), 133)], ids=str)
@@ -574,21 +459,6 @@ def test_fused_2d_256_sides(ctx, monkeypatch, shape, batch, dtype):
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
     want = _execute(ctx, shape, cd, batch, data, expect="chain")
     assert oracle.difference(want, got, batch) < (1e-14 if f64 else 5e-7)
-
-
-# ---- split-complex fp32 on the persistent 1-D kernel: sibling tiles per item ------------------------------------------------------
-def _execute_split(ctx, shape, rdtype, batch, re, im, inplace=False, inverse=False, expect=None):
-    plan = ctx.getPlan(shape, dtype=rdtype)
-    if expect is not None:
-        assert plan.strategy(batch)[0] == expect, plan.strategy(batch)
-    a_re, a_im = ctx.toGpu(re), ctx.toGpu(im)
-    if inplace:
-        plan.execute(a_re, a_im, batch=batch, inverse=inverse)
-        return a_re.get(), a_im.get()
-    b_re, b_im = ctx.allocate(re.shape, re.dtype), ctx.allocate(im.shape, im.dtype)
-    plan.execute(a_re, a_im, b_re, b_im, batch=batch, inverse=inverse)
-    assert numpy.array_equal(a_re.get(), re) and numpy.array_equal(a_im.get(), im), "an out-of-place execute touched its input"
-    return b_re.get(), b_im.get()
 
 
 SPLIT_1D_CASES = [(1 << 16, 1100, "fused2"), (1 << 17, 515, "fused2"), (1 << 18, 259, "fused2"), (1 << 19, 130, "fused2"), (1 << 20, 70, "fused2")]
@@ -778,3 +648,174 @@ def test_fused_split_planes_fp64(ctx, monkeypatch, shape, batch):
     monkeypatch.setenv("PYFFT_AMD_STRATEGY", "chain")
     want = _execute_split(ctx, shape, numpy.float64, batch, re, im, expect="chain")
     assert numpy.abs((want[0] - got[0]) + 1j * (want[1] - got[1])).sum() / numpy.abs(want[0] + 1j * want[1]).sum() < 1e-14
+
+
+N5 = 1 << 22           # configuration 5: 1-D c2c fp32 N = 2^22
+
+
+CHUNK5 = 256           # one resident chunk: 8 GiB in + 8 GiB out
+
+
+SHARE5 = 8192          # per GPU: 65536 transforms over 8 GPUs (BASELINE.json configs[4]; kernel.py:99-121: batch -> grid)
+
+
+BLK5 = 16              # the synthetic data set is periodic: 16 seeded transforms (512 MiB)
+
+
+_c5_cache = {}
+
+
+def _c5_block():
+    """The seeded block of configuration 5 and numpy's transform of every item of it (complex128), computed once per session."""
+    if "block" not in _c5_cache:
+        rng = numpy.random.default_rng(1005)
+        re = rng.standard_normal((BLK5, N5)).astype(numpy.float32)
+        im = rng.standard_normal((BLK5, N5)).astype(numpy.float32)
+        block = numpy.empty((BLK5, N5), numpy.complex64)
+        block.real = re
+        block.imag = im
+        _c5_cache["block"] = block
+        _c5_cache["refs"] = [numpy.fft.fft(block[i].astype(numpy.complex128)) for i in range(BLK5)]
+    return _c5_cache["block"], _c5_cache["refs"]
+
+
+def _fetch(N, ptr, item, size=N5):
+    out = numpy.empty(size, numpy.complex64)
+    N.check(N.lib.mifft_memcpy_d2h(out.ctypes.data, ptr + item * size * 8, out.nbytes, None))
+    return out
+
+
+def _close(got, ref):
+    got = got.astype(numpy.complex128)
+    return (numpy.abs(ref - got).sum() / numpy.abs(ref).sum() < EPS_F) and (numpy.abs(ref - got).max() <= MAX_F * numpy.abs(ref).max())
+
+
+def test_config5_per_gpu_share(ctx):
+    """The full per-GPU share of configuration 5 as the survey's streaming loop: 32 chunks of 256 transforms through ONE plan and
+    ONE pair of 8 GiB buffers.  Global transform g holds block item (g + g // 256) % 16 -- every chunk is the block rotated one item
+    further, so a chunk that was skipped, executed on stale data or mixed up with its neighbour cannot pass -- and the input buffer
+    is refilled between chunks from a device copy of the block.  First / middle / last transform of EVERY chunk against numpy."""
+    from pyfft_amd import _native as N
+    hip = ctx.hip
+    block, refs = _c5_block()
+    item_bytes = N5 * 8
+    dev_block = hip.to_gpu(block.reshape(-1))
+    a = hip.DeviceArray((CHUNK5 * N5,), numpy.complex64)
+    b = hip.DeviceArray((CHUNK5 * N5,), numpy.complex64)
+    plan = hip.Plan(N5, dtype=numpy.complex64)
+    assert plan.strategy(CHUNK5)[0] == "fused2"             # the persistent kernel of the stated configuration
+
+    def refill(c):
+        """a[s] <- block[(s + c) % 16] for the 256 transforms s of chunk c"""
+        rot = c % BLK5
+        head = (BLK5 - rot) * item_bytes
+        N.check(N.lib.mifft_memcpy_d2d(a.ptr, dev_block.ptr + rot * item_bytes, head, None))
+        if rot:
+            N.check(N.lib.mifft_memcpy_d2d(a.ptr + head, dev_block.ptr, rot * item_bytes, None))
+        done = BLK5 * item_bytes
+        while done < a.nbytes:
+            n = min(done, a.nbytes - done)
+            N.check(N.lib.mifft_memcpy_d2d(a.ptr + done, a.ptr, n, None))
+            done += n
+
+    chunks = SHARE5 // CHUNK5
+    checked = 0
+    for c in range(chunks):
+        refill(c)
+        plan.execute(a, b, batch=CHUNK5)
+        for s in (0, CHUNK5 // 2 + 1, CHUNK5 - 1):
+            g = c * CHUNK5 + s
+            assert _close(_fetch(N, b.ptr, s), refs[(g + g // CHUNK5) % BLK5]), ("chunk", c, "transform", g)
+            checked += 1
+        if c in (0, chunks // 2, chunks - 1):               # the input of an out-of-place execute stays what it was
+            assert numpy.array_equal(_fetch(N, a.ptr, CHUNK5 - 1), block[(CHUNK5 - 1 + c) % BLK5])
+    assert checked == 3 * chunks
+    # the last chunk's result, inverse in place: the round trip
+    plan.execute(b, batch=CHUNK5, inverse=True)
+    for s in (0, CHUNK5 - 1):
+        want = block[(s + chunks - 1) % BLK5].astype(numpy.complex128)
+        got = _fetch(N, b.ptr, s).astype(numpy.complex128)
+        assert numpy.abs(want - got).sum() / numpy.abs(want).sum() < EPS_F
+
+
+def test_config5_share_as_one_execute(ctx):
+    """The same share as ONE in-place execute(batch = 8192): 256 GiB resident (byte offsets up to 2^38, 2^35 elements, 16393 counters
+    per set), skipped with a message where the allocation is refused.  Sampled transforms against numpy, periodic input ->
+    bit-identical outputs across the whole buffer, inverse in place -> the input."""
+    from pyfft_amd import _native as N
+    hip = ctx.hip
+    block, refs = _c5_block()
+    try:
+        buf = hip.DeviceArray((SHARE5 * N5,), numpy.complex64)
+    except RuntimeError as e:
+        pytest.skip("mifft_malloc refuses 256 GiB on this device: %s" % (str(e)[:200],))
+    hb = block.reshape(-1).view(numpy.uint8)
+    N.check(N.lib.mifft_memcpy_h2d(buf.ptr, hb.ctypes.data, hb.nbytes, None))
+    done = hb.nbytes
+    while done < buf.nbytes:
+        n = min(done, buf.nbytes - done)
+        N.check(N.lib.mifft_memcpy_d2d(buf.ptr + done, buf.ptr, n, None))
+        done += n
+    N.check(N.lib.mifft_device_sync())
+    plan = hip.Plan(N5, dtype=numpy.complex64)
+    assert plan.strategy(SHARE5)[0] == "fused2"
+    plan.execute(buf, batch=SHARE5)
+    samples = [0, 1, BLK5 - 1, BLK5, SHARE5 // 2 - 1, SHARE5 // 2, SHARE5 // 2 + 5, SHARE5 - BLK5 - 3, SHARE5 - 2, SHARE5 - 1]
+    first = {}
+    for g in samples:
+        got = _fetch(N, buf.ptr, g)
+        assert _close(got, refs[g % BLK5]), g
+        # periodic input -> bit-identical output wherever the item lies in the 256 GiB
+        if g % BLK5 in first:
+            assert numpy.array_equal(first[g % BLK5].view(numpy.uint32), got.view(numpy.uint32)), g
+        else:
+            first[g % BLK5] = got
+    plan.execute(buf, batch=SHARE5, inverse=True)
+    for g in (0, SHARE5 // 2 + 5, SHARE5 - 1):
+        want = block[g % BLK5].astype(numpy.complex128)
+        got = _fetch(N, buf.ptr, g).astype(numpy.complex128)
+        assert numpy.abs(want - got).sum() / numpy.abs(want).sum() < EPS_F, g
+    plan.close()
+    del buf
+
+
+def test_direct_abi_two_set_launch_refuses_capture_and_null_error_word(ctx):
+    """C-ABI users of mifft_launch_fused2: the two-set form on a capturing stream is MIFFT_E_INVALID (a replay would start on dirty
+    counters), and so is the two-set form without an error word of its own (the next launch would zero the default one)."""
+    import ctypes
+    from pyfft_amd import _native as N
+    hip = ctx.hip
+    n, batch = 1 << 18, 160
+    s = hip.Stream()
+    plan = hip.Plan(n, dtype=numpy.complex64, stream=s)
+    a = hip.DeviceArray((n * batch,), numpy.complex64)
+    N.check(N.lib.mifft_memset(a.ptr, 0, a.nbytes, s.handle))
+    plan.execute(a, batch=batch)
+    s.synchronize()
+    strat = plan.strategy(batch)
+    assert strat[0] == "fused2"
+    _, lag, ring, grid = strat
+    descs = plan._descriptors(batch, True, False)
+    base = plan._context.pointer_of(plan._counters)
+    nb = plan._counter_bytes
+    N.check(N.lib.mifft_memset(base, 0, 3 * nb, s.handle))
+    s.synchronize()
+    plan._counters_clean, plan._counter_set = True, 0
+    tmp = plan._context.pointer_of(plan._tempmemobj)
+
+    def launch(sync):
+        return N.lib.mifft_launch_fused2(ctypes.byref(descs[0]), ctypes.byref(descs[1]), a.ptr, None, a.ptr, None, tmp, None, ring, lag,
+                                         ctypes.byref(sync), grid, s.handle)
+
+    assert launch(N.MifftFusedSync(base, base + nb, None)) == N.E_INVALID
+    assert b"error word" in N.lib.mifft_last_error()
+    N.check(N.lib.mifft_stream_begin_capture(s.handle))
+    rc = launch(N.MifftFusedSync(base, base + nb, plan._errword.ptr))
+    msg = N.lib.mifft_last_error()
+    rc_single = launch(N.MifftFusedSync(base + 2 * nb, None, plan._errword.ptr))
+    h = ctypes.c_void_p()
+    N.check(N.lib.mifft_stream_end_capture(s.handle, ctypes.byref(h)))
+    N.lib.mifft_graph_destroy(h)
+    assert rc == N.E_INVALID and b"capturing" in msg
+    assert rc_single == 0
+    s.synchronize()
