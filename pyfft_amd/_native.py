@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PYFFT_AMD_DEV_BUILD=1: the `make DEV=1` library (development strategies and A/B kernel forms, pyfft_amd/csrc/Makefile)
 LIB_PATH = os.path.join(_HERE, "libmifft_dev.so" if os.environ.get("PYFFT_AMD_DEV_BUILD") else "libmifft.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 E_INVALID = -1
 E_UNSUPPORTED = -2
@@ -45,6 +45,7 @@ DEBUG_NO_ND2, DEBUG_FUSED_NO_NT, DEBUG_NO_WAVE, DEBUG_FORCE_WAVE, DEBUG_PERSIST,
 DEBUG_ROWS_ND = 8
 DEBUG_NARROW_TILES = 9
 DEBUG_NO_ROWFIRST = 10
+DEBUG_NO_PREFETCH = 11
 FEATURE_XCD2, FEATURE_FUSED2X, FEATURE_SEQUENTIAL_LIST, FEATURE_AB_FORMS = 0, 1, 2, 3     # mifft_has_feature: parts only `make DEV=1` builds
 XCD2_TRACE = 2
 XCD2_TRACE_BYTES = 512 * 32 * 8

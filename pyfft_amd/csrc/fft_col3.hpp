@@ -74,10 +74,76 @@ __device__ __forceinline__ void col3_store_wt16(void* p, const cplx<double>& r) 
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
-// WT: write the result with write-through (agent-coherent) stores: the intermediate of the fused two-pass kernel (interleaved)
-template <typename T, int A, bool TR, bool TW, bool SPLIT, bool NTIN, bool NTOUT, bool SPLIT_OUT, bool WT = false, typename Hook = TileNoHook>
-__device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_in, const long long o_out, const long long rem0,
-                                          T* lds, Hook hook = Hook()) {
+// phase 1 of a tile on its own: v[a*16 + b1] = in[2*(b1*16A + a*16 + b0) + h][column c] -- 16 A loads per thread, all issued before
+// anything waits for them.  The persistent kernels of round 6 call it at the END of the previous tile (fft_fused2.hpp,
+// fused_list_prefetch), everything else from col3_tile below.
+template <typename T, int A, bool SPLIT, bool NTIN>
+__device__ __forceinline__ void col3_load(const TileArgs& a, const long long o_in, const long long rem0, cplx<T>* v) {
+    constexpr int PPT = 16 * A;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int h = lane >= 32 ? 1 : 0;
+    const int tl = (lane & 31) | ((tid >> 6) << 5);
+    const int c = tl & 15, b0 = tl >> 4;
+    int logMS = a.logMS;
+    asm volatile("" : "+s"(logMS));
+    const long long ubase = o_in * a.ostride_in + rem0;
+    const unsigned voff = ((unsigned)(2 * b0 + h) << logMS) + (unsigned)c;
+    if constexpr (!SPLIT) {
+        const char* src = reinterpret_cast<const char*>(reinterpret_cast<const cplx<T>*>(a.in0) + ubase);
+        const unsigned vb = voff * (unsigned)sizeof(cplx<T>);
+        static_for<PPT>([&](auto kk) {
+            constexpr int k = kk, ia = k >> 4, b1 = k & 15;
+            const char* p = src + (((long long)(2 * (b1 * 16 * A + ia * 16)) << logMS) * (long long)sizeof(cplx<T>));
+            if constexpr (NTIN) v[k] = __builtin_nontemporal_load(reinterpret_cast<const cplx<T>*>(p + vb));
+            else v[k] = *reinterpret_cast<const cplx<T>*>(p + vb);
+        });
+    } else {
+        const char* sre = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.in0) + ubase);
+        const char* sim = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.in1) + ubase);
+        const unsigned vb = voff * (unsigned)sizeof(T);
+        static_for<PPT>([&](auto kk) {
+            constexpr int k = kk, ia = k >> 4, b1 = k & 15;
+            const long long off = ((long long)(2 * (b1 * 16 * A + ia * 16)) << logMS) * (long long)sizeof(T);
+            if constexpr (NTIN) {
+                v[k].x = __builtin_nontemporal_load(reinterpret_cast<const T*>(sre + off + vb));
+                v[k].y = __builtin_nontemporal_load(reinterpret_cast<const T*>(sim + off + vb));
+            } else {
+                v[k].x = *reinterpret_cast<const T*>(sre + off + vb);
+                v[k].y = *reinterpret_cast<const T*>(sim + off + vb);
+            }
+        });
+    }
+}
+
+// The table factors of the two register stages of a tile (they depend on the thread, not on the tile): ONE batch of look-ups, issued by
+// the caller right behind the tile's own loads -- a wave's loads return in order, so they arrive with the last rows of the tile.
+template <typename T, int A> struct Col3StageTw {
+    ColStageTw<T> tw;
+    cplx<T> twA[A > 1 ? A - 1 : 1];
+    __device__ __forceinline__ void load(const TileArgs& a) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int b0 = (((tid & 63) & 31) | ((tid >> 6) << 5)) >> 4;
+        const cplx<T>* twL = reinterpret_cast<const cplx<T>*>(a.tw_L);
+        tw.load(twL, b0, 2);          // s = w(L')^b0 = w(L)^(2*b0)
+        if constexpr (A > 1) {
+            static_for<A - 1>([&](auto qq) {
+                constexpr int qa = qq + 1;
+                twA[qq] = twL[32 * b0 * qa];          // w(16A)^(b0*qa) = w(L)^(32*b0*qa)
+            });
+        }
+    }
+};
+
+// The tile from its loaded operands on: v = the 16 A points per thread col3_load delivers (the caller's registers), st = the stage
+// factors Col3StageTw::load delivers.  `hook` runs in
+// the middle of the tile (between the register stages and the exchange rounds), `hook2` in the LAST exchange round in front of its
+// barrier -- what thread 0 writes to LDS there, every thread may read once the tile is over.
+template <typename T, int A, bool TR, bool TW, bool NTOUT, bool SPLIT_OUT, bool WT, typename Hook, typename Hook2>
+__device__ __forceinline__ void col3_body(const TileArgs& a, const long long o_out, const long long rem0, T* lds, cplx<T>* v, Col3StageTw<T, A>& st,
+                                          Hook hook, Hook2 hook2) {
     constexpr int L = 512 * A;          // 2 * L'
     constexpr int PPT = 16 * A;
     constexpr int PITCH = Col3Lds<T, TR>::PITCH;
@@ -98,51 +164,12 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
     cplx<T>* const ldsh = reinterpret_cast<cplx<T>*>(lds) + h * BUF;   // whole points (8-byte points)
     T* const ldss = lds + h * BUF;                                      // one component at a time (16-byte points)
 
-    // ---- phase 1: v[a*16 + b1] = in[2*(b1*16A + a*16 + b0) + h][column c]
-    cplx<T> v[PPT];
-    {
-        const long long ubase = o_in * a.ostride_in + rem0;
-        const unsigned voff = ((unsigned)(2 * b0 + h) << logMS) + (unsigned)c;
-        if constexpr (!SPLIT) {
-            const char* src = reinterpret_cast<const char*>(reinterpret_cast<const cplx<T>*>(a.in0) + ubase);
-            const unsigned vb = voff * (unsigned)sizeof(cplx<T>);
-            static_for<PPT>([&](auto kk) {
-                constexpr int k = kk, ia = k >> 4, b1 = k & 15;
-                const char* p = src + (((long long)(2 * (b1 * 16 * A + ia * 16)) << logMS) * (long long)sizeof(cplx<T>));
-                if constexpr (NTIN) v[k] = __builtin_nontemporal_load(reinterpret_cast<const cplx<T>*>(p + vb));
-                else v[k] = *reinterpret_cast<const cplx<T>*>(p + vb);
-            });
-        } else {
-            const char* sre = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.in0) + ubase);
-            const char* sim = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.in1) + ubase);
-            const unsigned vb = voff * (unsigned)sizeof(T);
-            static_for<PPT>([&](auto kk) {
-                constexpr int k = kk, ia = k >> 4, b1 = k & 15;
-                const long long off = ((long long)(2 * (b1 * 16 * A + ia * 16)) << logMS) * (long long)sizeof(T);
-                if constexpr (NTIN) {
-                    v[k].x = __builtin_nontemporal_load(reinterpret_cast<const T*>(sre + off + vb));
-                    v[k].y = __builtin_nontemporal_load(reinterpret_cast<const T*>(sim + off + vb));
-                } else {
-                    v[k].x = *reinterpret_cast<const T*>(sre + off + vb);
-                    v[k].y = *reinterpret_cast<const T*>(sim + off + vb);
-                }
-            });
-        }
-    }
-    // The table factors of the two register stages: ONE batch of look-ups issued right behind the tile's own loads (the memory
-    // system returns a wave's loads in order, so they arrive with the last rows of the tile).  Round 6: left to the scheduler the
-    // look-ups were issued in three groups with a full wait after each, and the look-ups of every exchange round below sat behind
-    // the previous round's stores -- a wave then waited for those stores to be acknowledged and for up to six table look-ups ONE
-    // AFTER THE OTHER, four times per tile (profiles/r06_fused3_counters.log: waves parked 41 % of their cycles; ISA in DESIGN.md).
-    ColStageTw<T> tw;
-    cplx<T> twA[A > 1 ? A - 1 : 1];
-    tw.load(twL, b0, 2);          // s = w(L')^b0 = w(L)^(2*b0)
-    if constexpr (A > 1) {
-        static_for<A - 1>([&](auto qq) {
-            constexpr int qa = qq + 1;
-            twA[qq] = twL[32 * b0 * qa];          // w(16A)^(b0*qa) = w(L)^(32*b0*qa)
-        });
-    }
+    // (Round 6: left to the scheduler the stage look-ups were issued in three groups with a full wait after each, and the look-ups of
+    // every exchange round below sat behind the previous round's stores -- a wave then waited for those stores to be acknowledged and
+    // for up to six table look-ups ONE AFTER THE OTHER, four times per tile: profiles/r06_fused3_counters.log, waves parked 41 % of
+    // their cycles; the ISA sequences are in docs/kernels.md.)
+    ColStageTw<T>& tw = st.tw;
+    cplx<T>* const twA = st.twA;
     __builtin_amdgcn_sched_barrier(0);
     static_for<PPT>([&](auto kk) { v[kk].y *= csign; });
 
@@ -235,6 +262,7 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
                 if constexpr (TR) buf[(b0 * 16 + c) * PITCH + qb1] = v[qa * 16 + qb1];
                 else buf[(b0 * 16 + qb1) * 16 + c] = v[qa * 16 + qb1];
             });
+            if constexpr (qa == A - 1) hook2();
             __syncthreads();
             static_for<16>([&](auto bb) {
                 constexpr int bi = bb;
@@ -251,6 +279,7 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
                     if constexpr (TR) ldss[(b0 * 16 + c) * PITCH + qb1] = w;
                     else ldss[(b0 * 16 + qb1) * 16 + c] = w;
                 });
+                if constexpr (qa == A - 1 && comp == 1) hook2();
                 __syncthreads();
                 static_for<16>([&](auto bb) {
                     constexpr int bi = bb;
@@ -328,6 +357,17 @@ __device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_i
             }
         });
     });
+}
+
+// WT: write the result with write-through (agent-coherent) stores: the intermediate of the fused two-pass kernel (interleaved)
+template <typename T, int A, bool TR, bool TW, bool SPLIT, bool NTIN, bool NTOUT, bool SPLIT_OUT, bool WT = false, typename Hook = TileNoHook>
+__device__ __forceinline__ void col3_tile(const TileArgs& a, const long long o_in, const long long o_out, const long long rem0,
+                                          T* lds, Hook hook = Hook()) {
+    cplx<T> v[16 * A];
+    Col3StageTw<T, A> st;
+    col3_load<T, A, SPLIT, NTIN>(a, o_in, rem0, v);
+    st.load(a);
+    col3_body<T, A, TR, TW, NTOUT, SPLIT_OUT, WT>(a, o_out, rem0, lds, v, st, hook, TileNoHook());
 }
 
 template <typename T, int A, bool TR, bool TW, bool SPLIT, bool SPLIT_OUT>

@@ -480,6 +480,123 @@ __global__ void __launch_bounds__(512, 2) fft_fused3_kernel(const FusedArgs f) {
         });
 }
 
+// ---- round 6: the next tile's loads issued at the END of the current tile ---------------------------------------------------------------
+// With one 512-thread work-group per CU nothing overlaps a tile's dead time: at the top of every item the work-group drains its stores
+// (publish), polls the item's dependency (an agent-scope load: 1-3 us), runs an acquire, and only then issues the tile's loads and waits
+// a memory latency for the first of them -- 4-5 us of a 21 us tile in which this CU moves no data (profiles/r06_fused3_counters.log:
+// 102 read requests in flight per L2 channel against 127 for the 256-thread kernel at two work-groups per CU).  Here thread 0 hands
+// out the NEXT item from inside the current tile's last exchange round (hook2: the round's own barrier publishes it to the work-group),
+// and the loop issues that item's loads FIRST, right behind the previous tile's last stores -- before the publish (store drain +
+// barrier + counter), which then runs concurrently with the load latency; no barrier and no LDS round trip lie between two tiles.  A second-pass item is prefetched only if the early poll of its
+// dependency (the hook in the middle of the tile) has already seen it satisfied -- thread 0 then runs the acquire in hook2, in front
+// of the barrier; otherwise the item takes the ordinary path at the top of the loop.  First-pass items read the user's input, which
+// depends on nothing (their dependency guards the ring slot they WRITE, and is still waited for before the tile computes).
+// Tickets stay global and increasing, every work-group still works through its tickets in order and publishes before it waits: the
+// no-deadlock argument of the list above is unchanged.  LOAD0(t, tile) / LOAD1(slot, tile) issue a tile's loads into the caller's registers.
+template <unsigned PER0, unsigned PER1, typename LOAD0, typename LOAD1, typename TILE0, typename TILE1>
+__device__ __forceinline__ void fused_list_prefetch(const FusedCtl& f, unsigned* s_item, LOAD0& load0, LOAD1& load1, TILE0& tile0, TILE1& tile1) {
+    unsigned* const err = f.err;
+    unsigned* const next = f.counters;
+    unsigned* const wdone = f.counters + kFusedCS;
+    unsigned* const rdone = wdone + kFusedCS * f.batch;
+    const unsigned gsize = f.tiles0 + f.tiles1;
+    const unsigned total = (f.batch + f.lag) * gsize;
+    FusedPending pend = {nullptr};
+    FusedQueue q = {0u, 0u};
+    unsigned seen_cur = 0;       // thread 0: the early poll of the CURRENT item's dependency
+    if (threadIdx.x == 0) {
+        s_item[0] = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_item[1] = 0u;
+        q.t1 = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const FusedHook<PER0, PER1> hook = {f, q, total, gsize, wdone, rdone, 0u, 1u, f.batch};
+    // thread 0: hand out the next item (s_item[0]) and say whether its loads may be issued at once (s_item[1])
+    auto handout = [&]() {
+        if (threadIdx.x == 0) {
+            const unsigned nxt = q.t1;
+            unsigned ok = 0u;
+            seen_cur = q.seen1;
+            q.seen1 = 0u;
+            if (nxt < total) {
+                const FusedItem nx = fused_decode<PER0, PER1>(f, nxt, gsize, wdone, rdone);
+                if (nx.pass == 0u) {
+                    ok = 1u;
+                } else if (nx.pass == 1u && seen_cur >= nx.target) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    ok = 1u;
+                }
+                q.t1 = __hip_atomic_fetch_add(next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s_item[0] = nxt;
+            s_item[1] = ok;
+        }
+    };
+    for (;;) {
+        // (what thread 0 wrote in the previous tile's last round -- or in the prologue -- is visible: a barrier lies in between)
+        const unsigned item = __builtin_amdgcn_readfirstlane(s_item[0]);
+        const bool ok = __builtin_amdgcn_readfirstlane(s_item[1]) != 0u;
+        if (item >= total) break;
+        const FusedItem it = fused_decode<PER0, PER1>(f, item, gsize, wdone, rdone);
+        if (it.pass == 0u) {
+            load0(it.t, it.tile);                    // right behind the previous tile's last stores: the input depends on nothing
+            if (it.dep != nullptr) fused_wait_ge<false>(it.dep, it.target, seen_cur, err, pend);    // (the ring slot it WRITES is free)
+            else fused_flush(pend);
+            tile0(it.t, it.slot, it.tile, hook, handout);
+            pend.ctr = wdone + kFusedCS * it.t;     // published behind the next item's loads (or at the end)
+        } else if (it.pass == 1u) {
+            // ok: the early poll saw the dependency satisfied and thread 0 ran the acquire in front of the barrier that published this
+            // item; else the ordinary path -- publish what this work-group owes, THEN wait
+            if (!ok) fused_wait_ge<true>(it.dep, it.target, seen_cur, err, pend);
+            load1(it.slot, it.tile);
+            fused_flush(pend);
+            tile1(it.slot, it.t, it.tile, hook, handout);
+            fused_signal_read(rdone + kFusedCS * it.t);
+        } else {                          // fill / drain of the pipeline: nothing to do, but never sit on a publish
+            fused_flush(pend);
+            __syncthreads();             // (the previous hand-out has been read by everybody)
+            handout();
+            __syncthreads();
+        }
+    }
+    fused_flush(pend);
+}
+
+// fft_fused3_kernel with the prefetching list (interleaved data; A0 >= A1: the registers hold the larger tile)
+template <typename T, int A0, int A1, bool NT>
+__global__ void __launch_bounds__(512, 2) fft_fused3p_kernel(const FusedArgs f) {
+    constexpr int E0 = Col3Lds<T, true>::SCALARS, E1 = Col3Lds<T, false>::SCALARS;
+    __shared__ __attribute__((aligned(16))) T lds[E0 > E1 ? E0 : E1];
+    __shared__ unsigned s_item[2];
+    constexpr unsigned per0 = A0 > A1 ? 1u : (unsigned)(A1 / A0);
+    constexpr unsigned per1 = A1 > A0 ? 1u : (unsigned)(A0 / A1);
+    cplx<T> v[16 * (A0 > A1 ? A0 : A1)];
+    if (f.c.counters_next != nullptr) {      // the counter set of the NEXT launch (as fused_loop)
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < f.c.lines; i += gridDim.x * blockDim.x) {
+            f.c.counters_next[i * kFusedCS] = 0u;
+            f.c.counters_next[i * kFusedCS + 1u] = 0u;
+        }
+    }
+    Col3StageTw<T, A0> st0;
+    Col3StageTw<T, A1> st1;
+    auto l0 = [&](unsigned t, unsigned tile) {
+        col3_load<T, A0, false, NT>(f.p0, (long long)t, (long long)tile * 16, v);
+        st0.load(f.p0);
+    };
+    auto l1 = [&](unsigned slot, unsigned tile) {
+        col3_load<T, A1, false, false>(f.p1, (long long)slot, (long long)tile * 16, v);
+        st1.load(f.p1);
+    };
+    auto t0 = [&](unsigned t, unsigned slot, unsigned tile, auto hook, auto hook2) {
+        col3_body<T, A0, true, true, false, false, true>(f.p0, (long long)slot, (long long)tile * 16, lds, v, st0, hook, hook2);
+    };
+    auto t1 = [&](unsigned slot, unsigned t, unsigned tile, auto hook, auto hook2) {
+        col3_body<T, A1, false, false, NT, false, false>(f.p1, (long long)t, (long long)tile * 16, lds, v, st1, hook, hook2);
+    };
+    fused_list_prefetch<per0, per1>(f.c, s_item, l0, l1, t0, t1);
+}
+
 // 2-D shapes on the 512-thread tiles (axis length 512 * A): fp64 1024 x 1024 (the published double-precision shape), fp32 with a
 // 2048-point axis -- fft_fused2d_kernel's data flow
 template <typename T, int A0, int A1, bool SPLIT, bool NT>

@@ -1251,7 +1251,7 @@ int mifft_aux_count_mismatch(const void* a, const void* b, size_t nbytes, uint64
     if ((nbytes & 15) || (((uintptr_t)a | (uintptr_t)b) & 15) || ((uintptr_t)count & 7))
         return set_err(MIFFT_E_INVALID, "mifft_aux_count_mismatch: buffers and size in whole 16-byte words, an 8-byte aligned counter");
     const int rc = mifft_aux_mismatch_launch(a, b, (unsigned long long)(nbytes / 16), (unsigned long long*)count, (hipStream_t)stream);
-    return rc ? set_err(MIFFT_E_HIP, "mifft_aux_count_mismatch: launch failed") : 0;
+    return rc ? hip_check((hipError_t)rc, "kernel launch") : 0;
 }
 
 int mifft_mixed_supported(int32_t precision, int32_t n) {

@@ -50,6 +50,55 @@ def plan_for(shape, dtype):
     return _plans[key]
 
 
+_tables = {}
+
+
+def fixed_nd_shapes(prec):
+    """(x, y, z) of the generated fixed-shape N-D tables csrc/fft_nd2_<prec>_*.hip (tools/gen_nd2_tables.py is their single source)"""
+    if "fixed" not in _tables:
+        import importlib.util
+        import os
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gen_nd2_tables.py")
+        spec = importlib.util.spec_from_file_location("gen_nd2_tables", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        _tables["fixed"] = {"f32": frozenset(tuple(t) for t in mod.shapes("f32")), "f64": frozenset(tuple(t) for t in mod.shapes("f64"))}
+    return _tables["fixed"][prec]
+
+
+def nd2z_shapes(prec):
+    """(x, y, z) with a several-work-groups-per-transform instance, read off the instantiation tables csrc/fft_nd2z_<prec>.hip"""
+    if "nd2z" not in _tables:
+        import os
+        import re
+        out = {}
+        for name, ctype in (("f32", "float"), ("f64", "double")):
+            path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pyfft_amd", "csrc", "fft_nd2z_%s.hip" % name)
+            text = "\n".join(l for l in open(path).read().splitlines() if not l.lstrip().startswith("//") and "#define" not in l)
+            found = set()
+            for m in re.finditer(r"(?:SHAPE[A-Z0-9]*\(|go[x4]?<)\s*%s\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)" % ctype, text):
+                found.add(tuple(int(v) for v in m.groups()))
+            out[name] = frozenset(found)
+        _tables["nd2z"] = out
+    return _tables["nd2z"][prec]
+
+
+def _nd_key(prec, lay, x, y, z):
+    """The instance an N-D pass of this shape runs: the shape's own fixed instance (interleaved: the generated tables; planes: the tiled
+    fixed-shape kernel where it takes dense planes), else the ONE run-time-shaped kernel, whose instances differ by the tile's size class."""
+    from pyfft_amd import _native as N
+    p = N.F64 if prec == "f64" else N.F32
+    if lay == "interleaved":
+        if (x, y, z) in fixed_nd_shapes(prec) or N.lib.mifft_nd_shape_supported(p, x, y, z, 0) != 0:
+            return ("nd_fixed", prec, lay, x, y, z)
+    elif x * (8 if prec == "f64" else 4) >= 128 and N.lib.mifft_nd_tiled_supported(p, x, y, z) == 0:
+        return ("nd_fixed", prec, lay, x, y, z)
+    elif N.lib.mifft_nd_shape_supported(p, x, y, z, 0) != 0:
+        return ("nd_fixed", prec, lay, x, y, z)
+    n = x * y * z
+    return ("nd_generic", prec, lay, "dims%d" % ((x > 1) + (y > 1) + (z > 1)), "log2n=%d" % (n.bit_length() - 1))
+
+
 def _chain_keys(plan, chain):
     """one key per LAUNCH of a chain"""
     from pyfft_amd import _native as N
@@ -68,7 +117,7 @@ def _chain_keys(plan, chain):
             i += 2
             continue
         if k.kind == N.PASS_ND:
-            keys.add(("nd", prec, lay, int(k.L), int(k.M), int(k.S)))
+            keys.add(_nd_key(prec, lay, int(k.L), int(k.M), int(k.S)))
         elif k.kind == N.PASS_ROW:
             keys.add(("row", prec, lay, int(k.L)))
         else:
@@ -105,12 +154,21 @@ def keys_of(shape, dtype, batch, mode="auto"):
         keys.add(_persistent_key(plan))
     else:
         keys |= _chain_keys(plan, plan._kernels)
+    from pyfft_amd import _native as N
+    p = plan._params
+    prec = "f64" if p.precision == N.F64 else "f32"
     if plan._runs_oop_nd(int(batch)):
-        from pyfft_amd import _native as N
-        p = plan._params
-        keys.add(("nd_oop", "f64" if p.precision == N.F64 else "f32", int(p.x), int(p.y), int(p.z)))
+        keys.add(("nd_oop", prec, int(p.x), int(p.y), int(p.z)))
+    # a one-launch plan of a shape with a several-work-groups-per-transform instance: its OUT-OF-PLACE executes take that instance inside
+    # the library (csrc/mifft_runtime.cpp launch_nd; small launches only for some shapes -- the tests assert which)
+    if not p.split and len(plan._kernels) == 1 and plan._kernels[0].kind == N.PASS_ND and (int(p.x), int(p.y), int(p.z)) in nd2z_shapes(prec):
+        keys.add(("nd2z", prec, int(p.x), int(p.y), int(p.z)))
     return keys
 
+
+# pair kernels of the library that only a development switch selects (MIFFT_DEBUG_PAIR = 2: the other y split of 256^3, interleaved fp64);
+# tests/test_pairs_gpu.py::test_pass_pairs_256_cubed_alternative_split runs it
+DEV_ONLY_PAIR_KEYS = {("pairXY", "f64", "interleaved", 256, 64, 4), ("pairYZ", "f64", "interleaved", 16384, 4, 256)}
 
 MAX_LOG2_POINTS = 24          # shapes of up to 2^24 points: 4096 x 4096, 256^3, 2^24 (128 MiB fp32 / 256 MiB fp64 per transform)
 
@@ -230,6 +288,7 @@ REGISTRY = {
         "test_l2048_fp64_strided_pass": lambda p: [_c(p["shape"], C128, p["batch"])],
         "test_l2048_fp64_fallback_kernel": None,
         "test_register_only_short_strided_pass": None,
+        "test_long_strided_axes": lambda p: [_c(p["shape"], p["dtype"], 1 if _prod(p["shape"]) * numpy.dtype(p["dtype"]).itemsize * (2 if _split(p["dtype"]) else 1) >= (64 << 20) else 2)],
     },
     "test_persistent_gpu": {
         "test_async_error_mailbox": lambda p: [_c((1 << 20,), C64, 64)],
@@ -263,6 +322,7 @@ REGISTRY = {
     },
     "test_pairs_gpu": {
         "test_pass_pairs_256_cubed": lambda p: [_c((256, 256, 256), p["dtype"], 1)],
+        "test_pass_pairs_256_cubed_alternative_split": None,         # (a development A/B instance: DEV_ONLY_PAIR_KEYS below)
         "test_pair_chains_two_launches": lambda p: [_c(p["shape"], p["dtype"], p["batch"])],
         "test_pair_chains_pipelined_chunks": lambda p: [_c(p["shape"], p["dtype"], p["batch"])],
         "test_pass_pairs_for_256_point_rows": lambda p: [_c(p["shape"], p["dtype"], p["batch"])],
@@ -273,6 +333,8 @@ REGISTRY = {
             _c(p["shape"], p["dtype"], (261 * 65536 * 8) // (_prod(p["shape"]) * numpy.dtype(p["dtype"]).itemsize))],
         "test_tiny_nd_shapes_small_launches": lambda p: [_c(p["shape"], p["dtype"], p["batch"])],
         "test_tiny_nd_shapes_big_launches": lambda p: [_c(p["shape"], p["dtype"], p["batch"])],
+        "test_run_time_shaped_nd_kernel_size_classes": lambda p: [_c(p["shape"], p["dtype"], 5 if _prod(p["shape"]) >= 4096 else 4099 // _prod(p["shape"]))],
+        "test_dense_split_planes_on_the_tiled_fixed_kernels": lambda p: [_c(p["shape"], p["dtype"], p["batch"])],
     },
     "test_generic_gpu": None,            # opt-in extensions (any_size / parent_shape): their inner power-of-two plans are ordinary plans
     "test_interop_gpu": {

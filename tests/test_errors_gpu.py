@@ -128,7 +128,8 @@ def test_errors_batched(ctx, shape, batch, dtype):
 
 
 @pytest.mark.parametrize("dtype,n", [(numpy.complex64, 1 << k) for k in range(8, 16)] +
-                         [(numpy.complex128, 1 << k) for k in range(10, 15)],
+                         [(numpy.complex128, 1 << k) for k in range(10, 15)] +
+                         [(numpy.float32, 1 << 15), (numpy.float64, 1 << 14)],      # (round 6: the longest rows on split-complex planes)
                          ids=lambda v: str(v) if isinstance(v, int) else numpy.dtype(v).name)
 def test_register_edged_rows(ctx, dtype, n):
     """Every register-edged ROW kernel (csrc/fft_row2.hpp: several rows per work-group, plain and half-exchange

@@ -646,7 +646,7 @@ def test_round5_debug_switches_are_per_thread_over_a_process_default():
         N.lib.mifft_debug_set_default(key, 0)
         N.lib.mifft_debug_set(key, 0)
     assert seen == [("after the main thread's set", 0), ("after the default changed", 3)]
-    assert N.lib.mifft_debug_set(N.DEBUG_NO_ROWFIRST + 1, 1) == N.E_INVALID and N.lib.mifft_debug_set_default(-1, 1) == N.E_INVALID
+    assert N.lib.mifft_debug_set(N.DEBUG_NO_PREFETCH + 1, 1) == N.E_INVALID and N.lib.mifft_debug_set_default(-1, 1) == N.E_INVALID
 
 
 def test_round5_capture_entry_points_reject_bad_arguments_without_touching_the_gpu():
@@ -658,7 +658,7 @@ def test_round5_capture_entry_points_reject_bad_arguments_without_touching_the_g
     assert N.lib.mifft_stream_end_capture(None, None) == N.E_INVALID
     assert N.lib.mifft_graph_launch(None, None) == N.E_INVALID
     assert N.lib.mifft_graph_destroy(None) == 0
-    assert N.ABI_VERSION == 4 and N.lib.mifft_abi_version() == 4
+    assert N.ABI_VERSION == 5 and N.lib.mifft_abi_version() == 5
 
 
 def test_round5_no_split_rowfirst_follows_the_environment_into_the_library(monkeypatch):

@@ -478,3 +478,103 @@ def test_torch_cuda_graph_around_execute(ctx):
         want = torch.fft.fft(x.view(batch, n), dim=1).reshape(-1)
         assert (y - want).abs().sum() / want.abs().sum() < 2e-6, k
     plan.finish()
+
+
+# ---- the batch split as library code, driven from ONE process (pyfft_amd/sharded.py; round 6) --------------------------------------------
+SHARDED_CASES = [((1 << 20,), numpy.complex64, 96), ((128, 128, 128), numpy.complex64, 70), ((1024, 1024), numpy.float32, 75), ((4096,), numpy.complex128, 1001)]
+
+
+@pytest.mark.parametrize("shape,dtype,batch", SHARDED_CASES, ids=lambda v: getattr(v, "__name__", str(v)).replace(" ", ""))
+def test_sharded_plan_two_shards_on_one_device(ctx, shape, dtype, batch):
+    """ShardedPlan(devices=[0, 0]): two shards -- a plan, a stream and scratch each -- on ONE device, the global batch cut into two
+    contiguous slices (an odd batch: 38 + 37 ...), both executes enqueued asynchronously from one process and waited for once.  The
+    whole result against ONE ordinary plan on the global batch (the same kernels on other slices: the reference's thresholds; bit
+    identity where both run one strategy), first / last transform of EVERY shard against numpy on the global data set, out of place
+    with the input untouched, in place, the inverse.  (pyfft/kernel.py:99-121: batch -> grid; pyfft/cuda.py:67-72: one device per plan.)"""
+    from pyfft_amd.sharded import ShardedPlan
+    hip = ctx.hip
+    cdt = numpy.dtype(dtype)
+    split = cdt.kind == "f"
+    double = cdt in (numpy.dtype(numpy.complex128), numpy.dtype(numpy.float64))
+    eps, mx = (1e-11, 1e-10) if double else (EPS_F, MAX_F)
+    size = int(numpy.prod(shape))
+    fdt = numpy.float64 if double else numpy.float32
+    rng = numpy.random.default_rng(6100 + size % 97)
+    re = _noise(rng, size * batch, fdt)
+    im = _noise(rng, size * batch, fdt)
+    x = re.astype(numpy.complex128) + 1j * im
+    sp = ShardedPlan(shape if len(shape) > 1 else shape[0], dtype, devices=[0, 0])
+    assert sp.nshards == 2 and sp.slices(batch) == [(0, batch - batch // 2), (batch - batch // 2, batch // 2)]
+    assert sp.streams[0].handle != sp.streams[1].handle and sp.plans[0] is not sp.plans[1]
+    host = (re, im) if split else ((re + 1j * im).astype(cdt),)
+    ins, outs = sp.allocate(batch), sp.allocate(batch)
+    if split:
+        sp.upload(ins, re, batch, host_im=im)
+    else:
+        sp.upload(ins, host[0], batch)
+    args_in = ([b[0] for b in ins], [b[1] for b in ins]) if split else (ins,)
+    args_out = ([b[0] for b in outs], [b[1] for b in outs]) if split else (outs,)
+    assert sp.execute(*(args_in + args_out), batch=batch) is None            # waits: the reference's rule without a stream
+    got = sp.download(outs, batch)
+    got = (got[0].astype(numpy.complex128) + 1j * got[1]) if split else got.astype(numpy.complex128)
+    back_in = sp.download(ins, batch)
+    assert all(numpy.array_equal(a, b) for a, b in zip(back_in if split else (back_in,), host)), "an out-of-place execute touched its input"
+    for start, count in sp.slices(batch):
+        for g in (start, start + count - 1):
+            ref = numpy.fft.fftn(x[g * size:(g + 1) * size].reshape(shape)).reshape(-1)
+            d = got[g * size:(g + 1) * size]
+            assert numpy.abs(ref - d).sum() / numpy.abs(ref).sum() < eps and numpy.abs(ref - d).max() <= mx * numpy.abs(ref).max(), g
+    # one ordinary plan on the global batch
+    plan = hip.Plan(shape if len(shape) > 1 else shape[0], dtype=dtype)
+    a = [hip.to_gpu(h) for h in host]
+    b = [hip.DeviceArray(h.shape, h.dtype) for h in host]
+    plan.execute(*(a + b), batch=batch)
+    one = [t.get() for t in b]
+    one = (one[0].astype(numpy.complex128) + 1j * one[1]) if split else one[0].astype(numpy.complex128)
+    assert numpy.abs(one - got).sum() / numpy.abs(one).sum() < (1e-14 if double else 5e-7)
+    # in place, asynchronously, then the inverse in place: the round trip
+    streams = sp.execute(*args_in, batch=batch, wait_for_finish=False)
+    assert streams == sp.streams
+    sp.finish()
+    inp = sp.download(ins, batch)
+    inp = (inp[0].astype(numpy.complex128) + 1j * inp[1]) if split else inp.astype(numpy.complex128)
+    assert numpy.array_equal(inp, got), "in place differs from out of place"
+    sp.execute(*args_in, batch=batch, inverse=True)
+    rt = sp.download(ins, batch)
+    rt = (rt[0].astype(numpy.complex128) + 1j * rt[1]) if split else rt.astype(numpy.complex128)
+    assert numpy.abs(rt - x).sum() / numpy.abs(x).sum() < eps
+    assert [s_[0] for s_ in sp.strategy(batch)] == [plan.strategy(c)[0] for _, c in sp.slices(batch)]
+    sp.check()
+    sp.close()
+
+
+def test_bench_single_process_four_shards_share_one_gpu(tmp_path):
+    """`bench.py --gpus 4 --single-process --share-gpu`: the sharded job driven from ONE process through ShardedPlan (four shards on one
+    device here), the same JSON line as one process per GPU; every shard parity-checked in-process, its first / last transform again here
+    against numpy on the global data set regenerated independently."""
+    sys.path.insert(0, ROOT)
+    import bench
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    batch = 40
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--single-process", "--share-gpu", "--config", "c2",
+                          "--batch", str(batch), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--dump-dir", str(tmp_path)],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in res
+    assert res["n_gpus"] == 4 and res["steps"] == 3 and res["config"]["global_batch"] == 4 * batch and res["scaling"] == "weak"
+    assert "ONE process" in res["config"]["parallelism"] and res["config"]["devices"] == [0, 0, 0, 0]
+    ranks = res["config"]["ranks"]
+    assert [r["first_transform"] for r in ranks] == [batch * r for r in range(4)] and all(r["count"] == batch and r["parity_ok"] for r in ranks)
+    assert res["config"]["strategy"] == "fused2" and res["parity"]["ok"]
+    shape, dtname, _, seed = bench.CONFIGS["c2"]
+    for r in range(4):
+        for g in (r * batch, (r + 1) * batch - 1):
+            got = numpy.load(os.path.join(str(tmp_path), "xform_%d.npy" % g))
+            ref = numpy.fft.fft(bench.global_item(shape, dtname, batch, seed, g).astype(numpy.complex128))
+            assert numpy.abs(got - ref).sum() / numpy.abs(ref).sum() < EPS_F and numpy.abs(got - ref).max() <= MAX_F * numpy.abs(ref).max(), g
+    assert abs(res["transforms_per_s"] - 4 * batch * res["steps"] / (res["ms_per_step"] * 1e-3 * res["steps"])) < 1e-6 * res["transforms_per_s"]

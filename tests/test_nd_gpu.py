@@ -74,8 +74,11 @@ def test_two_work_groups_per_transform_nd(ctx, dtype):
 
 OOP_ND_CASES = [(sh, numpy.complex64) for sh in [(256, 256), (512, 128), (1024, 64), (64, 1024), (16, 64, 64),
                                                   # 32768-point shapes without a one-tile kernel: two work-groups per transform
-                                                  (64, 512), (16, 2048), (2048, 16), (64, 8, 64), (16, 128, 16), (128, 16, 16), (32, 16, 64), (32, 64, 16)]] + \
-               [(sh, numpy.complex128) for sh in [(16, 1024), (1024, 16), (8, 32, 64), (64, 8, 32), (4, 64, 64), (64, 4, 64), (32, 16, 32), (16, 64, 16), (32, 32, 16)]]
+                                                  (64, 512), (16, 2048), (2048, 16), (64, 8, 64), (16, 128, 16), (128, 16, 16), (32, 16, 64), (32, 64, 16),
+                                                  # (round 6: the three instances the coverage rule found without a test -- (z, y, x))
+                                                  (64, 16, 32), (16, 64, 32), (16, 32, 64)]] + \
+               [(sh, numpy.complex128) for sh in [(16, 1024), (1024, 16), (8, 32, 64), (64, 8, 32), (4, 64, 64), (64, 4, 64), (32, 16, 32), (16, 64, 16), (32, 32, 16),
+                                                  (8, 64, 32), (32, 8, 64)]]
 
 
 @pytest.mark.parametrize("shape,dtype", OOP_ND_CASES, ids=lambda v: getattr(v, "__name__", "x".join(map(str, v)) if isinstance(v, tuple) else str(v)))
@@ -165,3 +168,39 @@ def test_tiny_nd_shapes_big_launches(ctx, monkeypatch, shape, dtype, batch):
     want = b.get()
     assert numpy.abs(want - got).sum() / numpy.abs(want).sum() < eps
     assert numpy.abs(want - got).max() <= 1e-5 * numpy.abs(want).max()
+
+
+# ---- the run-time-shaped N-D kernel by tile size class, and dense split-complex planes on the tiled fixed-shape kernels (round 6) --------------
+# (what tests/test_kernel_coverage.py found without a default test: shapes with two-point rows of every size up to one tile in the four
+# dtypes -- no fixed instance exists for them, the ONE run-time-shaped kernel of csrc/fft_nd.hpp takes them with another tile / radix
+# choice per size -- and the split-complex shapes whose dense planes run the tiled fixed-shape kernel of csrc/fft_nd2t.hpp)
+GENERIC_ND_CASES = [((1 << (k - 1), 2), dt) for dt in (numpy.complex64, numpy.float32, numpy.complex128, numpy.float64) for k in range(2, 15)
+                    if (1 << k) <= (16384 if dt in (numpy.complex64, numpy.float32) else 8192)] + \
+                   [((1 << (k - 2), 2, 2), dt) for dt in (numpy.complex64, numpy.float32, numpy.complex128, numpy.float64) for k in range(3, 15)
+                    if (1 << k) <= (16384 if dt in (numpy.complex64, numpy.float32) else 8192)] + [((4, 4096), numpy.complex64)]
+
+
+@pytest.mark.parametrize("shape,dtype", GENERIC_ND_CASES, ids=lambda v: getattr(v, "__name__", str(v)).replace(" ", ""))
+def test_run_time_shaped_nd_kernel_size_classes(ctx, shape, dtype):
+    """One launch, any power-of-two shape inside a tile (pyfft/plan.py:135-171 runs one chain per axis): the reference's six-assertion
+    protocol at a ragged batch."""
+    from pyfft_amd import _native as N
+    plan = ctx.getPlan(shape, dtype=dtype)
+    assert len(plan.pass_list()) == 1 and plan.pass_list()[0].kind == N.PASS_ND, plan.pass_list()
+    size = int(numpy.prod(shape))
+    run_protocol(ctx, shape, dtype, 5 if size >= 4096 else 4099 // size, seed=6300 + size % 89, check_oracle=size <= 1024)
+
+
+DENSE_PLANES_CASES = [((16, 32), numpy.float32, 37), ((32, 64), numpy.float32, 21), ((8, 32, 32), numpy.float32, 5), ((16, 32), numpy.float64, 37),
+                      ((32, 32), numpy.float64, 19), ((32, 64), numpy.float64, 11), ((8, 16, 16), numpy.float64, 9), ((8, 32, 32), numpy.float64, 3),
+                      ((16, 32, 32), numpy.float64, 3)]
+
+
+@pytest.mark.parametrize("shape,dtype,batch", DENSE_PLANES_CASES, ids=lambda v: getattr(v, "__name__", str(v)).replace(" ", ""))
+def test_dense_split_planes_on_the_tiled_fixed_kernels(ctx, shape, dtype, batch):
+    """float32 / float64 plans (the reference's split layout, pyfft/plan.py:26-35) whose whole transform is one launch of the tiled
+    fixed-shape kernel with one tile per "parent" (rows of >= 128 bytes per plane): the six-assertion protocol."""
+    from pyfft_amd import _native as N
+    plan = ctx.getPlan(shape, dtype=dtype)
+    assert len(plan.pass_list()) == 1 and plan.pass_list()[0].kind == N.PASS_ND, plan.pass_list()
+    run_protocol(ctx, shape, dtype, batch, seed=6400 + batch, check_oracle=False)

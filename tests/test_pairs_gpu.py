@@ -60,6 +60,20 @@ def test_pass_pairs_256_cubed(ctx, dtype):
     assert oracle.difference(results[1], results[0], 2) < eps
 
 
+def test_pass_pairs_256_cubed_alternative_split(ctx):
+    """The other y split of 256^3 in complex128 (y = 64 x 4 instead of 32 x 8; MIFFT_DEBUG_PAIR = 2, the A/B form of tools/pair_probe.py,
+    profiles/r03_b_c4_pair_split.log) is a kernel instance of the library that no default plan selects: the six-assertion protocol, so that
+    it has a test of its own."""
+    from pyfft_amd import _native as N
+    N.check(N.lib.mifft_debug_set(N.DEBUG_PAIR, 2), "debug_set")
+    try:
+        plan = ctx.getPlan((256, 256, 256), dtype=numpy.complex128)
+        assert [k.pair_with_next for k in plan.pass_list()] == [True, False, True, False] and plan.pass_list()[1].L == 64
+        run_protocol(ctx, (256, 256, 256), numpy.complex128, 1, seed=660, check_oracle=False)
+    finally:
+        N.check(N.lib.mifft_debug_set(N.DEBUG_PAIR, 0), "debug_set")
+
+
 # ---- one pass pair instead of a third launch (csrc/fft_pair_f32.hip / _f64.hip, pyfft_amd/passes.py) ---------------------------------
 PAIR_CHAIN_CASES = [((4096, 256), numpy.complex64, 2), ((4096, 256), numpy.complex128, 1),
                     ((32, 32, 2048), numpy.complex64, 2), ((16, 16, 2048), numpy.complex64, 5),
@@ -71,6 +85,9 @@ _PAIR_CHAIN_SOAK = [((4096, 512), numpy.complex64, 1), ((4096, 512), numpy.compl
 
 
 PAIR_CHAIN_CASES += [((4096, 128), numpy.complex128, 3), ((4096, 128), numpy.complex64, 5)]      # (late in round 5: 128-point rows)
+# (round 6, found by tests/test_kernel_coverage.py: the YZ kernel keyed (S0 = 16384, R1 = 4, nz = 256) -- built for the second pair of 256^3
+# in the split layout -- is also what an interleaved (256, 4, 16384) plan selects for its y and z axes: 256 MiB per transform)
+PAIR_CHAIN_CASES += [((256, 4, 16384), numpy.complex128, 1)]
 
 
 # every one of these is a pair-kernel instance of its own (csrc/fft_pair_f32.hip / _f64.hip) that a default plan selects: all in the default suite

@@ -779,6 +779,68 @@ def test_config5_share_as_one_execute(ctx):
     del buf
 
 
+def test_config5_share_every_output_bit_identical_to_its_period_mate(ctx):
+    """The whole-array check of the stated configuration (the share tests sampled ten of 8192 transforms): the 256 GiB
+    data set is periodic with period 16 transforms, so EVERY one of the 8192 outputs of one in-place execute must carry the bits of the
+    output 16 transforms before it -- compared on the device (mifft_aux_count_mismatch: the buffer against itself shifted by one period,
+    255.5 GiB of 16-byte words), which a fault confined to any ring position, ticket range or address bit cannot survive; then the 16
+    distinct outputs against numpy, and the same after the inverse in place."""
+    import ctypes
+    from pyfft_amd import _native as N
+    hip = ctx.hip
+    block, refs = _c5_block()
+    try:
+        buf = hip.DeviceArray((SHARE5 * N5,), numpy.complex64)
+    except RuntimeError as e:
+        pytest.skip("mifft_malloc refuses 256 GiB on this device: %s" % (str(e)[:200],))
+    hb = block.reshape(-1).view(numpy.uint8)
+    N.check(N.lib.mifft_memcpy_h2d(buf.ptr, hb.ctypes.data, hb.nbytes, None))
+    done = hb.nbytes
+    while done < buf.nbytes:
+        n = min(done, buf.nbytes - done)
+        N.check(N.lib.mifft_memcpy_d2d(buf.ptr + done, buf.ptr, n, None))
+        done += n
+    N.check(N.lib.mifft_device_sync())
+    word = ctypes.c_void_p()
+    N.check(N.lib.mifft_host_alloc(ctypes.byref(word), 64), "mifft_host_alloc")
+    count = ctypes.c_uint64.from_address(word.value)
+    period = BLK5 * N5 * 8
+
+    def mismatches():
+        count.value = 0
+        N.check(N.lib.mifft_aux_count_mismatch(buf.ptr, buf.ptr + period, buf.nbytes - period, word.value, None), "mifft_aux_count_mismatch")
+        N.check(N.lib.mifft_device_sync())
+        return int(count.value)
+
+    try:
+        assert mismatches() == 0, "the periodic input is not periodic"
+        # (the checker itself: one flipped word in the middle of the buffer is two mismatches -- with the item before and the item after)
+        probe = numpy.zeros(4, numpy.uint32)
+        mid = buf.ptr + (SHARE5 // 2 + 3) * N5 * 8 + 4096
+        N.check(N.lib.mifft_memcpy_d2h(probe.ctypes.data, mid, 16, None))
+        flipped = probe ^ numpy.uint32(1)
+        N.check(N.lib.mifft_memcpy_h2d(mid, flipped.ctypes.data, 16, None))
+        assert mismatches() == 2
+        N.check(N.lib.mifft_memcpy_h2d(mid, probe.ctypes.data, 16, None))
+        plan = hip.Plan(N5, dtype=numpy.complex64)
+        assert plan.strategy(SHARE5)[0] == "fused2"
+        plan.execute(buf, batch=SHARE5)
+        assert mismatches() == 0, "some transform of the share differs from its period-mate"
+        for g in range(BLK5):
+            assert _close(_fetch(N, buf.ptr, g), refs[g]), g
+        plan.execute(buf, batch=SHARE5, inverse=True)
+        assert mismatches() == 0, "inverse: some transform of the share differs from its period-mate"
+        for g in (0, BLK5 - 1):
+            want = block[g].astype(numpy.complex128)
+            got = _fetch(N, buf.ptr, g).astype(numpy.complex128)
+            assert numpy.abs(want - got).sum() / numpy.abs(want).sum() < EPS_F, g
+        plan.close()
+    finally:
+        N.lib.mifft_device_sync()
+        N.lib.mifft_host_free(word.value)
+        del buf
+
+
 def test_direct_abi_two_set_launch_refuses_capture_and_null_error_word(ctx):
     """C-ABI users of mifft_launch_fused2: the two-set form on a capturing stream is MIFFT_E_INVALID (a replay would start on dirty
     counters), and so is the two-set form without an error word of its own (the next launch would zero the default one)."""

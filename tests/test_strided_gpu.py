@@ -134,3 +134,29 @@ def test_register_only_short_strided_pass(ctx, L, M, S, outer, dtype):
         for got in outs:
             assert numpy.abs(got - ref).sum() / numpy.abs(ref).sum() < eps
         assert numpy.abs(outs[0] - outs[1]).sum() / numpy.abs(ref).sum() < eps
+
+
+# ---- long STRIDED axes: a y / z axis too long for one strided pass behind short rows (round 6) ------------------------------------------------
+# Every (length, twiddled, stride class) of the strided-pass kernels that a default plan of up to 2^24 points selects and that no other
+# default test reached (tests/test_kernel_coverage.py found them: the transposing first pass of such an axis carries the inter-pass twiddle
+# with S > 1 -- S < 16: columns narrower than a tile, the generic tile kernel; S >= 16: whole 16-column tiles).  Reference shape of the
+# work: pyfft/kernel.py:259-283 splits a long axis, pyfft/kernel.mako:805-1047 runs it at any stride.
+_C64, _F32, _C128, _F64 = numpy.complex64, numpy.float32, numpy.complex128, numpy.float64
+LONG_STRIDED_CASES = [((2, 4096, 4), _C128), ((2, 16384, 2), _F32), ((2097152,), _F64), ((2097152, 2), _C128), ((8192, 2), _F64), ((16384, 2), _C64),
+                      ((4096, 2, 4), _F32)] + \
+                     [((32768, 2), d) for d in (_C64, _F32, _C128, _F64)] + [((4096, 16), d) for d in (_C64, _F32, _C128)] + \
+                     [((8192, 16), d) for d in (_C64, _F32)] + [((131072, 2), d) for d in (_C64, _F32, _C128, _F64)] + \
+                     [((32768, 16), d) for d in (_C64, _F32, _C128, _F64)] + [((524288, 2), d) for d in (_C64, _F32, _C128, _F64)] + \
+                     [((131072, 16), d) for d in (_C64, _F32, _C128, _F64)] + [((2097152, 2), d) for d in (_C64, _F32)] + \
+                     [((524288, 16), d) for d in (_C64, _F32, _C128, _F64)] + [((2097152, 8), _C128)]
+
+
+@pytest.mark.parametrize("shape,dtype", LONG_STRIDED_CASES, ids=lambda v: getattr(v, "__name__", str(v)).replace(" ", ""))
+def test_long_strided_axes(ctx, shape, dtype):
+    """The reference's six-assertion protocol against numpy (test/test_errors.py:18-114: out of place, in place, forward, inverse, input
+    untouched) on shapes whose slow axis needs two strided passes; two transforms where they are small, one where one is >= 64 MiB."""
+    from pyfft_amd import _native as N
+    plan = ctx.getPlan(shape, dtype=dtype, context=ctx.context)
+    assert sum(1 for p in plan.pass_list() if p.kind == N.PASS_COL and p.M > 1 and (p.S > 1 or len(shape) == 1)) >= 1, plan.pass_list()
+    nbytes = int(numpy.prod(shape)) * (8 if numpy.dtype(dtype) in (numpy.dtype(_C64), numpy.dtype(_F32)) else 16)
+    run_protocol(ctx, shape, dtype, 1 if nbytes >= (64 << 20) else 2, seed=6200 + len(shape), check_oracle=False)
