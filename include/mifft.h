@@ -166,7 +166,8 @@ const char *mifft_last_error(void);
                                     * route, no row-first 2-D kernel, no write-through in the run-time-shaped N-D kernel; 2 = 32-column tiles (and the
                                     * double tile of a plane-writing L = 1024 pass) also in plain launches */
 #define MIFFT_DEBUG_NO_ROWFIRST 10 /* split-complex fp32 2-D persistent launches: 1 = two transposing passes on sibling tiles instead of the row-first kernel (A/B) */
-#define MIFFT_DEBUG_NO_PREFETCH 11 /* persistent kernels on 512-thread tiles: 1 = the round-2 work list (no loads of the next tile issued at the end of the current one; A/B) */
+#define MIFFT_DEBUG_PREFETCH 11 /* persistent kernels on 512-thread tiles, `make DEV=1` builds: 1 = the work list that issues a tile's loads before the publish of
+                                  * the previous one (round 6; measured equal to the round-2 list: 0.392 / 0.393 on configuration 5) */
 #define MIFFT_DEBUG_KEYS 12
 /* mifft_debug_set changes a switch for the CALLING THREAD only (a thread that never set a key sees the process default), so a
  * measurement that flips a switch in one thread cannot change the kernels another thread's plan gets; mifft_debug_set_default sets

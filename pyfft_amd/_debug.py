@@ -139,8 +139,8 @@ def apply_native_switches(native):
         native.lib.mifft_debug_set_default(native.DEBUG_ROWS_ND, int(os.environ["MIFFT_ROWS_ND"]))
     if os.environ.get("MIFFT_NARROW_TILES"):   # fp32 2^16 ... 2^18 persistent: 16-column tiles (A/B)
         native.lib.mifft_debug_set_default(native.DEBUG_NARROW_TILES, int(os.environ["MIFFT_NARROW_TILES"]))
-    if os.environ.get("MIFFT_NO_PREFETCH"):  # persistent kernels on 512-thread tiles: the round-2 work list (A/B of the round-6 prefetching list)
-        native.lib.mifft_debug_set_default(native.DEBUG_NO_PREFETCH, 1)
+    if os.environ.get("MIFFT_PREFETCH"):    # persistent kernels on 512-thread tiles (development builds): the loads-first work list of round 6 (A/B)
+        native.lib.mifft_debug_set_default(native.DEBUG_PREFETCH, 1)
     if os.environ.get("MIFFT_PAIR"):        # pass pairs: 1 = off, 2 = the alternative y split
         native.lib.mifft_debug_set_default(native.DEBUG_PAIR, int(os.environ["MIFFT_PAIR"]))
     # the row-first switch steers the planner AND the launcher: the process default follows the environment here, so that a plan

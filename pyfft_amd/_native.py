@@ -45,7 +45,7 @@ DEBUG_NO_ND2, DEBUG_FUSED_NO_NT, DEBUG_NO_WAVE, DEBUG_FORCE_WAVE, DEBUG_PERSIST,
 DEBUG_ROWS_ND = 8
 DEBUG_NARROW_TILES = 9
 DEBUG_NO_ROWFIRST = 10
-DEBUG_NO_PREFETCH = 11
+DEBUG_PREFETCH = 11
 FEATURE_XCD2, FEATURE_FUSED2X, FEATURE_SEQUENTIAL_LIST, FEATURE_AB_FORMS = 0, 1, 2, 3     # mifft_has_feature: parts only `make DEV=1` builds
 XCD2_TRACE = 2
 XCD2_TRACE_BYTES = 512 * 32 * 8

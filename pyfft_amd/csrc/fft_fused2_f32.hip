@@ -62,17 +62,21 @@ template <int A0, int A1> int launch(const mifft::FusedArgs* f, int split, unsig
 extern "C" int mifft_fused2_f32_launch(int L0, int L1, const mifft::FusedArgs* f, int split, unsigned grid, hipStream_t s) {
     if (L0 == 2048 && L1 == 2048) {   // 512-thread tiles (fft_col3.hpp)
         if (split) hipLaunchKernelGGL((mifft::fft_fused3_kernel<float, 4, 4, true, true>), dim3(grid), dim3(512), 0, s, *f);   // (planes: non-temporal, 0.302 -> 0.312)
-        // (round 6: interleaved data on the list that issues the next tile's loads at the end of the current one; MIFFT_DEBUG_NO_PREFETCH = 1
-        // keeps the round-2 list for A/B, and the sequential list of a tiny batch -- lag 0, development builds -- has no prefetching form)
-        else if (f->c.lag != 0u && mifft_debug_get(MIFFT_DEBUG_NO_PREFETCH) != 1)
+#ifdef MIFFT_DEV_BUILD
+        // (round 6, measured and not adopted: the list that issues a tile's loads BEFORE the publish of the previous one, with the item handed
+        // out from inside the previous tile -- 0.392 against 0.393 on configuration 5, profiles/r06_d_loads_first_list_ab.log; MIFFT_DEBUG_PREFETCH = 1)
+        else if (f->c.lag != 0u && mifft_debug_get(MIFFT_DEBUG_PREFETCH) == 1)
             hipLaunchKernelGGL((mifft::fft_fused3p_kernel<float, 4, 4, true>), dim3(grid), dim3(512), 0, s, *f);
+#endif
         else hipLaunchKernelGGL((mifft::fft_fused3_kernel<float, 4, 4, false, true>), dim3(grid), dim3(512), 0, s, *f);
         return (int)hipGetLastError();
     }
     if (L0 == 2048 && L1 == 1024) {
         if (split) hipLaunchKernelGGL((mifft::fft_fused3_kernel<float, 4, 2, true, true>), dim3(grid), dim3(512), 0, s, *f);
-        else if (f->c.lag != 0u && mifft_debug_get(MIFFT_DEBUG_NO_PREFETCH) != 1)
+#ifdef MIFFT_DEV_BUILD
+        else if (f->c.lag != 0u && mifft_debug_get(MIFFT_DEBUG_PREFETCH) == 1)
             hipLaunchKernelGGL((mifft::fft_fused3p_kernel<float, 4, 2, true>), dim3(grid), dim3(512), 0, s, *f);
+#endif
         else hipLaunchKernelGGL((mifft::fft_fused3_kernel<float, 4, 2, false, true>), dim3(grid), dim3(512), 0, s, *f);
         return (int)hipGetLastError();
     }

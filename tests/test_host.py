@@ -646,7 +646,7 @@ def test_round5_debug_switches_are_per_thread_over_a_process_default():
         N.lib.mifft_debug_set_default(key, 0)
         N.lib.mifft_debug_set(key, 0)
     assert seen == [("after the main thread's set", 0), ("after the default changed", 3)]
-    assert N.lib.mifft_debug_set(N.DEBUG_NO_PREFETCH + 1, 1) == N.E_INVALID and N.lib.mifft_debug_set_default(-1, 1) == N.E_INVALID
+    assert N.lib.mifft_debug_set(N.DEBUG_PREFETCH + 1, 1) == N.E_INVALID and N.lib.mifft_debug_set_default(-1, 1) == N.E_INVALID
 
 
 def test_round5_capture_entry_points_reject_bad_arguments_without_touching_the_gpu():
