@@ -260,6 +260,26 @@ int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0,
     // 0.510 -> 0.584; shapes whose x rows are shorter than 128 bytes per plane stay below -- fp32 (16, 16) 0.717 against 0.460, 16^3 0.674
     // against 0.475: their tiles move scalars over short runs (profiles/r04_at_rows_split.log)
     // (planes in, interleaved out -- the plane pass of a split-complex multi-pass plan -- likewise: fft_nd2t_split_in.hip)
+    // Round 6: planes on BOTH sides of a published shape: the dense kernel that moves 16 bytes per lane and plane (fft_nd2p.hpp); the tiled
+    // kernel below moves one scalar per lane and plane through the tiling's address arithmetic (0.69-0.86 of the interleaved twin at 1 GiB).
+    // MIFFT_DEBUG_ALT_ROWS = 7: the tiled kernel (A/B)
+    if (p->layout == MIFFT_SPLIT && !(p->flags & (MIFFT_FLAG_SRC_INTERLEAVED | MIFFT_FLAG_DST_INTERLEAVED)) && !no_nd2 && in1 && out1 &&
+        g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 && g_debug[MIFFT_DEBUG_ALT_ROWS] != 7 &&
+        mifft_nd2p(f64nd ? 1 : 0, (int)p->L, (int)p->M, (int)p->S, nullptr, nullptr, 1) == 0) {
+        mifft::TileArgs t;
+        memset(&t, 0, sizeof(t));
+        t.in0 = in0; t.in1 = in1; t.out0 = out0; t.out1 = out1;
+        t.split = 1; t.split_out = 1;
+        t.tw_L = p->tw_L; t.tw_lo = p->tw_lo; t.tw_hi = p->tw_hi;
+        t.total = p->outer * p->L * p->M * p->S;
+        t.inverse = p->inverse ? 1 : 0;
+        t.scale = p->scale;
+        t.nt = stream_policy(p->flags);
+        const int rc = mifft_nd2p(f64nd ? 1 : 0, (int)p->L, (int)p->M, (int)p->S, &t, s, 0);
+        if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
+        if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
+        return 0;
+    }
     const bool planes_in_only = p->layout == MIFFT_SPLIT && !(p->flags & MIFFT_FLAG_SRC_INTERLEAVED) && (p->flags & MIFFT_FLAG_DST_INTERLEAVED);
     if (p->layout == MIFFT_SPLIT && !(p->flags & MIFFT_FLAG_SRC_INTERLEAVED) && !no_nd2 && in1 && (out1 || planes_in_only) &&
         g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 && p->L * (f64nd ? 8 : 4) >= 128 &&
@@ -663,8 +683,10 @@ int mifft_nd_shape_supported(int32_t precision, int32_t x, int32_t y, int32_t z,
     if (variant == MIFFT_VARIANT_SPLIT_ONLY)      // planes on both sides: the tiled fixed-shape kernel with one tile per parent (launch_nd)
         // (x rows of >= 256 bytes per plane: fp64 (128, 128) 0.374 as two passes -> 0.568, (16, 32, 32) 0.338 -> 0.499; fp32 32^3, 128-byte
         // rows, measured 0.285 against 0.307 for its two passes and keeps them -- profiles/r04_at_rows_split.log)
-        return (g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 && g_debug[MIFFT_DEBUG_NO_ND2] == 0 && x * (precision == MIFFT_F64 ? 8 : 4) >= 256 &&
-                mifft_nd2t_split(precision == MIFFT_F64, x, y, z, nullptr, nullptr, nullptr, 1) == 0) ? 0 : MIFFT_E_UNSUPPORTED;
+        // (round 6: or a dense planes instance of fft_nd2p.hip -- fp32 (16, 16, 128), 32^3)
+        return (g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 && g_debug[MIFFT_DEBUG_NO_ND2] == 0 &&
+                ((x * (precision == MIFFT_F64 ? 8 : 4) >= 256 && mifft_nd2t_split(precision == MIFFT_F64, x, y, z, nullptr, nullptr, nullptr, 1) == 0) ||
+                 (g_debug[MIFFT_DEBUG_ALT_ROWS] != 7 && mifft_nd2p(precision == MIFFT_F64 ? 1 : 0, x, y, z, nullptr, nullptr, 1) == 0))) ? 0 : MIFFT_E_UNSUPPORTED;
     if (variant == MIFFT_VARIANT_OUT_OF_PLACE_ONLY || variant == MIFFT_VARIANT_OUT_OF_PLACE_ANY_SIZE)
         // interleaved on both sides AND out of place: several work-groups per transform (fft_nd2z.hpp)
         return (g_debug[MIFFT_DEBUG_NO_ND2] == 0 && g_debug[MIFFT_DEBUG_ALT_ROWS] != 6 &&

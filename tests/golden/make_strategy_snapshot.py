@@ -86,7 +86,10 @@ def snapshot(with_chain_class=False):
                         npairs = sum(1 for k in plans[key]._kernels if k.pair_with_next)
                         late = dt in ("complex128", "complex64") and len(shape) == 3 and npairs == 2 and \
                             tuple(shape) not in ((256, 256, 256), (128, 128, 128))
-                        rows[-1].append(npairs == 1 or late)
+                        # round 6: float32 planes of (16, 16, 128) and 32^3 became ONE launch (dense kernel on 16-byte plane accesses,
+                        # csrc/fft_nd2p.hpp; two launches before)
+                        planes16 = dt == "float32" and tuple(shape) in ((16, 16, 128), (32, 32, 32)) and len(plans[key]._kernels) == 1
+                        rows[-1].append(npairs == 1 or late or planes16)
     finally:
         N.lib.mifft_debug_set(N.DEBUG_NARROW_TILES, 0)
         for k in ENV_KEYS:

@@ -83,6 +83,19 @@ def nd2z_shapes(prec):
     return _tables["nd2z"][prec]
 
 
+def nd2p_shapes(prec):
+    """(x, y, z) with a dense split-complex instance on 16-byte plane accesses, read off csrc/fft_nd2p.hip"""
+    if "nd2p" not in _tables:
+        import os
+        import re
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pyfft_amd", "csrc", "fft_nd2p.hip")
+        text = open(path).read()
+        _tables["nd2p"] = {name: frozenset(tuple(int(v) for v in m.groups())
+                                             for m in re.finditer(r"SHAPE\(%s,\s*(\d+),\s*(\d+),\s*(\d+)\)" % ctype, text))
+                           for name, ctype in (("f32", "float"), ("f64", "double"))}
+    return _tables["nd2p"][prec]
+
+
 def _nd_key(prec, lay, x, y, z):
     """The instance an N-D pass of this shape runs: the shape's own fixed instance (interleaved: the generated tables; planes: the tiled
     fixed-shape kernel where it takes dense planes), else the ONE run-time-shaped kernel, whose instances differ by the tile's size class."""
@@ -91,6 +104,8 @@ def _nd_key(prec, lay, x, y, z):
     if lay == "interleaved":
         if (x, y, z) in fixed_nd_shapes(prec) or N.lib.mifft_nd_shape_supported(p, x, y, z, 0) != 0:
             return ("nd_fixed", prec, lay, x, y, z)
+    elif (x, y, z) in nd2p_shapes(prec):
+        return ("nd_planes16", prec, x, y, z)
     elif x * (8 if prec == "f64" else 4) >= 128 and N.lib.mifft_nd_tiled_supported(p, x, y, z) == 0:
         return ("nd_fixed", prec, lay, x, y, z)
     elif N.lib.mifft_nd_shape_supported(p, x, y, z, 0) != 0:
@@ -335,6 +350,7 @@ REGISTRY = {
         "test_tiny_nd_shapes_big_launches": lambda p: [_c(p["shape"], p["dtype"], p["batch"])],
         "test_run_time_shaped_nd_kernel_size_classes": lambda p: [_c(p["shape"], p["dtype"], 5 if _prod(p["shape"]) >= 4096 else 4099 // _prod(p["shape"]))],
         "test_dense_split_planes_on_the_tiled_fixed_kernels": lambda p: [_c(p["shape"], p["dtype"], p["batch"])],
+        "test_dense_split_planes_16_byte_accesses": lambda p: [_c(p["shape"], p["dtype"], 1)],
     },
     "test_generic_gpu": None,            # opt-in extensions (any_size / parent_shape): their inner power-of-two plans are ordinary plans
     "test_interop_gpu": {

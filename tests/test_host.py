@@ -56,9 +56,12 @@ def test_supported_lengths():
     assert 128 * 128 > big and N.lib.mifft_nd_shape_supported(N.F64, 128, 128, 1, 0) == N.E_UNSUPPORTED
     assert N.lib.mifft_nd_shape_supported(N.F64, 128, 128, 1, N.VARIANT_INTERLEAVED_ONLY) == 0
     assert N.lib.mifft_nd_shape_supported(N.F64, 128, 128, 1, N.VARIANT_SPLIT_ONLY) == 0
-    assert N.lib.mifft_nd_shape_supported(N.F32, 32, 32, 32, N.VARIANT_SPLIT_ONLY) == N.E_UNSUPPORTED      # (128-byte rows: two passes measured faster)
+    # (fp32 planes beyond the run-time-shaped kernel's tile: the dense 16-byte kernel of round 6 has (16, 16, 128); a shape without such an
+    # instance stays two passes)
+    assert N.lib.mifft_nd_shape_supported(N.F32, 128, 16, 16, N.VARIANT_SPLIT_ONLY) == 0
+    assert N.lib.mifft_nd_shape_supported(N.F32, 64, 64, 8, N.VARIANT_SPLIT_ONLY) == N.E_UNSUPPORTED
     assert [k.kind for k in P.build_chain(128, 128, 1, N.F64, interleaved=False)] == [N.PASS_ND]
-    assert len(P.build_chain(32, 32, 32, N.F32, interleaved=False)) == 2
+    assert len(P.build_chain(64, 64, 8, N.F32, interleaved=False)) == 2
 
 
 def test_launch_rejects_bad_descriptors_without_touching_the_gpu():
@@ -763,7 +766,12 @@ def test_round5_tiny_nd_shapes_take_the_run_time_shaped_kernel(monkeypatch):
     assert variant((4, 4), c128, 100) == 0 and variant((4, 4), c128, 1 << 22) == 1
     assert variant((16, 16), c64, 1 << 20) == 0 and variant((16, 16, 16), c64, 1 << 16) == 0   # the published shapes stay on their instances
     assert variant((16, 2), numpy.float32, 1 << 22) == 0                                       # planes: lists of their own (f32_split / f64_split)
-    assert variant((32, 32), numpy.float32, 100) == 1 and variant((32, 32), c64, 100) == 0
+    # (round 6: the planes lists are empty in the shipped table -- (32, 32) float32 planes left it for the 16-byte dense kernel of
+    # csrc/fft_nd2p.hpp --, so the mechanism is shown on a doctored table)
+    planes = copy.deepcopy(tuning.default().table)
+    planes["nd_generic"]["f32_split"] = {"always": [[32, 32, 1]], "big": []}
+    assert variant((32, 32), numpy.float32, 100, planes) == 1 and variant((32, 32), c64, 100, planes) == 0
+    assert variant((32, 32), numpy.float32, 100) == 0
     bare = copy.deepcopy(tuning.default().table)
     del bare["nd_generic"]
     assert variant((16, 2), c64, 1 << 22, bare) == 0

@@ -204,3 +204,50 @@ def test_dense_split_planes_on_the_tiled_fixed_kernels(ctx, shape, dtype, batch)
     plan = ctx.getPlan(shape, dtype=dtype)
     assert len(plan.pass_list()) == 1 and plan.pass_list()[0].kind == N.PASS_ND, plan.pass_list()
     run_protocol(ctx, shape, dtype, batch, seed=6400 + batch, check_oracle=False)
+
+
+# ---- dense split-complex N-D shapes on 16-byte plane accesses (csrc/fft_nd2p.hpp, round 6) ------------------------------------------------
+PLANES16_CASES = [(sh, numpy.float32) for sh in [(16, 16), (32, 32), (64, 64), (128, 128), (16, 16, 16), (8, 8, 64), (16, 16, 128), (32, 32, 32)]] + \
+                 [(sh, numpy.float64) for sh in [(16, 16), (32, 32), (64, 64), (128, 128), (16, 16, 16), (8, 8, 64)]]
+
+
+@pytest.mark.parametrize("shape,dtype", PLANES16_CASES, ids=lambda v: getattr(v, "__name__", str(v)).replace(" ", ""))
+def test_dense_split_planes_16_byte_accesses(ctx, shape, dtype):
+    """The reference's published N-D shapes in its split layout (float32 / float64 planes, pyfft/plan.py:26-35): one launch that moves
+    16 bytes per lane and plane on either side.  The six-assertion protocol against numpy at a ragged batch
+    (the last work-group holds fewer transforms than its tile) and at a batch of one; the interleaved plan of the same shape on the same
+    numbers to rounding (same stage lists); the tiled kernel it replaces (MIFFT_DEBUG_ALT_ROWS = 7) within the same thresholds."""
+    from pyfft_amd import _native as N
+    hip = ctx.hip
+    rd = numpy.dtype(dtype)
+    double = rd == numpy.float64
+    cdt = numpy.complex128 if double else numpy.complex64
+    size = int(numpy.prod(shape))
+    plan = ctx.getPlan(shape, dtype=dtype)
+    assert len(plan.pass_list()) == 1 and plan.pass_list()[0].kind == N.PASS_ND, plan.pass_list()
+    tile = 4096 if not double else 2048
+    batch = 3 if size >= tile else (tile // size) * 2 + 1
+    run_protocol(ctx, shape, dtype, batch, seed=6500 + size % 83, check_oracle=size * batch <= 16384)
+    run_protocol(ctx, shape, dtype, 1, seed=6501, check_oracle=False)
+    # against the interleaved plan on the same numbers
+    rng = numpy.random.default_rng(6502)
+    re = rng.standard_normal(size * batch).astype(rd)
+    im = rng.standard_normal(size * batch).astype(rd)
+    a_re, a_im = hip.to_gpu(re), hip.to_gpu(im)
+    b_re, b_im = hip.DeviceArray((size * batch,), rd), hip.DeviceArray((size * batch,), rd)
+    plan.execute(a_re, a_im, b_re, b_im, batch=batch)
+    got = b_re.get().astype(numpy.complex128) + 1j * b_im.get()
+    twin = ctx.getPlan(shape, dtype=cdt)
+    c = hip.to_gpu((re + 1j * im).astype(cdt))
+    twin.execute(c, batch=batch)
+    want = c.get().astype(numpy.complex128)
+    assert numpy.abs(want - got).sum() / numpy.abs(want).sum() < (1e-14 if double else 5e-7)
+    N.check(N.lib.mifft_debug_set(N.DEBUG_ALT_ROWS, 7), "debug_set")
+    try:
+        old = ctx.getPlan(shape, dtype=dtype)
+        if len(old.pass_list()) == 1:                      # (fp32 (16, 16, 128) and 32^3 are two launches without the dense kernel)
+            old.execute(a_re, a_im, b_re, b_im, batch=batch)
+            other = b_re.get().astype(numpy.complex128) + 1j * b_im.get()
+            assert numpy.abs(other - got).sum() / numpy.abs(got).sum() < (1e-14 if double else 5e-7)
+    finally:
+        N.check(N.lib.mifft_debug_set(N.DEBUG_ALT_ROWS, 0), "debug_set")
