@@ -265,7 +265,7 @@ int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0,
     // MIFFT_DEBUG_ALT_ROWS = 7: the tiled kernel (A/B)
     if (p->layout == MIFFT_SPLIT && !(p->flags & (MIFFT_FLAG_SRC_INTERLEAVED | MIFFT_FLAG_DST_INTERLEAVED)) && !no_nd2 && in1 && out1 &&
         g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 && g_debug[MIFFT_DEBUG_ALT_ROWS] != 7 &&
-        mifft_nd2p(f64nd ? 1 : 0, (int)p->L, (int)p->M, (int)p->S, nullptr, nullptr, 1) == 0) {
+        mifft_nd2p(f64nd ? 1 : 0, (int)p->L, (int)p->M, (int)p->S, nullptr, nullptr, (p->flags & MIFFT_FLAG_WRITE_THROUGH) ? 2 : 1) == 0) {
         mifft::TileArgs t;
         memset(&t, 0, sizeof(t));
         t.in0 = in0; t.in1 = in1; t.out0 = out0; t.out1 = out1;

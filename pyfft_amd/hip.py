@@ -383,18 +383,45 @@ class ErrorWord(object):
     def __del__(self):
         try:
             if getattr(self, "ptr", None):
-                # a persistent kernel that is still running may write the word (on a time-out): wait for the device before the
-                # page goes away (plans are rarely destroyed with work in flight; FFTPlan.close() has synchronised already)
-                cur = ctypes.c_int()
-                switched = N.lib.mifft_get_device(ctypes.byref(cur)) == 0 and cur.value != self._device and \
-                    N.lib.mifft_set_device(self._device) == 0
-                N.lib.mifft_device_sync()
-                if switched:
-                    N.lib.mifft_set_device(cur.value)
-                N.lib.mifft_host_free(self.ptr)
+                # a persistent kernel that is still running may write the word (on a time-out): the device is synchronised before the
+                # page goes away (plans are rarely destroyed with work in flight; FFTPlan.close() has synchronised already).  Not while a
+                # stream capture is open anywhere in the process, though: a device synchronisation from a finaliser would invalidate the
+                # capture (whoever's it is) -- the page then waits in a graveyard that the next finaliser outside a capture empties.
+                ptr, dev = self.ptr, self._device
                 self.ptr = None
+                with Graph._lock:
+                    capturing = bool(Graph._open) or _foreign_capture_active()
+                    if capturing:
+                        ErrorWord._graveyard.append((ptr, dev))
+                        return
+                    dead = ErrorWord._graveyard + [(ptr, dev)]
+                    ErrorWord._graveyard = []
+                cur = ctypes.c_int()
+                have = N.lib.mifft_get_device(ctypes.byref(cur)) == 0
+                for d in sorted(set(d for _, d in dead)):
+                    if N.lib.mifft_set_device(d) == 0:
+                        N.lib.mifft_device_sync()
+                if have:
+                    N.lib.mifft_set_device(cur.value)
+                for p, _ in dead:
+                    N.lib.mifft_host_free(p)
         except Exception:
             pass
+
+    _graveyard = []      # (pinned word, device) released while a capture was open: freed by the next release outside one
+
+
+def _foreign_capture_active():
+    """A capture this module did not open itself (torch.cuda.graph(), another binding) on torch's current stream: the one place a plan
+    that follows torch's stream can be recorded from."""
+    try:
+        import sys
+        torch = sys.modules.get("torch")
+        if torch is None or not torch.cuda.is_available():
+            return False
+        return bool(torch.cuda.is_current_stream_capturing())
+    except Exception:
+        return False
 
 
 def _torch_current_stream(args):

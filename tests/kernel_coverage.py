@@ -91,7 +91,7 @@ def nd2p_shapes(prec):
         path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pyfft_amd", "csrc", "fft_nd2p.hip")
         text = open(path).read()
         _tables["nd2p"] = {name: frozenset(tuple(int(v) for v in m.groups())
-                                             for m in re.finditer(r"SHAPE\(%s,\s*(\d+),\s*(\d+),\s*(\d+)\)" % ctype, text))
+                                             for m in re.finditer(r"(?:ALL|BIG)\(%s,\s*(\d+),\s*(\d+),\s*(\d+)\)" % ctype, text))
                            for name, ctype in (("f32", "float"), ("f64", "double"))}
     return _tables["nd2p"][prec]
 

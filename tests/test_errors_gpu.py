@@ -31,8 +31,13 @@ def run_protocol(ctx, shape, dtype, batch, seed=1234, fast_math=True, check_orac
         data = oracle.get_test_data(shape, dtype, batch, seed)
 
     numpy_fw = oracle.numpy_fft(numpy.fft.fftn, data, batch)
-    numpy_res = oracle.numpy_fft(numpy.fft.ifftn, numpy_fw, batch)
-    numpy_err = oracle.difference(numpy_res, data, batch)
+    if data.size <= (1 << 22):
+        numpy_res = oracle.numpy_fft(numpy.fft.ifftn, numpy_fw, batch)
+        numpy_err = oracle.difference(numpy_res, data, batch)
+    else:
+        # (the reference's protocol also round-trips numpy itself, test/test_errors.py:41-43: a check of the checker, skipped for the
+        # 2^23 ... 2^24-point cases of round 6, where it is seconds of host time per case)
+        numpy_err = 0.0
 
     if split:
         a_re, a_im = ctx.toGpu(data_re), ctx.toGpu(data_im)

@@ -207,8 +207,8 @@ def test_dense_split_planes_on_the_tiled_fixed_kernels(ctx, shape, dtype, batch)
 
 
 # ---- dense split-complex N-D shapes on 16-byte plane accesses (csrc/fft_nd2p.hpp, round 6) ------------------------------------------------
-PLANES16_CASES = [(sh, numpy.float32) for sh in [(16, 16), (32, 32), (64, 64), (128, 128), (16, 16, 16), (8, 8, 64), (16, 16, 128), (32, 32, 32)]] + \
-                 [(sh, numpy.float64) for sh in [(16, 16), (32, 32), (64, 64), (128, 128), (16, 16, 16), (8, 8, 64)]]
+PLANES16_CASES = [(sh, numpy.float32) for sh in [(16, 16), (32, 32), (64, 64), (16, 16, 16), (8, 8, 64), (16, 16, 128), (32, 32, 32)]] + \
+                 [(sh, numpy.float64) for sh in [(16, 16), (32, 32), (64, 64), (16, 16, 16), (8, 8, 64)]]
 
 
 @pytest.mark.parametrize("shape,dtype", PLANES16_CASES, ids=lambda v: getattr(v, "__name__", str(v)).replace(" ", ""))
