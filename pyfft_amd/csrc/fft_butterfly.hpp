@@ -31,15 +31,28 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 // s_nop 1 = the TWO wait states gfx940+ needs between a store of more than 64 bits and a VALU write of its data registers (the
 // compiler's hazard recogniser does not look inside inline assembly; with one wait state the nd2 fp64 inverse kernels stored a
 // later value in a few lanes).
+// 16 bytes, write-through, at (wave-uniform base) + (32-bit per-lane byte offset): a RAW BUFFER store with the sc1 cache-policy bit
+// (round 6).  Rounds 2-5 spelled `global_store_dwordx4 ... sc1` out in inline assembly (HIP has no 16-byte agent-scope store): a store
+// the compiler does not see is a store its s_waitcnt bookkeeping does not count, so every wait it placed for a LATER load (the table
+// look-ups of the next exchange round) was short by the stores in flight and, with one in-order counter per wave, became a wait for
+// those stores to be acknowledged.  The buffer instruction is an ordinary machine instruction: counted, scheduled, and covered by the
+// hazard recogniser (the hand-placed s_nop of the assembly form is gone).  num_records = 2^32 - 1 bytes with stride 0: no lane of a tile
+// is ever out of range (tile-local offsets are 32-bit by construction).
+__device__ __forceinline__ void store_b128_sc1(const void* base, unsigned voff, unsigned __attribute__((ext_vector_type(4))) v) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffffu, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)voff, 0, 16 /* sc1 */);
+}
+
 template <typename T> __device__ __forceinline__ void store_wt(char* sbase, unsigned voff, cplx<T> r) {
     if constexpr (sizeof(cplx<T>) == 16) {
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
-        const u4 v = __builtin_bit_cast(u4, r);
-        asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+        store_b128_sc1(sbase, voff, __builtin_bit_cast(u4, r));
     } else {
-        typedef unsigned u2 __attribute__((ext_vector_type(2)));
-        const u2 v = __builtin_bit_cast(u2, r);
-        asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+        // (round 6: the 8-byte form is what a relaxed agent-scope atomic store compiles to -- global_store_dwordx2 ... sc1 with the same
+        // SGPR base + VGPR offset addressing -- and, unlike an asm statement, the compiler COUNTS it: behind spelled-out stores its
+        // s_waitcnt vmcnt(n) for a later load under-counted what is in flight and made the wave wait for the stores as well)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(sbase + voff), __builtin_bit_cast(unsigned long long, r), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -50,19 +63,15 @@ template <typename T> __device__ __forceinline__ void store_wt_ptr(void* p, cplx
         const u4 v = __builtin_bit_cast(u4, r);
         asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
     } else {
-        typedef unsigned u2 __attribute__((ext_vector_type(2)));
-        const u2 v = __builtin_bit_cast(u2, r);
-        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 // ... and of any 8 / 16 / 32-byte vector at a per-lane address (the small-launch store policy, MIFFT_FLAG_WRITE_THROUGH)
 template <typename VT> __device__ __forceinline__ void store_vec_wt(VT* p, const VT& w) {
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     if constexpr (sizeof(VT) == 8) {
-        const u2 v = __builtin_bit_cast(u2, w);
-        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if constexpr (sizeof(VT) == 16) {
         const u4 v = __builtin_bit_cast(u4, w);
         asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");

@@ -221,7 +221,7 @@ __device__ __forceinline__ void col2w_tile(const TileArgs& a, const long long o_
                 char* p = reinterpret_cast<char*>(reinterpret_cast<cplx<T>*>(a.out0) + gu);
                 f4 r;
                 r.x = res[0][qb0].x; r.y = res[0][qb0].y; r.z = res[1][qb0].x; r.w = res[1][qb0].y;
-                if constexpr (WT) store_vec_wt<f4>(reinterpret_cast<f4*>(p + ovoff * 8u), r);
+                if constexpr (WT) store_b128_sc1(p, ovoff * 8u, __builtin_bit_cast(unsigned __attribute__((ext_vector_type(4))), r));
                 else if constexpr (NTOUT) __builtin_nontemporal_store(r, reinterpret_cast<f4*>(p + ovoff * 8u));
                 else *reinterpret_cast<f4*>(p + ovoff * 8u) = r;
             });

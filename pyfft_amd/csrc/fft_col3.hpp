@@ -64,14 +64,13 @@ template <typename T, bool TR> struct Col3Lds {
     static constexpr int SCALARS = 2 * BUF * (HALF ? 1 : 2) * (DOUBLE ? 2 : 1);
 };
 
-// 16-byte agent-scope write-through store (the 8-byte form is what __hip_atomic_store(relaxed, agent) compiles to; clang has no
-// 16-byte atomic store, so the same encoding is spelled out).  The s_nop is the wait state gfx9 needs between a store of more
-// than 64 bits and a VALU write of its data registers: the compiler's hazard recogniser does not look inside inline assembly
-// (without it the first row of every pass-0 tile came out with a later value's real part in 4 lanes of 16).
-__device__ __forceinline__ void col3_store_wt16(void* p, const cplx<double>& r) {
+// 16-byte agent-scope write-through store of the fp64 tiles: fft_butterfly.hpp store_b128_sc1 (a raw buffer store with the sc1 bit since
+// round 6; rounds 2-5 spelled a global store out in assembly, with the wait state gfx9 needs between a store of more than 64 bits and a
+// VALU write of its data registers by hand -- without it the first row of every pass-0 tile came out with a later value's real part in 4
+// lanes of 16).
+__device__ __forceinline__ void col3_store_wt16(const char* base, unsigned voff, const cplx<double>& r) {
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    const u4 v = __builtin_bit_cast(u4, r);
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    store_b128_sc1(base, voff, __builtin_bit_cast(u4, r));
 }
 
 // phase 1 of a tile on its own: v[a*16 + b1] = in[2*(b1*16A + a*16 + b0) + h][column c] -- 16 A loads per thread, all issued before
@@ -338,7 +337,7 @@ __device__ __forceinline__ void col3_body(const TileArgs& a, const long long o_o
                         __hip_atomic_store(reinterpret_cast<unsigned long long*>(p + ovoff * (unsigned)sizeof(cplx<T>)),
                                            __builtin_bit_cast(unsigned long long, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     else
-                        col3_store_wt16(p + ovoff * (unsigned)sizeof(cplx<T>), r);
+                        col3_store_wt16(p, ovoff * (unsigned)sizeof(cplx<T>), r);
                 } else if constexpr (NTOUT) {
                     __builtin_nontemporal_store(r, reinterpret_cast<cplx<T>*>(p + ovoff * (unsigned)sizeof(cplx<T>)));
                 } else {

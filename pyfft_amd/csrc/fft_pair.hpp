@@ -94,25 +94,55 @@ __device__ __forceinline__ void pair_store(char* outb, char* outb1, const cplx<T
     // the two-level table, the three behind it are one multiplication each by the step w(ny)^(l * Ns) -- which is the same for the
     // whole tile (depth <= 3, as the strided kernels of fft_col2.hpp: fp32 error ~2.5e-7 max).  Rounds 2-3 looked every factor up:
     // two table loads and two complex multiplications per element, 32 cached loads per thread in the XY tile of 128^3.
+    // Round 6: the anchors are looked up TWO GROUPS AHEAD of their use.  Looked up inside their own group (round 4) the two table loads
+    // sat behind the group's predecessor's four stores, and with one in-order memory counter per wave the wait for them was a wait for
+    // those write-through stores to be acknowledged -- eight store round trips in a row per XY tile of 128^3 (the ISA read
+    // "2 x load, s_waitcnt vmcnt(0), 4 x store" eight times over).  Two groups ahead the wait covers stores that are two groups old.
     const cplx<T>* lo = reinterpret_cast<const cplx<T>*>(a.tw_lo);
     const cplx<T>* hi = reinterpret_cast<const cplx<T>*>(a.tw_hi);
-    auto look = [&](unsigned e) { return cmul<T>(lo[e & ((1u << a.tw_shift) - 1u)], hi[e >> a.tw_shift]); };
+    const unsigned lomask = (1u << a.tw_shift) - 1u;
+    auto look = [&](unsigned e) { return cmul<T>(lo[e & lomask], hi[e >> a.tw_shift]); };
     cplx<T> wstep = {(T)1, (T)0};
     if constexpr (TWOUT && St::R > 1) wstep = look((unsigned)(lrow * St::Ns));
+    constexpr int GR = (St::R + 3) / 4, NG = St::NB * GR;      // groups of four results per butterfly, groups per thread
+    cplx<T> alo[2], ahi[2];
+    auto issue = [&](auto gc) {
+        constexpr int gi = gc, b = gi / GR, k = (gi % GR) * 4;
+        int base, jb;
+        St::geom(b, tid, base, jb);
+        const int e0 = base + St::idxd(jb) * St::SA;
+        const int q0 = (e0 / MAP::E0) % MAP::E1;
+        const unsigned e = (unsigned)(lrow * (q0 + k * St::Ns));
+        alo[gi % 2] = lo[e & lomask];
+        ahi[gi % 2] = hi[e >> a.tw_shift];
+    };
+    if constexpr (TWOUT) {
+        issue(IC<0>{});
+        if constexpr (NG > 1) issue(IC<1>{});
+        __builtin_amdgcn_sched_barrier(0);
+    }
     static_for<St::NB>([&](auto bb) {
         constexpr int b = bb;
         int base, jb;
         St::geom(b, tid, base, jb);
         const int e0 = base + St::idxd(jb) * St::SA;
         const unsigned voff = MAP::out_off(e0) * ESZ;
-        const int q0 = (e0 / MAP::E0) % MAP::E1;
         cplx<T> wcur = {(T)1, (T)0};
         static_for<St::R>([&](auto kk) {
             constexpr int k = kk;
             cplx<T> p = v[b * St::R + k];
             if constexpr (TWOUT) {
-                if constexpr (k % 4 == 0) wcur = look((unsigned)(lrow * (q0 + k * St::Ns)));
-                else wcur = cmul<T>(wcur, wstep);
+                if constexpr (k % 4 == 0) {
+                    constexpr int gi = b * GR + k / 4;
+                    wcur = cmul<T>(alo[gi % 2], ahi[gi % 2]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (gi + 2 < NG) {
+                        issue(IC<gi + 2>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                    wcur = cmul<T>(wcur, wstep);
+                }
                 p = cmul<T>(p, wcur);
             }
             p.x *= sx;
