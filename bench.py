@@ -811,7 +811,7 @@ def main():
             "transforms_per_s_median": share / (st["median"] * 1e-3)})
     elif args.repeats > 0 and world == 1 and not args.inplace:
         # blocks of >= 20 ms of back-to-back executes (a burst of a few short launches behind a synchronisation measures the clock
-        # ramp and the fill / drain of the first launch: 3-4 points at 1 GiB per side)
+        # ramp and the fill / drain of the first launch: 3-4 points at 1 GiB per side, docs/measurement.md)
         per = max(2, min(args.steps, 10), int(20.0 / max(1e-3, est_step_ms)) + 1)
         per += per & 1
         protocol = {"executes_per_repeat": per, "repeats": args.repeats}

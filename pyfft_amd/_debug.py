@@ -1,6 +1,6 @@
 """Development switches, all in one place (nothing in the product path reads the environment directly).
 
-None of these is needed in production; they exist so that the measurements quoted in DESIGN.md can be reproduced
+None of these is needed in production; they exist so that the measurements quoted in DESIGN.md and docs/ can be reproduced (table: docs/switches.md)
 (tools/*.py set them).  Unset = the plan's own choice.
 """
 import os

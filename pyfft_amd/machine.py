@@ -3,7 +3,7 @@
 Everything `FFTPlan._select_strategy` sizes -- the ring of the persistent launches, the chunks of the pipelined chain, the
 thresholds of the plain chain and of the write-through store rule -- is a fraction of the LAST-LEVEL CACHE in front of HBM (the
 256 MiB Infinity Cache of an MI355X; `llc_bytes`, read from the HSA agent by mifft_device_props_get), and the grids of the
-persistent kernels are multiples of the compute-unit count.  The fractions are the measured ones; on the
+persistent kernels are multiples of the compute-unit count.  The fractions are the measured ones (docs/strategies.md); on the
 full part they give back the constants of rounds 1-3: 224 MiB ring, 64 MiB chunks, 128 MiB slabs, 256 MiB chain threshold,
 128 MiB write-through threshold.  A partition of the part (CPX / NPS4: 32 CUs, one XCD, a slice of the cache) gets
 proportionally smaller figures and loses the strategies that need the whole machine (XCD-cooperative kernels) or a ring of at

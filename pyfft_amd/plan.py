@@ -382,7 +382,7 @@ class FFTPlan(object):
 
     def _development_strategy(self, batch, forced, tiny):
         """The measured-and-not-adopted forms, on request (PYFFT_AMD_* switches; `make DEV=1` builds of the library): the sequential
-        list of a tiny batch, the per-XCD work lists, the XCD-resident single-crossing kernel.  DESIGN.md section 5."""
+        list of a tiny batch, the per-XCD work lists, the XCD-resident single-crossing kernel.  docs/strategies.md."""
         p = self._params
         mach = self._context.machine
         dev = mach.tuning.development
@@ -418,7 +418,7 @@ class FFTPlan(object):
         return None
 
     def _select_strategy(self, batch):
-        """How the batch is cut and overlapped.  Every measured constant comes from the tuning table
+        """How the batch is cut and overlapped (docs/strategies.md).  Every measured constant comes from the tuning table
         (pyfft_amd/tuning_gfx950.json) and every size from the device (pyfft_amd/machine.py)."""
         forced = D.forced_strategy()
         p = self._params

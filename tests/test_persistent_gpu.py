@@ -213,7 +213,7 @@ def test_sequential_single_launch_of_tiny_batches(ctx, monkeypatch, shape, dtype
     """The reference's own benchmark protocol runs 32 MiB buffers (test/test_performance.py:11,22-30): there the two passes of a
     transform are two dependent launches.  The sequential work list runs them in ONE persistent launch (lag 0: every first-pass
     tile, then every second-pass tile); it must give the chain's bits, in place and out of place, forward and inverse.  Measured
-    slower than the two launches: part of `make DEV=1` builds of the library only."""
+    slower than the two launches (docs/negative_results.md): part of `make DEV=1` builds of the library only."""
     from pyfft_amd import _native as N
     if N.lib.mifft_has_feature(N.FEATURE_SEQUENTIAL_LIST) != 1:
         pytest.skip("development form: not in the default build of libmifft.so (make DEV=1)")

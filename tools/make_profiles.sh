@@ -1,11 +1,11 @@
 #!/bin/bash
 # Regenerates the round's evidence under profiles/ ON THE GPU BOX (run through gpurun from the repo root):
-#     git rev-parse HEAD > .tree_commit; gpurun --timeout 3000 -- 'bash tools/make_profiles.sh r05'
+#     git rev-parse HEAD > .tree_commit; gpurun --timeout 3000 -- 'bash tools/make_profiles.sh r06'
 # Everything is written to gpurun_out/<tag>/ (scratch, merged back by gpurun); the summaries that are judged are gathered in
 # gpurun_out/<tag>/to_profiles/ under their final names -- back in the build container:
-#     cp gpurun_out/r04/to_profiles/* profiles/  rocprofv3 gets the program directly after `--` (no env/bash hop), counters in their own runs.
+#     cp gpurun_out/<tag>/to_profiles/* profiles/;  rocprofv3 gets the program directly after `--` (no env/bash hop), counters in their own runs.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT/to_profiles profiles
 P=$OUT/to_profiles
@@ -19,13 +19,14 @@ cp profiles/traffic_*.json profiles/${TAG}_*_kernel_stats.csv $P/ 2>/dev/null
 
 # 2. the bench lines (after the traffic files exist, so that every line carries roofline.traffic): default line (c2) and every other BASELINE configuration
 timeout 600 python3 bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
+# (round 6: no --steps: K = max(10, 250 ms / step) after an untimed spin-up, so that short steps are not measured on the clock ramp)
 for c in c1 c3 c4 c4s cube cubed c2s c3s; do
-    timeout 600 python3 bench.py --config $c --steps 10 --warmup 2 > $OUT/bench_$c.json 2> $OUT/bench_$c.err
+    timeout 600 python3 bench.py --config $c > $OUT/bench_$c.json 2> $OUT/bench_$c.err
 done
 # configuration 5 as BASELINE.json states it: the per-GPU share of 8192 transforms resident (256 GiB), 32 chunk executes = one sweep; and the
 # rounds 1-4 form (one resident chunk, out of place) next to it
 timeout 900 python3 bench.py --config c5 --warmup 2 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
-timeout 600 python3 bench.py --config c5 --chunk-only --steps 10 --warmup 2 > $OUT/bench_c5chunk.json 2> $OUT/bench_c5chunk.err
+timeout 600 python3 bench.py --config c5 --chunk-only > $OUT/bench_c5chunk.json 2> $OUT/bench_c5chunk.err
 for c in c1 c2 c3 c4 c4s c5 c5chunk cube cubed c2s c3s; do cp $OUT/bench_$c.json $P/${TAG}_bench_$c.json; done
 
 # 3. the reference's published shapes (test/test_performance.py method), the vendor yardstick (cuda/test.cu counterpart) and its
@@ -58,6 +59,14 @@ timeout 900 python3 tools/quick_bench.py tail 2>&1 | sed 's/passes=\[.*\]//' > $
 # 5c. the planner's tuning table re-measured (every rule's persistent launch against the pipelined chunks, 2 GiB per side)
 timeout 1500 python3 tools/fused_sweep.py --emit $OUT/tuning_emitted.json --gib 2 > $OUT/tuning_emit.log 2>&1
 cp $OUT/tuning_emit.log $P/${TAG}_tuning_emit.log; cp $OUT/tuning_emitted.json $P/${TAG}_tuning_emitted.json
+
+# 5d. round 6: SQ / TCP / TCC counters of the persistent kernels of C2 and C5 (one rocprofv3 --pmc run per counter group); the dense
+#     split-complex N-D kernel against what ran before it; the composed upper bounds for the three-launch shapes; one process, four shards
+timeout 1500 python3 tools/persistent_counters.py > $OUT/fused3_counters.log 2>&1; cp $OUT/fused3_counters.log $P/${TAG}_fused3_counters_final.log
+timeout 900 python3 tools/planes_probe.py > $OUT/planes_probe.log 2>&1; cp $OUT/planes_probe.log $P/${TAG}_planes_probe_final.log
+timeout 600 python3 tools/three_launch_probe.py > $OUT/three_launch.log 2>&1; cp $OUT/three_launch.log $P/${TAG}_three_launch_fused_final.log
+timeout 600 python3 bench.py --gpus 4 --single-process --share-gpu --no-cpu-baseline > $OUT/bench_c2_single_process_4.json 2> $OUT/bench_c2_single_process_4.err
+cp $OUT/bench_c2_single_process_4.json $P/${TAG}_bench_c2_single_process_4_shards_one_gpu.json
 
 # 6. SQ counters of the long fp32 rows (occupancy / LDS pressure)
 timeout 900 python3 tools/row_counters.py 32768 complex64 8192 16384 complex64 16384 8192 complex64 32768 > $OUT/row_counters.log 2>&1

@@ -14,6 +14,12 @@ UPPER BOUND of the proposal from launches that exist, moving exactly the proposa
 timed back to back between two HIP events, against the plan's own three launches on the same buffers.  (The composite is no transform of
 2^23 points -- its inter-pass twiddles are those of 2^20 -- only its data movement is the proposal's.)
 
+The same arithmetic for 512^3 (1 GiB per transform in complex64: x rows + y columns + z columns, three launches, no pass pair for a
+512-point y axis): x-row launch + ONE persistent launch over (y, z).  Here the hand-over unit IS small -- 16 x-columns of every (y, z)
+plane, 32 MiB -- so the ring rule carries over; the bound is composed of (a) the plan of 512-point rows over the same points and (b)
+the persistent 2-D launch of (512, 512) transforms over the same bytes (16-byte ... 4 KiB runs instead of 128-byte segments 4 KiB apart:
+an upper bound again).
+
     python3 tools/three_launch_probe.py [gib_per_side]
 """
 import ctypes
@@ -108,5 +114,41 @@ def main():
         del a, b
 
 
+def cube512():
+    n = 512
+    batch = 2
+    pts = n ** 3 * batch
+    a = DeviceArray((pts,), numpy.complex64)
+    b = DeviceArray((pts,), numpy.complex64)
+    fill(a)
+    plan3 = Plan((n, n, n), dtype=numpy.complex64, wait_for_finish=False)
+    plan3.execute(a, b, batch=batch)
+    stream = plan3._context.getQueue()
+    plan3.finish()
+    ms3 = timed(stream, lambda: plan3.execute(a, b, batch=batch), 4)
+    plan3.finish()
+    rows = Plan(n, dtype=numpy.complex64, stream=stream)
+    planes = Plan((n, n), dtype=numpy.complex64, stream=stream)
+    ms_a = timed(stream, lambda: rows.execute(a, b, batch=pts // n), 4)
+    ms_b = timed(stream, lambda: planes.execute(b, batch=pts // (n * n)), 4)
+
+    def composite():
+        rows.execute(a, b, batch=pts // n)
+        planes.execute(b, batch=pts // (n * n))
+    ms_c = timed(stream, composite, 4)
+    rows.finish()
+    alg = 2.0 * pts * 8
+    frac = lambda ms: alg / (ms * 1e-3) / 8e12      # noqa: E731
+    print("(512, 512, 512) x %d (%.1f GiB per side)  plan: %s %s" % (batch, pts * 8 / 2.0 ** 30, plan3.strategy(batch)[0], plan3.pass_list()))
+    print("   the plan's three launches            %8.3f ms  %.3f of the roofline" % (ms3, frac(ms3)))
+    print("   (a) 512-point rows, out of place     %8.3f ms  %.3f   [%s]" % (ms_a, frac(ms_a), rows.strategy(pts // n)[0]))
+    print("   (b) persistent (512, 512), in place  %8.3f ms  %.3f   [%s]" % (ms_b, frac(ms_b), planes.strategy(pts // (n * n))[0]))
+    print("   (a) + (b) back to back               %8.3f ms  %.3f   (1 / (1/a + 1/b) = %.3f)" % (ms_c, frac(ms_c), 1.0 / (1.0 / frac(ms_a) + 1.0 / frac(ms_b))), flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "cube":
+        cube512()
+    else:
+        main()
+        cube512()
