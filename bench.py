@@ -915,6 +915,8 @@ def main():
     elif strategy[0] in ("fused2", "fused2x", "fusedp"):
         what = {"fused2": "both passes", "fused2x": "both passes, one work list per XCD", "fusedp": "both pass pairs"}[strategy[0]]
         launches = "1 persistent launch per step (%s, lag %s, ring %s)" % ((what,) + tuple(strategy[1:3]))
+    elif strategy[0] == "fused2z":
+        launches = "1 persistent launch over the (y, x) planes (lag %s, ring %s) + %d plain z launch(es) per step" % (tuple(strategy[1:3]) + (nlaunch - 2,))
     elif strategy[0] == "xcd2":
         launches = "1 persistent launch per step (both passes, XCD-resident intermediate)"
     else:

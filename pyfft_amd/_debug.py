@@ -32,6 +32,11 @@ def no_slabs():
     return bool(os.environ.get("PYFFT_AMD_NO_SLABS"))
 
 
+def no_plane_fused():
+    """3-D transforms beyond a pipeline chunk: leading x / y passes slab by slab (rounds 1-5) instead of one persistent 2-D launch"""
+    return bool(os.environ.get("PYFFT_AMD_NO_PLANE_FUSED"))
+
+
 def no_stream_hints():
     return bool(os.environ.get("PYFFT_AMD_NO_STREAM_HINTS"))
 

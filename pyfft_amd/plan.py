@@ -325,15 +325,22 @@ class FFTPlan(object):
         if self._pair_alt is not None or (self._paired and len(k) == 4 and not p.split and
                                           N.lib.mifft_fused_pair_supported(p.precision, p.layout, int(p.x), int(p.y), int(p.z)) == 0):
             cls.update(kind="3d", planes=int(p.z) * int((self._pair_alt or k)[1].M))          # first-pass items: planes x R1
-        elif len(k) == 2 and int(p.z) == 1 and k[0].kind == N.PASS_ROW and k[0].L == int(p.x) and k[1].kind == N.PASS_COL and \
-                k[1].L == int(p.y) and k[1].M == 1 and k[1].S == int(p.x):
-            cls.update(kind="2d", ny=int(p.y), nx=int(p.x), M=0)
+        elif (len(k) == 2 and int(p.z) == 1 or self._plane_fused()) and k[0].kind == N.PASS_ROW and k[0].L == int(p.x) and \
+                k[1].kind == N.PASS_COL and k[1].L == int(p.y) and k[1].M == 1 and k[1].S == int(p.x):
+            # planes > 1: the (y, x) planes of a 3-D transform too big for cache-sized chunks -- its ROW x and COL y passes are the
+            # two passes of a 2-D plan over batch * nz planes, the z passes follow as plain launches (strategy "fused2z")
+            cls.update(kind="2d", ny=int(p.y), nx=int(p.x), M=0, planes=int(p.z))
         elif len(k) == 2 and int(p.y) == 1 and int(p.z) == 1 and k[0].kind == N.PASS_COL and k[1].kind == N.PASS_COL and k[0].S == 1 and \
                 k[0].M == k[1].L and k[1].M == 1 and self._temp_buffer_needed:
             cls.update(kind="1d", L0=int(k[0].L), L1=int(k[1].L), M=int(k[0].M))
         else:
             return None
         return cls
+
+    def _plane_fused(self):
+        """A 3-D transform larger than a pipeline chunk whose two leading passes are ROW x and COL y (what _slab_passes == 2 says) may
+        run them as ONE persistent 2-D launch over its planes instead of slab by slab (round 6).  PYFFT_AMD_NO_PLANE_FUSED: never."""
+        return self._slab_passes == 2 and int(self._params.z) > 1 and not D.no_plane_fused()
 
     def _persistent_rule(self):
         """The tuning rule of this plan's persistent launch (None: it has none) under the development switches in force."""
@@ -356,6 +363,13 @@ class FFTPlan(object):
         cls = self._shape_class()
         item_bytes = p.size * p.complex_nbytes
         name = rule["strategy"]
+        planes = int(cls.get("planes", 1)) if rule["kind"] == "2d" else 1
+        if planes > 1:
+            # the work list's "transforms" are the (y, x) planes of the batch
+            if name != "fused2" or rule.get("on_request"):
+                return None
+            item_bytes //= planes
+            batch *= planes
         tiles0 = max(1, int(cls[rule["extent0"]]) // int(rule["cols0"]))
         per_cu = D.fused_grid_per_cu(int(rule["per_cu"]))
         geo = mach.fused_geometry(item_bytes, tiles0, per_cu, fill_cache=rule.get("ring") == "cache", min_slots=rule.get("min_slots"))
@@ -378,7 +392,7 @@ class FFTPlan(object):
             lag = batch // 4
             ring = 2 * lag
         big = item_bytes >= int(rule.get("min_item_bytes", 0)) or forced == "fused"
-        return (name, lag, ring, grid) if (batch >= 2 * ring and big) else None
+        return ("fused2z" if planes > 1 else name, lag, ring, grid) if (batch >= 2 * ring and big) else None
 
     def _development_strategy(self, batch, forced, tiny):
         """The measured-and-not-adopted forms, on request (PYFFT_AMD_* switches; `make DEV=1` builds of the library): the sequential
@@ -390,7 +404,7 @@ class FFTPlan(object):
         item_bytes = p.size * p.complex_nbytes
         if tiny:
             if D.small_fused(int(dev["small_fused_lag_div"])) and N.lib.mifft_has_feature(N.FEATURE_SEQUENTIAL_LIST) == 1 and \
-                    not p.split and rule is not None and not rule.get("on_request"):
+                    not p.split and rule is not None and not rule.get("on_request") and not self._plane_fused():
                 # statically dealt list: every work-group must be resident (1 or 2 per CU by the kernels' resources)
                 return (rule["strategy"], 0, batch, int(rule["per_cu"]) * mach.compute_units)
             return None
@@ -446,7 +460,7 @@ class FFTPlan(object):
             return ("pipelined", chunk, D.pipeline_streams(pipe["streams"]), nslab)
         return ("chain",)
 
-    PERSISTENT = ("fused2", "fused2x", "fusedp")
+    PERSISTENT = ("fused2", "fused2x", "fusedp", "fused2z")
 
     def _prepare(self, batch):
         """Choose the strategy when the batch changes (plan.py:179-192); the plan-owned scratch of that strategy is allocated by the
@@ -501,7 +515,8 @@ class FFTPlan(object):
             items = self._strategy[2] * (8 if self._strategy[0] == "fused2x" else 1)
             # two counter sets: every launch runs on one and zeroes the other (mifft_fused_sync), so no memset precedes a launch;
             # a third one for launches captured into a graph (_fused_sync)
-            self._counter_bytes = N.fused2_counter_bytes(batch)
+            planes = int(p.z) if self._strategy[0] == "fused2z" else 1
+            self._counter_bytes = N.fused2_counter_bytes(batch * planes)
             self._counters = ctx.allocate_raw(3 * self._counter_bytes)
             self._counters_clean = False
             if self._errword is None:
@@ -513,7 +528,8 @@ class FFTPlan(object):
             items = batch
         # one interleaved buffer for both layouts (the reference allocates two scalar planes for split plans,
         # plan.py:189-190; same total size)
-        self._tempmemobj = ctx.allocate(p.size * items * p.complex_nbytes)
+        item = p.size // int(p.z) if self._strategy[0] == "fused2z" else p.size      # fused2z: the ring holds (y, x) planes
+        self._tempmemobj = ctx.allocate(item * items * p.complex_nbytes)
 
     def _fused_sync(self, stream, capturing=False):
         """mifft_fused_sync of the coming persistent launch: the counter set it runs on (zero: the previous launch cleared it, or
@@ -589,6 +605,10 @@ class FFTPlan(object):
                     N.check(N.lib.mifft_launch_fused2(ctypes.byref(d0), ctypes.byref(d1), bufs0[d0.src], in1, bufs0[d1.dst], out1,
                                                       bufs0[2], None, ring, lag, ctypes.byref(sync), grid, stream),
                             "mifft_launch_fused2")
+                    if strat[0] == "fused2z":
+                        # the (y, x) planes are done where the chain's second pass leaves them; the z passes as plain launches
+                        rest = ctypes.cast(ctypes.byref(descs, 2 * ctypes.sizeof(N.MifftPass)), ctypes.POINTER(N.MifftPass))
+                        N.check(N.lib.mifft_launch_chain(rest, len(self._kernels) - 2, bufs0, bufs1, stream), "mifft_launch_chain")
             except Exception:
                 self._counters_clean = False     # a launch that did not start cleared nothing
                 raise

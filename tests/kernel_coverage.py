@@ -149,8 +149,9 @@ def _persistent_key(plan):
     rule = plan._persistent_rule()
     if rule is None:
         return None
+    # (the planes of a big 3-D transform run the 2-D plan's instance: strategy "fused2z")
     return ("persistent", rule["name"], "f64" if p.precision == N.F64 else "f32", "split" if p.split else "interleaved",
-            int(p.x), int(p.y), int(p.z))
+            int(p.x), int(p.y), 1 if plan._plane_fused() else int(p.z))
 
 
 def keys_of(shape, dtype, batch, mode="auto"):
@@ -165,7 +166,14 @@ def keys_of(shape, dtype, batch, mode="auto"):
         k = _persistent_key(plan)
         return {k} if k is not None else set()
     strat = plan._select_strategy(int(batch))
-    if strat[0] in plan.PERSISTENT:
+    if strat[0] == "fused2z":
+        # one persistent 2-D launch over the (y, x) planes -- the 2-D plan's instance; what is new is the planner's route -- then the
+        # chain's z launches
+        pk = _persistent_key(plan)
+        keys.add(pk)
+        keys.add(("plane_fused",) + pk[1:4])
+        keys |= _chain_keys(plan, plan._kernels[2:])
+    elif strat[0] in plan.PERSISTENT:
         keys.add(_persistent_key(plan))
     else:
         keys |= _chain_keys(plan, plan._kernels)
@@ -327,6 +335,7 @@ REGISTRY = {
         "test_fused_pair_small_axes": lambda p: [_c(p["shape"], p["dtype"], p["batch"] // 2 + 1 if _is_double(p["dtype"]) else p["batch"]),
                                                  _c(p["shape"], p["dtype"], p["batch"], "chain")],
         "test_fused_pair_split_planes": lambda p: [_c(p["shape"], p["rdtype"], p["batch"]), _c(p["shape"], p["rdtype"], p["batch"], "chain")],
+        "test_plane_fused_3d": lambda p: [_c(p["shape"], p["dtype"], p["batch"]), _c(p["shape"], p["dtype"], p["batch"], "chain")],
         "test_fused_2d_split_row_first": lambda p: [_c(p["shape"], F32, p["batch"], "fused" if tuple(p["shape"]) == (256, 256) else "auto"),
                                                     _c(p["shape"], F32, p["batch"], "chain")],
         "test_fused_split_planes_fp64": lambda p: [_c(p["shape"], F64, p["batch"]), _c(p["shape"], F64, p["batch"], "chain")],

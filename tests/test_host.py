@@ -698,7 +698,11 @@ def test_strategy_snapshot_of_the_table_driven_planner():
     new_chain = [g for g in got if g[6]]
     # (2.6 k of the 38 k rows by the end of round 5: the 4096-point y axes, short (y, z) behind long rows, the 3-D shapes with a 256-point y axis)
     assert 0 < len(new_chain) < 4000 and all(g[5][0] in ("chain", "pipelined") for g in new_chain)
-    bad = [(w, g) for w, g in zip(want, got) if not g[6] and w != json.loads(json.dumps(g[:6])) and (lists or w[5][0] != "fused2x")]
+    # round 6: the one shape of the grid beyond a pipeline chunk with a ROW x + COL y + COL z chain runs its planes on the persistent 2-D
+    # kernels (strategy "fused2z") where the round-4 planner answered chain / pipelined slabs
+    planes = [g for g in got if g[5][0] == "fused2z"]
+    assert 0 < len(planes) < 200 and all(tuple(g[2]) == (512, 512, 512) and w[5][0] in ("chain", "pipelined") for w, g in zip(want, got) if g[5][0] == "fused2z")
+    bad = [(w, g) for w, g in zip(want, got) if not g[6] and g[5][0] != "fused2z" and w != json.loads(json.dumps(g[:6])) and (lists or w[5][0] != "fused2x")]
     assert not bad, bad[:10]
     assert not lists or sum(1 for g in got if g[5][0] == "fused2x") == 18
     assert set(r[5][0] for r in want) == {"chain", "pipelined", "fused2", "fusedp", "fused2x"}

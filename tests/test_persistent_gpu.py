@@ -881,3 +881,54 @@ def test_direct_abi_two_set_launch_refuses_capture_and_null_error_word(ctx):
     assert rc == N.E_INVALID and b"capturing" in msg
     assert rc_single == 0
     s.synchronize()
+
+# ---- round 6: the (y, x) planes of a 3-D transform bigger than a pipeline chunk on the persistent 2-D kernels ------------------------
+PLANE_FUSED_CASES = [((64, 1024, 256), numpy.complex64, 4), ((16, 2048, 512), numpy.complex64, 4), ((128, 512, 256), numpy.complex64, 4),
+                     ((64, 512, 512), numpy.complex64, 4), ((32, 1024, 512), numpy.complex64, 4), ((64, 512, 256), numpy.complex128, 4),
+                     ((16, 1024, 512), numpy.complex128, 4), ((8, 1024, 1024), numpy.float64, 4), ((512, 512, 512), numpy.complex64, 1)]
+
+
+@pytest.mark.parametrize("shape,dtype,batch", PLANE_FUSED_CASES, ids=str)
+def test_plane_fused_3d(ctx, monkeypatch, shape, dtype, batch):
+    """3-D transforms of more than 64 MiB whose chain is ROW x + COL y + COL z (no pass pair): the x and y passes run as ONE persistent
+    launch over the batch * nz (y, x) planes -- the 2-D plan's kernel and ring --, the z pass as the chain's plain launch (strategy
+    "fused2z"; rounds 1-5: the leading passes slab by slab through the pipelined launcher, or three plain launches for small batches;
+    pyfft/plan.py:135-171: the reference's chain is x kernels, then y, then z).  One case per 2-D rule of the tuning table that such a
+    shape can match, and 512^3 with batch 1.  First / last transform against numpy (reference thresholds), in place == out of place,
+    input untouched, the inverse round trip, and the whole result against the plan without the route (other kernels for x and y:
+    rounding-level agreement)."""
+    cdt = numpy.dtype(dtype)
+    split = cdt.kind == "f"
+    double = cdt in (numpy.dtype(numpy.complex128), numpy.dtype(numpy.float64))
+    eps, mx = (1e-11, 1e-10) if double else (EPS_F, MAX_F)
+    ctype = numpy.complex128 if double else numpy.complex64
+    size = int(numpy.prod(shape))
+    data = _test_data(shape, ctype, batch, 6600 + shape[0] + shape[1] // 256)
+    plan = ctx.getPlan(shape, dtype=dtype)
+    assert plan.strategy(batch)[0] == "fused2z", plan.strategy(batch)
+    assert len(plan.pass_list()) == 3
+
+    def run(inplace=False, inverse=False, src=None, expect="fused2z"):
+        d = data if src is None else src
+        if split:
+            re, im = _execute_split(ctx, shape, dtype, batch, numpy.ascontiguousarray(d.real), numpy.ascontiguousarray(d.imag),
+                                    inplace=inplace, inverse=inverse, expect=expect)
+            return (re + 1j * im).astype(ctype)
+        return _execute(ctx, shape, dtype, batch, d, inplace=inplace, inverse=inverse, expect=expect)
+    got = run()
+    assert numpy.array_equal(run(inplace=True), got)
+    flat, gflat = data.reshape(-1), got.reshape(-1)
+    for item in sorted({0, batch - 1}):
+        ref = numpy.fft.fftn(flat[item * size:(item + 1) * size].reshape(shape).astype(numpy.complex128)).reshape(-1)
+        d = gflat[item * size:(item + 1) * size]
+        assert numpy.abs(ref - d).sum() / numpy.abs(ref).sum() < eps
+        assert numpy.abs(ref - d).max() <= mx * numpy.abs(ref).max()
+        del ref
+    back = run(inverse=True, src=got)
+    assert oracle.difference(data, back, batch) < eps
+    del back
+    monkeypatch.setenv("PYFFT_AMD_NO_PLANE_FUSED", "1")
+    other = ctx.getPlan(shape, dtype=dtype).strategy(batch)[0]
+    assert other in ("chain", "pipelined")
+    want = run(expect=other)
+    assert oracle.difference(want, got, batch) < (1e-14 if double else 5e-7)

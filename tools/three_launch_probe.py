@@ -114,9 +114,8 @@ def main():
         del a, b
 
 
-def cube512():
+def cube512(batch=2):
     n = 512
-    batch = 2
     pts = n ** 3 * batch
     a = DeviceArray((pts,), numpy.complex64)
     b = DeviceArray((pts,), numpy.complex64)
@@ -137,6 +136,34 @@ def cube512():
         planes.execute(b, batch=pts // (n * n))
     ms_c = timed(stream, composite, 4)
     rows.finish()
+    # the other cut, and no bound but the real thing: the persistent 2-D launch over the batch * 512 (y, x) planes, out of place, then the
+    # plan's own strided z pass in place -- col(L = 512, M = 1, S = 512 * 512) through the C ABI: together a 3-D transform of the data
+    tw = DeviceArray((n,), numpy.complex64).set(_twiddle_table(n, n, 1, numpy.dtype(numpy.complex64)))
+    d = N.MifftPass()
+    d.kind, d.precision, d.layout, d.inverse, d.L, d.variant = N.PASS_COL, N.F32, N.INTERLEAVED, 0, n, 0
+    d.M, d.S, d.outer, d.outer_stride_in, d.outer_stride_out, d.scale = 1, n * n, batch, n ** 3, n ** 3, 1.0
+    d.tw_L = tw.ptr
+    d.flags = N.FLAG_STREAM_DST
+    sh = stream.handle if hasattr(stream, "handle") else stream
+
+    def z_pass():
+        N.check(N.lib.mifft_launch_pass(ctypes.byref(d), b.ptr, None, b.ptr, None, sh), "launch_pass")
+
+    def planes_then_z():
+        planes.execute(a, b, batch=pts // (n * n))
+        z_pass()
+    ms_p = timed(stream, lambda: planes.execute(a, b, batch=pts // (n * n)), 4)
+    ms_z = timed(stream, z_pass, 4)
+    ms_pz = timed(stream, planes_then_z, 4)
+    planes.finish()
+    # values: the composite is the transform (checked on the first transform against the plan's result)
+    plan3.execute(a, b, batch=batch)
+    plan3.finish()
+    ref = b.get()[:n ** 3].copy()
+    planes_then_z()
+    planes.finish()
+    got = b.get()[:n ** 3]
+    err = float(numpy.abs(got - ref).max() / numpy.abs(ref).max())
     alg = 2.0 * pts * 8
     frac = lambda ms: alg / (ms * 1e-3) / 8e12      # noqa: E731
     print("(512, 512, 512) x %d (%.1f GiB per side)  plan: %s %s" % (batch, pts * 8 / 2.0 ** 30, plan3.strategy(batch)[0], plan3.pass_list()))
@@ -144,11 +171,16 @@ def cube512():
     print("   (a) 512-point rows, out of place     %8.3f ms  %.3f   [%s]" % (ms_a, frac(ms_a), rows.strategy(pts // n)[0]))
     print("   (b) persistent (512, 512), in place  %8.3f ms  %.3f   [%s]" % (ms_b, frac(ms_b), planes.strategy(pts // (n * n))[0]))
     print("   (a) + (b) back to back               %8.3f ms  %.3f   (1 / (1/a + 1/b) = %.3f)" % (ms_c, frac(ms_c), 1.0 / (1.0 / frac(ms_a) + 1.0 / frac(ms_b))), flush=True)
+    print("   (c) persistent (512, 512), out of place %5.3f ms  %.3f" % (ms_p, frac(ms_p)))
+    print("   (d) the plan's z pass, in place      %8.3f ms  %.3f" % (ms_z, frac(ms_z)))
+    print("   (c) + (d) = the transform            %8.3f ms  %.3f   max |difference| to the plan's result %.2e of max |value|" % (ms_pz, frac(ms_pz), err), flush=True)
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "cube":
-        cube512()
+        cube512(2)
+        cube512(4)
     else:
         main()
-        cube512()
+        cube512(2)
+        cube512(4)
