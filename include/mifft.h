@@ -164,7 +164,8 @@ const char *mifft_last_error(void);
 #define MIFFT_DEBUG_NARROW_TILES 9 /* A/B of the round-4 tile forms: 1 = the rounds 1-3 forms -- fp32 L = 256 / 512 on 16-column tiles also in the persistent
                                     * kernel, and for split-complex planes no lane-interleaved double tiles, no register-edged rows, no fixed-shape N-D
                                     * route, no row-first 2-D kernel, no write-through in the run-time-shaped N-D kernel; 2 = 32-column tiles (and the
-                                    * double tile of a plane-writing L = 1024 pass) also in plain launches */
+                                    * double tile of a plane-writing L = 1024 pass) also in plain launches; 3 = 16-column tiles also for strided passes
+                                    * whose rows lie >= 2^16 points apart (round 6: those run on 32-column tiles by default) */
 #define MIFFT_DEBUG_NO_ROWFIRST 10 /* split-complex fp32 2-D persistent launches: 1 = two transposing passes on sibling tiles instead of the row-first kernel (A/B) */
 #define MIFFT_DEBUG_PREFETCH 11 /* persistent kernels on 512-thread tiles, `make DEV=1` builds: 1 = the work list that issues a tile's loads before the publish of
                                   * the previous one (round 6; measured equal to the round-2 list: 0.392 / 0.393 on configuration 5) */

@@ -340,7 +340,11 @@ class FFTPlan(object):
     def _plane_fused(self):
         """A 3-D transform larger than a pipeline chunk whose two leading passes are ROW x and COL y (what _slab_passes == 2 says) may
         run them as ONE persistent 2-D launch over its planes instead of slab by slab (round 6).  PYFFT_AMD_NO_PLANE_FUSED: never."""
-        return self._slab_passes == 2 and int(self._params.z) > 1 and not D.no_plane_fused()
+        p = self._params
+        # (transforms of up to half the cache -- one slab -- run their whole chain chunk-wise at the same rate: 0.244-0.265 either way,
+        # profiles/r06_i_plane_fused_probe.log)
+        return self._slab_passes == 2 and int(p.z) > 1 and p.size * p.complex_nbytes > self._context.machine.slab_bytes and \
+            not D.no_plane_fused()
 
     def _persistent_rule(self):
         """The tuning rule of this plan's persistent launch (None: it has none) under the development switches in force."""

@@ -138,7 +138,10 @@ def _chain_keys(plan, chain):
         else:
             # a strided pass: its length, whether it carries the inter-pass twiddle (M > 1), and the class of its stride (S == 1: the
             # transposing first pass of a long contiguous axis; S < 16: columns narrower than a tile; else whole 16-column tiles)
-            keys.add(("col", prec, lay, int(k.L), "twiddled" if k.M > 1 else "plain", "S1" if k.S == 1 else ("S<16" if k.S < 16 else "S>=16")))
+            # (fp32 interleaved 256 / 512 points with rows >= 2^16 points apart: the 32-column plain tiles of csrc/fft_col2_f32.hip)
+            far = prec == "f32" and lay == "interleaved" and k.L in (256, 512) and k.M == 1 and k.S >= 65536
+            keys.add(("col", prec, lay, int(k.L), "twiddled" if k.M > 1 else "plain",
+                      "S1" if k.S == 1 else ("S<16" if k.S < 16 else ("S>=65536" if far else "S>=16"))))
         i += 1
     return keys
 

@@ -883,18 +883,19 @@ def test_direct_abi_two_set_launch_refuses_capture_and_null_error_word(ctx):
     s.synchronize()
 
 # ---- round 6: the (y, x) planes of a 3-D transform bigger than a pipeline chunk on the persistent 2-D kernels ------------------------
-PLANE_FUSED_CASES = [((64, 1024, 256), numpy.complex64, 4), ((16, 2048, 512), numpy.complex64, 4), ((128, 512, 256), numpy.complex64, 4),
-                     ((64, 512, 512), numpy.complex64, 4), ((32, 1024, 512), numpy.complex64, 4), ((64, 512, 256), numpy.complex128, 4),
-                     ((16, 1024, 512), numpy.complex128, 4), ((8, 1024, 1024), numpy.float64, 4), ((512, 512, 512), numpy.complex64, 1)]
+PLANE_FUSED_CASES = [((128, 1024, 256), numpy.complex64, 2), ((32, 2048, 512), numpy.complex64, 2), ((256, 512, 256), numpy.complex64, 2),
+                     ((128, 512, 512), numpy.complex64, 2), ((64, 1024, 512), numpy.complex64, 2), ((128, 512, 256), numpy.complex128, 2),
+                     ((32, 1024, 512), numpy.complex128, 2), ((16, 1024, 1024), numpy.float64, 2), ((512, 512, 512), numpy.complex64, 1),
+                     ((256, 512, 512), numpy.complex64, 1)]
 
 
 @pytest.mark.parametrize("shape,dtype,batch", PLANE_FUSED_CASES, ids=str)
 def test_plane_fused_3d(ctx, monkeypatch, shape, dtype, batch):
-    """3-D transforms of more than 64 MiB whose chain is ROW x + COL y + COL z (no pass pair): the x and y passes run as ONE persistent
+    """3-D transforms of more than half the last-level cache whose chain is ROW x + COL y + COL z (no pass pair): the x and y passes run as ONE persistent
     launch over the batch * nz (y, x) planes -- the 2-D plan's kernel and ring --, the z pass as the chain's plain launch (strategy
     "fused2z"; rounds 1-5: the leading passes slab by slab through the pipelined launcher, or three plain launches for small batches;
     pyfft/plan.py:135-171: the reference's chain is x kernels, then y, then z).  One case per 2-D rule of the tuning table that such a
-    shape can match, and 512^3 with batch 1.  First / last transform against numpy (reference thresholds), in place == out of place,
+    shape can match, and 512^3 / (256, 512, 512) with batch 1 (their z passes run on 32-column tiles: rows 2 MiB apart).  First / last transform against numpy (reference thresholds), in place == out of place,
     input untouched, the inverse round trip, and the whole result against the plan without the route (other kernels for x and y:
     rounding-level agreement)."""
     cdt = numpy.dtype(dtype)

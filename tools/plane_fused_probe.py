@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Round 6: 3-D transforms bigger than a pipeline chunk, (y, x) planes on the persistent 2-D kernels + plain z launches (strategy
 "fused2z") against the route of rounds 1-5 (PYFFT_AMD_NO_PLANE_FUSED=1: three plain launches, or the leading passes slab by slab through the
-pipelined launcher), out of place on random data, best of three blocks of four executes between two HIP events.
+pipelined launcher), and with the far-apart rows of the z pass on 16-column tiles (MIFFT_NARROW_TILES=3), out of place on random data, best of three blocks of four executes between two HIP events.
 
     python3 tools/plane_fused_probe.py
 """
@@ -63,9 +63,9 @@ def main():
         for i, x in enumerate(a):
             fill(x, 7 + i)
         f1, s1 = run(shape, dtype, batch, {}, a, b)
-        f2, _ = run(shape, dtype, batch, {"MIFFT_NARROW_TILES": "2"}, a, b)
+        f2, _ = run(shape, dtype, batch, {"MIFFT_NARROW_TILES": "3"}, a, b)
         f0, s0 = run(shape, dtype, batch, {"PYFFT_AMD_NO_PLANE_FUSED": "1"}, a, b)
-        print("%-18s %-10s x %-3d  planes on the persistent kernel %.3f %s  (z pass on 32-column tiles: %.3f)   before %.3f %s" % (
+        print("%-18s %-10s x %-3d  planes on the persistent kernel %.3f %s  (z pass on 16-column tiles: %.3f)   before %.3f %s" % (
             shape, dtype, batch, f1, s1, f2, f0, s0), flush=True)
         del a, b
 
