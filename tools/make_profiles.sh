@@ -65,6 +65,7 @@ cp $OUT/tuning_emit.log $P/${TAG}_tuning_emit.log; cp $OUT/tuning_emitted.json $
 timeout 1500 python3 tools/persistent_counters.py > $OUT/fused3_counters.log 2>&1; cp $OUT/fused3_counters.log $P/${TAG}_fused3_counters_final.log
 timeout 900 python3 tools/planes_probe.py > $OUT/planes_probe.log 2>&1; cp $OUT/planes_probe.log $P/${TAG}_planes_probe_final.log
 timeout 600 python3 tools/three_launch_probe.py > $OUT/three_launch.log 2>&1; cp $OUT/three_launch.log $P/${TAG}_three_launch_fused_final.log
+timeout 900 python3 tools/plane_fused_probe.py > $OUT/plane_fused.log 2>&1; cp $OUT/plane_fused.log $P/${TAG}_plane_fused_probe_final.log
 timeout 600 python3 bench.py --gpus 4 --single-process --share-gpu --no-cpu-baseline > $OUT/bench_c2_single_process_4.json 2> $OUT/bench_c2_single_process_4.err
 cp $OUT/bench_c2_single_process_4.json $P/${TAG}_bench_c2_single_process_4_shards_one_gpu.json
 
