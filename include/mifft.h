@@ -251,6 +251,8 @@ int mifft_nd_max_points_for(int32_t precision);
 #define MIFFT_VARIANT_SPLIT_ONLY 3
 #define MIFFT_VARIANT_OUT_OF_PLACE_ONLY 4
 #define MIFFT_VARIANT_OUT_OF_PLACE_ANY_SIZE 5 /* ... and that kernel is the better choice at EVERY buffer size (else: beyond half the last-level cache per side) */
+#define MIFFT_VARIANT_SPLIT_OUT_OF_PLACE 6 /* round 6: the same for split-complex planes on both sides (csrc/fft_nd2zp.hpp) ... */
+#define MIFFT_VARIANT_SPLIT_OUT_OF_PLACE_ANY_SIZE 7 /* ... and at every buffer size */
 int mifft_nd_shape_supported(int32_t precision, int32_t x, int32_t y, int32_t z, int32_t variant);
 
 /* 0 if a compiled kernel exists for (kind, precision, L, variant), else MIFFT_E_UNSUPPORTED.

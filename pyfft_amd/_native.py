@@ -25,6 +25,8 @@ VARIANT_INTERLEAVED_ONLY = 2
 VARIANT_SPLIT_ONLY = 3
 VARIANT_OUT_OF_PLACE_ONLY = 4     # mifft_nd_shape_supported: several work-groups per transform, interleaved, input != output
 VARIANT_OUT_OF_PLACE_ANY_SIZE = 5  # ... and preferred at every buffer size
+VARIANT_SPLIT_OUT_OF_PLACE = 6       # planes on both sides, out of place: several work-groups per transform (csrc/fft_nd2zp.hpp)
+VARIANT_SPLIT_OUT_OF_PLACE_ANY_SIZE = 7
 PASS_COL, PASS_ROW, PASS_ND = 0, 1, 2
 FLAG_SRC_INTERLEAVED, FLAG_DST_INTERLEAVED = 1, 2
 FLAG_STREAM_SRC, FLAG_STREAM_DST = 4, 8

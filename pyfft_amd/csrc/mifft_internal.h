@@ -49,6 +49,7 @@ int mifft_nd2t(int f64, int x, int y, int z, const mifft::TileArgs* a, const mif
 int mifft_nd2t_split_in(int f64, int x, int y, int z, const mifft::TileArgs* a, const mifft::TiledGeom* g, hipStream_t s, int query);
 int mifft_nd2t_split(int f64, int x, int y, int z, const mifft::TileArgs* a, const mifft::TiledGeom* g, hipStream_t s, int query);
 int mifft_nd2p(int f64, int x, int y, int z, const mifft::TileArgs* a, hipStream_t s, int query);     // fft_nd2p.hip: dense planes, 16-byte accesses
+int mifft_nd2zp(int f64, int x, int y, int z, const mifft::TileArgs* a, hipStream_t s, int query);    // fft_nd2zp.hip: the same with several work-groups per transform (out of place)
 int mifft_mixed_supported_impl(int f64, int n);
 int mifft_mixed_launch(int f64, int n, long long rows, long long stride_in, long long stride_out, long long inner, const void* in,
                        void* out, const void* tw, int flags, double scale, hipStream_t s);

@@ -263,6 +263,25 @@ int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0,
     // Round 6: planes on BOTH sides of a published shape: the dense kernel that moves 16 bytes per lane and plane (fft_nd2p.hpp); the tiled
     // kernel below moves one scalar per lane and plane through the tiling's address arithmetic (0.69-0.86 of the interleaved twin at 1 GiB).
     // MIFFT_DEBUG_ALT_ROWS = 7: the tiled kernel (A/B)
+    // ... and its one-tile-per-CU shapes as two half-size work-groups per transform, out of place (fft_nd2zp.hpp; MIFFT_DEBUG_ALT_ROWS = 6:
+    // never several work-groups per transform, as for interleaved data)
+    if (p->layout == MIFFT_SPLIT && !(p->flags & (MIFFT_FLAG_SRC_INTERLEAVED | MIFFT_FLAG_DST_INTERLEAVED)) && !no_nd2 && in1 && out1 &&
+        in0 != out0 && in1 != out1 && g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 && g_debug[MIFFT_DEBUG_ALT_ROWS] != 7 &&
+        g_debug[MIFFT_DEBUG_ALT_ROWS] != 6 && mifft_nd2zp(f64nd ? 1 : 0, (int)p->L, (int)p->M, (int)p->S, nullptr, nullptr, 1) == 0) {
+        mifft::TileArgs t;
+        memset(&t, 0, sizeof(t));
+        t.in0 = in0; t.in1 = in1; t.out0 = out0; t.out1 = out1;
+        t.split = 1; t.split_out = 1;
+        t.tw_L = p->tw_L; t.tw_lo = p->tw_lo; t.tw_hi = p->tw_hi;
+        t.total = p->outer * p->L * p->M * p->S;
+        t.inverse = p->inverse ? 1 : 0;
+        t.scale = p->scale;
+        t.nt = stream_policy(p->flags);
+        const int rc = mifft_nd2zp(f64nd ? 1 : 0, (int)p->L, (int)p->M, (int)p->S, &t, s, 0);
+        if (rc == -1) return set_err(MIFFT_E_INVALID, "grid too large");
+        if (rc != 0) return hip_check((hipError_t)rc, "kernel launch");
+        return 0;
+    }
     if (p->layout == MIFFT_SPLIT && !(p->flags & (MIFFT_FLAG_SRC_INTERLEAVED | MIFFT_FLAG_DST_INTERLEAVED)) && !no_nd2 && in1 && out1 &&
         g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 && g_debug[MIFFT_DEBUG_ALT_ROWS] != 7 &&
         mifft_nd2p(f64nd ? 1 : 0, (int)p->L, (int)p->M, (int)p->S, nullptr, nullptr, (p->flags & MIFFT_FLAG_WRITE_THROUGH) ? 2 : 1) == 0) {
@@ -691,6 +710,12 @@ int mifft_nd_shape_supported(int32_t precision, int32_t x, int32_t y, int32_t z,
         // interleaved on both sides AND out of place: several work-groups per transform (fft_nd2z.hpp)
         return (g_debug[MIFFT_DEBUG_NO_ND2] == 0 && g_debug[MIFFT_DEBUG_ALT_ROWS] != 6 &&
                 mifft_nd2z(precision == MIFFT_F64 ? 1 : 0, x, y, z, nullptr, nullptr, variant == MIFFT_VARIANT_OUT_OF_PLACE_ONLY ? 1 : 2) == 0)
+                   ? 0 : MIFFT_E_UNSUPPORTED;
+    if (variant == MIFFT_VARIANT_SPLIT_OUT_OF_PLACE || variant == MIFFT_VARIANT_SPLIT_OUT_OF_PLACE_ANY_SIZE)
+        // planes on both sides AND out of place: several work-groups per transform on 16-byte plane accesses (fft_nd2zp.hpp)
+        return (g_debug[MIFFT_DEBUG_NO_ND2] == 0 && g_debug[MIFFT_DEBUG_ALT_ROWS] != 6 && g_debug[MIFFT_DEBUG_ALT_ROWS] != 7 &&
+                g_debug[MIFFT_DEBUG_NARROW_TILES] != 1 &&
+                mifft_nd2zp(precision == MIFFT_F64 ? 1 : 0, x, y, z, nullptr, nullptr, variant == MIFFT_VARIANT_SPLIT_OUT_OF_PLACE ? 1 : 2) == 0)
                    ? 0 : MIFFT_E_UNSUPPORTED;
     if (variant != MIFFT_VARIANT_INTERLEAVED_ONLY) return MIFFT_E_UNSUPPORTED;
     const int rc = precision == MIFFT_F64 ? mifft_nd2_f64_supported(x, y, z) : mifft_nd2_f32_supported(x, y, z);

@@ -178,12 +178,15 @@ class FFTPlan(object):
         self._oop_nd = None
         self._oop_tables = None
         self._oop_any_size = False
-        if not p.split and len(P.launch_units(self._kernels)) >= 2 and \
-                N.lib.mifft_nd_shape_supported(p.precision, int(p.x), int(p.y), int(p.z), N.VARIANT_OUT_OF_PLACE_ONLY) == 0:
+        # (round 6: split-complex planes likewise, csrc/fft_nd2zp.hpp)
+        v_oop, v_any = (N.VARIANT_SPLIT_OUT_OF_PLACE, N.VARIANT_SPLIT_OUT_OF_PLACE_ANY_SIZE) if p.split else \
+            (N.VARIANT_OUT_OF_PLACE_ONLY, N.VARIANT_OUT_OF_PLACE_ANY_SIZE)
+        if len(P.launch_units(self._kernels)) >= 2 and \
+                N.lib.mifft_nd_shape_supported(p.precision, int(p.x), int(p.y), int(p.z), v_oop) == 0:
             self._oop_nd = [P.PassSpec(N.PASS_ND, P.X_DIRECTION, p.size, int(p.x), int(p.y), int(p.z), 1, p.size, True)]
             self._oop_tables = self._pass_tables(self._oop_nd)
             # (two halves on two-per-CU tiles: better than the two launches at every size; four quarters: beyond half the cache per side)
-            self._oop_any_size = N.lib.mifft_nd_shape_supported(p.precision, int(p.x), int(p.y), int(p.z), N.VARIANT_OUT_OF_PLACE_ANY_SIZE) == 0
+            self._oop_any_size = N.lib.mifft_nd_shape_supported(p.precision, int(p.x), int(p.y), int(p.z), v_any) == 0
         # 3-D shapes whose chain is a plane pass + a strided z pass but that have a persistent two-pair kernel (64- and 128-point axes,
         # csrc/fft_fusedp2.hip): the four-pass list with the y axis factored R0 x R1 exists for that launch alone
         self._pair_alt = None

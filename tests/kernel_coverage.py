@@ -96,6 +96,19 @@ def nd2p_shapes(prec):
     return _tables["nd2p"][prec]
 
 
+def nd2zp_shapes(prec):
+    """(x, y, z) with a several-work-groups-per-transform instance for dense split-complex planes, read off csrc/fft_nd2zp.hip"""
+    if "nd2zp" not in _tables:
+        import os
+        import re
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pyfft_amd", "csrc", "fft_nd2zp.hip")
+        text = "\n".join(l for l in open(path).read().splitlines() if not l.lstrip().startswith("//") and "#define" not in l)
+        _tables["nd2zp"] = {name: frozenset(tuple(int(v) for v in m.groups())
+                                              for m in re.finditer(r"SHAPE\(%s,\s*\d,\s*(\d+),\s*(\d+),\s*(\d+)\)" % ctype, text))
+                            for name, ctype in (("f32", "float"), ("f64", "double"))}
+    return _tables["nd2zp"][prec]
+
+
 def _nd_key(prec, lay, x, y, z):
     """The instance an N-D pass of this shape runs: the shape's own fixed instance (interleaved: the generated tables; planes: the tiled
     fixed-shape kernel where it takes dense planes), else the ONE run-time-shaped kernel, whose instances differ by the tile's size class."""
@@ -184,7 +197,10 @@ def keys_of(shape, dtype, batch, mode="auto"):
     p = plan._params
     prec = "f64" if p.precision == N.F64 else "f32"
     if plan._runs_oop_nd(int(batch)):
-        keys.add(("nd_oop", prec, int(p.x), int(p.y), int(p.z)))
+        keys.add(("nd_oop", prec + ("_planes" if p.split else ""), int(p.x), int(p.y), int(p.z)))
+    # a one-launch plan of split-complex planes with a several-work-groups instance (csrc/fft_nd2zp.hip): its out-of-place executes
+    if p.split and len(plan._kernels) == 1 and plan._kernels[0].kind == N.PASS_ND and (int(p.x), int(p.y), int(p.z)) in nd2zp_shapes(prec):
+        keys.add(("nd2zp", prec, int(p.x), int(p.y), int(p.z)))
     # a one-launch plan of a shape with a several-work-groups-per-transform instance: its OUT-OF-PLACE executes take that instance inside
     # the library (csrc/mifft_runtime.cpp launch_nd; small launches only for some shapes -- the tests assert which)
     if not p.split and len(plan._kernels) == 1 and plan._kernels[0].kind == N.PASS_ND and (int(p.x), int(p.y), int(p.z)) in nd2z_shapes(prec):
@@ -358,6 +374,7 @@ REGISTRY = {
         "test_two_work_groups_per_transform_nd": "nd2z",        # (the shapes are a list inside the module: see collected_cases)
         "test_four_work_groups_per_transform_out_of_place": lambda p: [
             _c(p["shape"], p["dtype"], (261 * 65536 * 8) // (_prod(p["shape"]) * numpy.dtype(p["dtype"]).itemsize))],
+        "test_two_work_groups_per_transform_split_planes": lambda p: [_c(p["shape"], F32, 13 if p["small"] else (261 * 65536 * 8) // (_prod(p["shape"]) * 8))],
         "test_tiny_nd_shapes_small_launches": lambda p: [_c(p["shape"], p["dtype"], p["batch"])],
         "test_tiny_nd_shapes_big_launches": lambda p: [_c(p["shape"], p["dtype"], p["batch"])],
         "test_run_time_shaped_nd_kernel_size_classes": lambda p: [_c(p["shape"], p["dtype"], 5 if _prod(p["shape"]) >= 4096 else 4099 // _prod(p["shape"]))],

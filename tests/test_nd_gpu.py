@@ -120,6 +120,67 @@ def test_four_work_groups_per_transform_out_of_place(ctx, shape, dtype, monkeypa
     assert numpy.abs(a.get().astype(numpy.complex128) - data).sum() / numpy.abs(data).sum() < EPS
 
 
+# ---- round 6: the same for split-complex planes (csrc/fft_nd2zp.hpp) ------------------------------------------------------------------------
+OOP_ND_SPLIT_CASES = [(128, 256), (256, 128), (512, 64), (64, 512), (16, 2048), (2048, 16), (8, 64, 64), (64, 8, 64), (16, 128, 16),
+                      (128, 16, 16), (16, 32, 64), (32, 16, 64), (16, 64, 32), (64, 16, 32), (32, 64, 16), (16, 16, 128)]
+
+
+@pytest.mark.parametrize("shape", OOP_ND_SPLIT_CASES, ids=lambda v: "x".join(map(str, v)))
+@pytest.mark.parametrize("small", [False, True], ids=["large", "small"])
+def test_two_work_groups_per_transform_split_planes(ctx, shape, small, monkeypatch):
+    """float32 planes (pyfft/plan.py:26-35) of the 32768-point shapes: out of place ONE launch on two half-size work-groups per transform
+    that move 16 bytes per lane and plane (csrc/fft_nd2zp.hpp); in place the plan's chain ((16, 16, 128): its one-tile kernel).  A large
+    launch (130 MiB per side: non-temporal stores) and a small ragged one (write-through stores, the last group of eight transforms
+    partly empty): the reference's thresholds against numpy on sampled transforms, input untouched, the in-place result and the
+    interleaved twin to rounding, the route switched off (PYFFT_AMD_NO_OOP_ND / MIFFT_DEBUG_ALT_ROWS = 6), the inverse."""
+    from pyfft_amd import _native as N
+    hip = ctx.hip
+    size = int(numpy.prod(shape))
+    batch = 13 if small else (261 * 65536 * 8) // (size * 8)
+    rng = numpy.random.default_rng(4700 + shape[0] + small)
+    re = _noise(rng, size * batch, numpy.float32)
+    im = _noise(rng, size * batch, numpy.float32)
+    plan = hip.Plan(shape, dtype=numpy.float32)
+    one_launch = len(plan.pass_list()) == 1
+    assert one_launch == (shape == (16, 16, 128)) and (one_launch or plan._oop_nd is not None), plan.pass_list()
+    assert one_launch or plan.strategy(batch, inplace=False) == ("nd_oop",), plan.strategy(batch, inplace=False)
+    a_re, a_im = hip.to_gpu(re), hip.to_gpu(im)
+    b_re, b_im = hip.DeviceArray((size * batch,), numpy.float32), hip.DeviceArray((size * batch,), numpy.float32)
+    plan.execute(a_re, a_im, b_re, b_im, batch=batch)
+    got = b_re.get().astype(numpy.complex128) + 1j * b_im.get()
+    assert numpy.array_equal(a_re.get(), re) and numpy.array_equal(a_im.get(), im), "input modified"
+    x = re.astype(numpy.complex128) + 1j * im
+    for item in sorted({0, 1, 7, 8, 9, batch // 2, batch - 6, batch - 5, batch - 1}):
+        sl = slice(item * size, (item + 1) * size)
+        ref = numpy.fft.fftn(x[sl].reshape(shape)).reshape(-1)
+        assert numpy.abs(ref - got[sl]).sum() / numpy.abs(ref).sum() < EPS_F, (shape, item)
+        assert numpy.abs(ref - got[sl]).max() <= MAX_F * numpy.abs(ref).max(), (shape, item)
+    c_re, c_im = hip.to_gpu(re), hip.to_gpu(im)
+    plan.execute(c_re, c_im, batch=batch)                         # in place: the chain / the one-tile kernel
+    inplace = c_re.get().astype(numpy.complex128) + 1j * c_im.get()
+    assert numpy.abs(inplace - got).sum() / numpy.abs(got).sum() < 5e-7
+    twin = hip.Plan(shape, dtype=numpy.complex64)
+    t_in = hip.to_gpu((re + 1j * im).astype(numpy.complex64))
+    t_out = hip.DeviceArray((size * batch,), numpy.complex64)
+    twin.execute(t_in, t_out, batch=batch)
+    assert numpy.abs(t_out.get().astype(numpy.complex128) - got).sum() / numpy.abs(got).sum() < 5e-7
+    # the route switched off: the result of the in-place execute bit for bit
+    if one_launch:
+        N.check(N.lib.mifft_debug_set(N.DEBUG_ALT_ROWS, 6), "debug_set")
+    else:
+        monkeypatch.setenv("PYFFT_AMD_NO_OOP_ND", "1")
+    try:
+        d_re, d_im = hip.DeviceArray((size * batch,), numpy.float32), hip.DeviceArray((size * batch,), numpy.float32)
+        hip.Plan(shape, dtype=numpy.float32).execute(a_re, a_im, d_re, d_im, batch=batch)
+        assert numpy.array_equal(d_re.get().astype(numpy.complex128) + 1j * d_im.get(), inplace)
+    finally:
+        N.check(N.lib.mifft_debug_set(N.DEBUG_ALT_ROWS, 0), "debug_set")
+        monkeypatch.delenv("PYFFT_AMD_NO_OOP_ND", raising=False)
+    plan.execute(b_re, b_im, a_re, a_im, batch=batch, inverse=True)     # inverse, out of place
+    back = a_re.get().astype(numpy.complex128) + 1j * a_im.get()
+    assert numpy.abs(back - x).sum() / numpy.abs(x).sum() < EPS_F
+
+
 # ---- tiny one-launch N-D shapes routed to the run-time-shaped kernel (tuning table "nd_generic") -------------------------------------------
 @pytest.mark.parametrize("shape,dtype,batch", [((16, 2), numpy.complex64, 37), ((2, 8), numpy.complex64, 100), ((4, 4), numpy.complex128, 61)],
                          ids=lambda v: getattr(v, "__name__", str(v)).replace(" ", ""))

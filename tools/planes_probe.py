@@ -15,6 +15,9 @@ from pyfft_amd import _native as N                      # noqa: E402
 from pyfft_amd.hip import DeviceArray, Plan, device_props      # noqa: E402
 
 SHAPES = [(16, 16), (32, 32), (64, 64), (128, 128), (16, 16, 16), (8, 8, 64), (16, 16, 128), (32, 32, 32)]
+# float32 shapes of 32768 points: out of place on two half-size work-groups per transform (csrc/fft_nd2zp.hpp); `python3 tools/planes_probe.py halves`
+HALVES = [(16, 16, 128), (128, 256), (256, 128), (512, 64), (64, 512), (16, 2048), (2048, 16), (8, 64, 64), (64, 8, 64), (16, 128, 16), (128, 16, 16),
+          (16, 32, 64), (32, 16, 64), (16, 64, 32), (64, 16, 32), (32, 64, 16)]
 
 
 def fill(buf, seed):
@@ -63,8 +66,8 @@ def main():
     for side, name in ((1 << 30, "1 GiB per side"), (32 << 20, "32 MiB per side (the reference's protocol)")):
         print("## " + name)
         for cd, rd in ((numpy.complex64, numpy.float32), (numpy.complex128, numpy.float64)):
-            for shape in SHAPES:
-                if rd == numpy.float64 and int(numpy.prod(shape)) > 16384:
+            for shape in (HALVES if "halves" in sys.argv[1:] else SHAPES):
+                if rd == numpy.float64 and (int(numpy.prod(shape)) > 16384 or "halves" in sys.argv[1:]):
                     continue
                 twin, lt = measure(shape, cd, side, 0)
                 new, ln = measure(shape, rd, side, 0)
