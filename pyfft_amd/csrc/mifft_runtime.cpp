@@ -85,7 +85,9 @@ int validate(const mifft_pass* p) {
         // (interleaved shapes that exist out of place only: launch_nd refuses an in-place call, with its own message)
         if (n < 4 || (mifft_nd_shape_supported(p->precision, p->L, (int32_t)p->M, (int32_t)p->S,
                                                both_interleaved ? MIFFT_VARIANT_INTERLEAVED_ONLY : both_split ? MIFFT_VARIANT_SPLIT_ONLY : 0) != 0 &&
-                      !(both_interleaved && mifft_nd_shape_supported(p->precision, p->L, (int32_t)p->M, (int32_t)p->S, MIFFT_VARIANT_OUT_OF_PLACE_ONLY) == 0)))
+                      !(both_interleaved && mifft_nd_shape_supported(p->precision, p->L, (int32_t)p->M, (int32_t)p->S, MIFFT_VARIANT_OUT_OF_PLACE_ONLY) == 0) &&
+                      !(both_split && !(p->flags & MIFFT_FLAG_DST_INTERLEAVED) &&
+                        mifft_nd_shape_supported(p->precision, p->L, (int32_t)p->M, (int32_t)p->S, MIFFT_VARIANT_SPLIT_OUT_OF_PLACE) == 0)))
             return set_err(MIFFT_E_UNSUPPORTED, "ND pass: no kernel for %d x %lld x %lld (%lld points)", p->L, (long long)p->M, (long long)p->S, n);
         if ((p->L > 1 && !p->tw_L) || (p->M > 1 && !p->tw_lo) || (p->S > 1 && !p->tw_hi)) return set_err(MIFFT_E_INVALID, "ND pass: twiddle table missing");
         return 0;
@@ -321,8 +323,8 @@ int launch_nd(const mifft_pass* p, const void* in0, const void* in1, void* out0,
         return 0;
     }
     if ((long long)p->L * p->M * p->S > mifft_nd_max_points(f64nd))
-        return set_err(MIFFT_E_UNSUPPORTED, "ND pass %d x %d x %d: this shape has a one-launch kernel for interleaved data out of place only "
-                       "(several work-groups per transform, mifft_nd_shape_supported with MIFFT_VARIANT_OUT_OF_PLACE_ONLY)",
+        return set_err(MIFFT_E_UNSUPPORTED, "ND pass %d x %d x %d: this shape has a one-launch kernel out of place only, for interleaved data or planes on both sides "
+                       "(several work-groups per transform, mifft_nd_shape_supported with MIFFT_VARIANT_OUT_OF_PLACE_ONLY / _SPLIT_OUT_OF_PLACE)",
                        (int)p->S, (int)p->M, (int)p->L);
     mifft::NdArgs a;
     memset(&a, 0, sizeof(a));
