@@ -104,7 +104,7 @@ def nd2zp_shapes(prec):
         path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pyfft_amd", "csrc", "fft_nd2zp.hip")
         text = "\n".join(l for l in open(path).read().splitlines() if not l.lstrip().startswith("//") and "#define" not in l)
         _tables["nd2zp"] = {name: frozenset(tuple(int(v) for v in m.groups())
-                                              for m in re.finditer(r"SHAPE\(%s,\s*\d,\s*(\d+),\s*(\d+),\s*(\d+)\)" % ctype, text))
+                                              for m in re.finditer(r"SHAPE[L4]?\(%s,\s*\d,\s*(\d+),\s*(\d+),\s*(\d+)\)" % ctype, text))
                             for name, ctype in (("f32", "float"), ("f64", "double"))}
     return _tables["nd2zp"][prec]
 

@@ -122,14 +122,17 @@ def test_four_work_groups_per_transform_out_of_place(ctx, shape, dtype, monkeypa
 
 # ---- round 6: the same for split-complex planes (csrc/fft_nd2zp.hpp) ------------------------------------------------------------------------
 OOP_ND_SPLIT_CASES = [(128, 256), (256, 128), (512, 64), (64, 512), (16, 2048), (2048, 16), (8, 64, 64), (64, 8, 64), (16, 128, 16),
-                      (128, 16, 16), (16, 32, 64), (32, 16, 64), (16, 64, 32), (64, 16, 32), (32, 64, 16), (16, 16, 128)]
+                      (128, 16, 16), (16, 32, 64), (32, 16, 64), (16, 64, 32), (64, 16, 32), (32, 64, 16), (16, 16, 128),
+                      # 65536 points: four quarters, in large launches
+                      (256, 256), (512, 128), (1024, 64), (64, 1024), (16, 64, 64)]
+OOP_ND_SPLIT_LARGE_ONLY = {(64, 512), (256, 256), (512, 128), (1024, 64), (64, 1024), (16, 64, 64)}
 
 
 @pytest.mark.parametrize("shape", OOP_ND_SPLIT_CASES, ids=lambda v: "x".join(map(str, v)))
 @pytest.mark.parametrize("small", [False, True], ids=["large", "small"])
 def test_two_work_groups_per_transform_split_planes(ctx, shape, small, monkeypatch):
-    """float32 planes (pyfft/plan.py:26-35) of the 32768-point shapes: out of place ONE launch on two half-size work-groups per transform
-    that move 16 bytes per lane and plane (csrc/fft_nd2zp.hpp); in place the plan's chain ((16, 16, 128): its one-tile kernel).  A large
+    """float32 planes (pyfft/plan.py:26-35) of the 32768- / 65536-point shapes: out of place ONE launch on two half-size (four quarter-size)
+    work-groups per transform that move 16 bytes per lane and plane (csrc/fft_nd2zp.hpp); in place the plan's chain ((16, 16, 128): its one-tile kernel).  A large
     launch (130 MiB per side: non-temporal stores) and a small ragged one (write-through stores, the last group of eight transforms
     partly empty): the reference's thresholds against numpy on sampled transforms, input untouched, the in-place result and the
     interleaved twin to rounding, the route switched off (PYFFT_AMD_NO_OOP_ND / MIFFT_DEBUG_ALT_ROWS = 6), the inverse."""
@@ -143,6 +146,11 @@ def test_two_work_groups_per_transform_split_planes(ctx, shape, small, monkeypat
     plan = hip.Plan(shape, dtype=numpy.float32)
     one_launch = len(plan.pass_list()) == 1
     assert one_launch == (shape == (16, 16, 128)) and (one_launch or plan._oop_nd is not None), plan.pass_list()
+    # ((64, 512) loses to its two launches at 32 MiB, the 65536-point shapes like their interleaved twins: large launches only)
+    assert plan._oop_any_size == (shape not in OOP_ND_SPLIT_LARGE_ONLY) or one_launch
+    if not one_launch and not plan._oop_any_size and small:
+        assert plan.strategy(batch, inplace=False)[0] == "chain"
+        return
     assert one_launch or plan.strategy(batch, inplace=False) == ("nd_oop",), plan.strategy(batch, inplace=False)
     a_re, a_im = hip.to_gpu(re), hip.to_gpu(im)
     b_re, b_im = hip.DeviceArray((size * batch,), numpy.float32), hip.DeviceArray((size * batch,), numpy.float32)

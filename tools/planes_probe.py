@@ -17,7 +17,7 @@ from pyfft_amd.hip import DeviceArray, Plan, device_props      # noqa: E402
 SHAPES = [(16, 16), (32, 32), (64, 64), (128, 128), (16, 16, 16), (8, 8, 64), (16, 16, 128), (32, 32, 32)]
 # float32 shapes of 32768 points: out of place on two half-size work-groups per transform (csrc/fft_nd2zp.hpp); `python3 tools/planes_probe.py halves`
 HALVES = [(16, 16, 128), (128, 256), (256, 128), (512, 64), (64, 512), (16, 2048), (2048, 16), (8, 64, 64), (64, 8, 64), (16, 128, 16), (128, 16, 16),
-          (16, 32, 64), (32, 16, 64), (16, 64, 32), (64, 16, 32), (32, 64, 16)]
+          (16, 32, 64), (32, 16, 64), (16, 64, 32), (64, 16, 32), (32, 64, 16), (256, 256), (512, 128), (1024, 64), (64, 1024), (16, 64, 64)]
 
 
 def fill(buf, seed):
