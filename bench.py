@@ -652,6 +652,15 @@ def main():
     del host_re, host_im
 
     plan = Plan(shape if len(shape) > 1 else shape[0], dtype=dtype, wait_for_finish=False)
+    # every execute() of this process is counted (parity gate, spin-up, warm-up, timed steps ...): the profiler runs of
+    # tools/pmc_traffic.py divide the counters of the whole process by this number
+    executes_total = [0]
+    _plan_execute = plan.execute
+
+    def _counted_execute(*a, **k):
+        executes_total[0] += 1
+        return _plan_execute(*a, **k)
+    plan.execute = _counted_execute
     _trace("device buffers filled, plan built")
     stream = plan._context.getQueue()
 
@@ -983,6 +992,7 @@ def main():
             "ranks": rank_report,
             "passes": [repr(p) for p in timed_passes], "strategy": strategy[0]},
         "transforms_per_s": total_xforms / elapsed,
+        "executes_in_this_process": executes_total[0],
         "algorithmic_GBps": alg_gbs,
         "hbm_fraction_of_8TBps": alg_gbs / world / HBM_PEAK_GBS,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

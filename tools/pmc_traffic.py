@@ -23,7 +23,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEPS, WARMUP = 3, 1
-EXECUTES = 1 + WARMUP + STEPS            # parity gate + warm-up + timed (the counter runs)
+# (the number of executes of a run -- parity gate, clock spin-up, warm-up, timed steps -- is what bench.py itself counted:
+# "executes_in_this_process" of its line; rounds 1-5 assumed 1 + WARMUP + STEPS, which the spin-up of round 6 made wrong)
 STATS_STEPS = 12                         # the kernel-stats run: enough warm calls that the two cold ones (parity gate, warm-up)
                                          # move the average by < 2 %; the csv's MinNs column is the warm figure
 
@@ -74,27 +75,27 @@ def main():
         line = run("stats", cfg, os.path.join(scratch, cfg, "stats"))
         for fn in glob.glob(os.path.join(scratch, cfg, "stats") + "/**/*kernel_stats.csv", recursive=True):
             shutil.copy(fn, os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, cfg)))
-        run("FETCH_SIZE", cfg, os.path.join(scratch, cfg, "fetch"))
-        run("WRITE_SIZE", cfg, os.path.join(scratch, cfg, "write"))
+        ef = run("FETCH_SIZE", cfg, os.path.join(scratch, cfg, "fetch"))["executes_in_this_process"]
+        ew = run("WRITE_SIZE", cfg, os.path.join(scratch, cfg, "write"))["executes_in_this_process"]
         fetch_kib, nf = counter_sum(os.path.join(scratch, cfg, "fetch"), "FETCH_SIZE")
         write_kib, nw = counter_sum(os.path.join(scratch, cfg, "write"), "WRITE_SIZE")
         alg = line["roofline"]["algorithmic_bytes_per_step"]
-        traffic = (2.0 * fetch_kib + write_kib) * 1024.0 / EXECUTES
+        traffic = (2.0 * fetch_kib / ef + write_kib / ew) * 1024.0
         out = {"hbm_bytes_per_step": traffic,
                "traffic_over_algorithmic": traffic / alg,
                "strategy": line["config"]["strategy"],
                "algorithmic_bytes_per_step": alg,
-               "fetch_KiB_raw_per_step": fetch_kib / EXECUTES, "write_KiB_per_step": write_kib / EXECUTES,
-               "dispatches_counted": [nf, nw], "executes_per_run": EXECUTES,
+               "fetch_KiB_raw_per_step": fetch_kib / ef, "write_KiB_per_step": write_kib / ew,
+               "dispatches_counted": [nf, nw], "executes_per_run": [ef, ew],
                "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --config %s --plain --steps %d --warmup %d%s" % (cfg, STEPS, WARMUP, " --chunk-only" if cfg == "c5" else ""),
-               "method": "tools/pmc_traffic.py: separate passes per counter, every mifft:: dispatch of the run summed and divided by the %d executes; FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B); L2<->fabric bytes, Infinity-Cache hits included" % EXECUTES,
+               "method": "tools/pmc_traffic.py: separate passes per counter, every mifft:: dispatch of the run summed and divided by the executes bench.py counted in that run; FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B); L2<->fabric bytes, Infinity-Cache hits included",
                "bench_frac_under_profiler": line["roofline"]["frac"],
                # what was measured: the library by content, the tree by the commit gpurun shipped (.tree_commit, written by the caller:
                # `git rev-parse HEAD > .tree_commit` -- the GPU box has no .git)
                "libmifft_sha256_16": library_digest(), "commit": tree_commit()}
         json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_%s.json" % cfg), "w"), indent=1)
         print("%s: strategy %s  traffic %.3f x algorithmic  (fetch x2 %.2f GiB + write %.2f GiB per step)" % (
-            cfg, out["strategy"], out["traffic_over_algorithmic"], 2 * fetch_kib / EXECUTES / 2**20, write_kib / EXECUTES / 2**20), flush=True)
+            cfg, out["strategy"], out["traffic_over_algorithmic"], 2 * fetch_kib / ef / 2**20, write_kib / ew / 2**20), flush=True)
 
 
 if __name__ == "__main__":
