@@ -1,5 +1,5 @@
 """Counterpart of the reference's test/test_performance.py: the 11 published shapes, batch chosen to fill a
-32 MiB buffer (test_performance.py:11), 1 warm-up + 10 timed out-of-place executes, GFLOPS by
+32 MiB buffer (test_performance.py:11), warm-up + 10 timed out-of-place executes (median of 5 such blocks), GFLOPS by
 5e-9 * (log2 x + log2 y + log2 z) * x*y*z * batch / t (test_performance.py:24).  Prints a table next to the
 reference's published Tesla C2050 numbers (doc/source/index.rst:357-373)."""
 import sys, os
@@ -44,11 +44,15 @@ def run(shape, double, buffer_mib, split=False):
         for _ in range(16):
             plan.execute(*bufs, batch=batch, wait_for_finish=False)
         plan.finish()
-    e0 = Event().record(st)
-    for _ in range(10):
-        plan.execute(*bufs, batch=batch, wait_for_finish=False)
-    e1 = Event().record(st); e1.synchronize()
-    t = e1.time_since(e0) / 1e3 / 10
+    # the reference times ONE block of 10 executes; a block is 100 us here and a single hiccup moves a row by a third, so: the median of 5
+    ts = []
+    for _ in range(5):
+        e0 = Event().record(st)
+        for _ in range(10):
+            plan.execute(*bufs, batch=batch, wait_for_finish=False)
+        e1 = Event().record(st); e1.synchronize()
+        ts.append(e1.time_since(e0) / 1e3 / 10)
+    t = sorted(ts)[2]
     return batch, t, gflop / t
 
 if __name__ == "__main__":
