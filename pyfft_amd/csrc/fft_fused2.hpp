@@ -70,6 +70,9 @@ __device__ __forceinline__ unsigned fused_xcc_id() {
 // X owes a tile of transform T and waits for U while Y owes a tile of U and waits for T -- measured as dependency time-outs.)
 struct FusedPending {
     unsigned* ctr;   // wdone counter still to be bumped, or nullptr
+#ifdef MIFFT_DEV_BUILD
+    unsigned max_spins;   // `make DEV=1`: the longest dependency wait of this work-group in polls (tools/spin_margin.py)
+#endif
 };
 
 // wait until *ctr >= target (one lane polls, bounded); ACQ: also make other work-groups' published data visible.
@@ -94,6 +97,9 @@ template <bool ACQ> __device__ __forceinline__ void fused_wait_ge(unsigned* ctr,
                 break;
             }
         }
+#ifdef MIFFT_DEV_BUILD
+        if (spins > pend.max_spins) pend.max_spins = spins;
+#endif
         if constexpr (ACQ) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -275,9 +281,14 @@ __device__ __forceinline__ void fused_loop(const FusedCtl& f, unsigned* s_item, 
             f.counters_next[i * kFusedCS + 1u] = 0u;
         }
     }
-    FusedPending pend = {nullptr};
+    FusedPending pend = {};
     if constexpr (XCD == 0) {
         fused_list<PER0, PER1, EARLY>(f, s_item, tile0, tile1, pend, 0u, 1u, f.batch, f.counters);
+#ifdef MIFFT_DEV_BUILD
+        // word 2 of the ticket line: the longest dependency wait of the launches on this counter set, in polls of ~1 us (the time-out is
+        // 2^22); nothing else writes it, and only a memset of the set clears it
+        if (threadIdx.x == 0 && pend.max_spins) __hip_atomic_fetch_max(f.counters + 2, pend.max_spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     } else {
         // ticket counter of XCD x on its own line behind the dependency counters
         const unsigned home = fused_xcc_id();
