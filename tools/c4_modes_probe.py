@@ -38,13 +38,8 @@ def main():
                 done += m
             plan.timed_execute(2, False, False, batch, [a, None], [b, None])
             ms = [plan.timed_execute(3, False, False, batch, [a, None], [b, None]) / 3 for _ in range(3)]
-            # the same allocation with every XCD on a contiguous eighth of each launch's tiles (MIFFT_DEBUG_ALT_ROWS = 8, A/B)
-            N.check(N.lib.mifft_debug_set(N.DEBUG_ALT_ROWS, 8), "debug_set")
-            plan.timed_execute(1, False, False, batch, [a, None], [b, None])
-            ms8 = [plan.timed_execute(3, False, False, batch, [a, None], [b, None]) / 3 for _ in range(3)]
-            N.check(N.lib.mifft_debug_set(N.DEBUG_ALT_ROWS, 0), "debug_set")
-            print("pad %11d B  in %#x  out %#x   ms per step %s   XCD-contiguous tiles %s   %s" % (
-                pad_bytes, a.ptr, b.ptr, " ".join("%.3f" % m for m in ms), " ".join("%.3f" % m for m in ms8), plan.strategy(batch)[0]), flush=True)
+            print("pad %11d B  in %#x  out %#x   ms per step %s   %s" % (
+                pad_bytes, a.ptr, b.ptr, " ".join("%.3f" % m for m in ms), plan.strategy(batch)[0]), flush=True)
             del a, b, pad, mid
 
 
