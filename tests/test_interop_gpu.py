@@ -314,7 +314,8 @@ CAPTURE_CASES = [((1 << 18,), 160, numpy.complex64, "fused2"),        # 28 / 56 
                  ((1024, 1024), 64, numpy.complex64, "fused2"),       # the 2-D form
                  ((1 << 16,), 96, numpy.complex64, "chain"),
                  ((512, 1024), 80, numpy.complex128, "fused2"),
-                 ((256, 4096), 40, numpy.complex64, "pipelined")]     # cache-sized chunks: eager on the plan's side streams, recorded as a linear graph
+                 ((256, 4096), 40, numpy.complex64, "pipelined"),     # cache-sized chunks: eager on the plan's side streams, recorded as a linear graph
+                 ((128, 512, 512), 2, numpy.complex64, "fused2z")]    # round 6: persistent launch over the planes + a plain z launch in one graph
 
 
 @pytest.mark.parametrize("shape,batch,dtype,strategy", CAPTURE_CASES, ids=lambda v: getattr(v, "__name__", str(v)))
