@@ -22,6 +22,29 @@ def check(tag):
 with hip.Graph(s) as g:
     plan.execute(a, b, batch=batch)
 check("after capture")
+for i in range(5):
+    N.check(N.lib.mifft_memset(b.ptr, 0, b.nbytes, s.handle))
+    g.launch()
+    if i in (1, 2):
+        g.launch()
+    s.synchronize()
+    assert numpy.array_equal(b.get().view(numpy.uint32), want), ("replay", i)
+    if i in (0, 3):
+        N.check(N.lib.mifft_memset(b.ptr, 0, b.nbytes, s.handle))
+        plan.execute(a, b, batch=batch)
+        if i == 3:
+            plan.execute(a, b, batch=batch)
+        s.synchronize()
+        assert numpy.array_equal(b.get().view(numpy.uint32), want), ("eager after replay", i)
+plan.finish()
+check("after the loop")
+os.environ["PYFFT_AMD_NO_PLANE_FUSED"] = "1"
+other = hip.Plan(shape, dtype=dtype, stream=s)
+print("other", other.strategy(batch))
+other.execute(a, b, batch=batch)
+s.synchronize()
+del os.environ["PYFFT_AMD_NO_PLANE_FUSED"]
+check("after the other plan")
 with hip.Graph(s) as g2:
     plan.execute(a, b, batch=batch - 1)
 check("after capturing batch-1")
