@@ -48,6 +48,9 @@ check("after the other plan")
 with hip.Graph(s) as g2:
     plan.execute(a, b, batch=batch - 1)
 check("after capturing batch-1")
+N.check(N.lib.mifft_memset(b.ptr, 0, b.nbytes, s.handle))
+g2.launch(); s.synchronize()
+check("after launching the batch-1 graph")
 try:
     with hip.Graph(s):
         plan.execute(a, b, batch=batch, wait_for_finish=True)
