@@ -370,7 +370,7 @@ def test_captured_execute_replays_bit_identically(ctx, shape, batch, dtype, stra
         s.synchronize()
         got = b.get().view(numpy.uint32)
         bad = numpy.nonzero(got != want)[0]
-        print("DBG", tag, bad.size, bad[:3], bad[-3:] if bad.size else "", flush=True)
+        print("DBG", tag, bad.size, got[:4], want[:4], "nonzero", int(numpy.count_nonzero(got)), flush=True)
         b.set(keep)
     _dbg("after loop")
     # a batch the plan has not run yet cannot be captured when its scratch would be allocated inside the capture: loud, not wrong
