@@ -1,3 +1,7 @@
+try:
+    import torch
+except Exception:
+    pass
 import sys, os, gc
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy
