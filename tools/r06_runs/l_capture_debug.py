@@ -43,12 +43,19 @@ for i in range(5):
 plan.finish()
 check("after the loop")
 os.environ["PYFFT_AMD_NO_PLANE_FUSED"] = "1"
+junk = hip.DeviceArray((1 << 20,), numpy.uint8)
+check("after a device allocation")
+junk.set(numpy.zeros(1 << 20, numpy.uint8))
+check("after an h2d copy")
 other = hip.Plan(shape, dtype=dtype, stream=s)
+check("after creating the other plan")
 print("other", other.strategy(batch))
+check("after other.strategy")
 other.execute(a, b, batch=batch)
 s.synchronize()
 del os.environ["PYFFT_AMD_NO_PLANE_FUSED"]
-check("after the other plan")
+check("after the other plan's execute")
+sys.exit(0)
 with hip.Graph(s) as g2:
     plan.execute(a, b, batch=batch - 1)
 check("after capturing batch-1")
