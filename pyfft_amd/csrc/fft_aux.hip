@@ -155,3 +155,21 @@ extern "C" int mifft_aux_mismatch_launch(const void* a, const void* b, unsigned 
     hipLaunchKernelGGL(aux_mismatch_kernel, dim3(grid), dim3(256), 0, s, (const uint4*)a, (const uint4*)b, words, count);
     return (int)hipGetLastError();
 }
+
+// Zero `words16` 16-byte words at p (256-byte aligned counter sets of the persistent launches).  A captured persistent launch zeroes its
+// counter set with THIS kernel, not with hipMemsetAsync: graphs whose memset node preceded the kernel stopped zeroing -- every replay
+// after it found exhausted tickets and wrote nothing -- once the process built another plan, under the HIP runtime that PyTorch 2.10
+// bundles (kernel nodes of the same graphs kept working; tools/r06_runs/m_graph_vs_new_plan.py).
+__global__ void __launch_bounds__(256) aux_zero_kernel(uint4* __restrict__ p, unsigned long long words16) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < words16; i += (unsigned long long)gridDim.x * 256u)
+        p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+extern "C" int mifft_aux_zero_launch(void* p, unsigned long long nbytes, hipStream_t s) {
+    const unsigned long long words16 = nbytes / 16;
+    if (words16 == 0) return 0;
+    const unsigned long long want = (words16 + 255u) / 256u;
+    hipLaunchKernelGGL(aux_zero_kernel, dim3((unsigned)(want < 1024ull ? want : 1024ull)), dim3(256), 0, s, (uint4*)p, words16);
+    return (int)hipGetLastError();
+}
+

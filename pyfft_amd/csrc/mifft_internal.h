@@ -36,6 +36,7 @@ int mifft_fused3_f64_launch(int L0, int L1, const mifft::FusedArgs* f, int split
 int mifft_aux_copy_launch(const struct mifft_copy* c, const void* s0, const void* s1, void* d0, void* d1, hipStream_t s);
 int mifft_aux_mul_rows_launch(int f64, void* a, const void* b, long long rows, long long n, hipStream_t s);
 int mifft_aux_mismatch_launch(const void* a, const void* b, unsigned long long words, unsigned long long* count, hipStream_t s);
+int mifft_aux_zero_launch(void* p, unsigned long long nbytes, hipStream_t s);     // nbytes a multiple of 16, p 16-byte aligned
 int mifft_wave_supported(int f64, int N);
 int mifft_wave_launch(int f64, int N, const mifft::WaveArgs* a, int max_blocks, hipStream_t s);
 int mifft_wave_16x16_launch(const mifft::WaveArgs* a, int max_blocks, hipStream_t s);

@@ -526,8 +526,16 @@ int fill_ctl(mifft::FusedCtl* c, const mifft_fused_sync* sync, long long outer, 
     c->ring = (unsigned)ring_slots;
     c->tiles0 = tiles0;
     c->tiles1 = tiles1;
-    if (!sync->counters_next)
+    if (!sync->counters_next) {
+        // single-set form: zero the set in front of the launch.  On a CAPTURING stream with a kernel of our own (a kernel node) instead
+        // of a memset node: see mifft_aux_zero_launch (csrc/fft_aux.hip)
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &st) == hipSuccess && st == hipStreamCaptureStatusActive) {
+            const int rz = mifft_aux_zero_launch(sync->counters, MIFFT_FUSED2_COUNTER_BYTES(outer), stream);
+            return rz == 0 ? 0 : hip_check((hipError_t)rz, "kernel launch");
+        }
         return hip_check(hipMemsetAsync(sync->counters, 0, MIFFT_FUSED2_COUNTER_BYTES(outer), stream), "hipMemsetAsync");
+    }
     return 0;
 }
 
