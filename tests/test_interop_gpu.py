@@ -359,20 +359,16 @@ def test_captured_execute_replays_bit_identically(ctx, shape, batch, dtype, stra
             s.synchronize()
             assert numpy.array_equal(b.get().view(numpy.uint32), want), ("eager after replay", i)
     plan.finish()                                       # raises if any launch reported a dependency time-out
+    # a graph must survive whatever else the process does with the library -- building ANOTHER plan (tables allocated and uploaded)
+    # broke every later replay of a persistent launch under the HIP runtime PyTorch bundles while the counter set was zeroed by a
+    # memset NODE (round 6; the set is zeroed by a kernel of the library's own now, csrc/fft_aux.hip)
+    bystander = hip.Plan(64, dtype=numpy.complex64, stream=s)
+    N.check(N.lib.mifft_memset(b.ptr, 0, b.nbytes, s.handle))
+    g.launch()
+    s.synchronize()
+    assert numpy.array_equal(b.get().view(numpy.uint32), want), "replay after another plan was built"
+    del bystander
 
-    def _dbg(tag):
-        import os as _os
-        if not _os.environ.get("MIFFT_TEST_DEBUG"):
-            return
-        keep = b.get().copy()
-        N.check(N.lib.mifft_memset(b.ptr, 0, b.nbytes, s.handle))
-        g.launch()
-        s.synchronize()
-        got = b.get().view(numpy.uint32)
-        bad = numpy.nonzero(got != want)[0]
-        print("DBG", tag, bad.size, got[:4], want[:4], "nonzero", int(numpy.count_nonzero(got)), flush=True)
-        b.set(keep)
-    _dbg("after loop")
     # a batch the plan has not run yet cannot be captured when its scratch would be allocated inside the capture: loud, not wrong
     # (round 6: a plan whose chain runs in place throughout -- (256, 4096): ROW + in-place COL -- owns no scratch, and may)
     if plan._temp_buffer_needed or strategy in ("fused2", "fusedp"):
@@ -393,7 +389,6 @@ def test_captured_execute_replays_bit_identically(ctx, shape, batch, dtype, stra
             finally:
                 del os.environ["PYFFT_AMD_NO_PLANE_FUSED"]
             want1 = b.get().view(numpy.uint32).reshape(batch, -1)
-            _dbg("after other")
         else:
             want1 = want.reshape(batch, -1)
         N.check(N.lib.mifft_memset(b.ptr, 0, b.nbytes, s.handle))
@@ -402,21 +397,17 @@ def test_captured_execute_replays_bit_identically(ctx, shape, batch, dtype, stra
         g2.launch()
         s.synchronize()
         got = b.get().view(numpy.uint32).reshape(batch, -1)
-        _dbg("after g2")
         assert numpy.array_equal(got[:batch - 1], want1[:batch - 1]) and not got[batch - 1].any()
     # executes that wait cannot be recorded (waiting synchronises the stream): a clear error, and the capture ends cleanly
     with pytest.raises(RuntimeError, match="cannot wait"):
         with hip.Graph(s):
             plan.execute(a, b, batch=batch, wait_for_finish=True)
     assert not plan._context.capturing()
-    _dbg("after refused")
     # LIFETIME (hip.Graph docstring): the graph keeps the plan alive, the plan keeps the scratch the graph replays on -- another batch
     # re-prepares the plan, close() releases what it can, the last reference to the plan goes away; the first graph still replays
     assert any(p is plan for p in g._plans)
     plan.execute(a, b, batch=max(1, batch // 2))
-    _dbg("after eager half")
     plan.close()
-    _dbg("after close")
     del plan
     import gc
     gc.collect()
