@@ -334,7 +334,9 @@ int mifft_launch_chain_pipelined(const mifft_pass *passes, int32_t npasses, void
 /*
  * Synchronisation state of one persistent launch (all caller-owned device-accessible memory):
  *   counters       MIFFT_FUSED2_COUNTER_BYTES(outer) bytes.  With counters_next == NULL the call zeroes them on `stream` in front
- *                  of the launch (a memset node: ~5 us, what a 32 MiB execute cannot afford).  The ONLY form allowed on a
+ *                  of the launch (hipMemsetAsync: ~5 us, what a 32 MiB execute cannot afford; on a CAPTURING stream a small kernel
+ *                  of the library's own, i.e. a kernel node -- a memset node in front of the launch stopped zeroing once the process
+ *                  built another plan under the HIP runtime PyTorch bundles, round 6).  The ONLY form allowed on a
  *                  capturing stream (a replayed graph runs on the same set every time): MIFFT_E_INVALID otherwise.
  *   counters_next  a second buffer of the same size: the caller guarantees that `counters` is ALL ZERO when the launch starts, and
  *                  THIS launch zeroes `counters_next` -- a plan that alternates between two sets (set A zeroes B, B zeroes A) after
