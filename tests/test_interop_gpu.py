@@ -12,8 +12,7 @@ import numpy
 import pytest
 
 import pyfft_oracle as oracle
-from helpers import EPS_F, MAX_F, getDimensions, _execute, _execute_split, _noise, _test_data, _tiled_noise
-from test_errors_gpu import run_protocol
+from helpers import EPS_F, MAX_F, _noise, _test_data, _tiled_noise
 
 pytestmark = pytest.mark.gpu
 

@@ -1,17 +1,12 @@
 """GPU tests of the one-launch N-D kernels beyond the fixed-shape table (that table: tests/test_errors_gpu.py::test_fixed_shape_nd_kernels):
 several work-groups per transform (csrc/fft_nd2z.hpp) and the tiny shapes the tuning table routes to the run-time-shaped kernel
 (csrc/fft_nd.hpp).  Reference: one chain per axis, pyfft/plan.py:135-171."""
-import ctypes
-import json
 import os
-import subprocess
-import sys
 
 import numpy
 import pytest
 
-import pyfft_oracle as oracle
-from helpers import EPS_F, MAX_F, getDimensions, _execute, _execute_split, _noise, _test_data, _tiled_noise
+from helpers import EPS_F, MAX_F, _noise, _tiled_noise
 from test_errors_gpu import run_protocol
 
 pytestmark = pytest.mark.gpu

@@ -4,17 +4,13 @@ of the planner's tuning table (pyfft_amd/tuning_gfx950.json) in both precisions 
 synchronise through, and BASELINE.json configs[4] as stated on one GPU.  Whole arrays against the plain chain (same tile code: same bits)
 where that holds, sampled transforms against numpy.fft with the reference's thresholds (test/test_errors.py:20-23)."""
 import ctypes
-import json
 import os
-import subprocess
-import sys
 
 import numpy
 import pytest
 
 import pyfft_oracle as oracle
-from helpers import EPS_F, MAX_F, getDimensions, _execute, _execute_split, _noise, _test_data, _tiled_noise
-from test_errors_gpu import run_protocol
+from helpers import EPS_F, MAX_F, _execute, _execute_split, _noise, _test_data
 
 pytestmark = pytest.mark.gpu
 
