@@ -39,7 +39,14 @@ extern "C" int mifft_fusedp_more(int f64, int split, int x, int y, int z, const 
     using XY128x64d = PairXY<double, 128, 16, 4, 128, true, 1, RL(8, 16), RL(16), false>;
     using XY64x64f = PairXY<float, 64, 16, 4, 64, true, 1, RL(4, 16), RL(16), false>;
     using XY64x64d = PairXY<double, 64, 16, 4, 64, true, 1, RL(4, 16), RL(16), false>;
+    // round 6: (32, 32, 128), a shape of the reference's own benchmark list (test/test_performance.py:40-44) -- y = 8 x 4, the XY tile 128 x 8
+    // = 1024 points on one wave x 16 points, the YZ tile 64 x 4 x 32 = 8192 points; pipelined chunks -> persistent at 1 GiB per side:
+    // see the CASE lines below
+    using XY128x32f = PairXY<float, 128, 8, 4, 64, true, 1, RL(8, 16), RL(8), false>;
+    using XY128x32d = PairXY<double, 128, 8, 4, 64, true, 1, RL(8, 16), RL(8), false>;
     // YZ tile: W x 4 x NZ = 8192 points on 512 threads x 16 points -- W = 32 adjacent elements of [R0][NX] for nz = 64, 16 for nz = 128
+    // (64 for nz = 32)
+#define YZ32(T, S0) PairYZ<T, S0, 4, 32, 64, 512, true, 1, RL(4), RL(2, 16), false>
 #define YZ64(T, S0) PairYZ<T, S0, 4, 64, 32, 512, true, 1, RL(4), RL(4, 16), false>
 #define YZ128(T, S0) PairYZ<T, S0, 4, 128, 16, 512, true, 1, RL(4), RL(8, 16), false>
     //   (nz, ny, nx)                 NX   NY   NZ  R0 R1  W
@@ -57,6 +64,9 @@ extern "C" int mifft_fusedp_more(int f64, int split, int x, int y, int z, const 
     CASE(double, 1, 64, 64, 128, 16, 4, 16, XY64x64d, YZ128(double, 64 * 16))
     CASE(float, 0, 64, 64, 64, 16, 4, 32, XY64x64f, YZ64(float, 64 * 16))            // (64, 64, 64)
     CASE(double, 1, 64, 64, 64, 16, 4, 32, XY64x64d, YZ64(double, 64 * 16))
+    CASE(float, 0, 128, 32, 32, 8, 4, 64, XY128x32f, YZ32(float, 128 * 8))             // (32, 32, 128)
+    CASE(double, 1, 128, 32, 32, 8, 4, 64, XY128x32d, YZ32(double, 128 * 8))
+#undef YZ32
 #undef YZ64
 #undef YZ128
 #undef CASE

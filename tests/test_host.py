@@ -702,7 +702,11 @@ def test_strategy_snapshot_of_the_table_driven_planner():
     # kernels (strategy "fused2z") where the round-4 planner answered chain / pipelined slabs
     planes = [g for g in got if g[5][0] == "fused2z"]
     assert 0 < len(planes) < 200 and all(tuple(g[2]) == (512, 512, 512) and w[5][0] in ("chain", "pipelined") for w, g in zip(want, got) if g[5][0] == "fused2z")
-    bad = [(w, g) for w, g in zip(want, got) if not g[6] and g[5][0] != "fused2z" and w != json.loads(json.dumps(g[:6])) and (lists or w[5][0] != "fused2x")]
+    # ... and (32, 32, 128), a shape of the reference's benchmark list, got its persistent two-pair kernel (round-4 answer: the pipelined chunks)
+    cube32 = [g for w, g in zip(want, got) if tuple(g[2]) == (32, 32, 128) and g[5][0] == "fusedp"]
+    assert cube32 and all(w[5][0] in ("chain", "pipelined") for w, g in zip(want, got) if tuple(g[2]) == (32, 32, 128) and g[5][0] == "fusedp")
+    bad = [(w, g) for w, g in zip(want, got) if not g[6] and g[5][0] != "fused2z" and not (tuple(g[2]) == (32, 32, 128) and g[5][0] == "fusedp") and
+           w != json.loads(json.dumps(g[:6])) and (lists or w[5][0] != "fused2x")]
     assert not bad, bad[:10]
     assert not lists or sum(1 for g in got if g[5][0] == "fused2x") == 18
     assert set(r[5][0] for r in want) == {"chain", "pipelined", "fused2", "fusedp", "fused2x"}
