@@ -587,6 +587,9 @@ def test_round4_entry_points_reject_bad_arguments_without_touching_the_gpu():
                 assert N.lib.mifft_fused_pair_split(N.F64, S, x, y, z) == want
                 assert N.lib.mifft_fused_pair_split(N.F32, S, x, y, z) == want
     assert N.lib.mifft_fused_pair_split(N.F32, I, 64, 32, 64) == 0
+    # (round 6: and for (32, 32, 128), interleaved, y = 8 x 4)
+    assert N.lib.mifft_fused_pair_split(N.F32, I, 128, 32, 32) == 8 and N.lib.mifft_fused_pair_split(N.F64, I, 128, 32, 32) == 8
+    assert N.lib.mifft_fused_pair_split(N.F32, S, 128, 32, 32) == 0
     from pyfft_amd import passes as P
     chain = P.build_chain(128, 128, 128, N.F32, interleaved=True)
     assert [k.pair_with_next for k in chain] == [True, False, True, False]
