@@ -66,6 +66,20 @@ extern "C" int mifft_fusedp_more(int f64, int split, int x, int y, int z, const 
     CASE(double, 1, 64, 64, 64, 16, 4, 32, XY64x64d, YZ64(double, 64 * 16))
     CASE(float, 0, 128, 32, 32, 8, 4, 64, XY128x32f, YZ32(float, 128 * 8))             // (32, 32, 128)
     CASE(double, 1, 128, 32, 32, 8, 4, 64, XY128x32d, YZ32(double, 128 * 8))
+    // ... and its neighbours with one or two 32-point axes that the existing tile kinds cover (1 GiB per side, pipelined chunks -> persistent:
+    // profiles/r06_o_cube32_neighbours.log)
+    CASE(float, 0, 128, 64, 32, 16, 4, 64, XY128x64f, YZ32(float, 128 * 16))           // (32, 64, 128)
+    CASE(double, 1, 128, 64, 32, 16, 4, 64, XY128x64d, YZ32(double, 128 * 16))
+    CASE(float, 0, 128, 128, 32, 32, 4, 64, XY128x128f, YZ32(float, 128 * 32))         // (32, 128, 128)
+    CASE(double, 1, 128, 128, 32, 32, 4, 64, XY128x128d, YZ32(double, 128 * 32))
+    CASE(float, 0, 128, 32, 64, 8, 4, 32, XY128x32f, YZ64(float, 128 * 8))             // (64, 32, 128)
+    CASE(double, 1, 128, 32, 64, 8, 4, 32, XY128x32d, YZ64(double, 128 * 8))
+    CASE(float, 0, 128, 32, 128, 8, 4, 16, XY128x32f, YZ128(float, 128 * 8))           // (128, 32, 128)
+    CASE(double, 1, 128, 32, 128, 8, 4, 16, XY128x32d, YZ128(double, 128 * 8))
+    CASE(float, 0, 64, 64, 32, 16, 4, 64, XY64x64f, YZ32(float, 64 * 16))              // (32, 64, 64)
+    CASE(double, 1, 64, 64, 32, 16, 4, 64, XY64x64d, YZ32(double, 64 * 16))
+    CASE(float, 0, 64, 128, 32, 32, 4, 64, XY64x128f, YZ32(float, 64 * 32))            // (32, 128, 64)
+    CASE(double, 1, 64, 128, 32, 32, 4, 64, XY64x128d, YZ32(double, 64 * 32))
 #undef YZ32
 #undef YZ64
 #undef YZ128

@@ -586,7 +586,7 @@ def test_round4_entry_points_reject_bad_arguments_without_touching_the_gpu():
                 assert N.lib.mifft_fused_pair_split(N.F32, I, x, y, z) == want and N.lib.mifft_fused_pair_split(N.F64, I, x, y, z) == want
                 assert N.lib.mifft_fused_pair_split(N.F64, S, x, y, z) == want
                 assert N.lib.mifft_fused_pair_split(N.F32, S, x, y, z) == want
-    assert N.lib.mifft_fused_pair_split(N.F32, I, 64, 32, 64) == 0
+    assert N.lib.mifft_fused_pair_split(N.F32, I, 64, 32, 64) == 0 and N.lib.mifft_fused_pair_split(N.F32, I, 32, 32, 32) == 0
     # (round 6: and for (32, 32, 128), interleaved, y = 8 x 4)
     assert N.lib.mifft_fused_pair_split(N.F32, I, 128, 32, 32) == 8 and N.lib.mifft_fused_pair_split(N.F64, I, 128, 32, 32) == 8
     assert N.lib.mifft_fused_pair_split(N.F32, S, 128, 32, 32) == 0

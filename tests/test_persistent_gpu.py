@@ -497,7 +497,9 @@ def test_split_planes_on_per_xcd_lists(ctx, monkeypatch, n, batch, expect):
 # ---- persistent two-pair kernel for 3-D shapes with 64- and 128-point axes (csrc/fft_fusedp2.hip) --------------------------------
 PAIR_SMALL_AXES_CASES = [((64, 64, 64), 141), ((64, 128, 128), 59), ((128, 128, 64), 57), ((128, 64, 128), 61),
                          ((64, 128, 64), 115), ((64, 64, 128), 117), ((128, 64, 64), 113),
-                         ((32, 32, 128), 300)]        # round 6: a shape of the reference's own benchmark list, y = 8 x 4
+                         ((32, 32, 128), 300),        # round 6: a shape of the reference's own benchmark list, y = 8 x 4 ...
+                         ((32, 64, 128), 151), ((32, 128, 128), 75), ((64, 32, 128), 149), ((128, 32, 128), 77), ((32, 64, 64), 301),
+                         ((32, 128, 64), 153)]        # ... and its neighbours with 32-point axes on the same tile kinds
 
 
 @pytest.mark.parametrize("dtype", [numpy.complex64, numpy.complex128], ids=["c64", "c128"])
