@@ -16,7 +16,8 @@ c64, c128, f32, f64 = numpy.complex64, numpy.complex128, numpy.float32, numpy.fl
 SHAPES = [((1 << k,), dt) for k in range(16, 23) for dt in (c64, f32)] + [((1 << k,), c128) for k in range(16, 22)] + [((1 << k,), f64) for k in range(16, 21)] + \
     [((a, b), dt) for a in (256, 512, 1024, 2048) for b in (256, 512, 1024, 2048) for dt in (c64, c128)] + \
     [((a, b), f32) for a in (256, 512, 1024) for b in (256, 512, 1024)] + [((1024, 1024), f64)] + \
-    [((a, b, c), dt) for a in (64, 128) for b in (64, 128) for c in (64, 128) for dt in (c64, c128, f32, f64)]
+    [((a, b, c), dt) for a in (64, 128) for b in (64, 128) for c in (64, 128) for dt in (c64, c128, f32, f64)] + \
+    [(sh, dt) for sh in ((32, 32, 128), (32, 64, 128), (32, 128, 128), (64, 32, 128), (128, 32, 128), (32, 64, 64), (32, 128, 64)) for dt in (c64, c128)]   # round 6
 
 
 def fill(buf, blk):
